@@ -1,0 +1,239 @@
+/*
+ * pseudoaligner_amd.h — C ABI of the MI355X-native pseudoalignment hot path.
+ *
+ * This is the drop-in boundary for ONE path of 10XGenomics/rust-pseudoaligner
+ * (crate `debruijn_mapping` v0.6.0): per-read k-mer lookup + De Bruijn graph
+ * extension + equivalence-class intersection, i.e.
+ *
+ *     Pseudoaligner::map_read                 src/pseudoaligner.rs:381-384
+ *       -> map_read_with_mismatch             src/pseudoaligner.rs:361-376
+ *          -> map_read_to_nodes_with_mismatch src/pseudoaligner.rs:64-319
+ *          -> nodes_to_eq_class / intersect   src/pseudoaligner.rs:323-356, 389-418
+ *     process_reads (driver)                  src/pseudoaligner.rs:420-514
+ *
+ * The reference has no FFI of its own (it is a pure-Rust crate); the symbols
+ * below are what a Rust `extern "C"` block would bind to replace the body of
+ * `process_reads` / `map_read` (see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++/torch types; every function returns
+ *     0 (PA_OK) or a negative pa_status; the message of the last failure on the
+ *     calling thread is available from pa_last_error().
+ *   - nothing aborts or throws across the ABI (the reference panics instead:
+ *     src/pseudoaligner.rs:307,446,464).
+ *   - bases are 2-bit codes A=0 C=1 G=2 T=3, packed LSB-first: base j of a
+ *     sequence lives in bits [2*(j%32), 2*(j%32)+1] of 64-bit word j/32.
+ *   - "device" pointers are HIP device pointers on the GPU the index lives on;
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ */
+#ifndef PSEUDOALIGNER_AMD_H
+#define PSEUDOALIGNER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_ABI_VERSION 1u
+
+/* config.rs:16-18 — the three constants that parameterise the hot path. */
+#define PA_READ_COVERAGE_THRESHOLD 32u   /* src/config.rs:16 */
+#define PA_LEFT_EXTEND_NUM 1u            /* LEFT_EXTEND_FRACTION = 0.2 = 1/5, src/config.rs:17 */
+#define PA_LEFT_EXTEND_DEN 5u
+#define PA_DEFAULT_ALLOWED_MISMATCHES 2u /* src/config.rs:18 */
+#define PA_SEEK_STRIDE 3u                /* `*kmer_pos += 3`, src/pseudoaligner.rs:110 */
+
+#define PA_NO_EDGE 0xFFFFFFFFu
+#define PA_MIN_K 8u
+#define PA_MAX_K 32u                     /* one 64-bit word per k-mer (Kmer20/24/30/32 of the debruijn crate) */
+#define PA_MAX_READ_LEN 2048u
+
+typedef enum pa_status {
+    PA_OK = 0,
+    PA_ERR_INVALID_ARG = -1,
+    PA_ERR_IO = -2,
+    PA_ERR_FORMAT = -3,        /* malformed FASTA/FASTQ or inconsistent flat index */
+    PA_ERR_NO_DEVICE = -4,     /* HIP runtime / GPU not usable: the product never falls back to a CPU path */
+    PA_ERR_HIP = -5,
+    PA_ERR_OOM = -6,
+    PA_ERR_ARENA_FULL = -7,    /* caller-provided class arena too small; required size reported */
+    PA_ERR_UNSUPPORTED = -8,
+    PA_ERR_INTERNAL = -9
+} pa_status;
+
+/* ------------------------------------------------------------------------------------------
+ * Flat index: the interchange form of `pub struct Pseudoaligner<K>` (src/pseudoaligner.rs:26-33).
+ * A Rust exporter fills it from the struct's pub fields (dbg, eq_classes); `dbg_index` (the boomphf
+ * MPHF, :30) is NOT part of the interchange because every hit is verified against the node sequence
+ * (:99-107), which makes it equivalent to an exact k-mer dictionary that the library rebuilds.
+ * All arrays are borrowed for the duration of the call that receives the struct.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct pa_flat_index {
+    uint32_t k;                  /* K::k() */
+    uint32_t num_nodes;          /* dbg.len() */
+    uint32_t num_classes;        /* eq_classes.len() */
+    uint32_t num_transcripts;    /* tx_names.len() */
+    uint64_t seq_bases;          /* sum of node_len */
+    const uint64_t* node_seq;    /* packed bases of all nodes back to back (node i starts at base node_start[i]) */
+    const uint64_t* node_start;  /* [num_nodes + 1] base offsets into node_seq */
+    const uint32_t* node_len;    /* [num_nodes] node.len() in bases (>= k) */
+    const uint8_t*  node_exts;   /* [num_nodes] debruijn::Exts byte: bit b = right ext b, bit 4+b = left ext b */
+    const uint32_t* node_colour; /* [num_nodes] *node.data() = equivalence-class id */
+    const uint64_t* ec_offset;   /* [num_classes + 1] CSR offsets into ec_ids */
+    const uint32_t* ec_ids;      /* eq_classes[c] = ec_ids[ec_offset[c] .. ec_offset[c+1]) sorted, dedup'd */
+    /* optional (may be NULL): edges as node.r_edges()/l_edges() would resolve them, indexed by BASE
+     * (not by rank): node_redge[4*i + b] = r_edges()[rank of b among set right exts].0, PA_NO_EDGE when
+     * the ext bit is clear. When NULL the library derives them the way the debruijn crate does (look up
+     * the terminal k-mer extended by b). */
+    const uint32_t* node_redge;  /* [4 * num_nodes] */
+    const uint32_t* node_ledge;  /* [4 * num_nodes] */
+} pa_flat_index;
+
+/* ---------------- host-side index (CPU; "index construction stays on the CPU") ---------------- */
+typedef struct pa_host_index pa_host_index;
+
+/* build_index (src/build_index.rs:27-91) + utils::read_transcripts (src/utils.rs:61-97):
+ * FASTA -> stranded coloured compacted De Bruijn graph + equivalence classes. */
+int pa_host_index_build_fasta(const char* fasta_path, uint32_t k, int num_threads, pa_host_index** out);
+/* same from already packed transcripts: tx_start[num_tx+1] base offsets into `packed`. */
+int pa_host_index_build_packed(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx,
+                               uint32_t k, int num_threads, pa_host_index** out);
+/* wrap caller arrays (deep copy) — the import path for an index exported from the Rust side. */
+int pa_host_index_from_flat(const pa_flat_index* flat, pa_host_index** out);
+int pa_host_index_view(const pa_host_index* h, pa_flat_index* view);   /* pointers valid until destroy */
+int pa_host_index_save(const pa_host_index* h, const char* path);      /* own little-endian container, not bincode */
+int pa_host_index_load(const char* path, pa_host_index** out);
+/* transcript metadata: tx_names (:31) and the gene of each transcript (:32) */
+uint32_t pa_host_index_num_transcripts(const pa_host_index* h);
+const char* pa_host_index_tx_name(const pa_host_index* h, uint32_t tx);
+const char* pa_host_index_tx_gene(const pa_host_index* h, uint32_t tx);
+/* packed transcripts the index was built from (kept for read simulation / validation) */
+int pa_host_index_transcripts(const pa_host_index* h, const uint64_t** packed, const uint64_t** tx_start,
+                              uint32_t* num_tx);
+void pa_host_index_destroy(pa_host_index* h);
+
+/* ---------------- device index ---------------- */
+typedef struct pa_index pa_index;
+
+typedef struct pa_index_stats {
+    uint64_t num_kmers;        /* distinct k-mers = dictionary entries */
+    uint64_t table_slots;      /* dictionary capacity (16-byte slots) */
+    uint64_t bytes_table, bytes_graph, bytes_classes, bytes_total;
+    uint32_t num_nodes, num_classes, k, max_class_len;
+} pa_index_stats;
+
+/* Flatten for the GPU and upload to HIP device `device`. Fails with PA_ERR_NO_DEVICE when no GPU. */
+int pa_index_create(const pa_flat_index* flat, int device, pa_index** out);
+int pa_index_get_stats(const pa_index* idx, pa_index_stats* stats);
+void pa_index_destroy(pa_index* idx);
+
+/* ---------------- read batches ---------------- */
+/* Device tile layout ("coalesced HBM tiles"): reads are grouped 64 to a tile; a tile holds
+ * `words_per_read` 64-bit words per read, word-major: tiles[(t*words_per_read + w)*64 + r] is word w of
+ * read 64*t + r. lens[i] is the length in bases of read i. n_reads need not be a multiple of 64 but the
+ * tile buffer must be sized for ceil(n/64) whole tiles. */
+typedef struct pa_read_result {   /* one per read, same order as the input */
+    uint32_t coverage;            /* map_read .1 (bases aligned); 0 when unmapped */
+    uint32_t mismatches;          /* map_read_with_mismatch .2; bit 31 = mapped (Some vs None) */
+    uint32_t class_off;           /* offset of the class in the arena (u32 units) */
+    uint32_t class_len;           /* number of transcript ids */
+} pa_read_result;
+#define PA_MAPPED_BIT 0x80000000u
+
+size_t pa_tiles_words(uint64_t n_reads, uint32_t words_per_read);   /* u64 words in the tile buffer */
+uint32_t pa_words_per_read(uint32_t max_read_len);
+
+/* DnaString::from_dna_string (src/pseudoaligner.rs:449-450) for a batch, on the GPU:
+ * ASCII reads (concatenated, offsets[n+1]) already on the device -> tiles + lens. */
+int pa_encode_reads_device(const pa_index* idx, const uint8_t* d_ascii, const uint64_t* d_offsets, uint64_t n_reads,
+                           uint32_t words_per_read, uint64_t* d_tiles, uint32_t* d_lens, void* stream);
+/* host reference of the same packing (used by the host driver for the single-read path and by tests) */
+int pa_encode_reads_host(const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads, uint32_t words_per_read,
+                         uint64_t* tiles, uint32_t* lens);
+
+/* The hot path. map_read_with_mismatch for every read of a device-resident batch.
+ *   d_results  [n_reads] pa_read_result
+ *   d_arena    [arena_cap] u32: class ids, referenced by (class_off, class_len)
+ *   d_colour   optional [n_reads] u32: equivalence-class id of the result when it equals an index class
+ *              reached by the read, 0xFFFFFFFF otherwise (input of pa_counts_accumulate_device); may be NULL
+ * Asynchronous on `stream`; completion status is fetched with pa_map_finish (which synchronises the stream). */
+int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads,
+                        uint32_t words_per_read, uint32_t allowed_mismatches, pa_read_result* d_results,
+                        uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour, void* stream);
+/* Synchronise and report: PA_OK, or PA_ERR_ARENA_FULL with *arena_needed set (re-run with a larger arena). */
+int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed);
+
+/* Host-buffer convenience (H2D, map, D2H; grows its own arena). results[n], class ids returned as a
+ * CSR in read order: class_offsets[n+1], class_ids (library-owned, valid until the next call on idx
+ * from this thread or pa_index_destroy). Reads are ASCII, concatenated, offsets[n+1]. */
+int pa_map_batch(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads,
+                 uint32_t allowed_mismatches, pa_read_result* results, uint64_t* class_offsets,
+                 const uint32_t** class_ids);
+/* map_read (src/pseudoaligner.rs:381): returns 1 = Some, 0 = None, <0 error. */
+int pa_map_read(pa_index* idx, const uint8_t* ascii, uint32_t len, uint32_t* class_buf, uint32_t class_cap,
+                uint32_t* class_len, uint32_t* coverage);
+int pa_map_read_with_mismatch(pa_index* idx, const uint8_t* ascii, uint32_t len, uint32_t allowed_mismatches,
+                              uint32_t* class_buf, uint32_t class_cap, uint32_t* class_len, uint32_t* coverage,
+                              uint32_t* mismatches);
+/* map_read_to_nodes (src/pseudoaligner.rs:54-61, test surface): node ids in visit order. */
+int pa_map_read_to_nodes(pa_index* idx, const uint8_t* ascii, uint32_t len, uint32_t allowed_mismatches,
+                         uint32_t* node_buf, uint32_t node_cap, uint32_t* num_nodes, uint32_t* coverage,
+                         uint32_t* mismatches);
+
+/* process_reads (src/pseudoaligner.rs:420-514): FASTQ in, one Debug-formatted tuple per read on `out_path`
+ * ("-" = stdout) in INPUT order (the reference's order is completion order, :490). num_threads sizes the
+ * host parse/format pool. n_reads_out/n_flagged_out may be NULL. */
+int pa_process_reads(pa_index* idx, const pa_host_index* names, const char* fastq_path, const char* out_path,
+                     int num_threads, uint64_t* n_reads_out, uint64_t* n_flagged_out);
+
+/* ---------------- equivalence-class count table (multi-GPU reduction unit) ---------------- */
+/* counts[c] += number of reads whose class equals index class c; reads with a novel (non-index)
+ * non-empty class are counted in counts[num_classes] ("novel"), empty-class mapped reads in
+ * counts[num_classes+1], unmapped reads in counts[num_classes+2]. d_counts is a caller-owned device
+ * array of pa_counts_len(idx) u64 (so that the caller can all-reduce it with RCCL). */
+uint64_t pa_counts_len(const pa_index* idx);
+int pa_counts_accumulate_device(pa_index* idx, const pa_read_result* d_results, const uint32_t* d_arena,
+                                const uint32_t* d_colour, uint64_t n_reads, uint64_t* d_counts, void* stream);
+
+/* ---------------- synthetic workloads (BASELINE.json configs; deterministic, counter-based) ------------- */
+/* GENCODE-like transcriptome: returns a host index-less transcript set. */
+typedef struct pa_txome pa_txome;
+int pa_txome_synthesize(uint32_t num_genes, uint32_t target_transcripts, uint64_t seed, pa_txome** out);
+int pa_txome_from_host_index(const pa_host_index* h, pa_txome** out);
+int pa_txome_view(const pa_txome* t, const uint64_t** packed, const uint64_t** tx_start, uint32_t* num_tx);
+void pa_txome_destroy(pa_txome* t);
+/* reads: read i = transcript drawn with probability proportional to (len - read_len + 1), uniform start,
+ * forward strand, per-base substitution with probability sub_rate_ppm/1e6; function of (seed, first_read+i) only. */
+int pa_simulate_reads_host(const pa_txome* t, uint32_t read_len, uint64_t seed, uint32_t sub_rate_ppm,
+                           uint64_t first_read, uint64_t n_reads, uint32_t words_per_read, uint64_t* tiles,
+                           uint32_t* lens);
+typedef struct pa_txome_device pa_txome_device;
+int pa_txome_upload(const pa_txome* t, uint32_t read_len, int device, pa_txome_device** out);
+void pa_txome_device_destroy(pa_txome_device* t);
+int pa_simulate_reads_device(const pa_txome_device* t, uint64_t seed, uint32_t sub_rate_ppm, uint64_t first_read,
+                             uint64_t n_reads, uint32_t words_per_read, uint64_t* d_tiles, uint32_t* d_lens,
+                             void* stream);
+
+/* ---------------- misc ---------------- */
+uint32_t pa_abi_version(void);
+int pa_device_count(void);
+const char* pa_last_error(void);
+/* HIP-event timing on the stream kernels are launched on (bench.py's roofline leg). */
+int pa_event_create(void** ev);
+int pa_event_record(void* ev, void* stream);
+int pa_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises `stop` */
+int pa_event_destroy(void* ev);
+/* raw device memory for hosts without their own allocator */
+int pa_device_malloc(int device, size_t bytes, void** out);
+int pa_device_free(void* p);
+int pa_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int pa_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int pa_memset_device(void* dst, int value, size_t bytes, void* stream);
+int pa_stream_synchronize(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSEUDOALIGNER_AMD_H */

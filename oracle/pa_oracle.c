@@ -1,0 +1,588 @@
+/*
+ * pa_oracle.c — CPU restatement of the reference hot path. TEST INFRASTRUCTURE ONLY (see pa_oracle.h).
+ * Each function cites the reference lines it follows (paths relative to /root/reference).
+ */
+#include "pa_oracle.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* src/config.rs:16-18 */
+#define LEFT_EXTEND_FRACTION 0.2
+#define SEEK_STRIDE 3 /* src/pseudoaligner.rs:110 */
+
+#define NO_SLOT 0xFFFFFFFFu
+
+struct oracle_index {
+    uint32_t k, num_nodes, num_classes;
+    const uint64_t* seq; /* copies */
+    uint64_t* seq_own;
+    uint64_t* node_start;
+    uint32_t* node_len;
+    uint8_t* node_exts;
+    uint32_t* node_colour;
+    uint64_t* ec_offset;
+    uint32_t* ec_ids;
+    /* NoKeyBoomHashMap<K,(u32,u32)> stand-in: key-less slots, hits verified by the caller */
+    uint64_t dict_cap;
+    uint32_t* dict_node;
+    uint32_t* dict_off;
+    /* Node::r_edges()/l_edges(): targets of the set extensions in ascending base order (indexed by rank) */
+    uint32_t* r_edges; /* [4*num_nodes] */
+    uint32_t* l_edges;
+};
+
+static __thread char g_err[256];
+const char* oracle_last_error(void) { return g_err; }
+
+/* ---- DnaString::get / get_kmer restated on LSB-first packed words ---- */
+static inline uint8_t seq_get(const uint64_t* w, uint64_t pos) { return (uint8_t)((w[pos >> 5] >> ((pos & 31) * 2)) & 3u); }
+
+static inline uint64_t seq_get_kmer(const uint64_t* w, uint64_t pos, uint32_t k) {
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < k; ++i) v |= (uint64_t)seq_get(w, pos + i) << (2 * i);
+    return v;
+}
+
+static inline uint64_t dict_hash(uint64_t x) { /* splitmix64 finaliser; any hash works, hits are verified */
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+/* dbg_index.get(&read_kmer) followed by the verification of :99-107 */
+int oracle_lookup_kmer(const oracle_index* idx, uint64_t kmer, uint32_t* node, uint32_t* offset) {
+    uint64_t i = dict_hash(kmer) % idx->dict_cap;
+    for (;;) {
+        const uint32_t nid = idx->dict_node[i];
+        if (nid == NO_SLOT) return 0;
+        const uint32_t off = idx->dict_off[i];
+        /* let ref_kmer: K = ref_seq_slice.get_kmer(offset); if read_kmer == ref_kmer (:103-105) */
+        if (seq_get_kmer(idx->seq, idx->node_start[nid] + off, idx->k) == kmer) {
+            *node = nid;
+            *offset = off;
+            return 1;
+        }
+        if (++i == idx->dict_cap) i = 0;
+    }
+}
+
+static void dict_insert(oracle_index* idx, uint64_t kmer, uint32_t nid, uint32_t off) {
+    uint64_t i = dict_hash(kmer) % idx->dict_cap;
+    while (idx->dict_node[i] != NO_SLOT)
+        if (++i == idx->dict_cap) i = 0;
+    idx->dict_node[i] = nid;
+    idx->dict_off[i] = off;
+}
+
+static void* dup_mem(const void* p, size_t bytes) {
+    void* q = malloc(bytes ? bytes : 1);
+    if (q && bytes) memcpy(q, p, bytes);
+    return q;
+}
+
+void oracle_index_free(oracle_index* idx) {
+    if (!idx) return;
+    free(idx->seq_own);
+    free(idx->node_start);
+    free(idx->node_len);
+    free(idx->node_exts);
+    free(idx->node_colour);
+    free(idx->ec_offset);
+    free(idx->ec_ids);
+    free(idx->dict_node);
+    free(idx->dict_off);
+    free(idx->r_edges);
+    free(idx->l_edges);
+    free(idx);
+}
+
+oracle_index* oracle_index_new(uint32_t k, uint32_t num_nodes, const uint64_t* node_seq, const uint64_t* node_start,
+                               const uint32_t* node_len, const uint8_t* node_exts, const uint32_t* node_colour,
+                               uint32_t num_classes, const uint64_t* ec_offset, const uint32_t* ec_ids) {
+    g_err[0] = 0;
+    if (k < 2 || k > 32) {
+        snprintf(g_err, sizeof g_err, "k=%u unsupported", k);
+        return NULL;
+    }
+    oracle_index* idx = (oracle_index*)calloc(1, sizeof *idx);
+    if (!idx) return NULL;
+    idx->k = k;
+    idx->num_nodes = num_nodes;
+    idx->num_classes = num_classes;
+    const uint64_t bases = num_nodes ? node_start[num_nodes] : 0;
+    const size_t words = (size_t)((bases + 31) / 32 + 2);
+    idx->seq_own = (uint64_t*)calloc(words, 8);
+    if (idx->seq_own && bases) memcpy(idx->seq_own, node_seq, (size_t)((bases + 31) / 32) * 8);
+    idx->seq = idx->seq_own;
+    idx->node_start = (uint64_t*)dup_mem(node_start, ((size_t)num_nodes + 1) * 8);
+    idx->node_len = (uint32_t*)dup_mem(node_len, (size_t)num_nodes * 4);
+    idx->node_exts = (uint8_t*)dup_mem(node_exts, num_nodes);
+    idx->node_colour = (uint32_t*)dup_mem(node_colour, (size_t)num_nodes * 4);
+    idx->ec_offset = (uint64_t*)dup_mem(ec_offset, ((size_t)num_classes + 1) * 8);
+    idx->ec_ids = (uint32_t*)dup_mem(ec_ids, (size_t)ec_offset[num_classes] * 4);
+
+    /* make_dbg_index (src/build_index.rs:182-221): every k-mer of every node -> (node_id, offset) */
+    uint64_t total_kmers = 0;
+    for (uint32_t n = 0; n < num_nodes; ++n) total_kmers += node_len[n] - k + 1;
+    idx->dict_cap = total_kmers + total_kmers / 2 + 16;
+    idx->dict_node = (uint32_t*)malloc(idx->dict_cap * 4);
+    idx->dict_off = (uint32_t*)malloc(idx->dict_cap * 4);
+    idx->r_edges = (uint32_t*)malloc((size_t)num_nodes * 16 + 16);
+    idx->l_edges = (uint32_t*)malloc((size_t)num_nodes * 16 + 16);
+    if (!idx->seq_own || !idx->node_start || !idx->node_len || !idx->node_exts || !idx->node_colour || !idx->ec_offset ||
+        !idx->ec_ids || !idx->dict_node || !idx->dict_off || !idx->r_edges || !idx->l_edges) {
+        snprintf(g_err, sizeof g_err, "out of memory");
+        oracle_index_free(idx);
+        return NULL;
+    }
+    memset(idx->dict_node, 0xFF, idx->dict_cap * 4);
+    for (uint32_t n = 0; n < num_nodes; ++n) {
+        const uint64_t s = node_start[n];
+        uint64_t km = seq_get_kmer(idx->seq, s, k);
+        const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+        const uint32_t nk = node_len[n] - k + 1;
+        for (uint32_t o = 0; o < nk; ++o) {
+            if (o) km = ((km >> 2) | ((uint64_t)seq_get(idx->seq, s + o + k - 1) << (2 * (k - 1)))) & mask;
+            uint32_t a, b;
+            if (oracle_lookup_kmer(idx, km, &a, &b)) {
+                snprintf(g_err, sizeof g_err, "k-mer occurs twice in the graph (nodes %u and %u)", a, n);
+                oracle_index_free(idx);
+                return NULL;
+            }
+            dict_insert(idx, km, n, o);
+        }
+    }
+    /* Node::r_edges()/l_edges() (debruijn crate, graph.rs find_edges/find_link, stranded): for each set extension in
+     * ascending base order, the node whose left-terminal (for Right) / right-terminal (for Left) k-mer equals the
+     * node's terminal k-mer extended by that base; a missing link is a panic there, an error here. */
+    for (uint32_t n = 0; n < num_nodes; ++n) {
+        const uint64_t s = node_start[n];
+        const uint32_t len = node_len[n];
+        const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+        const uint64_t first = seq_get_kmer(idx->seq, s, k), last = seq_get_kmer(idx->seq, s + len - k, k);
+        uint32_t rr = 0, lr = 0;
+        for (uint32_t b = 0; b < 4; ++b) {
+            idx->r_edges[4 * n + b] = NO_SLOT;
+            idx->l_edges[4 * n + b] = NO_SLOT;
+        }
+        for (uint32_t b = 0; b < 4; ++b) {
+            uint32_t tn, to;
+            if (node_exts[n] & (1u << b)) {
+                const uint64_t nx = ((last >> 2) | ((uint64_t)b << (2 * (k - 1)))) & mask;
+                if (!oracle_lookup_kmer(idx, nx, &tn, &to) || to != 0) {
+                    snprintf(g_err, sizeof g_err, "missing link: node %u right ext %u", n, b);
+                    oracle_index_free(idx);
+                    return NULL;
+                }
+                idx->r_edges[4 * n + rr++] = tn;
+            }
+            if (node_exts[n] & (1u << (4 + b))) {
+                const uint64_t pv = ((first << 2) | b) & mask;
+                if (!oracle_lookup_kmer(idx, pv, &tn, &to) || to != node_len[tn] - k) {
+                    snprintf(g_err, sizeof g_err, "missing link: node %u left ext %u", n, b);
+                    oracle_index_free(idx);
+                    return NULL;
+                }
+                idx->l_edges[4 * n + lr++] = tn;
+            }
+        }
+    }
+    return idx;
+}
+
+/* fn intersect<T: Eq + Ord>(v1: &mut Vec<T>, v2: &[T])  — src/pseudoaligner.rs:389-418 */
+size_t oracle_intersect(uint32_t* v1, size_t n1, const uint32_t* v2, size_t n2) {
+    if (n1 == 0) return 0;          /* :390-392 */
+    if (n2 == 0) n1 = 0;            /* :394-396  v1.clear() (then the loop below does not run) */
+    size_t fill_idx1 = 0, idx1 = 0, idx2 = 0;
+    while (idx1 < n1 && idx2 < n2) { /* :402 */
+        /* rem_slice.binary_search(&v1[idx1]) (:403-404): Ok(pos) if found, Err(pos) = insertion point */
+        const uint32_t key = v1[idx1];
+        size_t lo = 0, hi = n2 - idx2;
+        int found = 0;
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo) / 2;
+            const uint32_t x = v2[idx2 + mid];
+            if (x == key) { lo = mid; found = 1; break; }
+            if (x < key) lo = mid + 1; else hi = mid;
+        }
+        if (found) {                 /* :405-410 */
+            const uint32_t t = v1[fill_idx1];
+            v1[fill_idx1] = v1[idx1];
+            v1[idx1] = t;
+            fill_idx1 += 1;
+            idx1 += 1;
+            idx2 = lo + 1;           /* :409 — `pos` is relative to rem_slice, yet the reference assigns it to the
+                                        absolute idx2 (so idx2 can move backwards). Harmless: the slice only grows
+                                        towards smaller elements; restated literally. */
+        } else {                     /* :411-414 */
+            idx1 += 1;
+            idx2 = lo;               /* :413 (same relative/absolute quirk) */
+        }
+    }
+    return fill_idx1;               /* v1.truncate(fill_idx1) :417 */
+}
+
+static inline uint32_t rank_of(uint32_t nibble, uint32_t b) { return (uint32_t)__builtin_popcount(nibble & ((1u << b) - 1u)); }
+
+/* growable usize list standing in for Vec<usize> */
+typedef struct { uint32_t* p; uint32_t n, cap; uint32_t inl[64]; } nodevec;
+static int nv_push(nodevec* v, uint32_t x) {
+    if (v->n == v->cap) {
+        const uint32_t nc = v->cap * 2;
+        uint32_t* q = (uint32_t*)malloc((size_t)nc * 4);
+        if (!q) return -1;
+        memcpy(q, v->p, (size_t)v->n * 4);
+        if (v->p != v->inl) free(v->p);
+        v->p = q;
+        v->cap = nc;
+    }
+    v->p[v->n++] = x;
+    return 0;
+}
+
+/* find_kmer_match closure — src/pseudoaligner.rs:91-114 */
+static int find_kmer_match(const oracle_index* idx, const uint64_t* read, size_t last_kmer_pos, size_t* kmer_pos,
+                           uint32_t* nid, uint32_t* offset, oracle_counters* ctr) {
+    while (*kmer_pos <= last_kmer_pos) {                                   /* :92 */
+        const uint64_t read_kmer = seq_get_kmer(read, *kmer_pos, idx->k);  /* :93 */
+        if (ctr) ctr->probes += 1;                                         /* :95 */
+        if (oracle_lookup_kmer(idx, read_kmer, nid, offset)) return 1;     /* :96-108 */
+        *kmer_pos += SEEK_STRIDE;                                          /* :110 */
+    }
+    return 0;                                                              /* :113 */
+}
+
+/* map_read_to_nodes_with_mismatch — src/pseudoaligner.rs:64-319. Returns 1 = Some, 0 = None, -1 = OOM. */
+static int map_read_to_nodes_with_mismatch(const oracle_index* idx, const uint64_t* read_seq, size_t read_length,
+                                           nodevec* nodes, size_t allowed_mismatches, size_t* out_coverage,
+                                           size_t* out_mismatch, oracle_counters* ctr) {
+    size_t read_coverage = 0, mismatch_count = 0;                                   /* :71-72 */
+    nodes->n = 0;                                                                   /* :75 */
+    const size_t left_extend_threshold = (size_t)(LEFT_EXTEND_FRACTION * (double)read_length); /* :77 */
+    size_t kmer_pos = 0;                                                            /* :79 */
+    const size_t kmer_length = idx->k;                                              /* :80 */
+    if (read_length < kmer_length) return 0;                                        /* :82-84 */
+    const size_t last_kmer_pos = read_length - kmer_length;                         /* :86 */
+
+    uint32_t node_id = 0, kmer_offset = 0;
+    int have = find_kmer_match(idx, read_seq, last_kmer_pos, &kmer_pos, &node_id, &kmer_offset, ctr); /* :118-121 */
+
+    if (have) {                                                                     /* :124 */
+        if (kmer_pos >= left_extend_threshold) {                                    /* :126 */
+            if (ctr) ctr->left_extensions += 1;
+            size_t last_pos = kmer_pos - 1;                                         /* :127 */
+            uint32_t prev_node_id = node_id;                                        /* :128 */
+            size_t prev_kmer_offset = kmer_offset > 0 ? kmer_offset - 1 : 0;        /* :129 (quirk Q1) */
+            for (;;) {                                                              /* :131 */
+                const uint64_t nstart = idx->node_start[prev_node_id];              /* :132 */
+                const size_t skipped_read = last_pos + 1;                           /* :139 */
+                const size_t skipped_ref = prev_kmer_offset + 1;                    /* :142 */
+                const size_t max_matchable_pos = skipped_read < skipped_ref ? skipped_read : skipped_ref; /* :145 */
+                int premature_break = 0;                                            /* :148 */
+                size_t matched_bases = 0, seen_snp = 0;                             /* :149-150 */
+                for (size_t i = 0; i < max_matchable_pos; ++i) {                    /* :151 */
+                    const size_t ref_pos = prev_kmer_offset - i;                    /* :152 */
+                    const size_t read_offset = last_pos - i;                        /* :153 */
+                    if (ctr) ctr->bases_compared += 1;
+                    if (seq_get(idx->seq, nstart + ref_pos) != seq_get(read_seq, read_offset)) { /* :156 */
+                        mismatch_count += 1;                                        /* :158 */
+                        seen_snp += 1;                                              /* :161 */
+                        if (seen_snp > allowed_mismatches) {                        /* :162 */
+                            premature_break = 1;
+                            break;
+                        }
+                    }
+                    matched_bases += 1;                                             /* :168 */
+                    read_coverage += 1;                                             /* :169 */
+                }
+                if (last_pos + 1 - matched_bases == 0 || premature_break) break;    /* :173-175 */
+                last_pos -= matched_bases;                                          /* :178 */
+                const uint8_t exts = idx->node_exts[prev_node_id];                  /* :181 */
+                const uint8_t next_base = seq_get(read_seq, last_pos);              /* :182 */
+                if (exts & (1u << (4 + next_base))) {                               /* :183 has_ext(Dir::Left, b) */
+                    const uint32_t index = rank_of((uint32_t)exts >> 4, next_base); /* :185-189 */
+                    const uint32_t edge0 = idx->l_edges[4 * prev_node_id + index];  /* :191 */
+                    prev_node_id = edge0;                                           /* :194 */
+                    prev_kmer_offset = idx->node_len[prev_node_id] - kmer_length;   /* :195-196 */
+                    if (nv_push(nodes, prev_node_id)) return -1;                    /* :199 */
+                    if (ctr) ctr->node_visits += 1;
+                } else {
+                    break;                                                          /* :200-202 */
+                }
+            }
+        }
+    }
+
+    if (kmer_pos <= last_kmer_pos) {                                                /* :208 */
+        for (;;) {                                                                  /* :209 */
+            const uint64_t nstart = idx->node_start[node_id];                       /* :210 */
+            kmer_pos += kmer_length;                                                /* :215 */
+            read_coverage += kmer_length;                                           /* :216 */
+            if (nv_push(nodes, node_id)) return -1;                                 /* :219 */
+            if (ctr) ctr->node_visits += 1;
+            const size_t remaining_read = read_length - kmer_pos;                   /* :222 */
+            const size_t ref_length = idx->node_len[node_id];                       /* :226 */
+            const size_t ref_offset = kmer_offset + kmer_length;                    /* :227 */
+            const size_t informative_ref = ref_length - ref_offset;                 /* :228 */
+            const size_t max_matchable_pos = remaining_read < informative_ref ? remaining_read : informative_ref; /* :231 */
+            int premature_break = 0;                                                /* :233 */
+            size_t matched_bases = 0, seen_snp = 0;                                 /* :234-235 */
+            for (size_t i = 0; i < max_matchable_pos; ++i) {                        /* :236 */
+                const size_t ref_pos = ref_offset + i;                              /* :237 */
+                const size_t read_offset = kmer_pos + i;                            /* :238 */
+                if (ctr) ctr->bases_compared += 1;
+                if (seq_get(idx->seq, nstart + ref_pos) != seq_get(read_seq, read_offset)) { /* :241 */
+                    mismatch_count += 1;                                            /* :243 */
+                    seen_snp += 1;                                                  /* :246 */
+                    if (seen_snp > allowed_mismatches) {                            /* :247 */
+                        premature_break = 1;
+                        break;
+                    }
+                }
+                matched_bases += 1;                                                 /* :253 */
+                read_coverage += 1;                                                 /* :254 */
+            }
+            kmer_pos += matched_bases;                                              /* :257 */
+            if (kmer_pos >= read_length) break;                                     /* :259-261 */
+            const uint8_t exts = idx->node_exts[node_id];                           /* :264 */
+            const uint8_t next_base = seq_get(read_seq, kmer_pos);                  /* :265 */
+            if (!premature_break && (exts & (1u << next_base))) {                   /* :267 has_ext(Dir::Right, b) */
+                const uint32_t index = rank_of((uint32_t)exts & 15u, next_base);    /* :269-273 */
+                node_id = idx->r_edges[4 * node_id + index];                        /* :275-278 */
+                kmer_offset = 0;                                                    /* :279 */
+                kmer_pos -= kmer_length - 1;                                        /* :282 */
+                read_coverage -= kmer_length - 1;                                   /* :283 */
+            } else {
+                if (kmer_pos > last_kmer_pos) break;                                /* :287-290 */
+                if (ctr) ctr->reseeks += 1;
+                if (!find_kmer_match(idx, read_seq, last_kmer_pos, &kmer_pos, &node_id, &kmer_offset, ctr)) break; /* :293-299 */
+            }
+        }
+    }
+
+    if (nodes->n == 0) {                                                            /* :305 */
+        if (read_coverage != 0) {                                                   /* :306-312 panic! */
+            fprintf(stderr, "oracle: coverage %zu with no nodes (reference would panic)\n", read_coverage);
+            abort();
+        }
+        return 0;                                                                   /* :314 */
+    }
+    *out_coverage = read_coverage;
+    *out_mismatch = mismatch_count;
+    return 1;                                                                       /* :317 */
+}
+
+/* nodes_to_eq_class — src/pseudoaligner.rs:323-356. Returns class length or -1 if class_cap is too small. */
+static long nodes_to_eq_class(const oracle_index* idx, nodevec* nodes, uint32_t* eq_class, uint32_t class_cap,
+                              oracle_counters* ctr) {
+    if (nodes->n == 0) return 0;                                                    /* :326-328 */
+    /* nodes.sort_by_key(len of eq class) (:331-334): stable -> insertion sort keeps equal keys in order */
+    for (uint32_t i = 1; i < nodes->n; ++i) {
+        const uint32_t x = nodes->p[i];
+        const uint64_t kx = idx->ec_offset[idx->node_colour[x] + 1] - idx->ec_offset[idx->node_colour[x]];
+        uint32_t j = i;
+        while (j > 0) {
+            const uint32_t y = nodes->p[j - 1];
+            const uint64_t ky = idx->ec_offset[idx->node_colour[y] + 1] - idx->ec_offset[idx->node_colour[y]];
+            if (ky <= kx) break;
+            nodes->p[j] = y;
+            --j;
+        }
+        nodes->p[j] = x;
+    }
+    const uint32_t first_color = idx->node_colour[nodes->p[0]];                     /* :346-349 */
+    const uint64_t o0 = idx->ec_offset[first_color];
+    size_t n = (size_t)(idx->ec_offset[first_color + 1] - o0);
+    if (n > class_cap) return -1;
+    memcpy(eq_class, idx->ec_ids + o0, n * 4);                                      /* :350 */
+    if (ctr) ctr->class_sizes += n;
+    for (uint32_t i = 1; i < nodes->n; ++i) {                                       /* :352 */
+        const uint32_t color = idx->node_colour[nodes->p[i]];                       /* :353 */
+        const uint64_t o = idx->ec_offset[color];
+        const size_t m = (size_t)(idx->ec_offset[color + 1] - o);
+        if (ctr) ctr->class_sizes += m;
+        n = oracle_intersect(eq_class, n, idx->ec_ids + o, m);                      /* :354 */
+    }
+    return (long)n;
+}
+
+/* map_read_with_mismatch — src/pseudoaligner.rs:361-376 */
+int oracle_map_read(const oracle_index* idx, const uint64_t* read, uint32_t len, uint32_t allowed_mismatches,
+                    uint32_t* class_out, uint32_t class_cap, uint32_t* class_len, uint32_t* coverage,
+                    uint32_t* mismatches, uint32_t* nodes_out, uint32_t nodes_cap, uint32_t* num_nodes,
+                    oracle_counters* ctr) {
+    nodevec nodes;                                                                  /* :366 */
+    nodes.p = nodes.inl;
+    nodes.n = 0;
+    nodes.cap = 64;
+    size_t cov = 0, mm = 0;
+    if (ctr) ctr->reads += 1;
+    int rc = map_read_to_nodes_with_mismatch(idx, read, len, &nodes, allowed_mismatches, &cov, &mm, ctr); /* :368 */
+    if (class_len) *class_len = 0;
+    if (coverage) *coverage = 0;
+    if (mismatches) *mismatches = 0;
+    if (num_nodes) *num_nodes = 0;
+    if (rc == 1) {                                                                  /* :369-373 */
+        if (ctr) ctr->mapped += 1;
+        if (nodes_out) {
+            if (nodes.n > nodes_cap) rc = -2;
+            else memcpy(nodes_out, nodes.p, (size_t)nodes.n * 4);
+        }
+        if (num_nodes) *num_nodes = nodes.n;
+        if (rc == 1) {
+            const long n = nodes_to_eq_class(idx, &nodes, class_out, class_cap, ctr); /* :371 */
+            if (n < 0) rc = -3;
+            else {
+                if (class_len) *class_len = (uint32_t)n;
+                if (coverage) *coverage = (uint32_t)cov;
+                if (mismatches) *mismatches = (uint32_t)mm;
+                if (ctr) ctr->result_sizes += (uint64_t)n;
+            }
+        }
+    }
+    if (nodes.p != nodes.inl) free(nodes.p);
+    return rc;
+}
+
+/* ---- batch driver: the worker-loop body of process_reads (:449-462) over static chunks ---- */
+typedef struct {
+    const oracle_index* idx;
+    const uint64_t* reads;
+    uint32_t wpr;
+    int tiled;
+    const uint32_t* lens;
+    uint64_t begin, end;
+    uint32_t allowed;
+    oracle_result* results;
+    uint32_t* cls; /* thread-local class buffer */
+    uint64_t cls_n, cls_cap;
+    uint32_t max_class;
+    oracle_counters ctr;
+    int rc;
+} job;
+
+static void* worker(void* arg) {
+    job* j = (job*)arg;
+    uint64_t* rbuf = (uint64_t*)calloc((size_t)j->wpr + 2, 8);
+    if (!rbuf) { j->rc = -1; return NULL; }
+    for (uint64_t i = j->begin; i < j->end; ++i) {
+        const uint64_t* rd;
+        if (j->tiled) {
+            const uint64_t t = i >> 6, r = i & 63;
+            for (uint32_t w = 0; w < j->wpr; ++w) rbuf[w] = j->reads[(t * j->wpr + w) * 64 + r];
+            rd = rbuf;
+        } else {
+            memcpy(rbuf, j->reads + i * j->wpr, (size_t)j->wpr * 8); /* +2 zero pad words for window reads */
+            rd = rbuf;
+        }
+        if (j->cls_cap - j->cls_n < j->max_class) {
+            const uint64_t nc = j->cls_cap * 2 + j->max_class;
+            uint32_t* q = (uint32_t*)realloc(j->cls, nc * 4);
+            if (!q) { j->rc = -1; break; }
+            j->cls = q;
+            j->cls_cap = nc;
+        }
+        uint32_t cl = 0, cov = 0, mm = 0;
+        const int rc = oracle_map_read(j->idx, rd, j->lens[i], j->allowed, j->cls + j->cls_n, j->max_class, &cl, &cov, &mm,
+                                       NULL, 0, NULL, &j->ctr);
+        if (rc < 0) { j->rc = rc; break; }
+        j->results[i].mapped = (uint32_t)rc;
+        j->results[i].coverage = cov;
+        j->results[i].mismatches = mm;
+        j->results[i].class_len = cl;
+        j->cls_n += cl;
+    }
+    free(rbuf);
+    return NULL;
+}
+
+static int map_batch_impl(const oracle_index* idx, const uint64_t* reads, uint32_t wpr, int tiled, const uint32_t* lens,
+                          uint64_t n, uint32_t allowed, int nthreads, oracle_result* results, uint64_t* class_offsets,
+                          uint32_t** class_ids, oracle_counters* ctr) {
+    if (nthreads < 1) nthreads = 1;
+    if ((uint64_t)nthreads > n && n > 0) nthreads = (int)n;
+    uint32_t max_class = 1;
+    for (uint32_t c = 0; c < idx->num_classes; ++c) {
+        const uint64_t l = idx->ec_offset[c + 1] - idx->ec_offset[c];
+        if (l > max_class) max_class = (uint32_t)l;
+    }
+    job* jobs = (job*)calloc((size_t)nthreads, sizeof(job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -1; }
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t].idx = idx;
+        jobs[t].reads = reads;
+        jobs[t].wpr = wpr;
+        jobs[t].tiled = tiled;
+        jobs[t].lens = lens;
+        jobs[t].begin = n * (uint64_t)t / (uint64_t)nthreads;
+        jobs[t].end = n * (uint64_t)(t + 1) / (uint64_t)nthreads;
+        jobs[t].allowed = allowed;
+        jobs[t].results = results;
+        jobs[t].max_class = max_class;
+    }
+    if (nthreads == 1) worker(&jobs[0]);
+    else {
+        for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, worker, &jobs[t]);
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    }
+    int rc = 0;
+    uint64_t total = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        if (jobs[t].rc) rc = jobs[t].rc;
+        total += jobs[t].cls_n;
+    }
+    if (ctr) {
+        memset(ctr, 0, sizeof *ctr);
+        for (int t = 0; t < nthreads; ++t) {
+            const uint64_t* s = (const uint64_t*)&jobs[t].ctr;
+            uint64_t* d = (uint64_t*)ctr;
+            for (size_t i = 0; i < sizeof(oracle_counters) / 8; ++i) d[i] += s[i];
+        }
+    }
+    if (rc == 0 && class_ids && class_offsets) {
+        uint32_t* all = (uint32_t*)malloc((size_t)(total ? total : 1) * 4);
+        if (!all) rc = -1;
+        else {
+            uint64_t o = 0;
+            for (int t = 0; t < nthreads; ++t) {
+                memcpy(all + o, jobs[t].cls, (size_t)jobs[t].cls_n * 4);
+                o += jobs[t].cls_n;
+            }
+            uint64_t acc = 0;
+            for (uint64_t i = 0; i < n; ++i) {
+                class_offsets[i] = acc;
+                acc += results[i].class_len;
+            }
+            class_offsets[n] = acc;
+            *class_ids = all;
+        }
+    }
+    for (int t = 0; t < nthreads; ++t) free(jobs[t].cls);
+    free(jobs);
+    free(th);
+    return rc;
+}
+
+int oracle_map_batch(const oracle_index* idx, const uint64_t* reads, uint32_t words_per_read, const uint32_t* lens,
+                     uint64_t n, uint32_t allowed_mismatches, int nthreads, oracle_result* results,
+                     uint64_t* class_offsets, uint32_t** class_ids, oracle_counters* ctr) {
+    return map_batch_impl(idx, reads, words_per_read, 0, lens, n, allowed_mismatches, nthreads, results, class_offsets,
+                          class_ids, ctr);
+}
+
+int oracle_map_batch_tiles(const oracle_index* idx, const uint64_t* tiles, uint32_t words_per_read, const uint32_t* lens,
+                           uint64_t n, uint32_t allowed_mismatches, int nthreads, oracle_result* results,
+                           uint64_t* class_offsets, uint32_t** class_ids, oracle_counters* ctr) {
+    return map_batch_impl(idx, tiles, words_per_read, 1, lens, n, allowed_mismatches, nthreads, results, class_offsets,
+                          class_ids, ctr);
+}
+
+void oracle_free(void* p) { free(p); }

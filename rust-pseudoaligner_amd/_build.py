@@ -1,0 +1,81 @@
+"""Build recipes: the product library (hipcc, gfx950), and — test infrastructure only — the CPU oracle and the
+host lane emulator. Everything is built in-tree so that the .so files travel with the repository snapshot."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+
+PRODUCT_SO = PKG / "libpseudoaligner_amd.so"
+ORACLE_SO = ROOT / "oracle" / "_build" / "libpa_oracle.so"
+EMU_SO = ROOT / "tests" / "emu" / "_build" / "libpa_emu.so"
+
+HOST_SOURCES = ["host_index.cpp", "dbg_build.cpp", "device_flatten.cpp", "synth.cpp", "fastq.cpp"]
+HIP_SOURCES = ["kernels.hip", "device_index.hip"]
+
+
+def _stale(target: Path, sources) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(s).stat().st_mtime > t for s in sources)
+
+
+def _run(cmd):
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s\n%s" % (" ".join(map(str, cmd)), proc.stdout, proc.stderr))
+    return proc
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the product library cannot be built")
+
+
+def build_product(force: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950: HIP kernels + C ABI + host runtime -> libpseudoaligner_amd.so"""
+    srcs = [CSRC / s for s in HOST_SOURCES + HIP_SOURCES]
+    deps = srcs + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
+    if force or _stale(PRODUCT_SO, deps):
+        cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+               "-Wall", "-Wno-unused-function", "-x", "hip"] + [str(s) for s in srcs] + ["-o", str(PRODUCT_SO)]
+        _run(cmd)
+    return PRODUCT_SO
+
+
+def build_oracle(force: bool = False) -> Path:
+    """gcc: the plain-C restatement of the reference path (checker only)."""
+    src = ROOT / "oracle" / "pa_oracle.c"
+    if force or _stale(ORACLE_SO, [src, ROOT / "oracle" / "pa_oracle.h"]):
+        ORACLE_SO.parent.mkdir(parents=True, exist_ok=True)
+        _run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-pthread", "-Wall", str(src), "-o", str(ORACLE_SO)])
+    return ORACLE_SO
+
+
+def build_emu(force: bool = False) -> Path:
+    """g++: host emulation of one kernel lane (checker for the CPU-only test tier)."""
+    srcs = [ROOT / "tests" / "emu" / "emu_map.cpp"] + [CSRC / s for s in ("host_index.cpp", "dbg_build.cpp", "device_flatten.cpp")]
+    deps = srcs + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
+    if force or _stale(EMU_SO, deps):
+        EMU_SO.parent.mkdir(parents=True, exist_ok=True)
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-function"]
+             + [str(s) for s in srcs] + ["-o", str(EMU_SO)])
+    return EMU_SO
+
+
+def build_all(force: bool = False):
+    return build_product(force), build_oracle(force), build_emu(force)
+
+
+if __name__ == "__main__":
+    import sys
+    for p in build_all("--force" in sys.argv):
+        print(p)

@@ -1,0 +1,210 @@
+// pa_flat_index -> GPU layout (device_layout.hpp). Pure host code; runs once per pa_index_create.
+//
+// Replaces make_dbg_index (src/build_index.rs:182-221: boomphf MPHF + (node, offset) scatter) by an exact bucketed
+// dictionary, and Node::r_edges()/l_edges() (debruijn crate: hash lookups at every hop) by edge handles stored in
+// the node header.
+#include "device_flatten.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <thread>
+
+#include "pa_common.hpp"
+
+namespace pa {
+
+DevIndexView FlatDevice::host_view() const {
+    DevIndexView v;
+    v.table = table.data();
+    v.nbuckets = nbuckets;
+    v.blobs = blobs.data();
+    v.ledge = ledge.data();
+    v.ec_off = ec_off.data();
+    v.ec_ids = ec_ids.data();
+    v.kmask = kmer_mask(k);
+    v.k = k;
+    v.num_nodes = num_nodes;
+    v.num_classes = num_classes;
+    return v;
+}
+
+namespace {
+
+template <class F>
+void par_ranges(int threads, uint64_t n, F f) {   // static contiguous ranges
+    if (threads <= 1 || n < 4096) { f(0, n, 0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back([=] { f(n * t / threads, n * (t + 1) / threads, t); });
+    for (auto& x : th) x.join();
+}
+
+struct Dict {
+    U4* slots;
+    uint64_t nbuckets;
+    uint64_t bucket_of(uint64_t kmer) const { return (uint64_t)(((unsigned __int128)mix64(kmer) * nbuckets) >> 64); }
+    void insert_mt(uint64_t kmer, uint32_t handle, uint32_t off) {
+        uint64_t b = bucket_of(kmer);
+        for (;;) {
+            U4* s = slots + b * SLOTS_PER_BUCKET;
+            for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i) {
+                uint32_t expect = NO_HANDLE;
+                if (__atomic_compare_exchange_n(&s[i].z, &expect, handle, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                    s[i].x = (uint32_t)kmer;
+                    s[i].y = (uint32_t)(kmer >> 32);
+                    s[i].w = off;
+                    return;
+                }
+            }
+            if (++b == nbuckets) b = 0;
+        }
+    }
+    bool find(uint64_t kmer, uint32_t& handle, uint32_t& off) const {
+        uint64_t b = bucket_of(kmer);
+        for (uint64_t probes = 0; probes < nbuckets; ++probes) {
+            const U4* s = slots + b * SLOTS_PER_BUCKET;
+            for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i) {
+                if (s[i].z == NO_HANDLE) return false;
+                if (s[i].x == (uint32_t)kmer && s[i].y == (uint32_t)(kmer >> 32)) { handle = s[i].z; off = s[i].w; return true; }
+            }
+            if (++b == nbuckets) b = 0;
+        }
+        return false;
+    }
+};
+
+}  // namespace
+
+int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
+    if (threads < 1) threads = 1;
+    const uint32_t k = f.k, N = f.num_nodes;
+    if (k < PA_MIN_K || k > PA_MAX_K) return fail(PA_ERR_UNSUPPORTED, "k=%u outside [%u,%u]", k, PA_MIN_K, PA_MAX_K);
+    out = FlatDevice();
+    out.k = k;
+    out.num_nodes = N;
+    out.num_classes = f.num_classes;
+    const uint64_t mask = kmer_mask(k);
+    const uint32_t topshift = 2 * (k - 1);
+
+    // ---- classes ----
+    if (f.ec_offset[f.num_classes] >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "class id lists exceed 2^32 entries");
+    out.ec_off.resize((size_t)f.num_classes + 1);
+    for (uint32_t c = 0; c <= f.num_classes; ++c) out.ec_off[c] = (uint32_t)f.ec_offset[c];
+    for (uint32_t c = 0; c < f.num_classes; ++c) out.max_class_len = std::max(out.max_class_len, out.ec_off[c + 1] - out.ec_off[c]);
+    out.ec_ids.assign(f.ec_ids, f.ec_ids + f.ec_offset[f.num_classes]);
+    out.ec_ids.resize(out.ec_ids.size() + 4, 0);   // tail pad for vector loads
+
+    // ---- blob placement: 32-byte granules; a blob that fits one 64-byte line does not straddle two ----
+    out.handle.resize(N);
+    uint64_t cursor = 0, nk = 0;
+    for (uint32_t i = 0; i < N; ++i) {
+        if (f.node_len[i] < k) return fail(PA_ERR_FORMAT, "node %u shorter than k", i);
+        const uint64_t size = (32 + 8ull * ((f.node_len[i] + 31) / 32) + 31) / 32 * 32;
+        if (size <= 64 && (cursor & 63) + size > 64) cursor = (cursor + 63) & ~63ull;
+        if (cursor / BLOB_GRANULE >= NO_HANDLE) return fail(PA_ERR_UNSUPPORTED, "graph exceeds the 128 GiB blob address space");
+        out.handle[i] = (uint32_t)(cursor / BLOB_GRANULE);
+        cursor += size;
+        nk += f.node_len[i] - k + 1;
+    }
+    out.num_kmers = nk;
+    out.blobs.assign(cursor + 64, 0);   // tail pad: fwd_step reads up to 3 words past a node's last word
+
+    // ---- dictionary: every k-mer of every node -> (handle, offset) ----
+    out.nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (SLOTS_PER_BUCKET * 0.5)) + 1);
+    out.table.assign(out.nbuckets * SLOTS_PER_BUCKET, U4{0, 0, NO_HANDLE, 0});
+    Dict dict{out.table.data(), out.nbuckets};
+    auto node_kmers = [&](uint32_t i, auto&& fn) {
+        const uint64_t s = f.node_start[i];
+        const uint32_t n = f.node_len[i] - k + 1;
+        uint64_t km = get_kmer(f.node_seq, s, k);
+        for (uint32_t o = 0; o < n; ++o) {
+            if (o) km = (km >> 2) | ((uint64_t)get_base(f.node_seq, s + o + k - 1) << topshift);
+            fn(km, o);
+        }
+    };
+    par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
+        for (uint64_t i = a; i < b; ++i) node_kmers((uint32_t)i, [&](uint64_t km, uint32_t o) { dict.insert_mt(km, out.handle[i], o); });
+    });
+    std::atomic<uint32_t> bad{NO_HANDLE};
+    par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
+        for (uint64_t i = a; i < b; ++i)
+            node_kmers((uint32_t)i, [&](uint64_t km, uint32_t o) {
+                uint32_t h, off;
+                if (!dict.find(km, h, off) || h != out.handle[i] || off != o) bad.store((uint32_t)i);
+            });
+    });
+    if (bad.load() != NO_HANDLE) return fail(PA_ERR_FORMAT, "a k-mer of node %u occurs twice in the graph", bad.load());
+
+    // ---- blobs + edges ----
+    out.ledge.assign(4ull * N + 4, NO_HANDLE);
+    std::atomic<uint32_t> dangling{NO_HANDLE};
+    par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
+        for (uint64_t i = a; i < b; ++i) {
+            uint8_t* blob = out.blobs.data() + (uint64_t)out.handle[i] * BLOB_GRANULE;
+            uint32_t* hd = reinterpret_cast<uint32_t*>(blob);
+            uint64_t* sq = reinterpret_cast<uint64_t*>(blob + 32);
+            const uint32_t len = f.node_len[i];
+            const uint64_t s = f.node_start[i];
+            hd[0] = len;
+            hd[1] = f.node_exts[i];
+            hd[2] = f.node_colour[i];
+            hd[3] = (uint32_t)i;
+            for (uint32_t w = 0; w < (len + 31) / 32; ++w) {
+                uint64_t v = window32(f.node_seq, s + 32ull * w);
+                const uint32_t rem = len - 32 * w;
+                if (rem < 32) v &= (1ull << (2 * rem)) - 1;
+                sq[w] = v;
+            }
+            const uint64_t first = get_kmer(f.node_seq, s, k), last = get_kmer(f.node_seq, s + len - k, k);
+            for (uint32_t base = 0; base < 4; ++base) {
+                uint32_t re = NO_HANDLE, le = NO_HANDLE;
+                if (f.node_exts[i] & (1u << base)) {
+                    if (f.node_redge) {
+                        const uint32_t t = f.node_redge[4 * i + base];
+                        if (t < N) re = out.handle[t];
+                    } else {
+                        // find_link(last.extend_right(b), Dir::Right): node whose FIRST k-mer it is (offset 0)
+                        uint32_t h, off;
+                        if (dict.find((last >> 2) | ((uint64_t)base << topshift), h, off) && off == 0) re = h;
+                    }
+                    if (re == NO_HANDLE) dangling.store((uint32_t)i);
+                }
+                if (f.node_exts[i] & (1u << (4 + base))) {
+                    if (f.node_ledge) {
+                        const uint32_t t = f.node_ledge[4 * i + base];
+                        if (t < N) le = out.handle[t];
+                    } else {
+                        // find_link(first.extend_left(b), Dir::Left): node whose LAST k-mer it is
+                        // (that it IS the last k-mer is verified below, once every header has been written)
+                        uint32_t h, off;
+                        if (dict.find(((first << 2) | base) & mask, h, off)) le = h;
+                    }
+                    if (le == NO_HANDLE) dangling.store((uint32_t)i);
+                }
+                hd[4 + base] = re;
+                out.ledge[4 * i + base] = le;
+            }
+        }
+    });
+    if (dangling.load() != NO_HANDLE)
+        return fail(PA_ERR_FORMAT, "node %u has an extension bit without a terminal neighbour k-mer (missing link)", dangling.load());
+    // left-edge targets must be entered at their LAST k-mer (offset len-k): check now that every header exists
+    if (!f.node_ledge) {
+        par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
+            for (uint64_t i = a; i < b; ++i) {
+                const uint64_t first = get_kmer(f.node_seq, f.node_start[i], k);
+                for (uint32_t base = 0; base < 4; ++base) {
+                    if (!(f.node_exts[i] & (1u << (4 + base)))) continue;
+                    uint32_t h = 0, off = 0;
+                    dict.find(((first << 2) | base) & mask, h, off);
+                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)h * BLOB_GRANULE);
+                    if (off != tlen - k) dangling.store((uint32_t)i);
+                }
+            }
+        });
+        if (dangling.load() != NO_HANDLE)
+            return fail(PA_ERR_FORMAT, "node %u: left neighbour k-mer is not the last k-mer of its node", dangling.load());
+    }
+    return PA_OK;
+}
+
+}  // namespace pa

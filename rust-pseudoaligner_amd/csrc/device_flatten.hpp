@@ -1,0 +1,25 @@
+// Host-side flattening of a pa_flat_index into the GPU layout of device_layout.hpp (pure host code, no HIP).
+#pragma once
+#include <vector>
+
+#include "device_layout.hpp"
+
+namespace pa {
+
+struct FlatDevice {
+    std::vector<U4> table;
+    uint64_t nbuckets = 0;
+    std::vector<uint8_t> blobs;
+    std::vector<uint32_t> handle;   // node id -> blob handle
+    std::vector<uint32_t> ledge;
+    std::vector<uint32_t> ec_off, ec_ids;
+    uint64_t num_kmers = 0;
+    uint32_t k = 0, num_nodes = 0, num_classes = 0, max_class_len = 0;
+    DevIndexView host_view() const;   // pointers into the vectors above
+};
+
+// Builds the dictionary, derives the edges (or takes them from the flat index), lays the blobs out and validates
+// (duplicate k-mers, dangling extensions). Returns PA_OK or a pa_status (message via pa_last_error).
+int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out);
+
+}  // namespace pa

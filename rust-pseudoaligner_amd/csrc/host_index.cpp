@@ -1,0 +1,315 @@
+// Host-side index object: FASTA ingest, flat view, own on-disk container, C ABI.
+#include <cerrno>
+#include <fstream>
+#include <thread>
+
+#include "pa_common.hpp"
+
+namespace pa {
+
+std::string& last_error_ref() {
+    static thread_local std::string s;
+    return s;
+}
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+namespace {
+
+// utils::detect_fasta_format / extract_tx_gene_id (src/utils.rs:99-150). The reference bails out on an unknown
+// header format (:118); index-side metadata is outside the hot path, so unknown headers fall back to gene = tx id.
+void tx_gene_from_header(const std::string& id, const std::string& desc, std::string& tx, std::string& gene) {
+    size_t bars = 0;
+    for (char c : id) bars += (c == '|');
+    if (bars == 8) {   // Gencode: 9 '|'-separated tokens
+        const size_t a = id.find('|');
+        const size_t b = id.find('|', a + 1);
+        tx = id.substr(0, a);
+        gene = id.substr(a + 1, b - a - 1);
+        return;
+    }
+    tx = id;
+    if (desc.compare(0, 5, "gene=") == 0) {   // Gffread
+        const size_t sp = desc.find(' ');
+        gene = desc.substr(5, sp == std::string::npos ? std::string::npos : sp - 5);
+        return;
+    }
+    const size_t g = desc.find("gene:");   // Ensembl: "... gene:ENSG... ..."
+    if (g != std::string::npos) {
+        const size_t sp = desc.find(' ', g);
+        gene = desc.substr(g + 5, sp == std::string::npos ? std::string::npos : sp - g - 5);
+        return;
+    }
+    gene = id;
+}
+
+}  // namespace
+
+// utils::read_transcripts (src/utils.rs:61-97). Non-ACGT bytes become a base derived from a hash of the record id
+// and the position, in the spirit of DnaString::from_acgt_bytes_hashn (:76; the crate's exact hash is not on disk —
+// unpinned; gencode_small.fa has no such bytes).
+int read_fasta(const char* path, Txome& out) {
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return fail(PA_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+    out = Txome();
+    out.tx_start.push_back(0);
+    std::string line, id, desc;
+    uint64_t pos = 0, name_hash = 0;
+    bool have = false;
+    auto push = [&](uint32_t b) {
+        if ((pos & 31) == 0) out.packed.push_back(0);
+        out.packed.back() |= (uint64_t)b << ((pos & 31) * 2);
+        ++pos;
+    };
+    auto finish = [&]() {
+        if (!have) return;
+        out.tx_start.push_back(pos);
+        std::string tx, gene;
+        tx_gene_from_header(id, desc, tx, gene);
+        out.names.push_back(tx);
+        out.genes.push_back(gene);
+    };
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') {
+            finish();
+            have = true;
+            const size_t sp = line.find_first_of(" \t");
+            id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
+            desc = sp == std::string::npos ? std::string() : line.substr(sp + 1);
+            name_hash = 0xcbf29ce484222325ull;
+            for (char c : id) name_hash = (name_hash ^ (uint8_t)c) * 0x100000001b3ull;
+        } else {
+            if (!have) return fail(PA_ERR_FORMAT, "%s: sequence before first header", path);
+            const uint64_t s = out.tx_start.back();
+            for (char c : line) {
+                uint32_t b = base_code((uint8_t)c);
+                if (b > 3) b = (uint32_t)(mix64(name_hash + (pos - s)) & 3u);
+                push(b);
+            }
+        }
+    }
+    finish();
+    out.packed.push_back(0);
+    out.packed.push_back(0);
+    return PA_OK;
+}
+
+static int check_flat(const pa_flat_index* f) {
+    if (!f) return fail(PA_ERR_INVALID_ARG, "null flat index");
+    if (f->k < PA_MIN_K || f->k > PA_MAX_K) return fail(PA_ERR_UNSUPPORTED, "k=%u outside [%u,%u]", f->k, PA_MIN_K, PA_MAX_K);
+    if (f->num_nodes && (!f->node_seq || !f->node_start || !f->node_len || !f->node_exts || !f->node_colour))
+        return fail(PA_ERR_INVALID_ARG, "flat index: null node array");
+    if (!f->ec_offset || (f->num_classes && f->ec_offset[f->num_classes] && !f->ec_ids))
+        return fail(PA_ERR_INVALID_ARG, "flat index: null class array");
+    for (uint32_t i = 0; i < f->num_nodes; ++i) {
+        if (f->node_len[i] < f->k) return fail(PA_ERR_FORMAT, "node %u shorter than k", i);
+        if (f->node_start[i + 1] - f->node_start[i] != f->node_len[i]) return fail(PA_ERR_FORMAT, "node %u: start/len mismatch", i);
+        if (f->node_colour[i] >= f->num_classes) return fail(PA_ERR_FORMAT, "node %u: colour out of range", i);
+    }
+    for (uint32_t c = 0; c < f->num_classes; ++c) {
+        if (f->ec_offset[c + 1] < f->ec_offset[c]) return fail(PA_ERR_FORMAT, "class %u: offsets not monotone", c);
+        for (uint64_t j = f->ec_offset[c]; j < f->ec_offset[c + 1]; ++j) {
+            if (f->ec_ids[j] >= f->num_transcripts) return fail(PA_ERR_FORMAT, "class %u: transcript id out of range", c);
+            if (j > f->ec_offset[c] && f->ec_ids[j] <= f->ec_ids[j - 1]) return fail(PA_ERR_FORMAT, "class %u not sorted/dedup'd", c);
+        }
+    }
+    return PA_OK;
+}
+
+}  // namespace pa
+
+using namespace pa;
+
+extern "C" {
+
+uint32_t pa_abi_version(void) { return PA_ABI_VERSION; }
+const char* pa_last_error(void) { return last_error_ref().c_str(); }
+
+int pa_host_index_build_packed(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx, uint32_t k,
+                               int num_threads, pa_host_index** out) {
+    if (!packed || !tx_start || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (num_threads <= 0) num_threads = (int)std::thread::hardware_concurrency();
+    pa_host_index* h = new (std::nothrow) pa_host_index();
+    if (!h) return fail(PA_ERR_OOM, "out of memory");
+    try {
+        int rc = build_graph(packed, tx_start, num_tx, k, num_threads, h->h);
+        if (rc != PA_OK) { delete h; return rc; }
+        const uint64_t nb = tx_start[num_tx];
+        h->h.tx_packed.assign(packed, packed + (nb + 31) / 32);
+        h->h.tx_packed.push_back(0);
+        h->h.tx_packed.push_back(0);
+        h->h.tx_start.assign(tx_start, tx_start + num_tx + 1);
+    } catch (const std::bad_alloc&) {
+        delete h;
+        return fail(PA_ERR_OOM, "out of memory while building the index");
+    }
+    *out = h;
+    return PA_OK;
+}
+
+int pa_host_index_build_fasta(const char* fasta_path, uint32_t k, int num_threads, pa_host_index** out) {
+    if (!fasta_path || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    Txome t;
+    int rc = read_fasta(fasta_path, t);
+    if (rc != PA_OK) return rc;
+    rc = pa_host_index_build_packed(t.packed.data(), t.tx_start.data(), t.num_tx(), k, num_threads, out);
+    if (rc != PA_OK) return rc;
+    (*out)->h.tx_names = std::move(t.names);
+    (*out)->h.tx_genes = std::move(t.genes);
+    return PA_OK;
+}
+
+int pa_host_index_from_flat(const pa_flat_index* f, pa_host_index** out) {
+    if (!out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    int rc = check_flat(f);
+    if (rc != PA_OK) return rc;
+    pa_host_index* h = new (std::nothrow) pa_host_index();
+    if (!h) return fail(PA_ERR_OOM, "out of memory");
+    HostIndex& x = h->h;
+    x.k = f->k;
+    x.num_transcripts = f->num_transcripts;
+    const uint64_t nb = f->num_nodes ? f->node_start[f->num_nodes] : 0;
+    x.node_seq.assign(f->node_seq, f->node_seq + (nb + 31) / 32);
+    x.node_seq.push_back(0);
+    x.node_seq.push_back(0);
+    x.node_start.assign(f->node_start, f->node_start + f->num_nodes + 1);
+    x.node_len.assign(f->node_len, f->node_len + f->num_nodes);
+    x.node_exts.assign(f->node_exts, f->node_exts + f->num_nodes);
+    x.node_colour.assign(f->node_colour, f->node_colour + f->num_nodes);
+    if (f->node_redge) x.node_redge.assign(f->node_redge, f->node_redge + 4ull * f->num_nodes);
+    if (f->node_ledge) x.node_ledge.assign(f->node_ledge, f->node_ledge + 4ull * f->num_nodes);
+    x.ec_offset.assign(f->ec_offset, f->ec_offset + f->num_classes + 1);
+    x.ec_ids.assign(f->ec_ids, f->ec_ids + f->ec_offset[f->num_classes]);
+    x.tx_start.push_back(0);
+    *out = h;
+    return PA_OK;
+}
+
+int pa_host_index_view(const pa_host_index* h, pa_flat_index* v) {
+    if (!h || !v) return fail(PA_ERR_INVALID_ARG, "null argument");
+    const HostIndex& x = h->h;
+    v->k = x.k;
+    v->num_nodes = (uint32_t)x.node_len.size();
+    v->num_classes = (uint32_t)(x.ec_offset.size() - 1);
+    v->num_transcripts = x.num_transcripts;
+    v->seq_bases = x.node_start.back();
+    v->node_seq = x.node_seq.data();
+    v->node_start = x.node_start.data();
+    v->node_len = x.node_len.data();
+    v->node_exts = x.node_exts.data();
+    v->node_colour = x.node_colour.data();
+    v->ec_offset = x.ec_offset.data();
+    v->ec_ids = x.ec_ids.data();
+    v->node_redge = x.node_redge.empty() ? nullptr : x.node_redge.data();
+    v->node_ledge = x.node_ledge.empty() ? nullptr : x.node_ledge.data();
+    return PA_OK;
+}
+
+uint32_t pa_host_index_num_transcripts(const pa_host_index* h) { return h ? h->h.num_transcripts : 0; }
+const char* pa_host_index_tx_name(const pa_host_index* h, uint32_t tx) {
+    return (h && tx < h->h.tx_names.size()) ? h->h.tx_names[tx].c_str() : "";
+}
+const char* pa_host_index_tx_gene(const pa_host_index* h, uint32_t tx) {
+    return (h && tx < h->h.tx_genes.size()) ? h->h.tx_genes[tx].c_str() : "";
+}
+int pa_host_index_transcripts(const pa_host_index* h, const uint64_t** packed, const uint64_t** tx_start, uint32_t* num_tx) {
+    if (!h) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (packed) *packed = h->h.tx_packed.data();
+    if (tx_start) *tx_start = h->h.tx_start.data();
+    if (num_tx) *num_tx = (uint32_t)(h->h.tx_start.size() - 1);
+    return PA_OK;
+}
+void pa_host_index_destroy(pa_host_index* h) { delete h; }
+
+}  // extern "C"
+
+// ---- own container: magic, then length-prefixed little-endian arrays (NOT the reference's bincode, utils.rs:22-43) ----
+namespace {
+constexpr char MAGIC[8] = {'P', 'A', 'A', 'M', 'D', 'I', 'X', '1'};
+template <class T>
+bool wr(FILE* f, const std::vector<T>& v) {
+    const uint64_t n = v.size();
+    return fwrite(&n, 8, 1, f) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
+}
+template <class T>
+bool rd(FILE* f, std::vector<T>& v) {
+    uint64_t n;
+    if (fread(&n, 8, 1, f) != 1 || n > (1ull << 40)) return false;
+    v.resize(n);
+    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+bool wr_strs(FILE* f, const std::vector<std::string>& v) {
+    std::vector<char> blob;
+    std::vector<uint64_t> off{0};
+    for (auto& s : v) { blob.insert(blob.end(), s.begin(), s.end()); off.push_back(blob.size()); }
+    return wr(f, off) && wr(f, blob);
+}
+bool rd_strs(FILE* f, std::vector<std::string>& v) {
+    std::vector<char> blob;
+    std::vector<uint64_t> off;
+    if (!rd(f, off) || !rd(f, blob) || off.empty()) return false;
+    v.clear();
+    for (size_t i = 0; i + 1 < off.size(); ++i) {
+        if (off[i + 1] < off[i] || off[i + 1] > blob.size()) return false;
+        v.emplace_back(blob.data() + off[i], blob.data() + off[i + 1]);
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int pa_host_index_save(const pa_host_index* h, const char* path) {
+    if (!h || !path) return fail(PA_ERR_INVALID_ARG, "null argument");
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(PA_ERR_IO, "cannot create %s: %s", path, strerror(errno));
+    const HostIndex& x = h->h;
+    const uint32_t hdr[2] = {x.k, x.num_transcripts};
+    bool ok = fwrite(MAGIC, 8, 1, f) == 1 && fwrite(hdr, 4, 2, f) == 2 && wr(f, x.node_seq) && wr(f, x.node_start) &&
+              wr(f, x.node_len) && wr(f, x.node_exts) && wr(f, x.node_colour) && wr(f, x.node_redge) && wr(f, x.node_ledge) &&
+              wr(f, x.ec_offset) && wr(f, x.ec_ids) && wr_strs(f, x.tx_names) && wr_strs(f, x.tx_genes) &&
+              wr(f, x.tx_packed) && wr(f, x.tx_start);
+    ok = (fclose(f) == 0) && ok;
+    return ok ? PA_OK : fail(PA_ERR_IO, "short write to %s", path);
+}
+
+int pa_host_index_load(const char* path, pa_host_index** out) {
+    if (!path || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(PA_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+    pa_host_index* h = new pa_host_index();
+    HostIndex& x = h->h;
+    char magic[8];
+    uint32_t hdr[2];
+    bool ok = fread(magic, 8, 1, f) == 1 && memcmp(magic, MAGIC, 8) == 0 && fread(hdr, 4, 2, f) == 2;
+    if (ok) {
+        x.k = hdr[0];
+        x.num_transcripts = hdr[1];
+        ok = rd(f, x.node_seq) && rd(f, x.node_start) && rd(f, x.node_len) && rd(f, x.node_exts) && rd(f, x.node_colour) &&
+             rd(f, x.node_redge) && rd(f, x.node_ledge) && rd(f, x.ec_offset) && rd(f, x.ec_ids) && rd_strs(f, x.tx_names) &&
+             rd_strs(f, x.tx_genes) && rd(f, x.tx_packed) && rd(f, x.tx_start);
+    }
+    fclose(f);
+    if (ok) {
+        pa_flat_index v;
+        ok = !x.node_start.empty() && !x.ec_offset.empty() && x.node_start.size() == x.node_len.size() + 1 &&
+             x.node_exts.size() == x.node_len.size() && x.node_colour.size() == x.node_len.size() &&
+             x.node_seq.size() >= (x.node_start.back() + 31) / 32 + 1 && x.ec_ids.size() == x.ec_offset.back();
+        if (ok) { pa_host_index_view(h, &v); ok = check_flat(&v) == PA_OK; }
+    }
+    if (!ok) { delete h; return fail(PA_ERR_FORMAT, "%s is not a valid index container", path); }
+    *out = h;
+    return PA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Shared host-side definitions: error plumbing, 2-bit sequence helpers, the k-mer hash, the host index.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pseudoaligner_amd.h"
+
+namespace pa {
+
+// ---- thread-local error message (pa_last_error) ----
+std::string& last_error_ref();
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// ---- 2-bit packed sequences, LSB-first (base j -> bits 2*(j%32) of word j/32) ----
+static inline uint64_t kmer_mask(uint32_t k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1); }
+
+static inline uint32_t get_base(const uint64_t* w, uint64_t pos) { return (uint32_t)(w[pos >> 5] >> ((pos & 31) * 2)) & 3u; }
+
+static inline void set_base(uint64_t* w, uint64_t pos, uint32_t b) {
+    const uint32_t s = (uint32_t)(pos & 31) * 2;
+    w[pos >> 5] = (w[pos >> 5] & ~(3ull << s)) | ((uint64_t)(b & 3) << s);
+}
+
+// 32 bases starting at base `pos` (caller guarantees word (pos>>5)+1 is readable)
+static inline uint64_t window32(const uint64_t* w, uint64_t pos) {
+    const uint64_t i = pos >> 5;
+    const uint32_t s = (uint32_t)(pos & 31) * 2;
+    return s ? (w[i] >> s) | (w[i + 1] << (64 - s)) : w[i];
+}
+
+static inline uint64_t get_kmer(const uint64_t* w, uint64_t pos, uint32_t k) { return window32(w, pos) & kmer_mask(k); }
+
+// ASCII -> 2-bit code; 4 = not ACGT (either case)
+static inline uint32_t base_code(uint8_t c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+
+// The dictionary hash (shared by the host table builder and the HIP kernel): murmur3 fmix64.
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+static inline uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+// ---- host index: the flat form of Pseudoaligner<K> (src/pseudoaligner.rs:26-33) ----
+struct HostIndex {
+    uint32_t k = 0;
+    uint32_t num_transcripts = 0;
+    // graph
+    std::vector<uint64_t> node_seq;     // packed, +1 pad word
+    std::vector<uint64_t> node_start;   // n+1
+    std::vector<uint32_t> node_len;
+    std::vector<uint8_t> node_exts;
+    std::vector<uint32_t> node_colour;
+    std::vector<uint32_t> node_redge, node_ledge;   // optional (empty = derive)
+    // classes
+    std::vector<uint64_t> ec_offset;    // c+1
+    std::vector<uint32_t> ec_ids;
+    // transcript metadata + the packed transcripts (tx_names :31, tx_gene_mapping :32)
+    std::vector<std::string> tx_names, tx_genes;
+    std::vector<uint64_t> tx_packed;    // +1 pad word
+    std::vector<uint64_t> tx_start;     // num_transcripts+1
+};
+
+struct Txome {
+    std::vector<uint64_t> packed;       // +1 pad word
+    std::vector<uint64_t> tx_start;     // n+1
+    std::vector<std::string> names, genes;
+    uint32_t num_tx() const { return tx_start.empty() ? 0 : (uint32_t)(tx_start.size() - 1); }
+};
+
+// dbg_build.cpp
+int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx, uint32_t k, int threads, HostIndex& out);
+// fasta.cpp
+int read_fasta(const char* path, Txome& out);
+
+}  // namespace pa
+
+struct pa_host_index { pa::HostIndex h; };
+struct pa_txome { pa::Txome t; };

@@ -1,0 +1,98 @@
+// Host emulation of ONE lane of the mapping kernel. TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the product's per-lane state machine (rust-pseudoaligner_amd/csrc/lane_steps.hpp) and its GPU index
+// flattener (device_flatten.cpp) for the host, and runs every read to completion by calling the same step
+// functions the HIP kernel calls. It lets the CPU-only test tier (`-m "not gpu"`) check the device data layout and
+// the step logic against the oracle bit for bit; wave scheduling, LDS staging and arena allocation exist only in
+// kernels.hip and are covered by the `-m gpu` tier. Nothing in the product links or loads this file.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../rust-pseudoaligner_amd/csrc/device_flatten.hpp"
+#include "../../rust-pseudoaligner_amd/csrc/lane_steps.hpp"
+#include "../../rust-pseudoaligner_amd/csrc/pa_common.hpp"
+
+using namespace pa;
+
+struct emu_index {
+    FlatDevice fd;
+};
+
+extern "C" {
+
+int emu_index_new(const pa_flat_index* f, int threads, emu_index** out) {
+    emu_index* e = new emu_index();
+    int rc = flatten_for_device(*f, threads, e->fd);
+    if (rc != PA_OK) { delete e; return rc; }
+    *out = e;
+    return PA_OK;
+}
+void emu_index_free(emu_index* e) { delete e; }
+const char* emu_last_error(void) { return last_error_ref().c_str(); }
+
+uint64_t emu_index_info(const emu_index* e, int what) {
+    switch (what) {
+        case 0: return e->fd.num_kmers;
+        case 1: return e->fd.nbuckets;
+        case 2: return e->fd.blobs.size();
+        case 3: return e->fd.max_class_len;
+        default: return 0;
+    }
+}
+
+// results as pa_read_result; class ids as malloc'd CSR in read order; optional step counters [4] = seek, fwd, left steps, spills
+int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const uint32_t* lens, uint64_t n, uint32_t allowed,
+                  uint32_t col_cap, pa_read_result* results, uint64_t* class_offsets, uint32_t** class_ids, uint32_t* colour_out,
+                  uint64_t* steps) {
+    const DevIndexView ix = e->fd.host_view();
+    std::vector<uint32_t> all;
+    std::vector<uint64_t> rd(wpr + 2);
+    std::vector<uint32_t> cols(col_cap ? col_cap : 1), spill;
+    uint64_t st_seek = 0, st_fwd = 0, st_left = 0, st_spill = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t t = i >> 6, r = i & 63;
+        for (uint32_t w = 0; w < wpr; ++w) rd[w] = tiles[(t * wpr + w) * 64 + r];
+        rd[wpr] = rd[wpr + 1] = 0;
+        const uint32_t L = lens[i];
+        spill.assign(2 * (size_t)L + 2, 0);
+        Lane s;
+        lane_start(s, (uint32_t)i, L, ix.k);
+        const ReadRef rr{rd.data(), 1};
+        const ColRef cr{cols.data(), 1, col_cap, spill.data(), (uint32_t)spill.size()};
+        while (s.st == ST_SEEK || s.st == ST_FWD || s.st == ST_LEFT) {
+            if (s.st == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
+            else if (s.st == ST_FWD) { fwd_step(s, ix, rr, cr, allowed); ++st_fwd; }
+            else { left_step(s, ix, rr, cr, allowed); ++st_left; }
+        }
+        if (s.flags & F_SPILL_OVERFLOW) return PA_ERR_INTERNAL;
+        if (s.ncol > col_cap) ++st_spill;
+        class_offsets[i] = all.size();
+        pa_read_result res{0, 0, 0, 0};
+        uint32_t colour = 0xFFFFFFFFu;
+        if (s.st == ST_ISECT) {
+            const Isect is = isect_count(s, ix, cr);
+            const size_t o = all.size();
+            all.resize(o + is.count);
+            isect_write(s, ix, cr, is, all.data() + o);
+            res.coverage = s.cov;
+            res.mismatches = s.mism | PA_MAPPED_BIT;
+            res.class_off = (uint32_t)o;
+            res.class_len = is.count;
+            if (is.count == is.base_len) colour = is.base_colour;
+        }
+        results[i] = res;
+        if (colour_out) colour_out[i] = colour;
+    }
+    class_offsets[n] = all.size();
+    uint32_t* p = (uint32_t*)malloc((all.size() ? all.size() : 1) * 4);
+    if (!p) return PA_ERR_OOM;
+    memcpy(p, all.data(), all.size() * 4);
+    *class_ids = p;
+    if (steps) { steps[0] = st_seek; steps[1] = st_fwd; steps[2] = st_left; steps[3] = st_spill; }
+    return PA_OK;
+}
+
+void emu_free(void* p) { free(p); }
+
+}  // extern "C"
