@@ -164,6 +164,8 @@ int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* 
                         uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour, void* stream);
 /* Synchronise and report: PA_OK, or PA_ERR_ARENA_FULL with *arena_needed set (re-run with a larger arena). */
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed);
+/* arena capacity (u32 entries) that suffices for typical batches of n_reads; the exact need is data dependent */
+uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads);
 
 /* Host-buffer convenience (H2D, map, D2H; grows its own arena). results[n], class ids returned as a
  * CSR in read order: class_offsets[n+1], class_ids (library-owned, valid until the next call on idx
@@ -182,11 +184,17 @@ int pa_map_read_to_nodes(pa_index* idx, const uint8_t* ascii, uint32_t len, uint
                          uint32_t* node_buf, uint32_t node_cap, uint32_t* num_nodes, uint32_t* coverage,
                          uint32_t* mismatches);
 
+/* node lists of a whole batch (test surface): nodes_flat[i*nodes_stride ..] holds the first min(nodes_len[i],
+ * nodes_stride) node ids of read i */
+int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads,
+                       uint32_t allowed_mismatches, pa_read_result* results, uint32_t* nodes_flat, uint32_t nodes_stride,
+                       uint32_t* nodes_len);
+
 /* process_reads (src/pseudoaligner.rs:420-514): FASTQ in, one Debug-formatted tuple per read on `out_path`
  * ("-" = stdout) in INPUT order (the reference's order is completion order, :490). num_threads sizes the
  * host parse/format pool. n_reads_out/n_flagged_out may be NULL. */
-int pa_process_reads(pa_index* idx, const pa_host_index* names, const char* fastq_path, const char* out_path,
-                     int num_threads, uint64_t* n_reads_out, uint64_t* n_flagged_out);
+int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads,
+                     uint64_t* n_reads_out, uint64_t* n_flagged_out);
 
 /* ---------------- equivalence-class count table (multi-GPU reduction unit) ---------------- */
 /* counts[c] += number of reads whose class equals index class c; reads with a novel (non-index)
@@ -202,6 +210,7 @@ int pa_counts_accumulate_device(pa_index* idx, const pa_read_result* d_results, 
 typedef struct pa_txome pa_txome;
 int pa_txome_synthesize(uint32_t num_genes, uint32_t target_transcripts, uint64_t seed, pa_txome** out);
 int pa_txome_from_host_index(const pa_host_index* h, pa_txome** out);
+int pa_txome_from_fasta(const char* fasta_path, pa_txome** out);
 int pa_txome_view(const pa_txome* t, const uint64_t** packed, const uint64_t** tx_start, uint32_t* num_tx);
 void pa_txome_destroy(pa_txome* t);
 /* reads: read i = transcript drawn with probability proportional to (len - read_len + 1), uniform start,

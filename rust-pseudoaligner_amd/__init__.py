@@ -1,0 +1,347 @@
+"""MI355X-native pseudoalignment hot path behind the API surface of rust-pseudoaligner's `Pseudoaligner`.
+
+Python here is plumbing over the C ABI (include/pseudoaligner_amd.h): the product is libpseudoaligner_amd.so
+(hand-written HIP for gfx950 + a C++ host runtime). Nothing in this package imports the CPU oracle and there is no
+CPU fallback: without the built library or without a GPU the mapping entry points raise.
+
+Mirrors (names and argument meaning follow the reference):
+    Pseudoaligner.map_read / map_read_with_mismatch / map_read_to_nodes   src/pseudoaligner.rs:381, 361, 54
+    process_reads                                                          src/pseudoaligner.rs:420
+    build_index                                                            src/build_index.rs:27 (CPU)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _build
+from ._ffi import (PA_DEFAULT_ALLOWED_MISMATCHES, PA_MAPPED_BIT, PA_READ_COVERAGE_THRESHOLD, FlatIndex, IndexStats, PaError,
+                   ReadResult, check, lib, vp)
+
+__all__ = ["HostIndex", "Txome", "Pseudoaligner", "build_index", "process_reads", "PaError", "lib", "concat_reads",
+           "gather_classes", "unpack_tiles", "RESULT_DTYPE", "PA_MAPPED_BIT", "PA_DEFAULT_ALLOWED_MISMATCHES",
+           "PA_READ_COVERAGE_THRESHOLD"]
+
+RESULT_DTYPE = np.dtype([("coverage", "<u4"), ("mismatches", "<u4"), ("class_off", "<u4"), ("class_len", "<u4")])
+
+
+def _np_view(ptr: int, n: int, dtype) -> np.ndarray:
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_uint8 * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype)
+
+
+def concat_reads(reads: Sequence) -> Tuple[np.ndarray, np.ndarray]:
+    """ASCII reads -> (concatenated uint8, offsets[n+1] uint64)."""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    data = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(data), offsets
+
+
+class HostIndex:
+    """CPU-side index: the flat form of `pub struct Pseudoaligner<K>` (src/pseudoaligner.rs:26-33)."""
+
+    def __init__(self, handle: int):
+        self._h = vp(handle)
+
+    @classmethod
+    def build_fasta(cls, fasta_path: str, k: int, num_threads: int = 0) -> "HostIndex":
+        h = vp()
+        check(lib().pa_host_index_build_fasta(str(fasta_path).encode(), k, num_threads, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def build_packed(cls, packed: np.ndarray, tx_start: np.ndarray, k: int, num_threads: int = 0) -> "HostIndex":
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        tx_start = np.ascontiguousarray(tx_start, dtype=np.uint64)
+        h = vp()
+        check(lib().pa_host_index_build_packed(packed.ctypes.data, tx_start.ctypes.data, len(tx_start) - 1, k, num_threads, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_txome(cls, txome: "Txome", k: int, num_threads: int = 0) -> "HostIndex":
+        packed, tx_start = txome.arrays()
+        return cls.build_packed(packed, tx_start, k, num_threads)
+
+    @classmethod
+    def from_flat(cls, flat: FlatIndex) -> "HostIndex":
+        h = vp()
+        check(lib().pa_host_index_from_flat(C.byref(flat), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def load(cls, path: str) -> "HostIndex":
+        h = vp()
+        check(lib().pa_host_index_load(str(path).encode(), C.byref(h)))
+        return cls(h.value)
+
+    def save(self, path: str) -> None:
+        check(lib().pa_host_index_save(self._h, str(path).encode()))
+
+    def flat(self) -> FlatIndex:
+        f = FlatIndex()
+        check(lib().pa_host_index_view(self._h, C.byref(f)))
+        return f
+
+    def arrays(self) -> dict:
+        """numpy views (no copy) of the flat arrays; valid while this object is alive."""
+        f = self.flat()
+        n, c = f.num_nodes, f.num_classes
+        ec_offset = _np_view(f.ec_offset, c + 1, np.uint64)
+        return dict(k=f.k, num_nodes=n, num_classes=c, num_transcripts=f.num_transcripts,
+                    node_seq=_np_view(f.node_seq, (f.seq_bases + 31) // 32 + 1, np.uint64),
+                    node_start=_np_view(f.node_start, n + 1, np.uint64), node_len=_np_view(f.node_len, n, np.uint32),
+                    node_exts=_np_view(f.node_exts, n, np.uint8), node_colour=_np_view(f.node_colour, n, np.uint32),
+                    ec_offset=ec_offset, ec_ids=_np_view(f.ec_ids, int(ec_offset[-1]) if c else 0, np.uint32))
+
+    @property
+    def k(self) -> int:
+        return self.flat().k
+
+    @property
+    def num_transcripts(self) -> int:
+        return lib().pa_host_index_num_transcripts(self._h)
+
+    def tx_names(self) -> List[str]:
+        return [lib().pa_host_index_tx_name(self._h, i).decode() for i in range(self.num_transcripts)]
+
+    def tx_genes(self) -> List[str]:
+        return [lib().pa_host_index_tx_gene(self._h, i).decode() for i in range(self.num_transcripts)]
+
+    def transcripts(self) -> Tuple[np.ndarray, np.ndarray]:
+        p, s, n = vp(), vp(), C.c_uint32()
+        check(lib().pa_host_index_transcripts(self._h, C.byref(p), C.byref(s), C.byref(n)))
+        tx_start = _np_view(s.value, n.value + 1, np.uint64)
+        return _np_view(p.value, (int(tx_start[-1]) + 31) // 32 + 1, np.uint64), tx_start
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().pa_host_index_destroy(self._h)
+                self._h = vp()
+        except Exception:
+            pass
+
+
+class Txome:
+    """A transcript set (packed) used to build indices and to simulate reads."""
+
+    def __init__(self, handle: int):
+        self._h = vp(handle)
+        self._dev = {}
+
+    @classmethod
+    def synthesize(cls, num_genes: int, target_transcripts: int, seed: int) -> "Txome":
+        h = vp()
+        check(lib().pa_txome_synthesize(num_genes, target_transcripts, seed, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_fasta(cls, path: str) -> "Txome":
+        h = vp()
+        check(lib().pa_txome_from_fasta(str(path).encode(), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_host_index(cls, index: HostIndex) -> "Txome":
+        h = vp()
+        check(lib().pa_txome_from_host_index(index._h, C.byref(h)))
+        return cls(h.value)
+
+    def arrays(self) -> Tuple[np.ndarray, np.ndarray]:
+        p, s, n = vp(), vp(), C.c_uint32()
+        check(lib().pa_txome_view(self._h, C.byref(p), C.byref(s), C.byref(n)))
+        tx_start = _np_view(s.value, n.value + 1, np.uint64)
+        return _np_view(p.value, (int(tx_start[-1]) + 31) // 32 + 1, np.uint64), tx_start
+
+    @property
+    def num_transcripts(self) -> int:
+        return len(self.arrays()[1]) - 1
+
+    def simulate_host(self, read_len: int, seed: int, n_reads: int, sub_rate_ppm: int = 0, first_read: int = 0,
+                      words_per_read: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        wpr = words_per_read or lib().pa_words_per_read(read_len)
+        tiles = np.zeros(lib().pa_tiles_words(n_reads, wpr), dtype=np.uint64)
+        lens = np.zeros(n_reads, dtype=np.uint32)
+        check(lib().pa_simulate_reads_host(self._h, read_len, seed, sub_rate_ppm, first_read, n_reads, wpr, tiles.ctypes.data, lens.ctypes.data))
+        return tiles, lens
+
+    def device_handle(self, read_len: int, device: int = 0) -> vp:
+        key = (read_len, device)
+        if key not in self._dev:
+            h = vp()
+            check(lib().pa_txome_upload(self._h, read_len, device, C.byref(h)))
+            self._dev[key] = h
+        return self._dev[key]
+
+    def simulate_device(self, read_len: int, seed: int, n_reads: int, d_tiles: int, d_lens: int, sub_rate_ppm: int = 0,
+                        first_read: int = 0, words_per_read: Optional[int] = None, device: int = 0, stream: int = 0) -> None:
+        wpr = words_per_read or lib().pa_words_per_read(read_len)
+        check(lib().pa_simulate_reads_device(self.device_handle(read_len, device), seed, sub_rate_ppm, first_read, n_reads, wpr,
+                                             d_tiles, d_lens, stream or None))
+
+    def __del__(self):
+        try:
+            for h in self._dev.values():
+                lib().pa_txome_device_destroy(h)
+            self._dev = {}
+            if self._h:
+                lib().pa_txome_destroy(self._h)
+                self._h = vp()
+        except Exception:
+            pass
+
+
+def build_index(fasta_path: str, k: int, num_threads: int = 0) -> HostIndex:
+    """build_index (src/build_index.rs:27-32) over utils::read_transcripts (src/utils.rs:61); CPU."""
+    return HostIndex.build_fasta(fasta_path, k, num_threads)
+
+
+def encode_reads_host(reads: Sequence, words_per_read: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray, int]:
+    """ASCII reads -> (tiles, lens, words_per_read) in the device tile layout, packed on the host."""
+    data, offsets = reads if isinstance(reads, tuple) else concat_reads(reads)
+    n = len(offsets) - 1
+    maxlen = int((offsets[1:] - offsets[:-1]).max()) if n else 1
+    wpr = words_per_read or lib().pa_words_per_read(maxlen)
+    tiles = np.zeros(lib().pa_tiles_words(n, wpr), dtype=np.uint64)
+    lens = np.zeros(max(n, 1), dtype=np.uint32)
+    check(lib().pa_encode_reads_host(data.ctypes.data, offsets.ctypes.data, n, wpr, tiles.ctypes.data, lens.ctypes.data))
+    return tiles, lens[:n], wpr
+
+
+def unpack_tiles(tiles: np.ndarray, lens: np.ndarray, words_per_read: int) -> List[str]:
+    """tile layout -> ASCII strings (tests / debugging)."""
+    t = tiles.reshape(-1, words_per_read, 64)
+    out = []
+    for i, L in enumerate(lens):
+        words = t[i >> 6, :, i & 63]
+        out.append("".join("ACGT"[(int(words[j >> 5]) >> (2 * (j & 31))) & 3] for j in range(int(L))))
+    return out
+
+
+class Pseudoaligner:
+    """GPU-resident index with the reference's mapping API (src/pseudoaligner.rs:35-385)."""
+
+    def __init__(self, index: HostIndex, device: int = 0):
+        self.host = index
+        self.device = device
+        flat = index.flat()
+        h = vp()
+        check(lib().pa_index_create(C.byref(flat), device, C.byref(h)))
+        self._h = h
+
+    def stats(self) -> IndexStats:
+        s = IndexStats()
+        check(lib().pa_index_get_stats(self._h, C.byref(s)))
+        return s
+
+    # ---- single reads -------------------------------------------------------------------------------
+    def map_read_with_mismatch(self, read_seq, allowed_mismatches: int) -> Optional[Tuple[List[int], int, int]]:
+        """-> Some((eq_class, read_coverage, mismatches)) | None (src/pseudoaligner.rs:361-376)"""
+        seq = read_seq.encode() if isinstance(read_seq, str) else bytes(read_seq)
+        cap = max(64, self.stats().max_class_len)
+        buf = (C.c_uint32 * cap)()
+        n, cov, mm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = check(lib().pa_map_read_with_mismatch(self._h, seq, len(seq), allowed_mismatches, buf, cap, C.byref(n), C.byref(cov), C.byref(mm)))
+        if rc == 0:
+            return None
+        return list(buf[: n.value]), cov.value, mm.value
+
+    def map_read(self, read_seq) -> Optional[Tuple[List[int], int]]:
+        """-> Some((eq_class, read_coverage)) | None with allowed mismatches = 2 (src/pseudoaligner.rs:381-384)"""
+        r = self.map_read_with_mismatch(read_seq, PA_DEFAULT_ALLOWED_MISMATCHES)
+        return None if r is None else (r[0], r[1])
+
+    def map_read_to_nodes(self, read_seq, allowed_mismatches: int = PA_DEFAULT_ALLOWED_MISMATCHES) -> Optional[Tuple[List[int], int]]:
+        """-> Some((nodes in visit order, read_coverage)) | None (src/pseudoaligner.rs:54-61)"""
+        seq = read_seq.encode() if isinstance(read_seq, str) else bytes(read_seq)
+        cap = 2 * len(seq) + 8
+        buf = (C.c_uint32 * cap)()
+        n, cov, mm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = check(lib().pa_map_read_to_nodes(self._h, seq, len(seq), allowed_mismatches, buf, cap, C.byref(n), C.byref(cov), C.byref(mm)))
+        if rc == 0:
+            return None
+        return list(buf[: n.value]), cov.value
+
+    # ---- batches ------------------------------------------------------------------------------------
+    def map_batch(self, reads: Sequence, allowed_mismatches: int = PA_DEFAULT_ALLOWED_MISMATCHES):
+        """-> (results[n] RESULT_DTYPE, class_offsets[n+1], class_ids) in input order; `mismatches` has bit 31 = mapped."""
+        data, offsets = reads if isinstance(reads, tuple) else concat_reads(reads)
+        n = len(offsets) - 1
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        coff = np.zeros(n + 1, dtype=np.uint64)
+        ids = vp()
+        check(lib().pa_map_batch(self._h, data.ctypes.data, offsets.ctypes.data, n, allowed_mismatches, results.ctypes.data,
+                                 coff.ctypes.data, C.byref(ids)))
+        class_ids = _np_view(ids.value, int(coff[-1]), np.uint32).copy()
+        return results, coff, class_ids
+
+    def map_batch_nodes(self, reads: Sequence, allowed_mismatches: int = PA_DEFAULT_ALLOWED_MISMATCHES):
+        data, offsets = reads if isinstance(reads, tuple) else concat_reads(reads)
+        n = len(offsets) - 1
+        maxlen = int((offsets[1:] - offsets[:-1]).max()) if n else 1
+        stride = 2 * maxlen + 8
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        nodes = np.zeros((n, stride), dtype=np.uint32)
+        nlen = np.zeros(n, dtype=np.uint32)
+        check(lib().pa_map_batch_nodes(self._h, data.ctypes.data, offsets.ctypes.data, n, allowed_mismatches, results.ctypes.data,
+                                       nodes.ctypes.data, stride, nlen.ctypes.data))
+        return results, nodes, nlen
+
+    def map_batch_device(self, d_tiles: int, d_lens: int, n_reads: int, words_per_read: int, d_results: int, d_arena: int,
+                         arena_cap: int, allowed_mismatches: int = PA_DEFAULT_ALLOWED_MISMATCHES, d_colour: int = 0, stream: int = 0) -> None:
+        """Asynchronous launch of the hot path on device-resident tiles (raw device pointers)."""
+        check(lib().pa_map_batch_device(self._h, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena,
+                                        arena_cap, d_colour or None, stream or None))
+
+    def map_finish(self, stream: int = 0) -> Tuple[int, int]:
+        used, need = C.c_uint64(), C.c_uint64()
+        check(lib().pa_map_finish(self._h, stream or None, C.byref(used), C.byref(need)))
+        return used.value, need.value
+
+    def arena_hint(self, n_reads: int) -> int:
+        return lib().pa_map_arena_hint(self._h, n_reads)
+
+    def counts_len(self) -> int:
+        return lib().pa_counts_len(self._h)
+
+    def counts_accumulate_device(self, d_results: int, d_arena: int, d_colour: int, n_reads: int, d_counts: int, stream: int = 0) -> None:
+        check(lib().pa_counts_accumulate_device(self._h, d_results, d_arena, d_colour or None, n_reads, d_counts, stream or None))
+
+    def encode_reads_device(self, d_ascii: int, d_offsets: int, n_reads: int, words_per_read: int, d_tiles: int, d_lens: int, stream: int = 0):
+        check(lib().pa_encode_reads_device(self._h, d_ascii, d_offsets, n_reads, words_per_read, d_tiles, d_lens, stream or None))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().pa_index_destroy(self._h)
+                self._h = vp()
+        except Exception:
+            pass
+
+
+def process_reads(fastq_path: str, index: Pseudoaligner, out_path: str = "-", num_threads: int = 2) -> Tuple[int, int]:
+    """process_reads (src/pseudoaligner.rs:420-425): one `(flag, "id", [ids], coverage)` line per read, input order.
+    Returns (reads, reads flagged true by the rule at :455)."""
+    n, flagged = C.c_uint64(), C.c_uint64()
+    check(lib().pa_process_reads(index._h, str(fastq_path).encode(), str(out_path).encode(), num_threads, C.byref(n), C.byref(flagged)))
+    return n.value, flagged.value
+
+
+def gather_classes(results: np.ndarray, arena: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(results with arena offsets, arena) -> (class_offsets[n+1], class_ids) in read order (vectorised)."""
+    lens = results["class_len"].astype(np.int64)
+    coff = np.zeros(len(results) + 1, dtype=np.uint64)
+    coff[1:] = np.cumsum(lens)
+    total = int(coff[-1])
+    if total == 0:
+        return coff, np.zeros(0, np.uint32)
+    starts = np.repeat(results["class_off"].astype(np.int64), lens)
+    within = np.arange(total, dtype=np.int64) - np.repeat(coff[:-1].astype(np.int64), lens)
+    return coff, arena[starts + within].astype(np.uint32)

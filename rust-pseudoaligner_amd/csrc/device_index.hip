@@ -1,0 +1,495 @@
+// Device-side index object and the C ABI entry points that launch the HIP kernels.
+// There is NO CPU fallback anywhere in this file: without a usable GPU every entry point fails with
+// PA_ERR_NO_DEVICE / PA_ERR_HIP and a message in pa_last_error().
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+#include <thread>
+
+#include "device_flatten.hpp"
+#include "kernels.hpp"
+#include "pa_common.hpp"
+#include "synth_common.hpp"
+
+using namespace pa;
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(PA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));  \
+    } while (0)
+
+namespace {
+
+struct DevBuf {   // grow-only device scratch
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return PA_OK;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return fail(PA_ERR_HIP, "hipFree: %s", hipGetErrorString(e)); }
+        const size_t want = need + need / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(PA_ERR_OOM, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
+        bytes = want;
+        return PA_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+uint64_t list_hash_host(const uint32_t* v, uint32_t n) {   // must equal list_hash_dev (kernels.hip)
+    uint64_t h = 0x243f6a8885a308d3ull ^ n;
+    for (uint32_t i = 0; i < n; ++i) h = mix64(h ^ v[i]) + 0x9e3779b97f4a7c15ull;
+    return h;
+}
+
+}  // namespace
+
+struct pa_index {
+    int device = 0;
+    int num_cus = 0;
+    DevIndexView dv{};
+    void *d_table = nullptr, *d_blobs = nullptr, *d_ledge = nullptr, *d_ec_off = nullptr, *d_ec_ids = nullptr, *d_class_table = nullptr;
+    uint64_t class_table_size = 0;
+    pa_index_stats stats{};
+    // per-launch scratch (one batch in flight per index handle; calls are serialised by `mu`)
+    std::mutex mu;
+    DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status
+    DevBuf spill, trace;
+    uint32_t last_grid = 0;
+    // host-buffer convenience path
+    DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
+    std::vector<uint32_t> h_class_ids;
+    std::vector<uint32_t> h_arena;
+};
+
+extern "C" {
+
+int pa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int use_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(PA_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(PA_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return PA_OK;
+}
+
+static int upload(const void* src, size_t bytes, void** dst) {
+    HIP_TRY(hipMalloc(dst, bytes ? bytes : 16));
+    if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return PA_OK;
+}
+
+void pa_index_destroy(pa_index* idx) {
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_ec_off, idx->d_ec_ids, idx->d_class_table})
+        if (p) (void)hipFree(p);
+    for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
+                      &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})
+        b->release();
+    delete idx;
+}
+
+int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
+    if (!flat || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    int rc = use_device(device);
+    if (rc != PA_OK) return rc;
+    FlatDevice fd;
+    int threads = (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    rc = flatten_for_device(*flat, threads, fd);
+    if (rc != PA_OK) return rc;
+
+    // class-list hash table for the count kernel: open addressing of class ids keyed by the hash of the id list
+    std::vector<uint32_t> ctab((size_t)fd.num_classes * 2 + 16, 0xFFFFFFFFu);
+    for (uint32_t c = 0; c < fd.num_classes; ++c) {
+        uint64_t j = list_hash_host(fd.ec_ids.data() + fd.ec_off[c], fd.ec_off[c + 1] - fd.ec_off[c]) % ctab.size();
+        while (ctab[j] != 0xFFFFFFFFu)
+            if (++j == ctab.size()) j = 0;
+        ctab[j] = c;
+    }
+
+    pa_index* idx = new (std::nothrow) pa_index();
+    if (!idx) return fail(PA_ERR_OOM, "out of memory");
+    idx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) idx->num_cus = prop.multiProcessorCount;
+    if (idx->num_cus <= 0) idx->num_cus = 256;
+    rc = upload(fd.table.data(), fd.table.size() * sizeof(U4), &idx->d_table);
+    if (rc == PA_OK) rc = upload(fd.blobs.data(), fd.blobs.size(), &idx->d_blobs);
+    if (rc == PA_OK) rc = upload(fd.ledge.data(), fd.ledge.size() * 4, &idx->d_ledge);
+    if (rc == PA_OK) rc = upload(fd.ec_off.data(), fd.ec_off.size() * 4, &idx->d_ec_off);
+    if (rc == PA_OK) rc = upload(fd.ec_ids.data(), fd.ec_ids.size() * 4, &idx->d_ec_ids);
+    if (rc == PA_OK) rc = upload(ctab.data(), ctab.size() * 4, &idx->d_class_table);
+    if (rc == PA_OK) rc = idx->ctl.ensure(64);
+    if (rc != PA_OK) { pa_index_destroy(idx); return rc; }
+    idx->class_table_size = ctab.size();
+    idx->dv = fd.host_view();
+    idx->dv.table = static_cast<const U4*>(idx->d_table);
+    idx->dv.blobs = static_cast<const uint8_t*>(idx->d_blobs);
+    idx->dv.ledge = static_cast<const uint32_t*>(idx->d_ledge);
+    idx->dv.ec_off = static_cast<const uint32_t*>(idx->d_ec_off);
+    idx->dv.ec_ids = static_cast<const uint32_t*>(idx->d_ec_ids);
+    pa_index_stats& s = idx->stats;
+    s.num_kmers = fd.num_kmers;
+    s.table_slots = fd.table.size();
+    s.bytes_table = fd.table.size() * sizeof(U4);
+    s.bytes_graph = fd.blobs.size() + fd.ledge.size() * 4;
+    s.bytes_classes = (fd.ec_off.size() + fd.ec_ids.size() + ctab.size()) * 4;
+    s.bytes_total = s.bytes_table + s.bytes_graph + s.bytes_classes;
+    s.num_nodes = fd.num_nodes;
+    s.num_classes = fd.num_classes;
+    s.k = fd.k;
+    s.max_class_len = fd.max_class_len;
+    *out = idx;
+    return PA_OK;
+}
+
+int pa_index_get_stats(const pa_index* idx, pa_index_stats* stats) {
+    if (!idx || !stats) return fail(PA_ERR_INVALID_ARG, "null argument");
+    *stats = idx->stats;
+    return PA_OK;
+}
+
+uint32_t pa_words_per_read(uint32_t max_read_len) { return (max_read_len + 31) / 32 ? (max_read_len + 31) / 32 : 1; }
+size_t pa_tiles_words(uint64_t n_reads, uint32_t words_per_read) { return (size_t)((n_reads + 63) / 64) * words_per_read * 64; }
+
+int pa_encode_reads_device(const pa_index* idx, const uint8_t* d_ascii, const uint64_t* d_offsets, uint64_t n_reads,
+                           uint32_t words_per_read, uint64_t* d_tiles, uint32_t* d_lens, void* stream) {
+    if (!idx || !d_ascii || !d_offsets || !d_tiles || !d_lens || words_per_read == 0) return fail(PA_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(idx->device));
+    const int e = launch_encode(d_ascii, d_offsets, n_reads, words_per_read, d_tiles, d_lens, static_cast<hipStream_t>(stream));
+    if (e) return fail(PA_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
+    return PA_OK;
+}
+
+// ---- launch geometry: enough waves to fill the chip, few enough that each owns several tiles ----
+static int map_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t* grid, size_t* lds, uint32_t* col_cap) {
+    *col_cap = PA_DEFAULT_COL_CAP;
+    const size_t wave_bytes = (size_t)(wpr + 1) * 512 + (size_t)*col_cap * 256;
+    *lds = wave_bytes * (PA_MAP_BLOCK / 64);
+    if (*lds > 160 * 1024) return fail(PA_ERR_UNSUPPORTED, "reads of %u words need %zu bytes of LDS per workgroup (> 160 KiB)", wpr, *lds);
+    int per_cu = 0;
+    if (map_kernel_occupancy(*lds, &per_cu) != 0 || per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    const uint64_t ntiles = (n_reads + 63) / 64;
+    const uint64_t waves_wanted = (ntiles + 3) / 4;                       // >= 4 tiles per wave when the batch allows
+    uint64_t blocks = (waves_wanted + PA_MAP_BLOCK / 64 - 1) / (PA_MAP_BLOCK / 64);
+    const uint64_t cap = (uint64_t)idx->num_cus * per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    *grid = (uint32_t)blocks;
+    return PA_OK;
+}
+
+static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads, uint32_t wpr,
+                             uint32_t allowed, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour,
+                             uint32_t* d_nodes, uint32_t* d_nodes_len, hipStream_t stream) {
+    if (n_reads >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "at most 2^32-2 reads per batch");
+    if (wpr == 0 || wpr > PA_MAX_READ_LEN / 32) return fail(PA_ERR_UNSUPPORTED, "words_per_read %u outside [1,%u]", wpr, PA_MAX_READ_LEN / 32);
+    uint32_t grid = 0, col_cap = 0;
+    size_t lds = 0;
+    int rc = map_geometry(idx, n_reads, wpr, &grid, &lds, &col_cap);
+    if (rc != PA_OK) return rc;
+    const uint32_t spill_cap = 64 * wpr + 2;   // >= 2 * max read length + 2 node visits
+    const size_t lanes = (size_t)grid * PA_MAP_BLOCK;
+    rc = idx->spill.ensure(lanes * spill_cap * 4);
+    if (rc != PA_OK) return rc;
+    if (d_nodes) { rc = idx->trace.ensure(lanes * spill_cap * 4); if (rc != PA_OK) return rc; }
+    HIP_TRY(hipMemsetAsync(idx->ctl.p, 0, 16, stream));
+    MapParams p{};
+    p.ix = idx->dv;
+    p.tiles = d_tiles;
+    p.lens = d_lens;
+    p.n_reads = n_reads;
+    p.wpr = wpr;
+    p.allowed = allowed;
+    p.results = d_results;
+    p.arena = d_arena;
+    p.arena_cap = arena_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_cap;
+    p.colour_out = d_colour;
+    p.arena_top = idx->ctl.as<unsigned long long>();
+    p.status = idx->ctl.as<uint32_t>() + 2;
+    p.spill = idx->spill.as<uint32_t>();
+    p.spill_cap = spill_cap;
+    p.col_cap = col_cap;
+    p.trace = d_nodes ? idx->trace.as<uint32_t>() : nullptr;
+    p.nodes_out = d_nodes;
+    p.nodes_len = d_nodes_len;
+    idx->last_grid = grid;
+    if (n_reads == 0) return PA_OK;
+    const int e = launch_map(p, grid, lds, stream);
+    if (e) return fail(PA_ERR_HIP, "map launch (grid %u, lds %zu): %s", grid, lds, hipGetErrorString((hipError_t)e));
+    return PA_OK;
+}
+
+static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_used, uint64_t* arena_needed) {
+    HIP_TRY(hipStreamSynchronize(stream));
+    struct { unsigned long long top; uint32_t status; uint32_t pad; } ctl;
+    HIP_TRY(hipMemcpy(&ctl, idx->ctl.p, 16, hipMemcpyDeviceToHost));
+    if (arena_used) *arena_used = ctl.top;
+    if (arena_needed) *arena_needed = ctl.top;
+    if (ctl.status & PA_STATUS_SPILL_OVERFLOW) return fail(PA_ERR_INTERNAL, "colour spill buffer overflow (should be impossible)");
+    if (ctl.status & PA_STATUS_ARENA_FULL) return fail(PA_ERR_ARENA_FULL, "class arena too small: %llu entries needed", ctl.top);
+    return PA_OK;
+}
+
+int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads, uint32_t words_per_read,
+                        uint32_t allowed_mismatches, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap,
+                        uint32_t* d_colour, void* stream) {
+    if (!idx || (n_reads && (!d_tiles || !d_lens || !d_results || !d_arena))) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIP_TRY(hipSetDevice(idx->device));
+    return map_launch_locked(idx, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, d_colour,
+                             nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed) {
+    if (!idx) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIP_TRY(hipSetDevice(idx->device));
+    return map_finish_locked(idx, static_cast<hipStream_t>(stream), arena_used, arena_needed);
+}
+
+uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads) {
+    // enough for ~8 ids per read plus one partially used chunk per wave; pa_map_finish reports the exact need
+    const uint64_t waves = idx ? (uint64_t)idx->num_cus * 8 * (PA_MAP_BLOCK / 64) : 8192;
+    return n_reads * 8 + waves * PA_ARENA_CHUNK + 4096;
+}
+
+// ---- host-buffer convenience: H2D, encode, map (retry on arena overflow), D2H, CSR in read order ----
+static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n, uint32_t allowed,
+                          pa_read_result* results, uint64_t* class_offsets, const uint32_t** class_ids, uint32_t* nodes_flat,
+                          uint32_t nodes_stride_cap, uint32_t* nodes_len) {
+    if (!idx || !offsets || (n && !ascii) || !results) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIP_TRY(hipSetDevice(idx->device));
+    uint64_t maxlen = 1;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(PA_ERR_INVALID_ARG, "offsets not monotone at read %llu", (unsigned long long)i);
+        maxlen = std::max<uint64_t>(maxlen, offsets[i + 1] - offsets[i]);
+    }
+    if (maxlen > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
+    const uint32_t wpr = pa_words_per_read((uint32_t)maxlen);
+    const uint64_t total_ascii = n ? offsets[n] - offsets[0] : 0;
+    hipStream_t st = nullptr;
+    int rc;
+    if ((rc = idx->b_ascii.ensure(total_ascii + 64)) || (rc = idx->b_offsets.ensure((n + 1) * 8)) ||
+        (rc = idx->b_tiles.ensure(pa_tiles_words(n, wpr) * 8 + 8)) || (rc = idx->b_lens.ensure((n + 64) * 4)) ||
+        (rc = idx->b_results.ensure((n + 1) * sizeof(pa_read_result))))
+        return rc;
+    if (n == 0) { if (class_offsets) class_offsets[0] = 0; if (class_ids) *class_ids = nullptr; return PA_OK; }
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
+    HIP_TRY(hipMemcpyAsync(idx->b_ascii.p, ascii + offsets[0], total_ascii, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(idx->b_offsets.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+    int e = launch_encode(idx->b_ascii.as<uint8_t>(), idx->b_offsets.as<uint64_t>(), n, wpr, idx->b_tiles.as<uint64_t>(),
+                          idx->b_lens.as<uint32_t>(), st);
+    if (e) return fail(PA_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
+    const uint32_t spill_cap = 64 * wpr + 2;
+    uint32_t *d_nodes = nullptr, *d_nodes_len = nullptr;
+    if (nodes_flat) {
+        if ((rc = idx->b_nodes.ensure(n * spill_cap * 4)) || (rc = idx->b_nodes_len.ensure(n * 4))) return rc;
+        d_nodes = idx->b_nodes.as<uint32_t>();
+        d_nodes_len = idx->b_nodes_len.as<uint32_t>();
+    }
+    uint64_t cap = pa_map_arena_hint(idx, n), used = 0, need = 0;
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = idx->b_arena.ensure(cap * 4))) return rc;
+        rc = map_launch_locked(idx, idx->b_tiles.as<uint64_t>(), idx->b_lens.as<uint32_t>(), n, wpr, allowed,
+                               idx->b_results.as<pa_read_result>(), idx->b_arena.as<uint32_t>(), cap, nullptr, d_nodes, d_nodes_len, st);
+        if (rc != PA_OK) return rc;
+        rc = map_finish_locked(idx, st, &used, &need);
+        if (rc == PA_ERR_ARENA_FULL && attempt < 3) { cap = need + need / 8 + 4096; continue; }
+        if (rc != PA_OK) return rc;
+        break;
+    }
+    HIP_TRY(hipMemcpy(results, idx->b_results.p, n * sizeof(pa_read_result), hipMemcpyDeviceToHost));
+    idx->h_arena.resize(used + 1);
+    if (used) HIP_TRY(hipMemcpy(idx->h_arena.data(), idx->b_arena.p, used * 4, hipMemcpyDeviceToHost));
+    if (class_offsets || class_ids) {
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < n; ++i) total += results[i].class_len;
+        idx->h_class_ids.resize(total + 1);
+        uint64_t o = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (class_offsets) class_offsets[i] = o;
+            if (results[i].class_len) memcpy(idx->h_class_ids.data() + o, idx->h_arena.data() + results[i].class_off, results[i].class_len * 4ull);
+            results[i].class_off = (uint32_t)o;
+            o += results[i].class_len;
+        }
+        if (class_offsets) class_offsets[n] = o;
+        if (class_ids) *class_ids = idx->h_class_ids.data();
+    }
+    if (nodes_flat) {
+        std::vector<uint32_t> hn(n * (size_t)spill_cap), hl(n);
+        HIP_TRY(hipMemcpy(hn.data(), d_nodes, hn.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hl.data(), d_nodes_len, n * 4, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) {
+            nodes_len[i] = hl[i];
+            const uint32_t m = std::min(std::min(hl[i], spill_cap), nodes_stride_cap);
+            memcpy(nodes_flat + i * nodes_stride_cap, hn.data() + i * spill_cap, m * 4ull);
+        }
+    }
+    return PA_OK;
+}
+
+int pa_map_batch(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads, uint32_t allowed_mismatches,
+                 pa_read_result* results, uint64_t* class_offsets, const uint32_t** class_ids) {
+    return map_batch_host(idx, ascii, offsets, n_reads, allowed_mismatches, results, class_offsets, class_ids, nullptr, 0, nullptr);
+}
+
+int pa_map_read_with_mismatch(pa_index* idx, const uint8_t* ascii, uint32_t len, uint32_t allowed_mismatches, uint32_t* class_buf,
+                              uint32_t class_cap, uint32_t* class_len, uint32_t* coverage, uint32_t* mismatches) {
+    const uint64_t offsets[2] = {0, len};
+    pa_read_result r;
+    uint64_t co[2];
+    const uint32_t* ids = nullptr;
+    const int rc = pa_map_batch(idx, ascii, offsets, 1, allowed_mismatches, &r, co, &ids);
+    if (rc != PA_OK) return rc;
+    if (class_len) *class_len = r.class_len;
+    if (coverage) *coverage = r.coverage;
+    if (mismatches) *mismatches = r.mismatches & ~PA_MAPPED_BIT;
+    if (!(r.mismatches & PA_MAPPED_BIT)) return 0;
+    if (r.class_len > class_cap) return fail(PA_ERR_INVALID_ARG, "class buffer too small: %u ids", r.class_len);
+    if (r.class_len && class_buf) memcpy(class_buf, ids, r.class_len * 4ull);
+    return 1;
+}
+
+int pa_map_read(pa_index* idx, const uint8_t* ascii, uint32_t len, uint32_t* class_buf, uint32_t class_cap, uint32_t* class_len,
+                uint32_t* coverage) {
+    return pa_map_read_with_mismatch(idx, ascii, len, PA_DEFAULT_ALLOWED_MISMATCHES, class_buf, class_cap, class_len, coverage, nullptr);
+}
+
+int pa_map_read_to_nodes(pa_index* idx, const uint8_t* ascii, uint32_t len, uint32_t allowed_mismatches, uint32_t* node_buf,
+                         uint32_t node_cap, uint32_t* num_nodes, uint32_t* coverage, uint32_t* mismatches) {
+    const uint64_t offsets[2] = {0, len};
+    pa_read_result r;
+    uint32_t nn = 0;
+    std::vector<uint32_t> tmp(node_cap ? node_cap : 1);
+    const int rc = map_batch_host(idx, ascii, offsets, 1, allowed_mismatches, &r, nullptr, nullptr, tmp.data(), node_cap, &nn);
+    if (rc != PA_OK) return rc;
+    if (num_nodes) *num_nodes = nn;
+    if (coverage) *coverage = r.coverage;
+    if (mismatches) *mismatches = r.mismatches & ~PA_MAPPED_BIT;
+    if (!(r.mismatches & PA_MAPPED_BIT)) return 0;
+    if (nn > node_cap) return fail(PA_ERR_INVALID_ARG, "node buffer too small: %u nodes", nn);
+    if (node_buf) memcpy(node_buf, tmp.data(), nn * 4ull);
+    return 1;
+}
+
+// batch variant of the node trace (test surface)
+int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads, uint32_t allowed_mismatches,
+                       pa_read_result* results, uint32_t* nodes_flat, uint32_t nodes_stride, uint32_t* nodes_len) {
+    return map_batch_host(idx, ascii, offsets, n_reads, allowed_mismatches, results, nullptr, nullptr, nodes_flat, nodes_stride, nodes_len);
+}
+
+// ---- counts ----
+uint64_t pa_counts_len(const pa_index* idx) { return idx ? (uint64_t)idx->stats.num_classes + 3 : 0; }
+
+int pa_counts_accumulate_device(pa_index* idx, const pa_read_result* d_results, const uint32_t* d_arena, const uint32_t* d_colour,
+                                uint64_t n_reads, uint64_t* d_counts, void* stream) {
+    if (!idx || !d_results || !d_arena || !d_counts) return fail(PA_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(idx->device));
+    const int e = launch_count(d_results, d_arena, d_colour, n_reads, idx->dv.ec_off, idx->dv.ec_ids,
+                               static_cast<const uint32_t*>(idx->d_class_table), idx->class_table_size, idx->stats.num_classes,
+                               reinterpret_cast<unsigned long long*>(d_counts), static_cast<hipStream_t>(stream));
+    if (e) return fail(PA_ERR_HIP, "count launch: %s", hipGetErrorString((hipError_t)e));
+    return PA_OK;
+}
+
+// ---- synthetic reads on the device ----
+struct pa_txome_device {
+    int device;
+    void *d_packed, *d_tx_start, *d_cum;
+    uint32_t num_tx, read_len;
+    uint64_t total;
+};
+
+int pa_txome_upload(const pa_txome* t, uint32_t read_len, int device, pa_txome_device** out) {
+    if (!t || !out || read_len == 0 || read_len > PA_MAX_READ_LEN) return fail(PA_ERR_INVALID_ARG, "bad argument");
+    int rc = use_device(device);
+    if (rc != PA_OK) return rc;
+    std::vector<uint64_t> cum;
+    synth::build_cum(t->t.tx_start.data(), t->t.num_tx(), read_len, cum);
+    if (cum.back() == 0) return fail(PA_ERR_INVALID_ARG, "no transcript is at least %u bases long", read_len);
+    pa_txome_device* d = new pa_txome_device{device, nullptr, nullptr, nullptr, t->t.num_tx(), read_len, cum.back()};
+    rc = upload(t->t.packed.data(), t->t.packed.size() * 8, &d->d_packed);
+    if (rc == PA_OK) rc = upload(t->t.tx_start.data(), t->t.tx_start.size() * 8, &d->d_tx_start);
+    if (rc == PA_OK) rc = upload(cum.data(), cum.size() * 8, &d->d_cum);
+    if (rc != PA_OK) { pa_txome_device_destroy(d); return rc; }
+    *out = d;
+    return PA_OK;
+}
+
+void pa_txome_device_destroy(pa_txome_device* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    for (void* p : {t->d_packed, t->d_tx_start, t->d_cum})
+        if (p) (void)hipFree(p);
+    delete t;
+}
+
+int pa_simulate_reads_device(const pa_txome_device* t, uint64_t seed, uint32_t sub_rate_ppm, uint64_t first_read, uint64_t n_reads,
+                             uint32_t words_per_read, uint64_t* d_tiles, uint32_t* d_lens, void* stream) {
+    if (!t || !d_tiles || !d_lens) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (words_per_read < (t->read_len + 31) / 32) return fail(PA_ERR_INVALID_ARG, "words_per_read too small");
+    HIP_TRY(hipSetDevice(t->device));
+    const int e = launch_simulate(static_cast<const uint64_t*>(t->d_packed), static_cast<const uint64_t*>(t->d_tx_start),
+                                  static_cast<const uint64_t*>(t->d_cum), t->num_tx, t->total, t->read_len, seed, sub_rate_ppm, first_read,
+                                  n_reads, words_per_read, d_tiles, d_lens, static_cast<hipStream_t>(stream));
+    if (e) return fail(PA_ERR_HIP, "simulate launch: %s", hipGetErrorString((hipError_t)e));
+    return PA_OK;
+}
+
+// ---- plumbing for hosts without their own allocator / event API ----
+int pa_event_create(void** ev) {
+    if (!ev) return fail(PA_ERR_INVALID_ARG, "null argument");
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    *ev = e;
+    return PA_OK;
+}
+int pa_event_record(void* ev, void* stream) { HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream))); return PA_OK; }
+int pa_event_elapsed_ms(void* start, void* stop, float* ms) {
+    HIP_TRY(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+    HIP_TRY(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return PA_OK;
+}
+int pa_event_destroy(void* ev) { HIP_TRY(hipEventDestroy(static_cast<hipEvent_t>(ev))); return PA_OK; }
+
+int pa_device_malloc(int device, size_t bytes, void** out) {
+    if (!out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    int rc = use_device(device);
+    if (rc != PA_OK) return rc;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(PA_ERR_OOM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return PA_OK;
+}
+int pa_device_free(void* p) { if (p) HIP_TRY(hipFree(p)); return PA_OK; }
+int pa_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return PA_OK;
+}
+int pa_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return PA_OK;
+}
+int pa_memset_device(void* dst, int value, size_t bytes, void* stream) {
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, static_cast<hipStream_t>(stream)));
+    return PA_OK;
+}
+int pa_stream_synchronize(void* stream) { HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream))); return PA_OK; }
+
+}  // extern "C"

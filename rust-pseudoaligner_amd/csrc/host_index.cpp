@@ -313,3 +313,25 @@ int pa_host_index_load(const char* path, pa_host_index** out) {
 }
 
 }  // extern "C"
+
+// DnaString::from_dna_string (src/pseudoaligner.rs:449-450) for a batch, into the device tile layout (host copy of
+// pa_encode_kernel; used to prepare device-resident batches from the host and by the tests).
+extern "C" int pa_encode_reads_host(const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads, uint32_t words_per_read,
+                                    uint64_t* tiles, uint32_t* lens) {
+    if (!offsets || !tiles || !lens || (n_reads && !ascii) || words_per_read == 0) return fail(PA_ERR_INVALID_ARG, "null argument");
+    const uint64_t ntiles = (n_reads + 63) / 64;
+    std::memset(tiles, 0, ntiles * words_per_read * 64 * sizeof(uint64_t));
+    for (uint64_t i = 0; i < n_reads; ++i) {
+        uint64_t len = offsets[i + 1] - offsets[i];
+        if (len > 32ull * words_per_read) return fail(PA_ERR_INVALID_ARG, "read %llu longer than words_per_read allows", (unsigned long long)i);
+        lens[i] = (uint32_t)len;
+        const uint8_t* s = ascii + offsets[i];
+        uint64_t* dst = tiles + ((i >> 6) * words_per_read) * 64 + (i & 63);
+        for (uint64_t j = 0; j < len; ++j) {
+            uint32_t b = base_code(s[j]);
+            if (b > 3) b = 0;   // non-ACGT -> A (unpinned)
+            dst[(j >> 5) * 64] |= (uint64_t)b << ((j & 31) * 2);
+        }
+    }
+    return PA_OK;
+}

@@ -29,6 +29,7 @@ struct Lane {
     uint32_t ph;         // LEFT: prev_node_id (:128)
     uint32_t ncol;       // distinct colours collected
     uint32_t flags;
+    uint32_t ntrace;     // TRACE builds only: nodes.len()
 };
 
 struct ReadRef {   // the lane's packed read: word w at p[w * stride]; word ceil(L/32) must be readable
@@ -41,6 +42,7 @@ struct ColRef {    // the lane's colour list: first `cap` entries at p[i*stride]
     uint32_t stride, cap;
     uint32_t* spill;
     uint32_t spill_cap;
+    uint32_t* trace;   // TRACE builds only: node ids in visit order (map_read_to_nodes, :54-61), capacity spill_cap
 };
 
 struct Hdr {
@@ -136,7 +138,12 @@ PA_HD uint32_t compare_chunk(uint64_t m, uint32_t n, uint32_t allowed, uint32_t&
     return pa_ctz64(m) >> 1;
 }
 
-PA_HD void push_colour(Lane& s, ColRef c, uint32_t colour) {
+template <bool TRACE>
+PA_HD void push_node(Lane& s, ColRef c, uint32_t colour, uint32_t nid) {
+    if (TRACE) {
+        if (s.ntrace < c.spill_cap) c.trace[s.ntrace] = nid;
+        s.ntrace += 1;
+    }
     const uint32_t inl = pa_min(s.ncol, c.cap);
     for (uint32_t i = 0; i < inl; ++i)
         if (c.p[i * c.stride] == colour) return;
@@ -155,6 +162,7 @@ PA_HD void lane_start(Lane& s, uint32_t rid, uint32_t L, uint32_t k) {
     s.mism = 0;
     s.ncol = 0;
     s.flags = F_FIRST_SEEK;
+    s.ntrace = 0;
     s.h = s.off = s.ro = s.rem = s.snp = s.ra = s.ph = 0;
     s.st = L < k ? ST_NONE : ST_SEEK;   // :82-84
 }
@@ -204,6 +212,7 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
 
 // ---------------------------------------------------------------------------------------------- FWD
 // Forward search (:209-301): one call = enter/continue one node and compare up to 64 bases.
+template <bool TRACE = false>
 PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
     const uint32_t K = ix.k;
     const bool fresh = s.flags & F_FRESH;
@@ -215,7 +224,7 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
     uint32_t rem = s.rem, snp = s.snp, ro = ro0;
     if (fresh) {
         s.cov += K;                                                 // :216
-        push_colour(s, cols, hd.colour);                            // nodes.push (:219)
+        push_node<TRACE>(s, cols, hd.colour, hd.nid);                // nodes.push (:219)
         rem = pa_min(s.L - kp, hd.len - ro);                        // max_matchable_pos (:222-231)
         snp = 0;                                                    // :235
         s.flags &= ~F_FRESH;
@@ -255,13 +264,14 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
 
 // ---------------------------------------------------------------------------------------------- LEFT
 // Left extension (:131-203): one call = enter/continue one node and compare up to 32 bases leftwards.
+template <bool TRACE = false>
 PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
     const uint32_t K = ix.k;
     const Hdr hd = load_hdr(ix, s.ph);                              // dbg.get_node(prev_node_id) (:132)
     uint32_t na = s.ro, rem = s.rem, snp = s.snp;
     if (s.flags & F_FRESH) {
         if (!(s.flags & F_LEFT_SEED)) {
-            push_colour(s, cols, hd.colour);                        // nodes.push(prev_node.node_id) (:199)
+            push_node<TRACE>(s, cols, hd.colour, hd.nid);            // nodes.push(prev_node.node_id) (:199)
             na = hd.len - K + 1;                                    // prev_kmer_offset = len - k (:196)
         }
         rem = pa_min(s.ra, na);                                     // max_matchable_pos (:139-145)

@@ -1,0 +1,34 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Product library + checkers built in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    import helpers
+    helpers._build.build_all()
+    return helpers
+
+
+_index_cache = {}
+
+
+@pytest.fixture(scope="session")
+def small_index(built):
+    """gencode_small.fa HostIndex per k (built on the CPU)."""
+    def get(k):
+        if k not in _index_cache:
+            _index_cache[k] = built.pa.build_index(str(built.FASTA), k, 8)
+        return _index_cache[k]
+    return get

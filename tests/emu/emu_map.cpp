@@ -44,11 +44,11 @@ uint64_t emu_index_info(const emu_index* e, int what) {
 // results as pa_read_result; class ids as malloc'd CSR in read order; optional step counters [4] = seek, fwd, left steps, spills
 int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const uint32_t* lens, uint64_t n, uint32_t allowed,
                   uint32_t col_cap, pa_read_result* results, uint64_t* class_offsets, uint32_t** class_ids, uint32_t* colour_out,
-                  uint64_t* steps) {
+                  uint64_t* steps, uint32_t* nodes_out, uint32_t nodes_stride, uint32_t* nodes_len) {
     const DevIndexView ix = e->fd.host_view();
     std::vector<uint32_t> all;
     std::vector<uint64_t> rd(wpr + 2);
-    std::vector<uint32_t> cols(col_cap ? col_cap : 1), spill;
+    std::vector<uint32_t> cols(col_cap ? col_cap : 1), spill, trace;
     uint64_t st_seek = 0, st_fwd = 0, st_left = 0, st_spill = 0;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t t = i >> 6, r = i & 63;
@@ -56,17 +56,22 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
         rd[wpr] = rd[wpr + 1] = 0;
         const uint32_t L = lens[i];
         spill.assign(2 * (size_t)L + 2, 0);
+        trace.assign(2 * (size_t)L + 2, 0);
         Lane s;
         lane_start(s, (uint32_t)i, L, ix.k);
         const ReadRef rr{rd.data(), 1};
-        const ColRef cr{cols.data(), 1, col_cap, spill.data(), (uint32_t)spill.size()};
+        const ColRef cr{cols.data(), 1, col_cap, spill.data(), (uint32_t)spill.size(), trace.data()};
         while (s.st == ST_SEEK || s.st == ST_FWD || s.st == ST_LEFT) {
             if (s.st == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
-            else if (s.st == ST_FWD) { fwd_step(s, ix, rr, cr, allowed); ++st_fwd; }
-            else { left_step(s, ix, rr, cr, allowed); ++st_left; }
+            else if (s.st == ST_FWD) { fwd_step<true>(s, ix, rr, cr, allowed); ++st_fwd; }
+            else { left_step<true>(s, ix, rr, cr, allowed); ++st_left; }
         }
         if (s.flags & F_SPILL_OVERFLOW) return PA_ERR_INTERNAL;
         if (s.ncol > col_cap) ++st_spill;
+        if (nodes_out) {
+            nodes_len[i] = s.ntrace;
+            for (uint32_t j = 0; j < s.ntrace && j < nodes_stride; ++j) nodes_out[i * nodes_stride + j] = trace[j];
+        }
         class_offsets[i] = all.size();
         pa_read_result res{0, 0, 0, 0};
         uint32_t colour = 0xFFFFFFFFu;
