@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — reads/sec pseudoaligned on synthetic 150 bp reads (BASELINE.json metric).
+
+One step = one pass of the hot path (pa_map_batch_device + the class-count kernel) over one batch of reads that is
+already resident in HBM as 2-bit tiles. Workload (default "config3", BASELINE.json configs[2]): synthetic GENCODE-like
+transcriptome (58 k genes -> ~202 k transcripts, seed 7), K = 24, error-free 150 bp reads (seed 2); --steps x --batch
+reads per GPU (defaults 10 x 10 M = the config's 100 M reads at N = 1). Multi-GPU: one process per GPU, reads sharded
+by rank (weak scaling: every rank maps its own --steps x --batch reads), index replicated, one RCCL all-reduce of the
+class-count table at the end of the timed region.
+
+The oracle (oracle/pa_oracle.c, a CPU port of the reference path) is used here only as (1) the parity checker of a
+sample and (2) the `cpu_baseline` leg; it is never part of the measured GPU path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path  # noqa: E402
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {
+    # name: (genes, transcripts, txome seed, k, read_len, read seed, substitution ppm)
+    "config3": dict(genes=58000, transcripts=203000, txome_seed=7, k=24, read_len=150, read_seed=2, ppm=0,
+                    desc="~202k-transcript synthetic GENCODE-scale index (K=24), error-free 150bp reads"),
+    "config5": dict(genes=58000, transcripts=203000, txome_seed=7, k=31, read_len=150, read_seed=4, ppm=10000,
+                    desc="same transcriptome at K=31, 150bp reads with 1% substitutions"),
+    "config2": dict(fasta=str(ROOT / "tests" / "golden" / "gencode_small.fa"), k=24, read_len=100, read_seed=1, ppm=0,
+                    desc="gencode_small (1832 transcripts) index (K=24), error-free 100bp reads"),
+}
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def algorithmic_bytes_per_read(ctr: dict, read_len: int, k: int) -> float:
+    """B = ceil(2L/8)+4 + p(8+ceil(2K/8)+12) + n(12+1+4+4) + ceil(2c/8) + 8n + 4E + 12 + 4r per read,
+    with p/n/c/E/r = per-read averages of the oracle's counters on a sample of the same reads."""
+    reads = max(ctr["reads"], 1)
+    p = ctr["probes"] / reads
+    n = ctr["node_visits"] / reads
+    c = ctr["bases_compared"] / reads
+    e = ctr["class_sizes"] / reads
+    r = ctr["result_sizes"] / reads
+    return (math.ceil(2 * read_len / 8) + 4 + p * (8 + math.ceil(2 * k / 8) + 12) + n * 21 + 2 * c / 8 + 8 * n + 4 * e + 12 + 4 * r)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=10_000_000, help="reads per step per GPU")
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--index-cache", default="", help="optional path to save/load the host index container")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        log("warning: WORLD_SIZE %d != --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    n_gpus = world
+
+    import numpy as np
+    import torch
+    import helpers
+    pa = helpers.pa
+
+    if not torch.cuda.is_available() or pa.lib().pa_device_count() < 1:
+        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    wl = WORKLOADS[args.workload]
+    k, read_len, ppm = wl["k"], wl["read_len"], wl["ppm"]
+    t0 = time.time()
+    if "fasta" in wl:
+        txome = pa.Txome.from_fasta(wl["fasta"])
+    else:
+        txome = pa.Txome.synthesize(wl["genes"], wl["transcripts"], wl["txome_seed"])
+    log("transcriptome: %d transcripts (%.1f s)" % (txome.num_transcripts, time.time() - t0))
+
+    # ---- index: CPU build on rank 0 (north_star: index construction stays on the CPU), shared through a file ----
+    t0 = time.time()
+    cache = args.index_cache or ("/tmp/pa_bench_%s_k%d_%d.idx" % (args.workload, k, os.getppid()) if world > 1 else "")
+    host = None
+    if cache and os.path.exists(cache) and args.index_cache:
+        host = pa.HostIndex.load(cache)
+    elif rank == 0:
+        host = pa.HostIndex.from_txome(txome, k, 0)
+        if cache:
+            host.save(cache + ".tmp")
+            os.replace(cache + ".tmp", cache)
+    barrier()
+    if host is None:
+        host = pa.HostIndex.load(cache)
+    log("host index ready (%.1f s)" % (time.time() - t0))
+    t0 = time.time()
+    aligner = pa.Pseudoaligner(host, local_rank)
+    st = aligner.stats()
+    log("device index: %d k-mers, %d nodes, %d classes, %.2f GB in HBM (%.1f s)" %
+        (st.num_kmers, st.num_nodes, st.num_classes, st.bytes_total / 1e9, time.time() - t0))
+    barrier()
+    if world > 1 and rank == 0 and not args.index_cache and cache:
+        try:
+            os.remove(cache)
+        except OSError:
+            pass
+
+    # ---- resident inputs: distinct batches of packed reads in HBM, generated on the device ----
+    B, K, W = args.batch, args.steps, args.warmup
+    wpr = pa.lib().pa_words_per_read(read_len)
+    n_batches = min(K + W, 12)
+    tile_words = pa.lib().pa_tiles_words(B, wpr)
+    stream = torch.cuda.current_stream().cuda_stream
+    tiles = [torch.empty(tile_words, dtype=torch.int64, device=dev) for _ in range(n_batches)]
+    lens = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(n_batches)]
+    # global read index: rank r owns reads [r*(K+W)*B, (r+1)*(K+W)*B) of one global stream (rank-count independent)
+    for b in range(n_batches):
+        first = (rank * (K + W) + b) * B
+        txome.simulate_device(read_len, wl["read_seed"], B, tiles[b].data_ptr(), lens[b].data_ptr(), ppm, first, wpr, local_rank, stream)
+    arena_cap = aligner.arena_hint(B)
+    results = torch.empty(B * 4, dtype=torch.int32, device=dev)
+    arena = torch.empty(arena_cap, dtype=torch.int32, device=dev)
+    colour = torch.empty(B, dtype=torch.int32, device=dev)
+    counts = torch.zeros(aligner.counts_len(), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    ev = [pa._ffi.vp() for _ in range(2 * max(K, 1))]
+    import ctypes as C
+    for e in ev:
+        pa.check(pa.lib().pa_event_create(C.byref(e)))
+
+    def step(i: int, timed_idx: int = -1):
+        nonlocal arena, arena_cap
+        b = i % n_batches
+        if timed_idx >= 0:
+            pa.check(pa.lib().pa_event_record(ev[2 * timed_idx], stream or None))
+        aligner.map_batch_device(tiles[b].data_ptr(), lens[b].data_ptr(), B, wpr, results.data_ptr(), arena.data_ptr(), arena_cap,
+                                 2, colour.data_ptr(), stream)
+        if timed_idx >= 0:
+            pa.check(pa.lib().pa_event_record(ev[2 * timed_idx + 1], stream or None))
+        aligner.counts_accumulate_device(results.data_ptr(), arena.data_ptr(), colour.data_ptr(), B, counts.data_ptr(), stream)
+        try:
+            return aligner.map_finish(stream)
+        except pa.PaError as e:
+            if e.code != pa._ffi.PA_ERR_ARENA_FULL:
+                raise
+            raise SystemExit("arena too small for this workload: %s" % e)
+
+    for i in range(W):
+        step(i)
+    counts.zero_()
+    torch.cuda.synchronize()
+    barrier()
+    t_start = time.perf_counter()
+    for i in range(K):
+        used, _ = step(W + i, i)
+    if dist is not None:
+        dist.all_reduce(counts)          # RCCL reduce of the eq-class count table over xGMI
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms = []
+    for i in range(K):
+        ms = C.c_float()
+        pa.check(pa.lib().pa_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], C.byref(ms)))
+        kernel_ms.append(ms.value)
+    kernel_avg_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+
+    total_reads = K * B * n_gpus
+    value = total_reads / elapsed
+    counts_host = counts.cpu().numpy()
+    assert int(counts_host.sum()) == total_reads, "count table does not add up: %d vs %d" % (int(counts_host.sum()), total_reads)
+
+    out = {
+        "metric": "reads/sec pseudoaligned (whole node) on synthetic 150bp reads",
+        "value": value, "unit": "reads/s", "n_gpus": n_gpus, "steps": K, "warmup": W,
+        "ms_per_step": 1000.0 * elapsed / max(K, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "reads_per_step_per_gpu": B, "read_len": read_len, "k": k,
+                   "transcripts": txome.num_transcripts, "kmers": int(st.num_kmers), "index_bytes": int(st.bytes_total),
+                   "parallelism": "reads sharded over %d GPU(s), index replicated, RCCL all-reduce of class counts" % n_gpus},
+    }
+
+    if rank == 0:
+        # ---- checker + CPU baseline (oracle = C port of the reference path), outside the timed region ----
+        t0 = time.time()
+        oracle = helpers.Oracle(host)
+        log("oracle index built (%.1f s)" % (time.time() - t0))
+        ncpu = os.cpu_count() or 1
+        sample_n = 200_000
+        first = (rank * (K + W) + (W % n_batches)) * B   # the first timed batch
+        s_tiles, s_lens = txome.simulate_host(read_len, wl["read_seed"], sample_n, ppm, first, wpr)
+        o_res, o_coff, o_ids, ctr = oracle.map_tiles(s_tiles, s_lens, wpr, 2, ncpu)
+        # parity of the sample: GPU results of the same reads (batch W % n_batches is still resident)
+        b = W % n_batches
+        aligner.map_batch_device(tiles[b].data_ptr(), lens[b].data_ptr(), sample_n, wpr, results.data_ptr(), arena.data_ptr(), arena_cap,
+                                 2, 0, stream)
+        used, _ = aligner.map_finish(stream)
+        g_res = results[: sample_n * 4].cpu().numpy().view(pa.RESULT_DTYPE)
+        g_arena = arena[: max(used, 1)].cpu().numpy().view(np.uint32)
+        g_coff, g_ids = pa.gather_classes(g_res, g_arena)
+        helpers.assert_same_as_oracle(g_res, g_coff, g_ids, o_res, o_coff, o_ids, "bench sample")
+        out["parity_sample"] = {"reads": sample_n, "bit_exact_vs_oracle": True}
+        bytes_per_read = algorithmic_bytes_per_read(ctr, read_len, k)
+        achieved = bytes_per_read * B / (kernel_avg_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                           "traffic": None, "kernel": "pa_map_kernel", "kernel_ms": kernel_avg_ms,
+                           "algorithmic_bytes_per_read": bytes_per_read, "reads_per_launch": B}
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            rate = sample_n / max(1e-9, _time_oracle(oracle, s_tiles, s_lens, wpr, ncpu))
+            big_n = int(min(max(rate * args.cpu_seconds, sample_n), 40_000_000))
+            b_tiles, b_lens = txome.simulate_host(read_len, wl["read_seed"], big_n, ppm, first, wpr)
+            secs = _time_oracle(oracle, b_tiles, b_lens, wpr, ncpu)
+            out["cpu_baseline"] = {"value": big_n / secs, "unit": "reads/s", "cores": ncpu, "kind": "port",
+                                   "sample": "first %d reads of the first timed batch, oracle/pa_oracle.c on %d pthreads, %.1f s" % (big_n, ncpu, secs)}
+        print(json.dumps(out), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _time_oracle(oracle, tiles, lens, wpr, threads) -> float:
+    oracle.map_tiles(tiles, lens, wpr, 2, threads)
+    return oracle.last_seconds   # wall time of the mapping threads only (excludes the serial output assembly)
+
+
+if __name__ == "__main__":
+    main()

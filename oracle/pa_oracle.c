@@ -8,6 +8,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 /* src/config.rs:16-18 */
 #define LEFT_EXTEND_FRACTION 0.2
@@ -35,6 +37,8 @@ struct oracle_index {
 };
 
 static __thread char g_err[256];
+static double g_last_batch_seconds;
+double oracle_last_batch_seconds(void) { return g_last_batch_seconds; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* ---- DnaString::get / get_kmer restated on LSB-first packed words ---- */
@@ -72,14 +76,6 @@ int oracle_lookup_kmer(const oracle_index* idx, uint64_t kmer, uint32_t* node, u
     }
 }
 
-static void dict_insert(oracle_index* idx, uint64_t kmer, uint32_t nid, uint32_t off) {
-    uint64_t i = dict_hash(kmer) % idx->dict_cap;
-    while (idx->dict_node[i] != NO_SLOT)
-        if (++i == idx->dict_cap) i = 0;
-    idx->dict_node[i] = nid;
-    idx->dict_off[i] = off;
-}
-
 static void* dup_mem(const void* p, size_t bytes) {
     void* q = malloc(bytes ? bytes : 1);
     if (q && bytes) memcpy(q, p, bytes);
@@ -100,6 +96,74 @@ void oracle_index_free(oracle_index* idx) {
     free(idx->r_edges);
     free(idx->l_edges);
     free(idx);
+}
+
+typedef struct { oracle_index* idx; int phase; uint32_t begin, end, bad; } build_job;
+
+static void dict_insert_mt(oracle_index* idx, uint64_t kmer, uint32_t nid, uint32_t off) {
+    uint64_t i = dict_hash(kmer) % idx->dict_cap;
+    for (;;) {
+        uint32_t expect = NO_SLOT;
+        /* the offset is published before the node id so that a concurrent reader never pairs a node with a stale offset;
+         * readers only run in later phases anyway */
+        if (__atomic_load_n(&idx->dict_node[i], __ATOMIC_RELAXED) == NO_SLOT) {
+            if (__atomic_compare_exchange_n(&idx->dict_node[i], &expect, 0xFFFFFFFEu, 0, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) {
+                idx->dict_off[i] = off;
+                __atomic_store_n(&idx->dict_node[i], nid, __ATOMIC_RELEASE);
+                return;
+            }
+        }
+        if (++i == idx->dict_cap) i = 0;
+    }
+}
+
+/* phase 0: make_dbg_index (src/build_index.rs:182-221): every k-mer of every node -> (node_id, offset)
+ * phase 1: every k-mer must look itself up (a k-mer present twice would resolve to the other copy)
+ * phase 2: Node::r_edges()/l_edges() (debruijn crate, graph.rs find_edges/find_link, stranded): for each set extension
+ *          in ascending base order, the node whose left-terminal (Right) / right-terminal (Left) k-mer equals the node's
+ *          terminal k-mer extended by that base; a missing link is a panic there, an error here. */
+static void* build_worker(void* arg) {
+    build_job* j = (build_job*)arg;
+    oracle_index* idx = j->idx;
+    const uint32_t k = idx->k;
+    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    for (uint32_t n = j->begin; n < j->end; ++n) {
+        const uint64_t s = idx->node_start[n];
+        const uint32_t len = idx->node_len[n];
+        if (j->phase < 2) {
+            uint64_t km = seq_get_kmer(idx->seq, s, k);
+            const uint32_t nk = len - k + 1;
+            for (uint32_t o = 0; o < nk; ++o) {
+                if (o) km = ((km >> 2) | ((uint64_t)seq_get(idx->seq, s + o + k - 1) << (2 * (k - 1)))) & mask;
+                if (j->phase == 0) dict_insert_mt(idx, km, n, o);
+                else {
+                    uint32_t a, b;
+                    if (!oracle_lookup_kmer(idx, km, &a, &b) || a != n || b != o) j->bad = n;
+                }
+            }
+        } else {
+            const uint64_t first = seq_get_kmer(idx->seq, s, k), last = seq_get_kmer(idx->seq, s + len - k, k);
+            uint32_t rr = 0, lr = 0;
+            for (uint32_t b = 0; b < 4; ++b) {
+                idx->r_edges[4 * n + b] = NO_SLOT;
+                idx->l_edges[4 * n + b] = NO_SLOT;
+            }
+            for (uint32_t b = 0; b < 4; ++b) {
+                uint32_t tn, to;
+                if (idx->node_exts[n] & (1u << b)) {
+                    const uint64_t nx = ((last >> 2) | ((uint64_t)b << (2 * (k - 1)))) & mask;
+                    if (!oracle_lookup_kmer(idx, nx, &tn, &to) || to != 0) j->bad = n;
+                    else idx->r_edges[4 * n + rr++] = tn;
+                }
+                if (idx->node_exts[n] & (1u << (4 + b))) {
+                    const uint64_t pv = ((first << 2) | b) & mask;
+                    if (!oracle_lookup_kmer(idx, pv, &tn, &to) || to != idx->node_len[tn] - k) j->bad = n;
+                    else idx->l_edges[4 * n + lr++] = tn;
+                }
+            }
+        }
+    }
+    return NULL;
 }
 
 oracle_index* oracle_index_new(uint32_t k, uint32_t num_nodes, const uint64_t* node_seq, const uint64_t* node_start,
@@ -142,57 +206,38 @@ oracle_index* oracle_index_new(uint32_t k, uint32_t num_nodes, const uint64_t* n
         return NULL;
     }
     memset(idx->dict_node, 0xFF, idx->dict_cap * 4);
-    for (uint32_t n = 0; n < num_nodes; ++n) {
-        const uint64_t s = node_start[n];
-        uint64_t km = seq_get_kmer(idx->seq, s, k);
-        const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-        const uint32_t nk = node_len[n] - k + 1;
-        for (uint32_t o = 0; o < nk; ++o) {
-            if (o) km = ((km >> 2) | ((uint64_t)seq_get(idx->seq, s + o + k - 1) << (2 * (k - 1)))) & mask;
-            uint32_t a, b;
-            if (oracle_lookup_kmer(idx, km, &a, &b)) {
-                snprintf(g_err, sizeof g_err, "k-mer occurs twice in the graph (nodes %u and %u)", a, n);
+    /* index construction is not on the measured path; it is spread over the host cores so that building the checker
+     * for a GENCODE-scale graph takes seconds rather than a minute */
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    int nt = ncpu < 1 ? 1 : (ncpu > 64 ? 64 : (int)ncpu);
+    if (num_nodes < 4096) nt = 1;
+    build_job* jobs = (build_job*)calloc((size_t)nt, sizeof(build_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)nt, sizeof(pthread_t));
+    for (int phase = 0; phase < 3 && jobs && th; ++phase) {
+        for (int t = 0; t < nt; ++t) {
+            jobs[t].idx = idx;
+            jobs[t].phase = phase;
+            jobs[t].begin = (uint32_t)((uint64_t)num_nodes * t / nt);
+            jobs[t].end = (uint32_t)((uint64_t)num_nodes * (t + 1) / nt);
+            jobs[t].bad = NO_SLOT;
+        }
+        if (nt == 1) build_worker(&jobs[0]);
+        else {
+            for (int t = 0; t < nt; ++t) pthread_create(&th[t], NULL, build_worker, &jobs[t]);
+            for (int t = 0; t < nt; ++t) pthread_join(th[t], NULL);
+        }
+        for (int t = 0; t < nt; ++t)
+            if (jobs[t].bad != NO_SLOT) {
+                snprintf(g_err, sizeof g_err, phase == 1 ? "k-mer of node %u occurs twice in the graph" : "missing link at node %u",
+                         jobs[t].bad);
+                free(jobs);
+                free(th);
                 oracle_index_free(idx);
                 return NULL;
             }
-            dict_insert(idx, km, n, o);
-        }
     }
-    /* Node::r_edges()/l_edges() (debruijn crate, graph.rs find_edges/find_link, stranded): for each set extension in
-     * ascending base order, the node whose left-terminal (for Right) / right-terminal (for Left) k-mer equals the
-     * node's terminal k-mer extended by that base; a missing link is a panic there, an error here. */
-    for (uint32_t n = 0; n < num_nodes; ++n) {
-        const uint64_t s = node_start[n];
-        const uint32_t len = node_len[n];
-        const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-        const uint64_t first = seq_get_kmer(idx->seq, s, k), last = seq_get_kmer(idx->seq, s + len - k, k);
-        uint32_t rr = 0, lr = 0;
-        for (uint32_t b = 0; b < 4; ++b) {
-            idx->r_edges[4 * n + b] = NO_SLOT;
-            idx->l_edges[4 * n + b] = NO_SLOT;
-        }
-        for (uint32_t b = 0; b < 4; ++b) {
-            uint32_t tn, to;
-            if (node_exts[n] & (1u << b)) {
-                const uint64_t nx = ((last >> 2) | ((uint64_t)b << (2 * (k - 1)))) & mask;
-                if (!oracle_lookup_kmer(idx, nx, &tn, &to) || to != 0) {
-                    snprintf(g_err, sizeof g_err, "missing link: node %u right ext %u", n, b);
-                    oracle_index_free(idx);
-                    return NULL;
-                }
-                idx->r_edges[4 * n + rr++] = tn;
-            }
-            if (node_exts[n] & (1u << (4 + b))) {
-                const uint64_t pv = ((first << 2) | b) & mask;
-                if (!oracle_lookup_kmer(idx, pv, &tn, &to) || to != node_len[tn] - k) {
-                    snprintf(g_err, sizeof g_err, "missing link: node %u left ext %u", n, b);
-                    oracle_index_free(idx);
-                    return NULL;
-                }
-                idx->l_edges[4 * n + lr++] = tn;
-            }
-        }
-    }
+    free(jobs);
+    free(th);
     return idx;
 }
 
@@ -528,11 +573,15 @@ static int map_batch_impl(const oracle_index* idx, const uint64_t* reads, uint32
         jobs[t].results = results;
         jobs[t].max_class = max_class;
     }
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
     if (nthreads == 1) worker(&jobs[0]);
     else {
         for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, worker, &jobs[t]);
         for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     }
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    g_last_batch_seconds = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
     int rc = 0;
     uint64_t total = 0;
     for (int t = 0; t < nthreads; ++t) {

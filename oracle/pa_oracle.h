@@ -78,6 +78,9 @@ int oracle_map_batch_tiles(const oracle_index* idx, const uint64_t* tiles, uint3
                            uint64_t n, uint32_t allowed_mismatches, int nthreads, oracle_result* results,
                            uint64_t* class_offsets, uint32_t** class_ids, oracle_counters* ctr);
 void oracle_free(void* p);
+/* wall time of the mapping threads (create -> join) of the last oracle_map_batch* call: the cpu_baseline figure, which
+ * excludes the serial assembly of the CSR output */
+double oracle_last_batch_seconds(void);
 
 /* dbg_index.get(kmer) + verification (:96-108): 1 = found. */
 int oracle_lookup_kmer(const oracle_index* idx, uint64_t kmer, uint32_t* node, uint32_t* offset);

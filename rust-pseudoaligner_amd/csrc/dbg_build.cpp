@@ -15,7 +15,11 @@
 // a pure cycle of joinable k-mers (no start k-mer exists; we break at the first k-mer in partition order).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <unordered_map>
 
@@ -24,7 +28,7 @@
 namespace pa {
 namespace {
 
-struct Rec {
+struct Rec {   // trivially default-constructible: arrays of it are left uninitialised
     uint64_t kmer;
     uint32_t tx;
     uint32_t exts;
@@ -42,11 +46,17 @@ struct KEntry {
 static_assert(sizeof(KEntry) == 16, "KEntry");
 
 struct KTable {
-    std::vector<KEntry> e;
     uint64_t cap = 0;
-    void init(uint64_t n) {
+    std::unique_ptr<KEntry[]> e;
+    void init(uint64_t n, int threads) {   // first touch in parallel: page faults dominate a serial fill
         cap = (uint64_t)((double)n / 0.55) + 64;
-        e.assign(cap, KEntry{0, EMPTY, 0, 0, 0});
+        e.reset(new KEntry[cap]);
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; ++t)
+            th.emplace_back([this, t, threads] {
+                for (uint64_t i = cap * t / threads; i < cap * (t + 1) / threads; ++i) e[i] = KEntry{0, EMPTY, 0, 0, 0};
+            });
+        for (auto& x : th) x.join();
     }
     uint64_t home(uint64_t kmer) const { return (uint64_t)(((unsigned __int128)mix64(kmer) * cap) >> 64); }
     void insert_mt(uint64_t kmer, uint32_t colour, uint8_t exts) {
@@ -150,6 +160,14 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
     const uint64_t mask = kmer_mask(k);
     const uint32_t topshift = 2 * (k - 1);
 
+    const bool verbose = std::getenv("PA_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pa build] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     // ---- 1. count k-mers, split transcripts over threads ----
     std::vector<uint64_t> kcum(num_tx + 1, 0);
     for (uint32_t t = 0; t < num_tx; ++t) {
@@ -198,6 +216,7 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
         auto& c = cnt[ti];
         for_each_kmer(tx_split[ti], tx_split[ti + 1], [&](uint64_t km, uint32_t, uint32_t) { ++c[mix64(km) >> (64 - logp)]; });
     });
+    stage("  count pass");
     std::vector<uint64_t> pstart(P + 1, 0);
     {
         uint64_t acc = 0;
@@ -207,7 +226,9 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
         }
         pstart[P] = acc;
     }
-    std::vector<Rec> recs(total);
+    // uninitialised on purpose: zero-filling 16 B x (#k-mers) on one thread costs more than the whole scatter pass
+    std::unique_ptr<Rec[]> recs(new (std::nothrow) Rec[total]);
+    if (!recs) return fail(PA_ERR_OOM, "out of memory for %llu k-mer records", (unsigned long long)total);
     parallel_for(T, T, [&](uint64_t ti, int) {
         auto& c = cnt[ti];
         for_each_kmer(tx_split[ti], tx_split[ti + 1], [&](uint64_t km, uint32_t t, uint32_t ex) {
@@ -215,13 +236,14 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
         });
     });
     cnt.clear();
+    stage("partition k-mers");
 
     // ---- 3. per partition: sort, group, intern colour lists ----
     Interner interner;
     std::vector<std::vector<DK>> dks(P);
     parallel_for(T, P, [&](uint64_t p, int) {
-        Rec* b = recs.data() + pstart[p];
-        Rec* e = recs.data() + pstart[p + 1];
+        Rec* b = recs.get() + pstart[p];
+        Rec* e = recs.get() + pstart[p + 1];
         std::sort(b, e, [](const Rec& a, const Rec& c) { return a.kmer != c.kmer ? a.kmer < c.kmer : a.tx < c.tx; });
         auto& dk = dks[p];
         std::vector<uint32_t> list;
@@ -237,7 +259,8 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
             i = j;
         }
     });
-    std::vector<Rec>().swap(recs);
+    recs.reset();
+    stage("sort + colour lists");
 
     // ---- 4. deterministic class numbering: lexicographic order of the id lists ----
     struct LRef { const uint32_t* p; uint32_t n; uint32_t temp; };
@@ -259,11 +282,12 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
         out.ec_offset.push_back(out.ec_ids.size());
     }
 
+    stage("class numbering");
     // ---- 5. k-mer table ----
     uint64_t ndistinct = 0;
     for (auto& d : dks) ndistinct += d.size();
     KTable tab;
-    tab.init(ndistinct);
+    tab.init(ndistinct, T);
     parallel_for(T, P, [&](uint64_t p, int) {
         for (auto& d : dks[p]) {
             d.colour = remap[d.colour & 255][d.colour >> 8];
@@ -271,6 +295,7 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
         }
     });
 
+    stage("k-mer table");
     // ---- 6. unitigs: walk right from every start k-mer (no joinable predecessor) ----
     auto popc4 = [](uint32_t x) { return __builtin_popcount(x & 15u); };
     // joinable successor of x, or nullptr
@@ -326,6 +351,7 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
             if (!e->visited) walk(e, nouts[P]);
         }
 
+    stage("unitig walks");
     // ---- 7. concatenate in partition order ----
     uint64_t nnodes = 0, nbases = 0;
     for (auto& no : nouts) { nnodes += no.len.size(); nbases += no.bases; }
@@ -350,6 +376,7 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
         }
         NodeOut().seq.swap(no.seq);
     }
+    stage("concatenate");
     return PA_OK;
 }
 

@@ -44,7 +44,9 @@ int pa_txome_synthesize(uint32_t num_genes, uint32_t target_transcripts, uint64_
     Xoshiro rng(seed);
     std::vector<std::vector<std::vector<uint8_t>>> gene_exons;   // kept for paralog copies
     gene_exons.reserve(num_genes);
-    const double extra = (double)target_transcripts / num_genes - 1.0;
+    // isoforms per gene = 1 + floor(Exp(m)); E[floor(Exp(m))] = 1/(e^(1/m) - 1) = x  <=>  m = 1/ln(1 + 1/x)
+    const double xmean = (double)target_transcripts / num_genes - 1.0;
+    const double extra = xmean > 0 ? 1.0 / std::log(1.0 + 1.0 / xmean) : 0.0;
     uint64_t pos = 0;
     auto push = [&](uint32_t b) {
         if ((pos & 31) == 0) x.packed.push_back(0);

@@ -55,6 +55,7 @@ def oracle_lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_last_batch_seconds.restype = C.c_double
         L.oracle_lookup_kmer.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         _oracle_lib = L
     return _oracle_lib
@@ -126,6 +127,7 @@ class Oracle:
         rc = oracle_lib().oracle_map_batch_tiles(self._h, tiles.ctypes.data, wpr, lens.ctypes.data, n, allowed, nthreads, res.ctypes.data,
                                                  coff.ctypes.data, C.byref(ids), C.byref(ctr))
         assert rc == 0, rc
+        self.last_seconds = oracle_lib().oracle_last_batch_seconds()
         total = int(coff[-1])
         out = np.frombuffer((C.c_uint32 * max(total, 1)).from_address(ids.value), np.uint32)[:total].copy()
         oracle_lib().oracle_free(ids)
