@@ -1,5 +1,4 @@
-"""Build recipes: the product library (hipcc, gfx950), and — test infrastructure only — the CPU oracle and the
-host lane emulator. Everything is built in-tree so that the .so files travel with the repository snapshot."""
+"""Build recipe of the product library (hipcc, gfx950), in-tree so that the .so travels with the repository snapshot."""
 from __future__ import annotations
 
 import os
@@ -12,8 +11,6 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 
 PRODUCT_SO = PKG / "libpseudoaligner_amd.so"
-ORACLE_SO = ROOT / "oracle" / "_build" / "libpa_oracle.so"
-EMU_SO = ROOT / "tests" / "emu" / "_build" / "libpa_emu.so"
 
 HOST_SOURCES = ["host_index.cpp", "dbg_build.cpp", "device_flatten.cpp", "synth.cpp", "fastq.cpp"]
 HIP_SOURCES = ["kernels.hip", "device_index.hip"]
@@ -51,31 +48,6 @@ def build_product(force: bool = False) -> Path:
     return PRODUCT_SO
 
 
-def build_oracle(force: bool = False) -> Path:
-    """gcc: the plain-C restatement of the reference path (checker only)."""
-    src = ROOT / "oracle" / "pa_oracle.c"
-    if force or _stale(ORACLE_SO, [src, ROOT / "oracle" / "pa_oracle.h"]):
-        ORACLE_SO.parent.mkdir(parents=True, exist_ok=True)
-        _run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-pthread", "-Wall", str(src), "-o", str(ORACLE_SO)])
-    return ORACLE_SO
-
-
-def build_emu(force: bool = False) -> Path:
-    """g++: host emulation of one kernel lane (checker for the CPU-only test tier)."""
-    srcs = [ROOT / "tests" / "emu" / "emu_map.cpp"] + [CSRC / s for s in ("host_index.cpp", "dbg_build.cpp", "device_flatten.cpp")]
-    deps = srcs + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
-    if force or _stale(EMU_SO, deps):
-        EMU_SO.parent.mkdir(parents=True, exist_ok=True)
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-function"]
-             + [str(s) for s in srcs] + ["-o", str(EMU_SO)])
-    return EMU_SO
-
-
-def build_all(force: bool = False):
-    return build_product(force), build_oracle(force), build_emu(force)
-
-
 if __name__ == "__main__":
     import sys
-    for p in build_all("--force" in sys.argv):
-        print(p)
+    print(build_product("--force" in sys.argv))

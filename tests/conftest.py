@@ -17,7 +17,7 @@ def pytest_configure(config):
 def built():
     """Product library + checkers built in-tree (hipcc cross-compiles gfx950 without a GPU)."""
     import helpers
-    helpers._build.build_all()
+    helpers.build_all()
     return helpers
 
 

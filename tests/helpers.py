@@ -17,6 +17,23 @@ if str(ROOT) not in sys.path:
 pa = importlib.import_module("rust-pseudoaligner_amd")
 _build = importlib.import_module("rust-pseudoaligner_amd._build")
 
+
+def _load_recipe(path, name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, str(path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_oracle_build = _load_recipe(ROOT / "oracle" / "build.py", "pa_oracle_build")
+_emu_build = _load_recipe(ROOT / "tests" / "emu" / "build.py", "pa_emu_build")
+
+
+def build_all(force: bool = False):
+    """product (hipcc, gfx950) + the two checkers (gcc / g++)"""
+    return _build.build_product(force), _oracle_build.build_oracle(force), _emu_build.build_emu(force)
+
 GOLDEN = ROOT / "tests" / "golden"
 FASTA = GOLDEN / "gencode_small.fa"
 FASTQ = GOLDEN / "small.fq"
@@ -40,7 +57,7 @@ _emu_lib = None
 def oracle_lib():
     global _oracle_lib
     if _oracle_lib is None:
-        so = _build.build_oracle()
+        so = _oracle_build.build_oracle()
         L = C.CDLL(str(so))
         L.oracle_index_new.restype = C.c_void_p
         L.oracle_index_new.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -64,7 +81,7 @@ def oracle_lib():
 def emu_lib():
     global _emu_lib
     if _emu_lib is None:
-        so = _build.build_emu()
+        so = _emu_build.build_emu()
         L = C.CDLL(str(so))
         L.emu_index_new.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
         L.emu_index_free.argtypes = [C.c_void_p]
@@ -256,3 +273,23 @@ def assert_same_as_oracle(got_results, got_coff, got_ids, o_res, o_coff, o_ids, 
         what, len(bad), bad[0], (mapped[bad[0]], got_results[bad[0]]), o_res[bad[0]])
     assert np.array_equal(got_coff, o_coff), what + ": class offsets differ"
     assert np.array_equal(got_ids, o_ids), what + ": class ids differ"
+
+
+def counts_reference(results, coff, cids, host_index):
+    """Checker for the class-count table (pa_counts_*): counts[c] = reads whose class equals index class c, then
+    [novel non-empty, mapped-but-empty, unmapped]."""
+    a = host_index.arrays()
+    nc = a["num_classes"]
+    off = a["ec_offset"].astype(np.int64)
+    table = {tuple(a["ec_ids"][off[c]:off[c + 1]].tolist()): c for c in range(nc)}
+    counts = np.zeros(nc + 3, np.int64)
+    mapped = (results["mismatches"] >> 31).astype(bool) if "mapped" not in results.dtype.names else results["mapped"].astype(bool)
+    for i in range(len(results)):
+        if not mapped[i]:
+            counts[nc + 2] += 1
+        elif results["class_len"][i] == 0:
+            counts[nc + 1] += 1
+        else:
+            c = table.get(tuple(cids[int(coff[i]):int(coff[i + 1])].tolist()))
+            counts[nc if c is None else c] += 1
+    return counts

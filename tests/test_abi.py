@@ -1,0 +1,94 @@
+"""The C-ABI library loads, exports every symbol include/pseudoaligner_amd.h declares, and its host-side entry points
+behave (no GPU compute here)."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+
+pa = helpers.pa
+
+
+def declared_symbols():
+    text = (helpers.ROOT / "include" / "pseudoaligner_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(built):
+    names = declared_symbols()
+    assert len(names) > 40
+    lib = C.CDLL(str(pa._ffi.library_path()))
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+    assert set(names) == set(pa._ffi.SIGNATURES), set(names) ^ set(pa._ffi.SIGNATURES)
+    assert pa.lib().pa_abi_version() == 1
+
+
+def test_product_never_references_the_oracle():
+    """the oracle is test infrastructure: nothing under the package may mention it"""
+    pkg = helpers.ROOT / "rust-pseudoaligner_amd"
+    for f in list(pkg.glob("*.py")) + list((pkg / "csrc").glob("*")):
+        text = f.read_text(errors="ignore")
+        assert "pa_oracle" not in text and "oracle/" not in text and "libpa_emu" not in text, f
+
+
+def test_no_gpu_means_loud_failure(built, small_index):
+    if pa.lib().pa_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pa.PaError) as e:
+        pa.Pseudoaligner(small_index(20))
+    assert e.value.code == pa._ffi.PA_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+    p = C.c_void_p()
+    assert pa.lib().pa_device_malloc(0, 1024, C.byref(p)) == pa._ffi.PA_ERR_NO_DEVICE
+
+
+def test_encode_reads_host_layout(built):
+    reads = ["ACGT", "", "TTTTGGGGCCCCAAAATTTTGGGGCCCCAAAATTTTG", "acgtn"]   # 4, 0, 37 (two words), lower case + N
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    assert wpr == 2 and lens.tolist() == [4, 0, 37, 5] and len(tiles) == 128
+    t = tiles.reshape(1, 2, 64)
+    assert int(t[0, 0, 0]) == 0b11100100                       # A=0 C=1 G=2 T=3, base j at bits 2j
+    assert int(t[0, 0, 1]) == 0 and int(t[0, 1, 2]) == 0b10_11_11_11_11   # TTTTG: bases 32..36
+    assert int(t[0, 0, 3]) == 0b00_11_10_01_00                 # n -> A
+    assert pa.unpack_tiles(tiles, lens, wpr) == ["ACGT", "", reads[2], "ACGTA"]
+    assert helpers.pack_read("ACGT")[0] == 0b11100100
+
+
+def test_simulator_is_a_pure_function_of_seed_and_index(built, small_index):
+    tx = pa.Txome.from_host_index(small_index(24))
+    a, la = tx.simulate_host(100, 1, 1000)
+    b, lb = tx.simulate_host(100, 1, 300, first_read=700)
+    ra, rb = pa.unpack_tiles(a, la, 4), pa.unpack_tiles(b, lb, 4)
+    assert ra[700:] == rb                                      # sharding by read index is rank-count independent
+    c, _ = tx.simulate_host(100, 2, 1000)
+    assert pa.unpack_tiles(c, la, 4) != ra
+    _, seqs = helpers.read_fasta()
+    joined = set()
+    for r in ra[:50]:
+        assert any(r in s for s in seqs)                       # error-free reads are substrings of transcripts
+    e, _ = tx.simulate_host(100, 1, 1000, sub_rate_ppm=10000)
+    diffs = sum(x != y for r1, r2 in zip(ra, pa.unpack_tiles(e, la, 4)) for x, y in zip(r1, r2))
+    assert 700 < diffs < 1300                                  # ~1 % of 100 000 bases
+    with pytest.raises(pa.PaError):
+        tx.simulate_host(100000, 1, 10)                        # no transcript that long
+
+
+def test_synthetic_transcriptome_shape(built):
+    tx = pa.Txome.synthesize(2000, 7000, 7)
+    packed, tx_start = tx.arrays()
+    lens = np.diff(tx_start.astype(np.int64))
+    assert 6000 < len(lens) < 8000 and 1200 < lens.mean() < 1800 and lens.min() >= 60
+    tx2 = pa.Txome.synthesize(2000, 7000, 7)
+    assert np.array_equal(tx2.arrays()[0], packed)
+
+
+def test_counts_reference_definition(small_index):
+    host = small_index(24)
+    _, seqs = helpers.read_fastq()
+    res, coff, cids, _ = helpers.Oracle(host).map_reads(seqs[:2000], 2, 2)
+    counts = helpers.counts_reference(res, coff, cids, host)
+    nc = host.arrays()["num_classes"]
+    assert counts.sum() == 2000 and counts[nc + 2] == int((res["mapped"] == 0).sum())

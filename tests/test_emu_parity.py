@@ -1,0 +1,104 @@
+"""CPU tier of the parity tests: the product's per-lane state machine (lane_steps.hpp) and GPU index layout
+(device_flatten.cpp), executed on the host by tests/emu, against the oracle — bit exact."""
+import numpy as np
+import pytest
+
+import helpers
+
+pa = helpers.pa
+
+
+def check(host, tiles, lens, wpr, allowed=2, col_cap=8, nodes=False):
+    o_res, o_coff, o_ids, ctr = helpers.Oracle(host).map_tiles(tiles, lens, wpr, allowed, 4)
+    r = helpers.Emu(host).map_tiles(tiles, lens, wpr, allowed, col_cap, want_nodes=nodes)
+    helpers.assert_same_as_oracle(r["results"], r["coff"], r["ids"], o_res, o_coff, o_ids, "emu")
+    return r, (o_res, o_coff, o_ids, ctr)
+
+
+@pytest.mark.parametrize("k", [20, 24, 31])
+def test_small_fq(small_index, k):
+    _, seqs = helpers.read_fastq()
+    tiles, lens, wpr = pa.encode_reads_host(seqs)
+    check(small_index(k), tiles, lens, wpr)
+
+
+@pytest.mark.parametrize("k,read_len,ppm,allowed", [(24, 100, 0, 2), (24, 150, 10000, 2), (31, 150, 10000, 2), (20, 75, 50000, 2),
+                                                    (31, 150, 30000, 0), (24, 150, 30000, 1), (24, 150, 60000, 3), (32, 150, 10000, 2),
+                                                    (8, 40, 20000, 2)])
+def test_simulated_reads(small_index, built, k, read_len, ppm, allowed):
+    host = small_index(k) if k in (20, 24, 31) else pa.build_index(str(helpers.FASTA), k, 8)
+    tx = pa.Txome.from_host_index(host)
+    tiles, lens = tx.simulate_host(read_len, 4, 30000, ppm)
+    r, (o_res, _, _, ctr) = check(host, tiles, lens, pa.lib().pa_words_per_read(read_len), allowed)
+    if ppm:
+        assert ctr["reseeks"] > 0 and (k < 20 or ctr["left_extensions"] > 0)   # the error paths were exercised
+    else:
+        assert np.all(o_res["coverage"] == read_len)
+
+
+def test_ragged_short_and_unmappable_reads(small_index):
+    host = small_index(24)
+    _, seqs = helpers.read_fastq()
+    rng = np.random.RandomState(3)
+    reads = [s[: rng.randint(0, 61)] for s in seqs[:600]]                       # 0..60 bases, many shorter than k
+    reads += ["".join(rng.choice(list("ACGT"), rng.randint(24, 200))) for _ in range(300)]   # random: unmappable
+    reads += ["A" * 80, "ACGT" * 30, "N" * 50, seqs[0][:30] + "NNNN" + seqs[0][34:], seqs[0].lower()]
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    r, (o_res, _, _, _) = check(host, tiles, lens, wpr)
+    assert np.all(o_res["mapped"][np.asarray(lens) < 24] == 0)                  # L < K -> None (:82-84)
+    assert o_res["mapped"][-1] == 1                                             # lower case maps like upper case
+
+
+def test_colour_spill_and_node_traces(small_index):
+    """col_cap = 1 forces the distinct-colour list through the HBM spill path; node traces equal map_read_to_nodes."""
+    host = small_index(20)
+    ids, seqs = helpers.read_fastq()
+    tiles, lens, wpr = pa.encode_reads_host(seqs)
+    r, _ = check(host, tiles, lens, wpr, 2, col_cap=1, nodes=True)
+    assert r["steps"][3] > 0
+    o = helpers.Oracle(host)
+    a = host.arrays()
+    for i in list(range(0, 400)) + [885, 1229, 153, 377]:
+        rc, _, _, _, nodes = o.map_read(seqs[i])
+        got = r["nodes"][i][: r["nodes_len"][i]].tolist()
+        assert got == (nodes if rc else []), i
+
+
+def test_long_reads_cross_many_nodes(small_index):
+    host = small_index(31)
+    _, seqs = helpers.read_fasta()
+    reads = [s[:2000] for s in seqs if len(s) >= 300][:200]
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    check(host, tiles, lens, wpr, 2, col_cap=4)
+
+
+def test_golden_synthetic_error_reads(small_index):
+    lines = (helpers.GOLDEN / "synth_err_k31.tsv").read_text().splitlines()
+    reads = [l.split("\t")[0] for l in lines]
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    r = helpers.Emu(small_index(31)).map_tiles(tiles, lens, wpr)
+    res = r["results"]
+    got = helpers.result_lines(reads, res["mismatches"] >> 31, res["coverage"], res["mismatches"] & 0x7FFFFFFF, r["coff"], r["ids"])
+    assert [g.rstrip("\n") for g in got] == lines
+
+
+def test_device_dictionary_layout(small_index):
+    info = helpers.Emu(small_index(24)).info()
+    assert info["num_kmers"] == 1165762
+    assert info["nbuckets"] * 4 >= 2 * info["num_kmers"]   # load factor <= 0.5
+
+
+def test_flatten_rejects_inconsistent_graphs(small_index):
+    """a k-mer present in two nodes / a dangling extension must be refused at index creation."""
+    host = small_index(20)
+    a = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in host.arrays().items()}
+    flat = host.flat()
+    exts = a["node_exts"].copy()
+    # set a right-extension bit that has no neighbour: pick a node and a base not in its exts
+    n = int(np.flatnonzero((exts & 15) == 0)[0]) if np.any((exts & 15) == 0) else 0
+    exts[n] |= 1 << int(np.flatnonzero([(exts[n] >> b) & 1 == 0 for b in range(4)])[0])
+    flat.node_exts = exts.ctypes.data
+    import ctypes as C
+    h = C.c_void_p()
+    assert helpers.emu_lib().emu_index_new(C.byref(flat), 2, C.byref(h)) != 0
+    assert b"missing link" in helpers.emu_lib().emu_last_error()

@@ -1,0 +1,241 @@
+"""`-m gpu` tier: the HIP path (through the C ABI) against the oracle on the same inputs — bit exact — plus the
+committed golden fixtures and size-independent properties at BASELINE.json's batch sizes."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+pa = helpers.pa
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aligners(small_index):
+    cache = {}
+
+    def get(k):
+        if k not in cache:
+            if pa.lib().pa_device_count() < 1:
+                raise RuntimeError("the gpu tier needs a GPU and the HIP library: %s" % pa.lib().pa_last_error().decode())
+            cache[k] = pa.Pseudoaligner(small_index(k), 0)
+        return cache[k]
+    return get
+
+
+def gpu_vs_oracle(aligner, reads, allowed=2, what=""):
+    res, coff, cids = aligner.map_batch(reads, allowed)
+    o_res, o_coff, o_ids, ctr = helpers.Oracle(aligner.host).map_reads(reads, allowed, 8)
+    helpers.assert_same_as_oracle(res, coff, cids, o_res, o_coff, o_ids, what)
+    return res, coff, cids, ctr
+
+
+@pytest.mark.parametrize("k", [20, 24, 31])
+def test_small_fq_vs_oracle_and_fixture(aligners, k):
+    ids, seqs = helpers.read_fastq()
+    res, coff, cids, _ = gpu_vs_oracle(aligners(k), seqs, 2, "small.fq K=%d" % k)
+    lines = helpers.result_lines(ids, res["mismatches"] >> 31, res["coverage"], res["mismatches"] & 0x7FFFFFFF, coff, cids)
+    assert "".join(lines) == (helpers.GOLDEN / ("small_fq_k%d.tsv" % k)).read_text()
+
+
+def test_reference_literals_through_map_read(aligners):
+    a = aligners(20)
+    ex1 = "GGCTGTCAACCAGTCCATAGGCAGGGCCATCAGGCACCAAAGGGATTCTGCCAGCATAGT"          # src/build_index.rs:429-434
+    snp = "GGCTGTCAACCAGTCCATAGGCGGGGCCATCAGGCACCAAAGGGATTCTGCCAGCATAGT"          # :436-441
+    assert a.map_read(ex1) == ([1, 30], len(ex1))
+    assert a.map_read(snp) == ([1, 30], len(snp))
+    assert a.map_read_with_mismatch(snp, 2) == ([1, 30], 60, 1)
+    assert a.map_read("ACGT") is None                                           # shorter than k (:82-84)
+    assert a.map_read("ACGTTGCA" * 10) is None                                  # no k-mer in the graph
+    nodes, cov = a.map_read_to_nodes(ex1)
+    rc, _, ocov, _, onodes = helpers.Oracle(a.host).map_read(ex1)
+    assert (nodes, cov) == (onodes, ocov)
+
+
+@pytest.mark.parametrize("k,read_len,ppm,allowed,n", [(24, 100, 0, 2, 300000), (24, 150, 10000, 2, 300000), (31, 150, 10000, 2, 300000),
+                                                      (20, 75, 50000, 2, 100000), (31, 150, 30000, 0, 100000), (24, 150, 30000, 1, 100000),
+                                                      (24, 150, 60000, 3, 100000)])
+def test_simulated_reads_device_batches(aligners, k, read_len, ppm, allowed, n):
+    """device-resident API: reads simulated on the GPU, mapped, compared with the oracle on the host-simulated twins"""
+    import torch
+    a = aligners(k)
+    tx = pa.Txome.from_host_index(a.host)
+    wpr = pa.lib().pa_words_per_read(read_len)
+    dev = torch.device("cuda", 0)
+    d_tiles = torch.zeros(pa.lib().pa_tiles_words(n, wpr), dtype=torch.int64, device=dev)
+    d_lens = torch.zeros(n, dtype=torch.int32, device=dev)
+    tx.simulate_device(read_len, 4, n, d_tiles.data_ptr(), d_lens.data_ptr(), ppm, 0, wpr)
+    h_tiles, h_lens = tx.simulate_host(read_len, 4, n, ppm, 0, wpr)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_tiles.cpu().numpy().view(np.uint64), h_tiles) and np.array_equal(d_lens.cpu().numpy().view(np.uint32), h_lens)
+    cap = a.arena_hint(n)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_col = torch.zeros(n, dtype=torch.int32, device=dev)
+    a.map_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, allowed, d_col.data_ptr())
+    used, _ = a.map_finish()
+    res = d_res.cpu().numpy().view(pa.RESULT_DTYPE)
+    coff, cids = pa.gather_classes(res, d_arena[: max(used, 1)].cpu().numpy().view(np.uint32))
+    o_res, o_coff, o_ids, ctr = helpers.Oracle(a.host).map_tiles(h_tiles, h_lens, wpr, allowed, 8)
+    helpers.assert_same_as_oracle(res, coff, cids, o_res, o_coff, o_ids, "simulated k=%d" % k)
+    # the count kernel against its numpy definition
+    d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    a.counts_accumulate_device(d_res.data_ptr(), d_arena.data_ptr(), d_col.data_ptr(), n, d_counts.data_ptr())
+    torch.cuda.synchronize()
+    sub = slice(0, 20000)
+    want_sub = helpers.counts_reference(o_res[sub], o_coff[: 20001], o_ids, a.host)
+    d_counts2 = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    a.counts_accumulate_device(d_res.data_ptr(), d_arena.data_ptr(), d_col.data_ptr(), 20000, d_counts2.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts2.cpu().numpy(), want_sub)
+    assert int(d_counts.sum().item()) == n
+    # without the colour hint every class goes through the content lookup: same table
+    d_counts3 = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    a.counts_accumulate_device(d_res.data_ptr(), d_arena.data_ptr(), 0, 20000, d_counts3.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts3.cpu().numpy(), want_sub)
+
+
+def test_ragged_empty_short_and_odd_reads(aligners):
+    a = aligners(24)
+    _, seqs = helpers.read_fastq()
+    rng = np.random.RandomState(3)
+    reads = [s[: rng.randint(0, 61)] for s in seqs[:600]]
+    reads += ["".join(rng.choice(list("ACGT"), rng.randint(24, 200))) for _ in range(300)]
+    reads += ["A" * 80, "ACGT" * 30, "N" * 50, seqs[0][:30] + "NNNN" + seqs[0][34:], seqs[0].lower(), ""]
+    res, coff, cids, _ = gpu_vs_oracle(a, reads, 2, "ragged")
+    lens = np.array([len(r) for r in reads])
+    assert np.all((res["mismatches"] >> 31)[lens < 24] == 0)
+    r0, c0, i0 = a.map_batch([])                                                 # empty batch
+    assert len(r0) == 0 and c0.tolist() == [0] and len(i0) == 0
+    one = a.map_batch([seqs[0]])                                                 # batch of one
+    assert one[0]["coverage"][0] == 60
+
+
+def test_long_reads_and_max_length(aligners):
+    a = aligners(31)
+    _, seqs = helpers.read_fasta()
+    reads = [s[:2048] for s in seqs if len(s) >= 300][:300] + [s[:600] for s in seqs if len(s) >= 600][:300]
+    gpu_vs_oracle(a, reads, 2, "long reads")
+    with pytest.raises(pa.PaError):
+        a.map_batch(["A" * 2049])                                                # beyond PA_MAX_READ_LEN
+
+
+def test_self_mapping_of_transcripts(aligners):
+    """validate_dbg part 2 (src/build_index.rs:300-367) through the GPU for every transcript that fits a read tile"""
+    a = aligners(20)
+    _, seqs = helpers.read_fasta()
+    idx = [i for i, s in enumerate(seqs) if 20 <= len(s) <= 2048]
+    res, coff, cids = a.map_batch([seqs[i] for i in idx])
+    for j, i in enumerate(idx):
+        assert res["mismatches"][j] >> 31 == 1 and res["coverage"][j] == len(seqs[i])
+        cls = cids[int(coff[j]):int(coff[j + 1])].tolist()
+        assert (i in cls) if len(cls) > 1 else cls == [i]
+
+
+def test_node_traces_match_map_read_to_nodes(aligners):
+    a = aligners(20)
+    _, seqs = helpers.read_fastq()
+    sel = seqs[:1500]
+    res, nodes, nlen = a.map_batch_nodes(sel)
+    o = helpers.Oracle(a.host)
+    for i, s in enumerate(sel):
+        rc, _, cov, _, onodes = o.map_read(s)
+        assert nodes[i][: nlen[i]].tolist() == (onodes if rc else []) and res["coverage"][i] == cov
+
+
+def test_arena_overflow_is_reported_not_silent(aligners):
+    import torch
+    a = aligners(24)
+    tx = pa.Txome.from_host_index(a.host)
+    n, wpr = 50000, 4
+    h_tiles, h_lens = tx.simulate_host(100, 9, n)
+    dev = torch.device("cuda", 0)
+    d_tiles = torch.from_numpy(h_tiles.view(np.int64)).to(dev)
+    d_lens = torch.from_numpy(h_lens.view(np.int32)).to(dev)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(1000, dtype=torch.int32, device=dev)
+    a.map_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), 1000)
+    with pytest.raises(pa.PaError) as e:
+        a.map_finish()
+    assert e.value.code == pa._ffi.PA_ERR_ARENA_FULL
+
+
+def test_encode_kernel_equals_host_packing(aligners):
+    import torch
+    a = aligners(24)
+    _, seqs = helpers.read_fastq()
+    reads = seqs[:1000] + ["acgtnNRY" * 9, "", "T"]
+    data, offsets = pa.concat_reads(reads)
+    h_tiles, h_lens, wpr = pa.encode_reads_host((data, offsets))
+    dev = torch.device("cuda", 0)
+    d_ascii = torch.from_numpy(data.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    d_tiles = torch.zeros(len(h_tiles), dtype=torch.int64, device=dev)
+    d_lens = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+    a.encode_reads_device(d_ascii.data_ptr(), d_off.data_ptr(), len(reads), wpr, d_tiles.data_ptr(), d_lens.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_tiles.cpu().numpy().view(np.uint64), h_tiles) and np.array_equal(d_lens.cpu().numpy().view(np.uint32), h_lens)
+
+
+def test_process_reads_output_format(aligners, tmp_path):
+    """process_reads (src/pseudoaligner.rs:420-514): Rust Debug tuples, flag rule of :455, input order"""
+    a = aligners(20)
+    out = tmp_path / "out.txt"
+    n, flagged = pa.process_reads(str(helpers.FASTQ), a, str(out), 3)
+    ids, seqs = helpers.read_fastq()
+    res, coff, cids, _ = helpers.Oracle(a.host).map_reads(seqs, 2, 4)
+    want = []
+    for i, rid in enumerate(ids):
+        cl = cids[int(coff[i]):int(coff[i + 1])].tolist()
+        flag = bool(res["mapped"][i]) and res["coverage"][i] >= 32 and not cl
+        want.append('(%s, "%s", [%s], %d)' % ("true" if flag else "false", rid, ", ".join(map(str, cl)), res["coverage"][i] if res["mapped"][i] else 0))
+    got = out.read_text().splitlines()
+    assert n == len(ids) == len(got) and got == want
+    assert got[0] == '(false, "gencode_small_line15", [0, 1, 30], 60)'
+    assert flagged == sum(1 for w in want if w.startswith("(true")) == 12        # 12 flagged at K=20
+    with pytest.raises(pa.PaError):
+        pa.process_reads(str(tmp_path / "missing.fq"), a, str(out))
+    bad = tmp_path / "bad.fq"
+    bad.write_text("@r1\nACGT\n+\nIIII\nnot a record\n")
+    with pytest.raises(pa.PaError):
+        pa.process_reads(str(bad), a, str(out))
+
+
+def test_full_size_batch_properties(aligners):
+    """BASELINE.json configs[1] size (10 M x 100 bp on gencode_small, K=24) through size-independent properties:
+    every error-free read maps over its full length with 0 mismatches and a non-empty class; the count table adds up;
+    a re-run is idempotent; the first 200 k reads are bit-exact against the oracle."""
+    import torch
+    a = aligners(24)
+    tx = pa.Txome.from_host_index(a.host)
+    n, wpr = 10_000_000, 4
+    dev = torch.device("cuda", 0)
+    d_tiles = torch.zeros(pa.lib().pa_tiles_words(n, wpr), dtype=torch.int64, device=dev)
+    d_lens = torch.zeros(n, dtype=torch.int32, device=dev)
+    tx.simulate_device(100, 1, n, d_tiles.data_ptr(), d_lens.data_ptr(), 0, 0, wpr)
+    cap = a.arena_hint(n)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_col = torch.zeros(n, dtype=torch.int32, device=dev)
+    a.map_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, 2, d_col.data_ptr())
+    used, _ = a.map_finish()
+    res = d_res.view(n, 4)
+    assert bool((res[:, 0] == 100).all()) and bool((res[:, 1] == -2**31).all()) and bool((res[:, 3] > 0).all())
+    d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    a.counts_accumulate_device(d_res.data_ptr(), d_arena.data_ptr(), d_col.data_ptr(), n, d_counts.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_counts.sum().item()) == n and int(d_counts[-3:].sum().item()) == int(d_counts[-3].item())
+    checksum1 = (int(res[:, 3].sum().item()), int(res[:, 0].sum().item()))
+    # checksum of the class ids, independent of arena placement
+    host_res = d_res.cpu().numpy().view(pa.RESULT_DTYPE)
+    sample = host_res[:200000]
+    coff, cids = pa.gather_classes(sample, d_arena[: max(used, 1)].cpu().numpy().view(np.uint32))
+    h_tiles, h_lens = tx.simulate_host(100, 1, 200000, 0, 0, wpr)
+    o_res, o_coff, o_ids, _ = helpers.Oracle(a.host).map_tiles(h_tiles, h_lens, wpr, 2, 8)
+    helpers.assert_same_as_oracle(sample, coff, cids, o_res, o_coff, o_ids, "10M batch sample")
+    a.map_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, 2, d_col.data_ptr())
+    a.map_finish()
+    assert (int(res[:, 3].sum().item()), int(res[:, 0].sum().item())) == checksum1

@@ -1,0 +1,186 @@
+"""CPU index construction (dbg_build.cpp) against a naive Python builder with the reference's semantics
+(src/build_index.rs:127-179, src/equiv_classes.rs:62-91), determinism, and the container / flat-index round trips."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+
+pa = helpers.pa
+
+
+def pack(seqs):
+    tx_start = np.zeros(len(seqs) + 1, np.uint64)
+    tx_start[1:] = np.cumsum([len(s) for s in seqs])
+    words = np.zeros(int(tx_start[-1]) // 32 + 3, np.uint64)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    pos = 0
+    for s in seqs:
+        for ch in s:
+            words[pos >> 5] |= np.uint64(code[ch]) << np.uint64(2 * (pos & 31))
+            pos += 1
+    return words, tx_start
+
+
+def naive_graph(seqs, k):
+    """stranded coloured compacted DBG: nodes = maximal paths of k-mers that are each other's unique extension and share
+    a colour. Returns ({(sequence, colour tuple, left exts, right exts)} for paths with a start, set of k-mers on pure cycles)."""
+    colour, lext, rext = {}, {}, {}
+    for i, s in enumerate(seqs):
+        for p in range(len(s) - k + 1):
+            km = s[p:p + k]
+            colour.setdefault(km, set()).add(i)
+            lext.setdefault(km, set())
+            rext.setdefault(km, set())
+            if p > 0:
+                lext[km].add(s[p - 1])
+            if p + k < len(s):
+                rext[km].add(s[p + k])
+    colour = {km: tuple(sorted(v)) for km, v in colour.items()}
+
+    def right_join(x):
+        if len(rext[x]) != 1:
+            return None
+        y = x[1:] + next(iter(rext[x]))
+        if y == x or len(lext[y]) != 1 or colour[y] != colour[x]:
+            return None
+        return y
+
+    def left_joinable(x):
+        if len(lext[x]) != 1:
+            return False
+        z = next(iter(lext[x])) + x[:-1]
+        return z != x and len(rext[z]) == 1 and colour[z] == colour[x]
+
+    nodes, seen = set(), set()
+    for x in colour:
+        if left_joinable(x):
+            continue
+        path, cur = x, x
+        seen.add(x)
+        while True:
+            y = right_join(cur)
+            if y is None or y in seen:
+                break
+            seen.add(y)
+            path += y[-1]
+            cur = y
+        nodes.add((path, colour[x], "".join(sorted(lext[x])), "".join(sorted(rext[cur]))))
+    return nodes, set(colour) - seen
+
+
+def graph_of(host):
+    a = host.arrays()
+    k = a["k"]
+    nodes = []
+    for n in range(a["num_nodes"]):
+        s, l = int(a["node_start"][n]), int(a["node_len"][n])
+        pos = np.arange(s, s + l)
+        codes = (a["node_seq"][pos >> 5] >> ((pos & 31) * 2).astype(np.uint64)) & np.uint64(3)
+        seq = "".join("ACGT"[int(c)] for c in codes)
+        c = int(a["node_colour"][n])
+        cl = tuple(a["ec_ids"][int(a["ec_offset"][c]):int(a["ec_offset"][c + 1])].tolist())
+        e = int(a["node_exts"][n])
+        nodes.append((seq, cl, "".join("ACGT"[b] for b in range(4) if e >> (4 + b) & 1), "".join("ACGT"[b] for b in range(4) if e >> b & 1)))
+    return k, nodes
+
+
+def random_txome(rng, n_tx, alphabet="ACGT"):
+    segs = ["".join(rng.choice(list(alphabet), rng.randint(5, 60))) for _ in range(12)]
+    out = []
+    for _ in range(n_tx):
+        out.append("".join(segs[j] for j in rng.choice(len(segs), rng.randint(1, 6))))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_builder_matches_naive_graph(built, seed):
+    rng = np.random.RandomState(seed)
+    k = int(rng.choice([8, 9, 12, 16]))
+    seqs = random_txome(rng, rng.randint(2, 25), "ACGT" if seed % 3 else "AC")
+    words, tx_start = pack(seqs)
+    host = pa.HostIndex.build_packed(words, tx_start, k, 1 + seed % 4)
+    _, got = graph_of(host)
+    want, cyc = naive_graph(seqs, k)
+    got_set = set(got)
+    assert len(got_set) == len(got)
+    cyc_nodes = {g for g in got_set if g[0][:k] in cyc}
+    assert got_set - cyc_nodes == want
+    kmers_in_cyc_nodes = {g[0][p:p + k] for g in cyc_nodes for p in range(len(g[0]) - k + 1)}
+    assert kmers_in_cyc_nodes == cyc
+    # every class is referenced, sorted, non-empty
+    a = host.arrays()
+    assert set(a["node_colour"].tolist()) == set(range(a["num_classes"]))
+
+
+def test_hand_made_graph(built):
+    #   tx0 = P + M + Q,  tx1 = R + M + S  (shared middle M): M is one node with colour [0,1] and two exts on both sides
+    P, M, Q, R, S = "ACGTACGGTTCA", "GGATCCTTAGCAAT", "TTTGACCGTA", "CCCATTGAGG", "AAGTCGGCAT"
+    seqs = [P + M + Q, R + M + S]
+    k = 8
+    words, tx_start = pack(seqs)
+    _, nodes = graph_of(pa.HostIndex.build_packed(words, tx_start, k, 2))
+    by_colour = {}
+    for seq, cl, le, re in nodes:
+        by_colour.setdefault(cl, []).append((seq, le, re))
+    shared = by_colour[(0, 1)]
+    assert len(shared) == 1
+    seq, le, re = shared[0]
+    assert seq == M and sorted(le) == sorted({P[-1], R[-1]}) and sorted(re) == sorted({Q[0], S[0]})
+    assert sorted(s for s, _, _ in by_colour[(0,)]) == sorted([(P + M)[: len(P) + k - 1], (M + Q)[len(M) - k + 1:]])
+    assert sorted(s for s, _, _ in by_colour[(1,)]) == sorted([(R + M)[: len(R) + k - 1], (M + S)[len(M) - k + 1:]])
+
+
+def test_short_transcripts_contribute_nothing(built):
+    seqs = ["ACGTACG", "ACGTACGTTGCAAGGCT"]   # first is shorter than k = 8 (src/build_index.rs:134,148-150)
+    words, tx_start = pack(seqs)
+    host = pa.HostIndex.build_packed(words, tx_start, 8, 1)
+    a = host.arrays()
+    assert a["num_transcripts"] == 2 and a["num_classes"] == 1 and a["ec_ids"].tolist() == [1]
+
+
+def test_builder_is_deterministic_across_thread_counts(built):
+    i1 = pa.HostIndex.build_fasta(str(helpers.FASTA), 24, 1)
+    i8 = pa.HostIndex.build_fasta(str(helpers.FASTA), 24, 8)
+    h1, h8 = i1.arrays(), i8.arrays()
+    for key in ("node_seq", "node_start", "node_len", "node_exts", "node_colour", "ec_offset", "ec_ids"):
+        assert np.array_equal(h1[key], h8[key]), key
+    # gencode_small at K=24 -> 1 165 762 distinct 24-mers
+    assert int((h1["node_len"] - 23).sum()) == 1165762
+
+
+def test_container_and_flat_round_trip(built, small_index, tmp_path):
+    host = small_index(20)
+    path = tmp_path / "idx.bin"
+    host.save(str(path))
+    back = pa.HostIndex.load(str(path))
+    a, b = host.arrays(), back.arrays()
+    for key in a:
+        assert np.array_equal(a[key], b[key]), key
+    assert back.tx_names()[:3] == host.tx_names()[:3] == ["ENST00000456328.2", "ENST00000450305.2", "ENST00000488147.1"]
+    assert back.tx_genes()[0] == "ENSG00000223972.5"          # Gencode header format (src/utils.rs:126-134)
+    reimported = pa.HostIndex.from_flat(host.flat())
+    flat = reimported.arrays()
+    for key in a:
+        assert np.array_equal(a[key], flat[key]), key
+    path.write_bytes(b"not an index")
+    with pytest.raises(pa.PaError):
+        pa.HostIndex.load(str(path))
+    with pytest.raises(pa.PaError):
+        pa.HostIndex.load(str(tmp_path / "missing.bin"))
+
+
+def test_invalid_arguments_fail_loudly(built):
+    words, tx_start = pack(["ACGTACGTACGTACGT"])
+    for k in (0, 7, 33):
+        with pytest.raises(pa.PaError):
+            pa.HostIndex.build_packed(words, tx_start, k, 1)
+    with pytest.raises(pa.PaError):
+        pa.HostIndex.build_fasta("/nonexistent.fa", 20, 1)
+    tiny = pa.HostIndex.build_packed(words, tx_start, 8, 1)
+    flat = tiny.flat()
+    bad = np.array([3], np.uint32)          # colour out of range
+    flat.node_colour = bad.ctypes.data
+    with pytest.raises(pa.PaError):
+        pa.HostIndex.from_flat(flat)
