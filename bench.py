@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — reads/sec pseudoaligned on synthetic 150 bp reads (BASELINE.json metric).
 
-One step = one pass of the hot path (pa_map_batch_device + the class-count kernel) over one batch of reads that is
+One step = one pass of the hot path (pa_map_count_batch_device: mapping with the class-count table fused in) over one batch of reads that is
 already resident in HBM as 2-bit tiles. Workload (default "config3", BASELINE.json configs[2]): synthetic GENCODE-like
 transcriptome (58 k genes -> ~202 k transcripts, seed 7), K = 24, error-free 150 bp reads (seed 2); --steps x --batch
 reads per GPU (defaults 10 x 10 M = the config's 100 M reads at N = 1). Multi-GPU: one process per GPU, reads sharded
@@ -63,6 +63,7 @@ def main() -> None:
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-count", action="store_true", help="class counts in their own kernel instead of fused into the map kernel")
     ap.add_argument("--index-cache", default="", help="optional path to save/load the host index container")
     args = ap.parse_args()
 
@@ -157,11 +158,16 @@ def main() -> None:
         b = i % n_batches
         if timed_idx >= 0:
             pa.check(pa.lib().pa_event_record(ev[2 * timed_idx], stream or None))
-        aligner.map_batch_device(tiles[b].data_ptr(), lens[b].data_ptr(), B, wpr, results.data_ptr(), arena.data_ptr(), arena_cap,
-                                 2, colour.data_ptr(), stream)
+        if args.separate_count:
+            aligner.map_batch_device(tiles[b].data_ptr(), lens[b].data_ptr(), B, wpr, results.data_ptr(), arena.data_ptr(), arena_cap,
+                                     2, colour.data_ptr(), stream)
+        else:   # class-count table fused into the mapping kernel
+            aligner.map_count_batch_device(tiles[b].data_ptr(), lens[b].data_ptr(), B, wpr, results.data_ptr(), arena.data_ptr(),
+                                           arena_cap, counts.data_ptr(), 2, stream)
         if timed_idx >= 0:
             pa.check(pa.lib().pa_event_record(ev[2 * timed_idx + 1], stream or None))
-        aligner.counts_accumulate_device(results.data_ptr(), arena.data_ptr(), colour.data_ptr(), B, counts.data_ptr(), stream)
+        if args.separate_count:
+            aligner.counts_accumulate_device(results.data_ptr(), arena.data_ptr(), colour.data_ptr(), B, counts.data_ptr(), stream)
         try:
             return aligner.map_finish(stream)
         except pa.PaError as e:

@@ -162,6 +162,12 @@ int pa_encode_reads_host(const uint8_t* ascii, const uint64_t* offsets, uint64_t
 int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads,
                         uint32_t words_per_read, uint32_t allowed_mismatches, pa_read_result* d_results,
                         uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour, void* stream);
+/* Same launch with the class-count table fused in: d_counts[pa_counts_len(idx)] (u64, caller-owned so that it can be
+ * all-reduced with RCCL) is incremented once per read as pa_counts_accumulate_device would. On PA_ERR_ARENA_FULL the
+ * counts of that launch are still complete (they do not depend on the arena), the class ids are not. */
+int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads,
+                              uint32_t words_per_read, uint32_t allowed_mismatches, pa_read_result* d_results,
+                              uint32_t* d_arena, uint64_t arena_cap, uint64_t* d_counts, void* stream);
 /* Synchronise and report: PA_OK, or PA_ERR_ARENA_FULL with *arena_needed set (re-run with a larger arena). */
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed);
 /* arena capacity (u32 entries) that suffices for typical batches of n_reads; the exact need is data dependent */

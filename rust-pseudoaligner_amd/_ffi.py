@@ -64,6 +64,7 @@ SIGNATURES = {
     "pa_encode_reads_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp]),
     "pa_encode_reads_host": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "pa_map_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),
+    "pa_map_count_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),
     "pa_map_finish": (C.c_int, [vp, vp, u64p, u64p]),
     "pa_map_arena_hint": (C.c_uint64, [vp, C.c_uint64]),
     "pa_map_batch": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.POINTER(vp)]),

@@ -194,7 +194,7 @@ static int map_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t*
 
 static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads, uint32_t wpr,
                              uint32_t allowed, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour,
-                             uint32_t* d_nodes, uint32_t* d_nodes_len, hipStream_t stream) {
+                             uint64_t* d_counts, uint32_t* d_nodes, uint32_t* d_nodes_len, hipStream_t stream) {
     if (n_reads >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "at most 2^32-2 reads per batch");
     if (wpr == 0 || wpr > PA_MAX_READ_LEN / 32) return fail(PA_ERR_UNSUPPORTED, "words_per_read %u outside [1,%u]", wpr, PA_MAX_READ_LEN / 32);
     uint32_t grid = 0, col_cap = 0;
@@ -223,6 +223,9 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.spill = idx->spill.as<uint32_t>();
     p.spill_cap = spill_cap;
     p.col_cap = col_cap;
+    p.counts = reinterpret_cast<unsigned long long*>(d_counts);
+    p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
+    p.class_table_size = idx->class_table_size;
     p.trace = d_nodes ? idx->trace.as<uint32_t>() : nullptr;
     p.nodes_out = d_nodes;
     p.nodes_len = d_nodes_len;
@@ -251,7 +254,17 @@ int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* 
     std::lock_guard<std::mutex> g(idx->mu);
     HIP_TRY(hipSetDevice(idx->device));
     return map_launch_locked(idx, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, d_colour,
-                             nullptr, nullptr, static_cast<hipStream_t>(stream));
+                             nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads, uint32_t words_per_read,
+                              uint32_t allowed_mismatches, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap,
+                              uint64_t* d_counts, void* stream) {
+    if (!idx || !d_counts || (n_reads && (!d_tiles || !d_lens || !d_results || !d_arena))) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    HIP_TRY(hipSetDevice(idx->device));
+    return map_launch_locked(idx, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, nullptr,
+                             d_counts, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed) {
@@ -307,7 +320,7 @@ static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* o
     for (int attempt = 0;; ++attempt) {
         if ((rc = idx->b_arena.ensure(cap * 4))) return rc;
         rc = map_launch_locked(idx, idx->b_tiles.as<uint64_t>(), idx->b_lens.as<uint32_t>(), n, wpr, allowed,
-                               idx->b_results.as<pa_read_result>(), idx->b_arena.as<uint32_t>(), cap, nullptr, d_nodes, d_nodes_len, st);
+                               idx->b_results.as<pa_read_result>(), idx->b_arena.as<uint32_t>(), cap, nullptr, nullptr, d_nodes, d_nodes_len, st);
         if (rc != PA_OK) return rc;
         rc = map_finish_locked(idx, st, &used, &need);
         if (rc == PA_ERR_ARENA_FULL && attempt < 3) { cap = need + need / 8 + 4096; continue; }

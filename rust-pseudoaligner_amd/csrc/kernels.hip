@@ -36,6 +36,30 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
     return v;
 }
 
+// hash of a sorted id list; must equal list_hash_host (device_index.hip)
+__device__ __forceinline__ uint64_t list_hash_dev(const uint32_t* v, uint32_t n) {
+    uint64_t h = 0x243f6a8885a308d3ull ^ n;
+    for (uint32_t i = 0; i < n; ++i) h = pa_mix64(h ^ v[i]) + 0x9e3779b97f4a7c15ull;
+    return h;
+}
+
+// index class whose id list equals v[0..n), or 0xFFFFFFFF (content lookup in the class-list hash table)
+__device__ __forceinline__ uint32_t class_of_list(const uint32_t* v, uint32_t n, const uint32_t* ec_off, const uint32_t* ec_ids,
+                                                  const uint32_t* class_table, uint64_t class_table_size) {
+    uint64_t j = list_hash_dev(v, n) % class_table_size;
+    for (;;) {
+        const uint32_t cand = class_table[j];
+        if (cand == 0xFFFFFFFFu) return cand;
+        const uint32_t st = ec_off[cand], ln = ec_off[cand + 1] - st;
+        if (ln == n) {
+            bool eq = true;
+            for (uint32_t t = 0; t < ln && eq; ++t) eq = ec_ids[st + t] == v[t];
+            if (eq) return cand;
+        }
+        if (++j == class_table_size) j = 0;
+    }
+}
+
 template <bool TRACE>
 __global__ __launch_bounds__(PA_MAP_BLOCK) void pa_map_kernel(const MapParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -135,6 +159,18 @@ __global__ __launch_bounds__(PA_MAP_BLOCK) void pa_map_kernel(const MapParams p)
                 }
                 reinterpret_cast<U4*>(p.results)[s.rid] = U4{r.coverage, r.mismatches, r.class_off, r.class_len};
                 if (p.colour_out) p.colour_out[s.rid] = colour;
+                if (p.counts) {   // fused class-count table: fire-and-forget atomics overlap the other lanes' walks
+                    uint32_t slot = p.ix.num_classes + 2;                      // unmapped
+                    if (s.st == ST_ISECT) {
+                        if (cnt == 0) slot = p.ix.num_classes + 1;             // mapped, empty class
+                        else {
+                            if (colour == 0xFFFFFFFFu && my_off + cnt <= p.arena_cap)   // strict subset of every visited class
+                                colour = class_of_list(p.arena + my_off, cnt, p.ix.ec_off, p.ix.ec_ids, p.class_table, p.class_table_size);
+                            slot = colour == 0xFFFFFFFFu ? p.ix.num_classes : colour;
+                        }
+                    }
+                    atomicAdd(p.counts + slot, 1ull);
+                }
                 if (TRACE) {   // node lists, read-major, stride spill_cap (map_read_to_nodes test surface)
                     const uint32_t nn = s.st == ST_ISECT ? (s.ntrace < p.spill_cap ? s.ntrace : p.spill_cap) : 0;
                     p.nodes_len[s.rid] = s.st == ST_ISECT ? s.ntrace : 0;
@@ -201,12 +237,6 @@ __global__ __launch_bounds__(256) void pa_simulate_kernel(const uint64_t* __rest
 // ---------------------------------------------------------------------------------------------- counts
 // counts[c] for reads whose class is index class c; [nc] novel non-empty, [nc+1] mapped-but-empty, [nc+2] unmapped.
 // A result that is a strict subset of every visited class is looked up by content in the class-list hash table.
-__device__ __forceinline__ uint64_t list_hash_dev(const uint32_t* v, uint32_t n) {
-    uint64_t h = 0x243f6a8885a308d3ull ^ n;
-    for (uint32_t i = 0; i < n; ++i) h = pa_mix64(h ^ v[i]) + 0x9e3779b97f4a7c15ull;
-    return h;
-}
-
 __global__ __launch_bounds__(256) void pa_count_kernel(const pa_read_result* __restrict__ results, const uint32_t* __restrict__ arena,
                                                        const uint32_t* __restrict__ colour, uint64_t n_reads,
                                                        const uint32_t* __restrict__ ec_off, const uint32_t* __restrict__ ec_ids,
@@ -220,21 +250,7 @@ __global__ __launch_bounds__(256) void pa_count_kernel(const pa_read_result* __r
     else if (r.class_len == 0) slot = num_classes + 1;
     else {
         uint32_t c = colour ? colour[i] : 0xFFFFFFFFu;
-        if (c == 0xFFFFFFFFu) {   // content lookup
-            const uint32_t* v = arena + r.class_off;
-            uint64_t j = list_hash_dev(v, r.class_len) % class_table_size;
-            for (;;) {
-                const uint32_t cand = class_table[j];
-                if (cand == 0xFFFFFFFFu) break;
-                const uint32_t st = ec_off[cand], ln = ec_off[cand + 1] - st;
-                if (ln == r.class_len) {
-                    bool eq = true;
-                    for (uint32_t t = 0; t < ln && eq; ++t) eq = ec_ids[st + t] == v[t];
-                    if (eq) { c = cand; break; }
-                }
-                if (++j == class_table_size) j = 0;
-            }
-        }
+        if (c == 0xFFFFFFFFu) c = class_of_list(arena + r.class_off, r.class_len, ec_off, ec_ids, class_table, class_table_size);
         slot = c == 0xFFFFFFFFu ? num_classes : c;
     }
     atomicAdd(counts + slot, 1ull);

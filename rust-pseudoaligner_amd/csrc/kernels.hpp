@@ -28,6 +28,10 @@ struct MapParams {
     uint32_t* spill;
     uint32_t spill_cap;
     uint32_t col_cap;
+    // optional fused class-count table (pa_counts_len entries) and the class-list hash table it needs for novel subsets
+    unsigned long long* counts;
+    const uint32_t* class_table;
+    uint64_t class_table_size;
     // trace launches only (pa_map_read_to_nodes): per-lane scratch, per-read node lists (stride spill_cap) and lengths
     uint32_t* trace;
     uint32_t* nodes_out;

@@ -91,6 +91,14 @@ def test_simulated_reads_device_batches(aligners, k, read_len, ppm, allowed, n):
     torch.cuda.synchronize()
     assert np.array_equal(d_counts2.cpu().numpy(), want_sub)
     assert int(d_counts.sum().item()) == n
+    # fused variant: map + count in one launch
+    d_counts4 = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    a.map_count_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), 20000, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, d_counts4.data_ptr(), allowed)
+    a.map_finish()
+    assert np.array_equal(d_counts4.cpu().numpy(), want_sub)
+    a.map_count_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, d_counts4.data_ptr(), allowed)
+    a.map_finish()
+    assert np.array_equal((d_counts4 - d_counts).cpu().numpy(), want_sub)
     # without the colour hint every class goes through the content lookup: same table
     d_counts3 = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
     a.counts_accumulate_device(d_res.data_ptr(), d_arena.data_ptr(), 0, 20000, d_counts3.data_ptr())
