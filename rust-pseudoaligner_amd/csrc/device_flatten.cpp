@@ -9,6 +9,7 @@
 #include <atomic>
 #include <thread>
 
+#include "lane_steps.hpp"
 #include "pa_common.hpp"
 
 namespace pa {
@@ -19,8 +20,9 @@ DevIndexView FlatDevice::host_view() const {
     v.nbuckets = nbuckets;
     v.blobs = blobs.data();
     v.ledge = ledge.data();
-    v.ec_off = ec_off.data();
-    v.ec_ids = ec_ids.data();
+    v.ec = ec.data();
+    v.class_ref = class_ref.data();
+    v.class_len = class_len.data();
     v.kmask = kmer_mask(k);
     v.k = k;
     v.num_nodes = num_nodes;
@@ -38,20 +40,21 @@ void par_ranges(int threads, uint64_t n, F f) {   // static contiguous ranges
     for (auto& x : th) x.join();
 }
 
-struct Dict {
-    U4* slots;
+struct Dict {   // host-side builder/reader of the bucket lines described in device_layout.hpp
+    uint32_t* words;
     uint64_t nbuckets;
-    uint64_t bucket_of(uint64_t kmer) const { return (uint64_t)(((unsigned __int128)mix64(kmer) * nbuckets) >> 64); }
+    uint64_t bucket_of(uint64_t kmer) const { return pa_bucket(kmer, (uint32_t)nbuckets); }   // same function as the kernel
     void insert_mt(uint64_t kmer, uint32_t handle, uint32_t off) {
+        const uint32_t klo = (uint32_t)kmer, want = klo & 0x7FFFFFFFu;
         uint64_t b = bucket_of(kmer);
         for (;;) {
-            U4* s = slots + b * SLOTS_PER_BUCKET;
+            uint32_t* line = words + b * BUCKET_WORDS;
             for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i) {
-                uint32_t expect = NO_HANDLE;
-                if (__atomic_compare_exchange_n(&s[i].z, &expect, handle, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
-                    s[i].x = (uint32_t)kmer;
-                    s[i].y = (uint32_t)(kmer >> 32);
-                    s[i].w = off;
+                uint32_t expect = FP_EMPTY;
+                if (__atomic_compare_exchange_n(&line[i], &expect, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                    line[4 + 3 * i] = (uint32_t)(kmer >> 32);
+                    line[5 + 3 * i] = handle;
+                    line[6 + 3 * i] = off | (klo & 0x80000000u);
                     return;
                 }
             }
@@ -59,13 +62,20 @@ struct Dict {
         }
     }
     bool find(uint64_t kmer, uint32_t& handle, uint32_t& off) const {
+        const uint32_t klo = (uint32_t)kmer, want = klo & 0x7FFFFFFFu, khi = (uint32_t)(kmer >> 32);
         uint64_t b = bucket_of(kmer);
         for (uint64_t probes = 0; probes < nbuckets; ++probes) {
-            const U4* s = slots + b * SLOTS_PER_BUCKET;
+            const uint32_t* line = words + b * BUCKET_WORDS;
+            bool full = true;
             for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i) {
-                if (s[i].z == NO_HANDLE) return false;
-                if (s[i].x == (uint32_t)kmer && s[i].y == (uint32_t)(kmer >> 32)) { handle = s[i].z; off = s[i].w; return true; }
+                if (line[i] == FP_EMPTY) { full = false; continue; }
+                if (line[i] == want && line[4 + 3 * i] == khi && (line[6 + 3 * i] >> 31) == (klo >> 31)) {
+                    handle = line[5 + 3 * i];
+                    off = line[6 + 3 * i] & 0x7FFFFFFFu;
+                    return true;
+                }
             }
+            if (!full) return false;
             if (++b == nbuckets) b = 0;
         }
         return false;
@@ -85,19 +95,28 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
     const uint64_t mask = kmer_mask(k);
     const uint32_t topshift = 2 * (k - 1);
 
-    // ---- classes ----
-    if (f.ec_offset[f.num_classes] >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "class id lists exceed 2^32 entries");
-    out.ec_off.resize((size_t)f.num_classes + 1);
-    for (uint32_t c = 0; c <= f.num_classes; ++c) out.ec_off[c] = (uint32_t)f.ec_offset[c];
-    for (uint32_t c = 0; c < f.num_classes; ++c) out.max_class_len = std::max(out.max_class_len, out.ec_off[c + 1] - out.ec_off[c]);
-    out.ec_ids.assign(f.ec_ids, f.ec_ids + f.ec_offset[f.num_classes]);
-    out.ec_ids.resize(out.ec_ids.size() + 4, 0);   // tail pad for vector loads
+    // ---- classes: 16-byte aligned records {class id, id0, id1, ...} ----
+    out.class_ref.resize(f.num_classes);
+    out.class_len.resize(f.num_classes);
+    for (uint32_t c = 0; c < f.num_classes; ++c) {
+        const uint64_t len = f.ec_offset[c + 1] - f.ec_offset[c];
+        if (len >= 0xFFFFFFFFull || out.ec.size() / 4 >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "class id lists too large");
+        out.class_ref[c] = (uint32_t)(out.ec.size() / 4);
+        out.class_len[c] = (uint32_t)len;
+        out.max_class_len = std::max(out.max_class_len, (uint32_t)len);
+        out.ec.push_back(c);
+        out.ec.insert(out.ec.end(), f.ec_ids + f.ec_offset[c], f.ec_ids + f.ec_offset[c + 1]);
+        while (out.ec.size() % 4) out.ec.push_back(0xFFFFFFFFu);
+    }
+    out.ec.resize(out.ec.size() + 8, 0xFFFFFFFFu);   // tail pad: records are read two 16-byte words at a time
 
     // ---- blob placement: 32-byte granules; a blob that fits one 64-byte line does not straddle two ----
     out.handle.resize(N);
     uint64_t cursor = 0, nk = 0;
     for (uint32_t i = 0; i < N; ++i) {
         if (f.node_len[i] < k) return fail(PA_ERR_FORMAT, "node %u shorter than k", i);
+        if (f.node_len[i] >= (1u << 24)) return fail(PA_ERR_UNSUPPORTED, "node %u longer than 2^24 bases", i);
+        if (f.node_colour[i] >= f.num_classes) return fail(PA_ERR_FORMAT, "node %u: colour out of range", i);
         const uint64_t size = (32 + 8ull * ((f.node_len[i] + 31) / 32) + 31) / 32 * 32;
         if (size <= 64 && (cursor & 63) + size > 64) cursor = (cursor + 63) & ~63ull;
         if (cursor / BLOB_GRANULE >= NO_HANDLE) return fail(PA_ERR_UNSUPPORTED, "graph exceeds the 128 GiB blob address space");
@@ -106,11 +125,12 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
         nk += f.node_len[i] - k + 1;
     }
     out.num_kmers = nk;
-    out.blobs.assign(cursor + 64, 0);   // tail pad: fwd_step reads up to 3 words past a node's last word
+    out.blobs.assign(cursor + 64, 0);   // tail pad: fwd_step reads up to 5 words past a node's last word
 
     // ---- dictionary: every k-mer of every node -> (handle, offset) ----
     out.nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (SLOTS_PER_BUCKET * 0.5)) + 1);
-    out.table.assign(out.nbuckets * SLOTS_PER_BUCKET, U4{0, 0, NO_HANDLE, 0});
+    if (out.nbuckets >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "dictionary exceeds 2^32 buckets");
+    out.table.assign(out.nbuckets * BUCKET_WORDS, FP_EMPTY);
     Dict dict{out.table.data(), out.nbuckets};
     auto node_kmers = [&](uint32_t i, auto&& fn) {
         const uint64_t s = f.node_start[i];
@@ -144,10 +164,10 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
             uint64_t* sq = reinterpret_cast<uint64_t*>(blob + 32);
             const uint32_t len = f.node_len[i];
             const uint64_t s = f.node_start[i];
-            hd[0] = len;
-            hd[1] = f.node_exts[i];
-            hd[2] = f.node_colour[i];
-            hd[3] = (uint32_t)i;
+            hd[0] = len | ((uint32_t)f.node_exts[i] << 24);
+            hd[1] = (uint32_t)i;
+            hd[2] = out.class_ref[f.node_colour[i]];
+            hd[3] = out.class_len[f.node_colour[i]];
             for (uint32_t w = 0; w < (len + 31) / 32; ++w) {
                 uint64_t v = window32(f.node_seq, s + 32ull * w);
                 const uint32_t rem = len - 32 * w;
@@ -196,7 +216,7 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
                     if (!(f.node_exts[i] & (1u << (4 + base)))) continue;
                     uint32_t h = 0, off = 0;
                     dict.find(((first << 2) | base) & mask, h, off);
-                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)h * BLOB_GRANULE);
+                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)h * BLOB_GRANULE) & 0xFFFFFFu;
                     if (off != tlen - k) dangling.store((uint32_t)i);
                 }
             }

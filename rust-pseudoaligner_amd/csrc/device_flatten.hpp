@@ -7,12 +7,13 @@
 namespace pa {
 
 struct FlatDevice {
-    std::vector<U4> table;
+    std::vector<uint32_t> table;   // nbuckets * BUCKET_WORDS
     uint64_t nbuckets = 0;
     std::vector<uint8_t> blobs;
     std::vector<uint32_t> handle;   // node id -> blob handle
     std::vector<uint32_t> ledge;
-    std::vector<uint32_t> ec_off, ec_ids;
+    std::vector<uint32_t> ec;                      // class records (16-byte aligned)
+    std::vector<uint32_t> class_ref, class_len;    // by class id
     uint64_t num_kmers = 0;
     uint32_t k = 0, num_nodes = 0, num_classes = 0, max_class_len = 0;
     DevIndexView host_view() const;   // pointers into the vectors above

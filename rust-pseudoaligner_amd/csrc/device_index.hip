@@ -4,11 +4,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 
 #include "device_flatten.hpp"
 #include "kernels.hpp"
+#include "lane_steps.hpp"
 #include "pa_common.hpp"
 #include "synth_common.hpp"
 
@@ -50,7 +52,8 @@ struct pa_index {
     int device = 0;
     int num_cus = 0;
     DevIndexView dv{};
-    void *d_table = nullptr, *d_blobs = nullptr, *d_ledge = nullptr, *d_ec_off = nullptr, *d_ec_ids = nullptr, *d_class_table = nullptr;
+    void *d_table = nullptr, *d_blobs = nullptr, *d_ledge = nullptr, *d_ec = nullptr, *d_class_ref = nullptr, *d_class_len = nullptr,
+         *d_class_table = nullptr;
     uint64_t class_table_size = 0;
     pa_index_stats stats{};
     // per-launch scratch (one batch in flight per index handle; calls are serialised by `mu`)
@@ -92,7 +95,7 @@ static int upload(const void* src, size_t bytes, void** dst) {
 void pa_index_destroy(pa_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
-    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_ec_off, idx->d_ec_ids, idx->d_class_table})
+    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table})
         if (p) (void)hipFree(p);
     for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
                       &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})
@@ -113,7 +116,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     // class-list hash table for the count kernel: open addressing of class ids keyed by the hash of the id list
     std::vector<uint32_t> ctab((size_t)fd.num_classes * 2 + 16, 0xFFFFFFFFu);
     for (uint32_t c = 0; c < fd.num_classes; ++c) {
-        uint64_t j = list_hash_host(fd.ec_ids.data() + fd.ec_off[c], fd.ec_off[c + 1] - fd.ec_off[c]) % ctab.size();
+        uint64_t j = list_hash_host(fd.ec.data() + 4ull * fd.class_ref[c] + 1, fd.class_len[c]) % ctab.size();
         while (ctab[j] != 0xFFFFFFFFu)
             if (++j == ctab.size()) j = 0;
         ctab[j] = c;
@@ -125,27 +128,29 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) idx->num_cus = prop.multiProcessorCount;
     if (idx->num_cus <= 0) idx->num_cus = 256;
-    rc = upload(fd.table.data(), fd.table.size() * sizeof(U4), &idx->d_table);
+    rc = upload(fd.table.data(), fd.table.size() * 4, &idx->d_table);
     if (rc == PA_OK) rc = upload(fd.blobs.data(), fd.blobs.size(), &idx->d_blobs);
     if (rc == PA_OK) rc = upload(fd.ledge.data(), fd.ledge.size() * 4, &idx->d_ledge);
-    if (rc == PA_OK) rc = upload(fd.ec_off.data(), fd.ec_off.size() * 4, &idx->d_ec_off);
-    if (rc == PA_OK) rc = upload(fd.ec_ids.data(), fd.ec_ids.size() * 4, &idx->d_ec_ids);
+    if (rc == PA_OK) rc = upload(fd.ec.data(), fd.ec.size() * 4, &idx->d_ec);
+    if (rc == PA_OK) rc = upload(fd.class_ref.data(), fd.class_ref.size() * 4, &idx->d_class_ref);
+    if (rc == PA_OK) rc = upload(fd.class_len.data(), fd.class_len.size() * 4, &idx->d_class_len);
     if (rc == PA_OK) rc = upload(ctab.data(), ctab.size() * 4, &idx->d_class_table);
-    if (rc == PA_OK) rc = idx->ctl.ensure(64);
+    if (rc == PA_OK) rc = idx->ctl.ensure(256);
     if (rc != PA_OK) { pa_index_destroy(idx); return rc; }
     idx->class_table_size = ctab.size();
     idx->dv = fd.host_view();
-    idx->dv.table = static_cast<const U4*>(idx->d_table);
+    idx->dv.table = static_cast<const uint32_t*>(idx->d_table);
     idx->dv.blobs = static_cast<const uint8_t*>(idx->d_blobs);
     idx->dv.ledge = static_cast<const uint32_t*>(idx->d_ledge);
-    idx->dv.ec_off = static_cast<const uint32_t*>(idx->d_ec_off);
-    idx->dv.ec_ids = static_cast<const uint32_t*>(idx->d_ec_ids);
+    idx->dv.ec = static_cast<const uint32_t*>(idx->d_ec);
+    idx->dv.class_ref = static_cast<const uint32_t*>(idx->d_class_ref);
+    idx->dv.class_len = static_cast<const uint32_t*>(idx->d_class_len);
     pa_index_stats& s = idx->stats;
     s.num_kmers = fd.num_kmers;
-    s.table_slots = fd.table.size();
-    s.bytes_table = fd.table.size() * sizeof(U4);
+    s.table_slots = fd.nbuckets * SLOTS_PER_BUCKET;
+    s.bytes_table = fd.table.size() * 4;
     s.bytes_graph = fd.blobs.size() + fd.ledge.size() * 4;
-    s.bytes_classes = (fd.ec_off.size() + fd.ec_ids.size() + ctab.size()) * 4;
+    s.bytes_classes = (fd.ec.size() + fd.class_ref.size() + fd.class_len.size() + ctab.size()) * 4;
     s.bytes_total = s.bytes_table + s.bytes_graph + s.bytes_classes;
     s.num_nodes = fd.num_nodes;
     s.num_classes = fd.num_classes;
@@ -174,16 +179,22 @@ int pa_encode_reads_device(const pa_index* idx, const uint8_t* d_ascii, const ui
 }
 
 // ---- launch geometry: enough waves to fill the chip, few enough that each owns several tiles ----
-static int map_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t* grid, size_t* lds, uint32_t* col_cap) {
-    *col_cap = PA_DEFAULT_COL_CAP;
-    const size_t wave_bytes = (size_t)(wpr + 1) * 512 + (size_t)*col_cap * 256;
-    *lds = wave_bytes * (PA_MAP_BLOCK / 64);
+static int env_int(const char* name, int dflt) {   // tuning knobs for A/B runs (documented in DESIGN.md); unset in production
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+static int map_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t* grid, size_t* lds, int* waves) {
+    *waves = env_int("PA_MAP_WAVES", PA_DEFAULT_MAP_WAVES);
+    const size_t wave_bytes = 64 + (size_t)(wpr + 1) * 512 + 2 * LDS_CLASSES * 256;
+    *lds = (sizeof(MapParams) + 15) / 16 * 16 + wave_bytes * (PA_MAP_BLOCK / 64);
     if (*lds > 160 * 1024) return fail(PA_ERR_UNSUPPORTED, "reads of %u words need %zu bytes of LDS per workgroup (> 160 KiB)", wpr, *lds);
     int per_cu = 0;
-    if (map_kernel_occupancy(*lds, &per_cu) != 0 || per_cu < 1) per_cu = 1;
+    if (map_kernel_occupancy(*lds, *waves, &per_cu) != 0 || per_cu < 1) per_cu = 1;
     if (per_cu > 8) per_cu = 8;
+    per_cu = env_int("PA_MAP_BLOCKS_PER_CU", per_cu);
     const uint64_t ntiles = (n_reads + 63) / 64;
-    const uint64_t waves_wanted = (ntiles + 3) / 4;                       // >= 4 tiles per wave when the batch allows
+    const uint64_t waves_wanted = (ntiles + 3) / 4;                      // >= 4 tiles per wave when the batch allows
     uint64_t blocks = (waves_wanted + PA_MAP_BLOCK / 64 - 1) / (PA_MAP_BLOCK / 64);
     const uint64_t cap = (uint64_t)idx->num_cus * per_cu;
     if (blocks > cap) blocks = cap;
@@ -197,16 +208,17 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
                              uint64_t* d_counts, uint32_t* d_nodes, uint32_t* d_nodes_len, hipStream_t stream) {
     if (n_reads >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "at most 2^32-2 reads per batch");
     if (wpr == 0 || wpr > PA_MAX_READ_LEN / 32) return fail(PA_ERR_UNSUPPORTED, "words_per_read %u outside [1,%u]", wpr, PA_MAX_READ_LEN / 32);
-    uint32_t grid = 0, col_cap = 0;
+    uint32_t grid = 0;
     size_t lds = 0;
-    int rc = map_geometry(idx, n_reads, wpr, &grid, &lds, &col_cap);
+    int waves = 0;
+    int rc = map_geometry(idx, n_reads, wpr, &grid, &lds, &waves);
     if (rc != PA_OK) return rc;
-    const uint32_t spill_cap = 64 * wpr + 2;   // >= 2 * max read length + 2 node visits
+    const uint32_t spill_cap = 128 * wpr + 4;   // u32 words: (ref, len) pairs for >= 2 * max read length + 2 node visits
     const size_t lanes = (size_t)grid * PA_MAP_BLOCK;
     rc = idx->spill.ensure(lanes * spill_cap * 4);
     if (rc != PA_OK) return rc;
     if (d_nodes) { rc = idx->trace.ensure(lanes * spill_cap * 4); if (rc != PA_OK) return rc; }
-    HIP_TRY(hipMemsetAsync(idx->ctl.p, 0, 16, stream));
+    HIP_TRY(hipMemsetAsync(idx->ctl.p, 0, 128, stream));
     MapParams p{};
     p.ix = idx->dv;
     p.tiles = d_tiles;
@@ -222,16 +234,16 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.status = idx->ctl.as<uint32_t>() + 2;
     p.spill = idx->spill.as<uint32_t>();
     p.spill_cap = spill_cap;
-    p.col_cap = col_cap;
     p.counts = reinterpret_cast<unsigned long long*>(d_counts);
     p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
     p.class_table_size = idx->class_table_size;
+    p.dbg = env_int("PA_MAP_STATS", 0) ? idx->ctl.as<unsigned long long>() + 2 : nullptr;
     p.trace = d_nodes ? idx->trace.as<uint32_t>() : nullptr;
     p.nodes_out = d_nodes;
     p.nodes_len = d_nodes_len;
     idx->last_grid = grid;
     if (n_reads == 0) return PA_OK;
-    const int e = launch_map(p, grid, lds, stream);
+    const int e = launch_map(p, grid, lds, waves, stream);
     if (e) return fail(PA_ERR_HIP, "map launch (grid %u, lds %zu): %s", grid, lds, hipGetErrorString((hipError_t)e));
     return PA_OK;
 }
@@ -240,6 +252,14 @@ static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_
     HIP_TRY(hipStreamSynchronize(stream));
     struct { unsigned long long top; uint32_t status; uint32_t pad; } ctl;
     HIP_TRY(hipMemcpy(&ctl, idx->ctl.p, 16, hipMemcpyDeviceToHost));
+    if (env_int("PA_MAP_STATS", 0)) {
+        unsigned long long d[10];
+        HIP_TRY(hipMemcpy(d, idx->ctl.as<unsigned long long>() + 2, sizeof d, hipMemcpyDeviceToHost));
+        static const char* names[5] = {"refill", "seek", "fwd", "finish", "left"};
+        fprintf(stderr, "[pa map stats] grid=%u", idx->last_grid);
+        for (int i = 0; i < 5; ++i) fprintf(stderr, " %s: %llu iters x %.1f lanes", names[i], d[i], d[i] ? (double)d[5 + i] / (double)d[i] : 0.0);
+        fprintf(stderr, "\n");
+    }
     if (arena_used) *arena_used = ctl.top;
     if (arena_needed) *arena_needed = ctl.top;
     if (ctl.status & PA_STATUS_SPILL_OVERFLOW) return fail(PA_ERR_INTERNAL, "colour spill buffer overflow (should be impossible)");
@@ -309,7 +329,7 @@ static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* o
     int e = launch_encode(idx->b_ascii.as<uint8_t>(), idx->b_offsets.as<uint64_t>(), n, wpr, idx->b_tiles.as<uint64_t>(),
                           idx->b_lens.as<uint32_t>(), st);
     if (e) return fail(PA_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
-    const uint32_t spill_cap = 64 * wpr + 2;
+    const uint32_t spill_cap = 128 * wpr + 4;
     uint32_t *d_nodes = nullptr, *d_nodes_len = nullptr;
     if (nodes_flat) {
         if ((rc = idx->b_nodes.ensure(n * spill_cap * 4)) || (rc = idx->b_nodes_len.ensure(n * 4))) return rc;
@@ -414,9 +434,8 @@ int pa_counts_accumulate_device(pa_index* idx, const pa_read_result* d_results, 
                                 uint64_t n_reads, uint64_t* d_counts, void* stream) {
     if (!idx || !d_results || !d_arena || !d_counts) return fail(PA_ERR_INVALID_ARG, "null argument");
     HIP_TRY(hipSetDevice(idx->device));
-    const int e = launch_count(d_results, d_arena, d_colour, n_reads, idx->dv.ec_off, idx->dv.ec_ids,
-                               static_cast<const uint32_t*>(idx->d_class_table), idx->class_table_size, idx->stats.num_classes,
-                               reinterpret_cast<unsigned long long*>(d_counts), static_cast<hipStream_t>(stream));
+    const int e = launch_count(d_results, d_arena, d_colour, n_reads, idx->dv, static_cast<const uint32_t*>(idx->d_class_table),
+                               idx->class_table_size, reinterpret_cast<unsigned long long*>(d_counts), static_cast<hipStream_t>(stream));
     if (e) return fail(PA_ERR_HIP, "count launch: %s", hipGetErrorString((hipError_t)e));
     return PA_OK;
 }

@@ -3,18 +3,27 @@
 //
 // HBM layout (all little-endian, all read-only after pa_index_create):
 //
-//   dictionary  bucketed open addressing, 64-byte buckets of four 16-byte slots {key:u64, handle:u32, off:u32};
-//               bucket = mulhi64(fmix64(key), nbuckets), linear probing over buckets. A slot carries the k-mer itself,
-//               so one 64-byte fetch both finds and VERIFIES a k-mer (the reference needs MPHF levels + a table read +
-//               a node-sequence read for the same answer: src/pseudoaligner.rs:96-107). handle == NO_HANDLE = empty.
+//   dictionary  bucketed open addressing, one 64-byte line per bucket of four k-mers:
+//                 +0   u32 fp[4]      low 31 bits of the k-mer (bit 31 clear); 0xFFFFFFFF = empty slot
+//                 +16  {u32 key_hi, u32 handle, u32 off | key bit 31 << 31}[4]
+//               bucket = mulhi64(fmix64(key), nbuckets), linear probing over buckets (a bucket with a free slot ends
+//               the probe sequence). A lookup is ONE 16-byte load of the fingerprints and, on a fingerprint match, one
+//               dependent 12-byte load from the same line that both returns (handle, off) and VERIFIES the remaining
+//               33 key bits — the dictionary stores whole keys, so unlike the reference's MPHF (src/pseudoaligner.rs:
+//               96-107) no node sequence has to be fetched to confirm a hit.
 //   node blobs  one blob per unitig, 32-byte granules, addressed by handle = byte offset / 32:
-//                 +0  u32 len (bases)   +4  u32 exts (debruijn::Exts byte)   +8  u32 colour   +12 u32 node id
+//                 +0  u32 len (bits 0..23) | debruijn::Exts byte (bits 24..31)
+//                 +4  u32 node id          +8  u32 class record ref      +12 u32 class length (ids)
 //                 +16 u32 redge[4]      handle of the node reached by right-extending with base b (Node::r_edges)
 //                 +32 u64 seq[ceil(len/32)]  2-bit packed, LSB-first
-//               so a node visit is ONE dependent fetch (header + sequence share a line for len <= 128) and the hop to the
-//               next node needs no further lookup (the reference re-derives every edge by hashing: SURVEY.md §3.2).
+//               so a node visit is ONE dependent fetch (header + sequence share a line for len <= 128), the hop to the
+//               next node needs no further lookup (the reference re-derives every edge by hashing: SURVEY.md §3.2) and
+//               the colour's id list is addressable without an offsets table.
 //   ledge       u32[4*num_nodes] handles by node id (Node::l_edges), only touched by the left extension
-//   ec_off/ids  CSR of the sorted transcript-id lists (eq_classes: Vec<Vec<u32>>, src/pseudoaligner.rs:29)
+//   ec          class records, 16-byte aligned: record r = words [4r, ...) = {class id, id0, id1, ...} — the sorted
+//               transcript-id lists of eq_classes: Vec<Vec<u32>> (src/pseudoaligner.rs:29); a class of <= 3 ids is one
+//               16-byte load, <= 7 ids two.
+//   class_ref/class_len  u32[num_classes] record ref and length by class id (only the count table's content lookup)
 #pragma once
 #include <cstdint>
 
@@ -32,18 +41,27 @@ namespace pa {
 constexpr uint32_t NO_HANDLE = 0xFFFFFFFFu;
 constexpr uint32_t BLOB_GRANULE = 32;
 constexpr uint32_t SLOTS_PER_BUCKET = 4;
+constexpr uint32_t BUCKET_WORDS = 16;
+constexpr uint32_t FP_EMPTY = 0xFFFFFFFFu;
 
 struct alignas(16) U4 {
     uint32_t x, y, z, w;
 };
+struct U3 {   // 12-byte, 4-byte aligned (global_load_dwordx3)
+    uint32_t x, y, z;
+};
+struct alignas(8) Q2 {   // two sequence words, 8-byte aligned (global_load_dwordx4)
+    uint64_t a, b;
+};
 
 struct DevIndexView {
-    const U4* table;          // nbuckets * 4 slots
+    const uint32_t* table;    // nbuckets * 16 words
     uint64_t nbuckets;
     const uint8_t* blobs;     // node blobs
     const uint32_t* ledge;    // [4 * num_nodes]
-    const uint32_t* ec_off;   // [num_classes + 1]
-    const uint32_t* ec_ids;
+    const uint32_t* ec;       // class records (16-byte aligned records of u32)
+    const uint32_t* class_ref;   // [num_classes]
+    const uint32_t* class_len;   // [num_classes]
     uint64_t kmask;
     uint32_t k;
     uint32_t num_nodes, num_classes;

@@ -44,37 +44,177 @@ __device__ __forceinline__ uint64_t list_hash_dev(const uint32_t* v, uint32_t n)
 }
 
 // index class whose id list equals v[0..n), or 0xFFFFFFFF (content lookup in the class-list hash table)
-__device__ __forceinline__ uint32_t class_of_list(const uint32_t* v, uint32_t n, const uint32_t* ec_off, const uint32_t* ec_ids,
+__device__ __forceinline__ uint32_t class_of_list(const uint32_t* v, uint32_t n, const DevIndexView& ix,
                                                   const uint32_t* class_table, uint64_t class_table_size) {
     uint64_t j = list_hash_dev(v, n) % class_table_size;
     for (;;) {
         const uint32_t cand = class_table[j];
         if (cand == 0xFFFFFFFFu) return cand;
-        const uint32_t st = ec_off[cand], ln = ec_off[cand + 1] - st;
-        if (ln == n) {
+        if (ix.class_len[cand] == n) {
+            const uint32_t* ids = class_ids(ix, ix.class_ref[cand]);
             bool eq = true;
-            for (uint32_t t = 0; t < ln && eq; ++t) eq = ec_ids[st + t] == v[t];
+            for (uint32_t t = 0; t < n && eq; ++t) eq = ids[t] == v[t];
             if (eq) return cand;
         }
         if (++j == class_table_size) j = 0;
     }
 }
 
+// ---- state sections as separately register-allocated device functions -------------------------------------------
+// Inlined into one loop body the four sections cost >100 VGPRs (the allocator keeps every section's temporaries alive
+// around the scheduler loop); as real calls each section gets its own allocation (27-41 VGPRs) and the loop only
+// carries the 9-register lane state, so the kernel fits 8 waves per SIMD without scratch spills. LDS pointers are
+// passed with their address space so that the callee emits ds_* (not flat_*) accesses.
+typedef __attribute__((address_space(3))) uint64_t* lds_u64;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+
+__device__ __forceinline__ ReadRef make_read_ref(lds_u64 rdp, uint32_t wmax) { return ReadRef{(const uint64_t*)rdp, 64, wmax}; }
+__device__ __forceinline__ ColRef make_col_ref(lds_u32 refs, uint32_t* spill_base, uint32_t slot, uint32_t spill_cap, uint32_t* trace_base) {
+    return ColRef{(uint32_t*)refs, (uint32_t*)(refs + 64 * LDS_CLASSES), spill_base + (uint64_t)slot * spill_cap, spill_cap,
+                  trace_base ? trace_base + (uint64_t)slot * spill_cap : nullptr};
+}
+
+__device__ __attribute__((noinline)) Lane seek_call(Lane s, const uint32_t* table, uint32_t nbuckets, uint64_t kmask, uint32_t k, lds_u64 rdp,
+                                                    uint32_t wmax) {
+    DevIndexView ix{};
+    ix.table = table;
+    ix.nbuckets = nbuckets;
+    ix.kmask = kmask;
+    ix.k = k;
+    seek_step(s, ix, make_read_ref(rdp, wmax));
+    return s;
+}
+
 template <bool TRACE>
-__global__ __launch_bounds__(PA_MAP_BLOCK) void pa_map_kernel(const MapParams p) {
+__device__ __attribute__((noinline)) Lane fwd_call(Lane s, const uint8_t* blobs, uint32_t k, lds_u64 rdp, uint32_t wmax, lds_u32 refs,
+                                                   uint32_t* spill_base, uint32_t slot, uint32_t spill_cap, uint32_t* trace_base,
+                                                   uint32_t allowed) {
+    DevIndexView ix{};
+    ix.blobs = blobs;
+    ix.k = k;
+    fwd_step<TRACE>(s, ix, make_read_ref(rdp, wmax), make_col_ref(refs, spill_base, slot, spill_cap, trace_base), allowed);
+    return s;
+}
+
+template <bool TRACE>
+__device__ __attribute__((noinline)) Lane left_call(Lane s, const uint8_t* blobs, const uint32_t* ledge, uint32_t k, lds_u64 rdp, uint32_t wmax,
+                                                    lds_u32 refs, uint32_t* spill_base, uint32_t slot, uint32_t spill_cap,
+                                                    uint32_t* trace_base, uint32_t allowed) {
+    DevIndexView ix{};
+    ix.blobs = blobs;
+    ix.ledge = ledge;
+    ix.k = k;
+    left_step<TRACE>(s, ix, make_read_ref(rdp, wmax), make_col_ref(refs, spill_base, slot, spill_cap, trace_base), allowed);
+    return s;
+}
+
+// FINISH section: nodes_to_eq_class + output for the lanes whose walk has ended. Runs with the whole wave active (the
+// caller's branch is wave-uniform); kernel parameters and the wave's arena chunk live in LDS so that the call carries
+// almost no arguments.
+typedef __attribute__((address_space(3))) const MapParams* lds_params;
+typedef __attribute__((address_space(3))) unsigned long long* lds_u64w;
+
+template <bool TRACE>
+__device__ __attribute__((noinline)) void finish_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk) {
+    const uint32_t st = l_st(s);
+    const bool fin = st == ST_ISECT || st == ST_NONE;
+    DevIndexView ix{};
+    ix.ec = pp->ix.ec;
+    uint32_t* const spill_base = pp->spill;
+    const uint32_t spill_cap = pp->spill_cap;
+    const ColRef cols = make_col_ref(refs_lane, spill_base, slot, spill_cap, nullptr);
+    Isect is{0, 0, 0, 0, 0};
+    if (st == ST_ISECT) is = isect_count(s, ix, cols);
+    const uint32_t cnt = fin ? is.count : 0;
+    const uint32_t incl = wave_incl_scan(cnt, lane);
+    const uint32_t total = __shfl(incl, 63, 64);
+    unsigned long long chunk_cur = chunk[0];
+    if (total > 0) {
+        if (chunk_cur + total > chunk[1]) {   // wave-uniform branch: take a new private slice of the class arena
+            const unsigned long long want = total > PA_ARENA_CHUNK ? total : PA_ARENA_CHUNK;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(pp->arena_top, want);
+            base = __shfl(base, 0, 64);
+            chunk_cur = base;
+            if (lane == 0) chunk[1] = base + want;
+        }
+        if (lane == 0) chunk[0] = chunk_cur + total;
+    }
+    if (!fin) return;
+    const uint64_t my_off = chunk_cur + (incl - cnt);
+    pa_read_result r{0, 0, 0, 0};
+    uint32_t colour = 0xFFFFFFFFu;
+    const uint64_t arena_cap = pp->arena_cap;
+    uint32_t* const arena = pp->arena;
+    if (st == ST_ISECT) {
+        r.coverage = l_cov(s);
+        r.mismatches = l_mism(s) | PA_MAPPED_BIT;
+        r.class_len = cnt;
+        r.class_off = (uint32_t)my_off;
+        if (cnt) {
+            if (my_off + cnt <= arena_cap) isect_write(s, ix, cols, is, arena + my_off);
+            else atomicOr(pp->status, PA_STATUS_ARENA_FULL);
+        }
+        if (cnt == is.base_len) colour = is.base_colour;
+        if (l_flags(s) & F_SPILL_OVERFLOW) atomicOr(pp->status, PA_STATUS_SPILL_OVERFLOW);
+    }
+    reinterpret_cast<U4*>(pp->results)[s.rid] = U4{r.coverage, r.mismatches, r.class_off, r.class_len};
+    uint32_t* const colour_out = pp->colour_out;
+    if (colour_out) colour_out[s.rid] = colour;
+    unsigned long long* const counts = pp->counts;
+    if (counts) {   // fused class-count table: fire-and-forget atomics overlap the other lanes' walks
+        const uint32_t num_classes = pp->ix.num_classes;
+        uint32_t cslot = num_classes + 2;                              // unmapped
+        if (st == ST_ISECT) {
+            if (cnt == 0) cslot = num_classes + 1;                     // mapped, empty class
+            else {
+                if (colour == 0xFFFFFFFFu && my_off + cnt <= arena_cap) {   // strict subset of every visited class
+                    ix.class_ref = pp->ix.class_ref;
+                    ix.class_len = pp->ix.class_len;
+                    colour = class_of_list(arena + my_off, cnt, ix, pp->class_table, pp->class_table_size);
+                }
+                cslot = colour == 0xFFFFFFFFu ? num_classes : colour;
+            }
+        }
+        atomicAdd(counts + cslot, 1ull);
+    }
+    if (TRACE) {   // node lists, read-major, stride spill_cap (map_read_to_nodes test surface)
+        const uint32_t nt = l_ntrace(s);
+        const uint32_t nn = st == ST_ISECT ? (nt < spill_cap ? nt : spill_cap) : 0;
+        pp->nodes_len[s.rid] = st == ST_ISECT ? nt : 0;
+        const uint32_t* tr = pp->trace + (uint64_t)slot * spill_cap;
+        uint32_t* out = pp->nodes_out + (uint64_t)s.rid * spill_cap;
+        for (uint32_t j = 0; j < nn; ++j) out[j] = tr[j];
+    }
+}
+
+constexpr uint32_t PA_LDS_PARAMS_BYTES = (sizeof(MapParams) + 15) / 16 * 16;
+constexpr uint32_t PA_LDS_WAVE_FIXED = 64;   // per-wave: arena chunk state {cur, end}, scheduler statistics [10] u32
+
+template <bool TRACE, int WAVES>
+__global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
     const uint32_t waves_per_block = PA_MAP_BLOCK / 64;
-    const uint64_t wave = (uint64_t)blockIdx.x * waves_per_block + wave_in_block;
-    const uint64_t nwaves = (uint64_t)gridDim.x * waves_per_block;
+    const uint32_t wave = blockIdx.x * waves_per_block + wave_in_block;
+    const uint32_t nwaves = gridDim.x * waves_per_block;
+    const uint32_t slot = wave * 64 + lane;   // this lane's slice of the spill / trace scratch
 
-    const uint32_t wave_bytes = (p.wpr + 1) * 512 + p.col_cap * 256;
-    uint64_t* rd_base = reinterpret_cast<uint64_t*>(smem + wave_in_block * wave_bytes);
-    uint32_t* col_base = reinterpret_cast<uint32_t*>(smem + wave_in_block * wave_bytes + (p.wpr + 1) * 512);
-    const ReadRef rd{rd_base + lane, 64};
-    const ColRef cols{col_base + lane, 64, p.col_cap, p.spill + ((uint64_t)wave * 64 + lane) * p.spill_cap, p.spill_cap,
-                      TRACE ? p.trace + ((uint64_t)wave * 64 + lane) * p.spill_cap : nullptr};
+    // LDS: [kernel parameters][per wave: arena chunk state | read tile (wpr+1 words x 64 lanes) | class refs | class lens]
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&p);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+        for (uint32_t i = threadIdx.x; i < sizeof(MapParams) / 4; i += PA_MAP_BLOCK) dst[i] = src[i];
+    }
+    const uint32_t wave_bytes = PA_LDS_WAVE_FIXED + (p.wpr + 1) * 512 + 2 * LDS_CLASSES * 256;
+    uint8_t* const wbase = smem + PA_LDS_PARAMS_BYTES + wave_in_block * wave_bytes;
+    const lds_u64w chunk = (lds_u64w)wbase;
+    const lds_u64 rd_lane = (lds_u64)(wbase + PA_LDS_WAVE_FIXED) + lane;
+    const lds_u32 refs_lane = (lds_u32)(wbase + PA_LDS_WAVE_FIXED + (p.wpr + 1) * 512) + lane * LDS_CLASSES;
+    const lds_params pp = (lds_params)smem;
+    if (lane == 0) { chunk[0] = 0; chunk[1] = 0; }
+    __syncthreads();
 
     // static partition of the tiles over the waves (no global work queue: one hot atomic would cap the rate)
     const uint64_t ntiles = (p.n_reads + 63) >> 6;
@@ -84,15 +224,16 @@ __global__ __launch_bounds__(PA_MAP_BLOCK) void pa_map_kernel(const MapParams p)
     if (next > end) next = end;
 
     Lane s;
-    s.st = ST_EMPTY;
-    s.rid = s.L = s.kp = s.cov = s.mism = s.h = s.off = s.ro = s.rem = s.snp = s.ra = s.ph = s.ncol = s.flags = s.ntrace = 0;
-    uint64_t chunk_cur = 0, chunk_end = 0;   // wave-uniform: private slice of the class arena
+    s.rid = s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0;   // state ST_EMPTY
+    const lds_u32 dbg = (lds_u32)(wbase + 16);   // scheduler statistics (only kept when p.dbg)
+    if (lane < 10) dbg[lane] = 0;
 
     for (;;) {
-        const uint64_t mE = __ballot(s.st == ST_EMPTY);
-        const uint64_t mS = __ballot(s.st == ST_SEEK);
-        const uint64_t mF = __ballot(s.st == ST_FWD);
-        const uint64_t mL = __ballot(s.st == ST_LEFT);
+        const uint32_t st = l_st(s);
+        const uint64_t mE = __ballot(st == ST_EMPTY);
+        const uint64_t mS = __ballot(st == ST_SEEK);
+        const uint64_t mF = __ballot(st == ST_FWD);
+        const uint64_t mL = __ballot(st == ST_LEFT);
         const uint32_t nS = __popcll(mS), nF = __popcll(mF), nL = __popcll(mL);
         const uint32_t nFin = 64 - __popcll(mE) - nS - nF - nL;
         const uint64_t left = end - next;
@@ -104,82 +245,35 @@ __global__ __launch_bounds__(PA_MAP_BLOCK) void pa_map_kernel(const MapParams p)
         if (nFin > best) { best = nFin; sel = 3; }
         if (nL > best) { best = nL; sel = 4; }
         if (best == 0) break;
+        if (p.dbg && lane == 0) {
+            dbg[sel] += 1;
+            dbg[5 + sel] += best;
+        }
 
         if (sel == 0) {   // ---- REFILL: empty lanes take the next reads of this wave's range (coalesced by rank)
             const uint32_t rank = __popcll(mE & ((1ull << lane) - 1));
-            if (s.st == ST_EMPTY && rank < nR) {
+            if (st == ST_EMPTY && rank < nR) {
                 const uint64_t rid = next + rank;
                 uint32_t L = p.lens[rid];
                 if (L > p.wpr * 32) L = p.wpr * 32;
                 const uint64_t* src = p.tiles + ((rid >> 6) * p.wpr) * 64 + (rid & 63);
-                for (uint32_t w = 0; w < p.wpr; ++w) rd_base[w * 64 + lane] = src[(uint64_t)w * 64];
-                rd_base[p.wpr * 64 + lane] = 0;
+                for (uint32_t w = 0; w < p.wpr; ++w) rd_lane[w * 64] = src[(uint64_t)w * 64];
+                rd_lane[p.wpr * 64] = 0;
                 lane_start(s, (uint32_t)rid, L, p.ix.k);
             }
             next += nR;
         } else if (sel == 1) {
-            if (s.st == ST_SEEK) seek_step(s, p.ix, rd);
+            if (st == ST_SEEK) s = seek_call(s, p.ix.table, (uint32_t)p.ix.nbuckets, p.ix.kmask, p.ix.k, rd_lane, p.wpr);
         } else if (sel == 2) {
-            if (s.st == ST_FWD) fwd_step<TRACE>(s, p.ix, rd, cols, p.allowed);
+            if (st == ST_FWD) s = fwd_call<TRACE>(s, p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, p.spill, slot, p.spill_cap, TRACE ? p.trace : nullptr, p.allowed);
         } else if (sel == 4) {
-            if (s.st == ST_LEFT) left_step<TRACE>(s, p.ix, rd, cols, p.allowed);
-        } else {          // ---- FINISH: nodes_to_eq_class + output
-            const bool fin = s.st == ST_ISECT || s.st == ST_NONE;
-            Isect is{0, 0, 0, 0, 0};
-            if (s.st == ST_ISECT) is = isect_count(s, p.ix, cols);
-            const uint32_t cnt = fin ? is.count : 0;
-            const uint32_t incl = wave_incl_scan(cnt, lane);
-            const uint32_t total = __shfl(incl, 63, 64);
-            if (total > 0) {
-                if (chunk_cur + total > chunk_end) {   // wave-uniform branch
-                    const uint64_t want = total > PA_ARENA_CHUNK ? total : PA_ARENA_CHUNK;
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(p.arena_top, (unsigned long long)want);
-                    base = __shfl(base, 0, 64);
-                    chunk_cur = base;
-                    chunk_end = base + want;
-                }
-            }
-            const uint64_t my_off = chunk_cur + (incl - cnt);
-            chunk_cur += total;
-            if (fin) {
-                pa_read_result r{0, 0, 0, 0};
-                uint32_t colour = 0xFFFFFFFFu;
-                if (s.st == ST_ISECT) {
-                    r.coverage = s.cov;
-                    r.mismatches = s.mism | PA_MAPPED_BIT;
-                    r.class_len = cnt;
-                    r.class_off = (uint32_t)my_off;
-                    if (cnt) {
-                        if (my_off + cnt <= p.arena_cap) isect_write(s, p.ix, cols, is, p.arena + my_off);
-                        else atomicOr(p.status, PA_STATUS_ARENA_FULL);
-                    }
-                    if (cnt == is.base_len) colour = is.base_colour;
-                    if (s.flags & F_SPILL_OVERFLOW) atomicOr(p.status, PA_STATUS_SPILL_OVERFLOW);
-                }
-                reinterpret_cast<U4*>(p.results)[s.rid] = U4{r.coverage, r.mismatches, r.class_off, r.class_len};
-                if (p.colour_out) p.colour_out[s.rid] = colour;
-                if (p.counts) {   // fused class-count table: fire-and-forget atomics overlap the other lanes' walks
-                    uint32_t slot = p.ix.num_classes + 2;                      // unmapped
-                    if (s.st == ST_ISECT) {
-                        if (cnt == 0) slot = p.ix.num_classes + 1;             // mapped, empty class
-                        else {
-                            if (colour == 0xFFFFFFFFu && my_off + cnt <= p.arena_cap)   // strict subset of every visited class
-                                colour = class_of_list(p.arena + my_off, cnt, p.ix.ec_off, p.ix.ec_ids, p.class_table, p.class_table_size);
-                            slot = colour == 0xFFFFFFFFu ? p.ix.num_classes : colour;
-                        }
-                    }
-                    atomicAdd(p.counts + slot, 1ull);
-                }
-                if (TRACE) {   // node lists, read-major, stride spill_cap (map_read_to_nodes test surface)
-                    const uint32_t nn = s.st == ST_ISECT ? (s.ntrace < p.spill_cap ? s.ntrace : p.spill_cap) : 0;
-                    p.nodes_len[s.rid] = s.st == ST_ISECT ? s.ntrace : 0;
-                    for (uint32_t j = 0; j < nn; ++j) p.nodes_out[(uint64_t)s.rid * p.spill_cap + j] = cols.trace[j];
-                }
-                s.st = ST_EMPTY;
-            }
+            if (st == ST_LEFT) s = left_call<TRACE>(s, p.ix.blobs, p.ix.ledge, p.ix.k, rd_lane, p.wpr, refs_lane, p.spill, slot, p.spill_cap, TRACE ? p.trace : nullptr, p.allowed);
+        } else {          // ---- FINISH: nodes_to_eq_class + output (whole wave enters: the scan inside needs every lane)
+            finish_call<TRACE>(s, lane, slot, refs_lane, pp, chunk);
+            if (st == ST_ISECT || st == ST_NONE) s.of = 0;   // ST_EMPTY
         }
     }
+    if (p.dbg && lane < 10) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
 }
 
 // ---------------------------------------------------------------------------------------------- encode
@@ -238,10 +332,10 @@ __global__ __launch_bounds__(256) void pa_simulate_kernel(const uint64_t* __rest
 // counts[c] for reads whose class is index class c; [nc] novel non-empty, [nc+1] mapped-but-empty, [nc+2] unmapped.
 // A result that is a strict subset of every visited class is looked up by content in the class-list hash table.
 __global__ __launch_bounds__(256) void pa_count_kernel(const pa_read_result* __restrict__ results, const uint32_t* __restrict__ arena,
-                                                       const uint32_t* __restrict__ colour, uint64_t n_reads,
-                                                       const uint32_t* __restrict__ ec_off, const uint32_t* __restrict__ ec_ids,
+                                                       const uint32_t* __restrict__ colour, uint64_t n_reads, const DevIndexView ix,
                                                        const uint32_t* __restrict__ class_table, uint64_t class_table_size,
-                                                       uint32_t num_classes, unsigned long long* __restrict__ counts) {
+                                                       unsigned long long* __restrict__ counts) {
+    const uint32_t num_classes = ix.num_classes;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_reads) return;
     const pa_read_result r = results[i];
@@ -250,26 +344,41 @@ __global__ __launch_bounds__(256) void pa_count_kernel(const pa_read_result* __r
     else if (r.class_len == 0) slot = num_classes + 1;
     else {
         uint32_t c = colour ? colour[i] : 0xFFFFFFFFu;
-        if (c == 0xFFFFFFFFu) c = class_of_list(arena + r.class_off, r.class_len, ec_off, ec_ids, class_table, class_table_size);
+        if (c == 0xFFFFFFFFu) c = class_of_list(arena + r.class_off, r.class_len, ix, class_table, class_table_size);
         slot = c == 0xFFFFFFFFu ? num_classes : c;
     }
     atomicAdd(counts + slot, 1ull);
 }
 
 // ---------------------------------------------------------------------------------------------- launchers
-int launch_map(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
+// WAVES = waves per SIMD the register allocator must leave room for (launch-bounds variant; tuning knob PA_MAP_WAVES)
+template <bool TRACE, int WAVES>
+static int launch_map_variant(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
     if (lds_bytes > 48 * 1024) {   // long-read tiles: opt in to more than the default dynamic LDS limit
-        const void* fn = p.trace ? reinterpret_cast<const void*>(&pa_map_kernel<true>) : reinterpret_cast<const void*>(&pa_map_kernel<false>);
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pa_map_kernel<TRACE, WAVES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    if (p.trace) hipLaunchKernelGGL(pa_map_kernel<true>, dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
-    else hipLaunchKernelGGL(pa_map_kernel<false>, dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
+    hipLaunchKernelGGL((pa_map_kernel<TRACE, WAVES>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
     return (int)hipGetLastError();
 }
 
-int map_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu) {
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, pa_map_kernel<false>, PA_MAP_BLOCK, lds_bytes);
+int launch_map(const MapParams& p, uint32_t grid, size_t lds_bytes, int waves, hipStream_t stream) {
+    if (p.trace) return launch_map_variant<true, 4>(p, grid, lds_bytes, stream);
+    switch (waves) {
+        case 8: return launch_map_variant<false, 8>(p, grid, lds_bytes, stream);
+        case 6: return launch_map_variant<false, 6>(p, grid, lds_bytes, stream);
+        case 5: return launch_map_variant<false, 5>(p, grid, lds_bytes, stream);
+        default: return launch_map_variant<false, 4>(p, grid, lds_bytes, stream);
+    }
+}
+
+int map_kernel_occupancy(size_t lds_bytes, int waves, int* blocks_per_cu) {
+    const void* fn = waves == 8 ? reinterpret_cast<const void*>(&pa_map_kernel<false, 8>)
+                   : waves == 6 ? reinterpret_cast<const void*>(&pa_map_kernel<false, 6>)
+                   : waves == 5 ? reinterpret_cast<const void*>(&pa_map_kernel<false, 5>)
+                                : reinterpret_cast<const void*>(&pa_map_kernel<false, 4>);
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, PA_MAP_BLOCK, lds_bytes);
 }
 
 int launch_encode(const uint8_t* ascii, const uint64_t* offsets, uint64_t n, uint32_t wpr, uint64_t* tiles, uint32_t* lens,
@@ -290,12 +399,11 @@ int launch_simulate(const uint64_t* packed, const uint64_t* tx_start, const uint
     return (int)hipGetLastError();
 }
 
-int launch_count(const pa_read_result* results, const uint32_t* arena, const uint32_t* colour, uint64_t n, const uint32_t* ec_off,
-                 const uint32_t* ec_ids, const uint32_t* class_table, uint64_t class_table_size, uint32_t num_classes,
-                 unsigned long long* counts, hipStream_t stream) {
+int launch_count(const pa_read_result* results, const uint32_t* arena, const uint32_t* colour, uint64_t n, const DevIndexView& ix,
+                 const uint32_t* class_table, uint64_t class_table_size, unsigned long long* counts, hipStream_t stream) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(pa_count_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, results, arena, colour, n, ec_off, ec_ids,
-                       class_table, class_table_size, num_classes, counts);
+    hipLaunchKernelGGL(pa_count_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, results, arena, colour, n, ix,
+                       class_table, class_table_size, counts);
     return (int)hipGetLastError();
 }
 

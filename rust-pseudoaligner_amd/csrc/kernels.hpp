@@ -8,7 +8,7 @@ namespace pa {
 
 constexpr uint32_t PA_MAP_BLOCK = 256;          // 4 independent waves per workgroup, no barriers
 constexpr uint32_t PA_ARENA_CHUNK = 1024;       // u32 entries a wave reserves per global atomic
-constexpr uint32_t PA_DEFAULT_COL_CAP = 8;      // distinct colours per lane kept in LDS before spilling to HBM
+constexpr int PA_DEFAULT_MAP_WAVES = 6;         // launch-bounds variant of the map kernel (waves per SIMD)
 constexpr uint32_t PA_STATUS_ARENA_FULL = 1u;
 constexpr uint32_t PA_STATUS_SPILL_OVERFLOW = 2u;
 
@@ -27,26 +27,26 @@ struct MapParams {
     uint32_t* status;
     uint32_t* spill;
     uint32_t spill_cap;
-    uint32_t col_cap;
     // optional fused class-count table (pa_counts_len entries) and the class-list hash table it needs for novel subsets
     unsigned long long* counts;
     const uint32_t* class_table;
     uint64_t class_table_size;
+    // optional scheduler statistics: [0..4] iterations of refill/seek/fwd/finish/left, [5..9] lanes served by them
+    unsigned long long* dbg;
     // trace launches only (pa_map_read_to_nodes): per-lane scratch, per-read node lists (stride spill_cap) and lengths
     uint32_t* trace;
     uint32_t* nodes_out;
     uint32_t* nodes_len;
 };
 
-int launch_map(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream);
-int map_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu);
+int launch_map(const MapParams& p, uint32_t grid, size_t lds_bytes, int waves, hipStream_t stream);
+int map_kernel_occupancy(size_t lds_bytes, int waves, int* blocks_per_cu);
 int launch_encode(const uint8_t* ascii, const uint64_t* offsets, uint64_t n, uint32_t wpr, uint64_t* tiles, uint32_t* lens,
                   hipStream_t stream);
 int launch_simulate(const uint64_t* packed, const uint64_t* tx_start, const uint64_t* cum, uint32_t num_tx, uint64_t total,
                     uint32_t read_len, uint64_t seed, uint32_t ppm, uint64_t first_read, uint64_t n, uint32_t wpr, uint64_t* tiles,
                     uint32_t* lens, hipStream_t stream);
-int launch_count(const pa_read_result* results, const uint32_t* arena, const uint32_t* colour, uint64_t n, const uint32_t* ec_off,
-                 const uint32_t* ec_ids, const uint32_t* class_table, uint64_t class_table_size, uint32_t num_classes,
-                 unsigned long long* counts, hipStream_t stream);
+int launch_count(const pa_read_result* results, const uint32_t* arena, const uint32_t* colour, uint64_t n, const DevIndexView& ix,
+                 const uint32_t* class_table, uint64_t class_table_size, unsigned long long* counts, hipStream_t stream);
 
 }  // namespace pa

@@ -4,9 +4,13 @@
 // 64-wide wavefront: the three data-dependent loops of the reference (dictionary scan :91-114, left extension
 // :131-203, forward extension :209-301) become the states SEEK / LEFT / FWD, each advancing by one dependent HBM
 // fetch per call, so that a wave can run the same state for many reads at once (kernels.hip schedules the states).
-// The per-base comparison loops (:151-170, :236-255) are replaced by XOR + popcount/ctz on 32-base windows; the
-// nodes Vec (:219) is replaced by the set of DISTINCT colours seen, because nodes_to_eq_class (:323-356) only uses
-// the colour lists and intersection is idempotent/commutative.
+// The per-base comparison loops (:151-170, :236-255) are replaced by XOR + popcount on 32-base windows with a slow
+// path (position of the (allowed+1)-th mismatch) that only runs when a node visit exceeds its mismatch budget; the
+// nodes Vec (:219) is replaced by the set of DISTINCT classes seen, because nodes_to_eq_class (:323-356) only uses
+// the id lists and intersection is idempotent/commutative.
+//
+// Written for instruction economy on gfx950: the lane state is packed into 9 VGPRs, 64-bit funnel shifts are two
+// v_alignbit_b32, the bucket index is one v_mul_hi_u32, the lane's class list is one ds_read_b128.
 //
 // Compiled for gfx950 by kernels.hip and for the host by tests/emu (CPU parity tests of exactly this text).
 #pragma once
@@ -15,42 +19,57 @@
 namespace pa {
 
 enum : uint32_t { ST_EMPTY = 0, ST_SEEK = 1, ST_FWD = 2, ST_LEFT = 3, ST_ISECT = 4, ST_NONE = 5 };
-enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_PROBE_SHIFT = 8 };
+enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_CAREFUL = 16u };
+constexpr uint32_t LDS_CLASSES = 4;   // distinct classes per lane kept in LDS (one 16-byte vector of refs + one of lengths)
 
+// Packed lane state (9 VGPRs). Limits: read length <= 2048 (PA_MAX_READ_LEN), node length < 2^24.
 struct Lane {
-    uint32_t st, rid, L;
-    uint32_t kp;         // kmer_pos (:79)
-    uint32_t cov, mism;  // read_coverage, mismatch_count (:71-72)
-    uint32_t h, off;     // node_id / kmer_offset of the forward search (:118-121), h = blob handle
-    uint32_t ro;         // FWD: ref offset inside the node; LEFT: node bases still to the left (prev_kmer_offset + 1)
-    uint32_t rem;        // bases of max_matchable_pos not yet compared in this node visit (:145, :231)
-    uint32_t snp;        // seen_snp of this node visit (:150, :235)
-    uint32_t ra;         // LEFT: read bases still to the left (last_pos + 1)
-    uint32_t ph;         // LEFT: prev_node_id (:128)
-    uint32_t ncol;       // distinct colours collected
-    uint32_t flags;
-    uint32_t ntrace;     // TRACE builds only: nodes.len()
+    uint32_t rid;
+    uint32_t lk;    // L (bits 0..15) | kmer_pos (16..31)                                   (:70, :79)
+    uint32_t cm;    // read_coverage (0..15) | mismatch_count (16..31)                      (:71-72)
+    uint32_t h;     // node_id of the forward search as a blob handle                       (:118-121)
+    uint32_t of;    // kmer_offset (0..23) | state (24..26) | flags (27..31)
+    uint32_t rr;    // FWD: ref offset in the node, LEFT: node bases still to the left (0..23) | seen_snp (24..31)
+    uint32_t rm;    // bases of max_matchable_pos not yet compared (0..15) | LEFT: read bases still to the left (16..31)
+    uint32_t ph;    // LEFT: prev_node_id as a blob handle                                  (:128)
+    uint32_t nc;    // distinct classes collected (0..11) | dictionary probe index (12..15) | TRACE: nodes.len() (16..31)
 };
 
-struct ReadRef {   // the lane's packed read: word w at p[w * stride]; word ceil(L/32) must be readable
+PA_HD uint32_t l_st(const Lane& s) { return (s.of >> 24) & 7u; }
+PA_HD void l_set_st(Lane& s, uint32_t st) { s.of = (s.of & ~(7u << 24)) | (st << 24); }
+PA_HD uint32_t l_flags(const Lane& s) { return s.of >> 27; }
+PA_HD void l_or_flags(Lane& s, uint32_t f) { s.of |= f << 27; }
+PA_HD void l_clr_flags(Lane& s, uint32_t f) { s.of &= ~(f << 27); }
+PA_HD uint32_t l_off(const Lane& s) { return s.of & 0xFFFFFFu; }
+PA_HD uint32_t l_L(const Lane& s) { return s.lk & 0xFFFFu; }
+PA_HD uint32_t l_kp(const Lane& s) { return s.lk >> 16; }
+PA_HD void l_set_kp(Lane& s, uint32_t kp) { s.lk = (s.lk & 0xFFFFu) | (kp << 16); }
+PA_HD uint32_t l_cov(const Lane& s) { return s.cm & 0xFFFFu; }
+PA_HD uint32_t l_mism(const Lane& s) { return s.cm >> 16; }
+PA_HD uint32_t l_ncol(const Lane& s) { return s.nc & 0xFFFu; }
+PA_HD uint32_t l_probe(const Lane& s) { return (s.nc >> 12) & 15u; }
+PA_HD uint32_t l_ntrace(const Lane& s) { return s.nc >> 16; }
+
+struct ReadRef {   // the lane's packed read: word w at p[w * stride]; words 0..wmax are readable (word wmax is zero pad)
     const uint64_t* p;
     uint32_t stride;
+    uint32_t wmax;
 };
 
-struct ColRef {    // the lane's colour list: first `cap` entries at p[i*stride] (LDS), the rest in `spill` (HBM)
-    uint32_t* p;
-    uint32_t stride, cap;
+struct ColRef {    // the lane's list of distinct classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] (LDS, each one
+    uint32_t* refs;   // 16-byte vector), the rest as (ref, len) pairs in `spill` (HBM)
+    uint32_t* lens;
     uint32_t* spill;
-    uint32_t spill_cap;
-    uint32_t* trace;   // TRACE builds only: node ids in visit order (map_read_to_nodes, :54-61), capacity spill_cap
+    uint32_t spill_cap;   // u32 words
+    uint32_t* trace;      // TRACE builds only: node ids in visit order (map_read_to_nodes, :54-61), capacity spill_cap
 };
 
-struct Hdr {
-    uint32_t len, exts, colour, nid, e0, e1, e2, e3;
+struct Hdr {   // first 16 bytes of a node blob; the edge handles (+16) are fetched only when a hop is taken
+    uint32_t len, exts, nid, ec_ref, ec_len;
 };
 
 // ---------------------------------------------------------------------------------------------- helpers
-PA_HD uint64_t pa_mix64(uint64_t x) {
+PA_HD uint64_t pa_mix64(uint64_t x) {   // murmur3 fmix64
     x ^= x >> 33;
     x *= 0xff51afd7ed558ccdull;
     x ^= x >> 33;
@@ -59,27 +78,37 @@ PA_HD uint64_t pa_mix64(uint64_t x) {
     return x;
 }
 
-PA_HD uint64_t pa_mulhi64(uint64_t a, uint64_t b) {
+// dictionary bucket of a k-mer: the high half of the mixed hash scaled to [0, nbuckets) — nbuckets < 2^32
+PA_HD uint32_t pa_bucket(uint64_t kmer, uint32_t nbuckets) {
+    const uint32_t hi = (uint32_t)(pa_mix64(kmer) >> 32);
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(a, b);
+    return __umulhi(hi, nbuckets);
 #else
-    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+    return (uint32_t)(((uint64_t)hi * nbuckets) >> 32);
 #endif
 }
 
-PA_HD uint32_t pa_popc64(uint64_t x) {
+PA_HD uint32_t pa_popc32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__popcll(x);
+    return (uint32_t)__popc(x);
 #else
-    return (uint32_t)__builtin_popcountll(x);
+    return (uint32_t)__builtin_popcount(x);
 #endif
 }
+PA_HD uint32_t pa_popc64(uint64_t x) { return pa_popc32((uint32_t)x) + pa_popc32((uint32_t)(x >> 32)); }
 
 PA_HD uint32_t pa_ctz64(uint64_t x) {   // x != 0
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)(__ffsll((unsigned long long)x) - 1);
 #else
     return (uint32_t)__builtin_ctzll(x);
+#endif
+}
+PA_HD uint32_t pa_ctz32(uint32_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)(__ffs((int)x) - 1);
+#else
+    return (uint32_t)__builtin_ctz(x);
 #endif
 }
 
@@ -96,12 +125,23 @@ PA_HD uint64_t pa_brev64(uint64_t x) {
 
 PA_HD uint32_t pa_min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
-PA_HD uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh) { return sh ? (lo >> sh) | (hi << (64 - sh)) : lo; }
+// 64 bits starting at bit `sh` (0..63) of the 128-bit value hi:lo
+PA_HD uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32), w2 = (uint32_t)hi, w3 = (uint32_t)(hi >> 32);
+    const bool up = sh >= 32;                 // v_alignbit_b32 uses sh[4:0]
+    const uint32_t t0 = up ? w1 : w0, t1 = up ? w2 : w1, t2 = up ? w3 : w2;
+    return (uint64_t)__builtin_amdgcn_alignbit(t1, t0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(t2, t1, sh) << 32);
+#else
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+#endif
+}
 
+PA_HD uint64_t read_word(ReadRef r, uint32_t w) { return r.p[pa_min(w, r.wmax) * r.stride]; }
 // 32 bases of the read starting at base `pos`
 PA_HD uint64_t read_window(ReadRef r, uint32_t pos) {
     const uint32_t w = pos >> 5;
-    return funnel(r.p[w * r.stride], r.p[(w + 1) * r.stride], (pos & 31) * 2);
+    return funnel(read_word(r, w), read_word(r, w + 1), (pos & 31) * 2);
 }
 // 32 bases ENDING at base p (base p lands in the top 2 bits; missing low bases are zero)
 PA_HD uint64_t read_window_end(ReadRef r, uint32_t p) { return p >= 31 ? read_window(r, p - 31) : r.p[0] << (2 * (31 - p)); }
@@ -110,20 +150,30 @@ PA_HD uint32_t read_base(ReadRef r, uint32_t pos) { return (uint32_t)(r.p[(pos >
 
 PA_HD Hdr load_hdr(const DevIndexView& ix, uint32_t h) {
     const U4* p = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)h * BLOB_GRANULE);
-    const U4 a = p[0], b = p[1];
-    return Hdr{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const U4 a = p[0];
+    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, a.z, a.w};
+}
+PA_HD uint32_t load_redge(const DevIndexView& ix, uint32_t h, uint32_t base) {
+    return reinterpret_cast<const uint32_t*>(ix.blobs + (uint64_t)h * BLOB_GRANULE + 16)[base];
 }
 PA_HD const uint64_t* node_seq(const DevIndexView& ix, uint32_t h) {
     return reinterpret_cast<const uint64_t*>(ix.blobs + (uint64_t)h * BLOB_GRANULE + 32);
 }
 
-// mismatch mask of a 32-base XOR: bit 2i set <=> base i differs
-PA_HD uint64_t diff_mask(uint64_t x) { return (x | (x >> 1)) & 0x5555555555555555ull; }
+// mismatch mask of a 32-base XOR restricted to its first n bases (1 <= n <= 32): bit 2i set <=> base i differs.
+// (the 32-bit halves can be shifted separately: the bit that would cross lands on an odd position and is masked away)
+PA_HD uint64_t diff_mask(uint64_t x, uint32_t n) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    lo = (lo | (lo >> 1)) & 0x55555555u;
+    hi = (hi | (hi >> 1)) & 0x55555555u;
+    const uint32_t mlo = n >= 16 ? 0xFFFFFFFFu : ((1u << (2 * n)) - 1);
+    const uint32_t mhi = n >= 32 ? 0xFFFFFFFFu : (n > 16 ? ((1u << (2 * n - 32)) - 1) : 0u);
+    return (uint64_t)(lo & mlo) | ((uint64_t)(hi & mhi) << 32);
+}
 
 // The body of the compare loops (:151-170 / :236-255) over n <= 32 bases given their mismatch mask (bit 2i = i-th base
-// compared). Returns matched_bases for the chunk; updates seen_snp / mismatch_count; sets premature.
+// compared). Returns matched_bases for the chunk; updates seen_snp / mismatch_count; sets premature. (slow path)
 PA_HD uint32_t compare_chunk(uint64_t m, uint32_t n, uint32_t allowed, uint32_t& snp, uint32_t& mism, bool& premature) {
-    if (n < 32) m &= (1ull << (2 * n)) - 1;
     const uint32_t cnt = pa_popc64(m);
     if (snp + cnt <= allowed) {
         snp += cnt;
@@ -138,128 +188,156 @@ PA_HD uint32_t compare_chunk(uint64_t m, uint32_t n, uint32_t allowed, uint32_t&
     return pa_ctz64(m) >> 1;
 }
 
+// nodes.push(node_id) (:199, :219): record the node's class unless already present
 template <bool TRACE>
-PA_HD void push_node(Lane& s, ColRef c, uint32_t colour, uint32_t nid) {
+PA_HD void push_node(Lane& s, ColRef c, uint32_t ec_ref, uint32_t ec_len, uint32_t nid) {
     if (TRACE) {
-        if (s.ntrace < c.spill_cap) c.trace[s.ntrace] = nid;
-        s.ntrace += 1;
+        const uint32_t nt = l_ntrace(s);
+        if (nt < c.spill_cap) c.trace[nt] = nid;
+        s.nc += 1u << 16;
     }
-    const uint32_t inl = pa_min(s.ncol, c.cap);
-    for (uint32_t i = 0; i < inl; ++i)
-        if (c.p[i * c.stride] == colour) return;
-    if (s.ncol < c.cap) c.p[s.ncol * c.stride] = colour;
-    else if (s.ncol - c.cap < c.spill_cap) c.spill[s.ncol - c.cap] = colour;
-    else { s.flags |= F_SPILL_OVERFLOW; return; }
-    s.ncol += 1;
+    const uint32_t n = l_ncol(s);
+    const U4 r = *reinterpret_cast<const U4*>(c.refs);
+    const bool dup = (n > 0 && r.x == ec_ref) | (n > 1 && r.y == ec_ref) | (n > 2 && r.z == ec_ref) | (n > 3 && r.w == ec_ref);
+    if (dup) return;
+    if (n < LDS_CLASSES) {
+        c.refs[n] = ec_ref;
+        c.lens[n] = ec_len;
+    } else {
+        const uint32_t o = 2 * (n - LDS_CLASSES);
+        if (o + 1 >= c.spill_cap) { l_or_flags(s, F_SPILL_OVERFLOW); return; }
+        c.spill[o] = ec_ref;
+        c.spill[o + 1] = ec_len;
+    }
+    s.nc += 1;
 }
-PA_HD uint32_t get_colour(ColRef c, uint32_t i) { return i < c.cap ? c.p[i * c.stride] : c.spill[i - c.cap]; }
 
 PA_HD void lane_start(Lane& s, uint32_t rid, uint32_t L, uint32_t k) {
     s.rid = rid;
-    s.L = L;
-    s.kp = 0;
-    s.cov = 0;
-    s.mism = 0;
-    s.ncol = 0;
-    s.flags = F_FIRST_SEEK;
-    s.ntrace = 0;
-    s.h = s.off = s.ro = s.rem = s.snp = s.ra = s.ph = 0;
-    s.st = L < k ? ST_NONE : ST_SEEK;   // :82-84
+    s.lk = L;
+    s.cm = 0;
+    s.h = s.rr = s.rm = s.ph = s.nc = 0;
+    s.of = ((L < k ? ST_NONE : ST_SEEK) << 24) | (F_FIRST_SEEK << 27);   // :82-84
 }
 
 // ---------------------------------------------------------------------------------------------- SEEK
-// One dictionary probe of find_kmer_match (:91-114): dbg_index.get + verification collapse into one bucket fetch.
+// One dictionary probe of find_kmer_match (:91-114): dbg_index.get + verification collapse into one bucket line.
 PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
-    const uint32_t K = ix.k;
-    const uint32_t last = s.L - K;                                  // last_kmer_pos (:86)
-    const uint64_t kmer = read_window(rd, s.kp) & ix.kmask;         // read_seq.get_kmer(kmer_pos) (:93)
-    const uint32_t probe = s.flags >> F_PROBE_SHIFT;
-    uint64_t b = pa_mulhi64(pa_mix64(kmer), ix.nbuckets) + probe;
-    if (b >= ix.nbuckets) b -= ix.nbuckets;
-    const U4* slot = ix.table + b * SLOTS_PER_BUCKET;
-    const U4 s0 = slot[0], s1 = slot[1], s2 = slot[2], s3 = slot[3];
+    const uint32_t K = ix.k, L = l_L(s), kp = l_kp(s);
+    const uint64_t kmer = read_window(rd, kp) & ix.kmask;           // read_seq.get_kmer(kmer_pos) (:93)
+    const uint32_t probe = l_probe(s);
+    uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + probe;
+    if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
+    const uint32_t* line = ix.table + (uint64_t)b * BUCKET_WORDS;
+    const U4 fp = *reinterpret_cast<const U4*>(line);
     const uint32_t klo = (uint32_t)kmer, khi = (uint32_t)(kmer >> 32);
+    const uint32_t want = klo & 0x7FFFFFFFu;
+    uint32_t cand = (fp.x == want ? 1u : 0u) | (fp.y == want ? 2u : 0u) | (fp.z == want ? 4u : 0u) | (fp.w == want ? 8u : 0u);
     uint32_t h = NO_HANDLE, off = 0;
-    if (s0.x == klo && s0.y == khi && s0.z != NO_HANDLE) { h = s0.z; off = s0.w; }
-    if (s1.x == klo && s1.y == khi && s1.z != NO_HANDLE) { h = s1.z; off = s1.w; }
-    if (s2.x == klo && s2.y == khi && s2.z != NO_HANDLE) { h = s2.z; off = s2.w; }
-    if (s3.x == klo && s3.y == khi && s3.z != NO_HANDLE) { h = s3.z; off = s3.w; }
-    s.flags &= (1u << F_PROBE_SHIFT) - 1;
+    while (cand) {                                                  // almost always exactly one candidate on a hit
+        const uint32_t j = pa_ctz32(cand);
+        cand &= cand - 1;
+        const U3 e = *reinterpret_cast<const U3*>(line + 4 + 3 * j);
+        if (e.x == khi && (e.z >> 31) == (klo >> 31)) { h = e.y; off = e.z & 0x7FFFFFFFu; cand = 0; }
+    }
+    s.nc &= ~(15u << 12);                                           // probe index back to 0
     if (h != NO_HANDLE) {                                           // Some((nid, offset)) (:106)
         s.h = h;
-        s.off = off;
-        const uint32_t thr = s.L / 5;                               // (0.2 * L as f64) as usize (:77) == L/5 for L < 2^31
-        if ((s.flags & F_FIRST_SEEK) && s.kp >= thr) {              // :124-126
-            s.st = ST_LEFT;
-            s.ra = s.kp;                                            // last_pos + 1 (:127)
+        const uint32_t fl = l_flags(s);
+        const uint32_t thr = L / 5;                                 // (0.2 * L as f64) as usize (:77) == L/5 for L < 2^31
+        if ((fl & F_FIRST_SEEK) && kp >= thr) {                     // :124-126
+            s.rm = (s.rm & 0xFFFFu) | (kp << 16);                   // last_pos + 1 (:127)
             s.ph = h;                                               // :128
-            s.ro = (off > 0 ? off - 1 : 0) + 1;                     // prev_kmer_offset + 1 (:129, quirk Q1 kept)
-            s.flags = (s.flags & ~F_FIRST_SEEK) | F_FRESH | F_LEFT_SEED;
+            s.rr = (off > 0 ? off - 1 : 0) + 1;                     // prev_kmer_offset + 1 (:129, quirk Q1 kept); snp = 0
+            s.of = off | (ST_LEFT << 24) | (((fl & ~F_FIRST_SEEK) | F_FRESH | F_LEFT_SEED) << 27);
         } else {
-            s.st = ST_FWD;
-            s.flags = (s.flags & ~F_FIRST_SEEK) | F_FRESH;
+            s.of = off | (ST_FWD << 24) | (((fl & ~F_FIRST_SEEK) | F_FRESH) << 27);
         }
         return;
     }
-    const bool full = s0.z != NO_HANDLE && s1.z != NO_HANDLE && s2.z != NO_HANDLE && s3.z != NO_HANDLE;
-    if (full && probe + 1 < ix.nbuckets) {                          // key may live in the next bucket
-        s.flags |= (probe + 1) << F_PROBE_SHIFT;
+    const bool full = ((fp.x | fp.y | fp.z | fp.w) >> 31) == 0;     // no free slot: the key may live in the next bucket
+    if (full && probe < 15) {
+        s.nc |= (probe + 1) << 12;
         return;
     }
-    s.kp += PA_SEEK_STRIDE;                                         // :110
-    if (s.kp > last) s.st = s.ncol ? ST_ISECT : ST_NONE;            // None (:113) -> :294 break / :305-314
+    const uint32_t nkp = kp + PA_SEEK_STRIDE;                       // :110
+    l_set_kp(s, nkp);
+    if (nkp > L - K) l_set_st(s, l_ncol(s) ? ST_ISECT : ST_NONE);   // None (:113) -> :294 break / :305-314
 }
 
 // ---------------------------------------------------------------------------------------------- FWD
-// Forward search (:209-301): one call = enter/continue one node and compare up to 64 bases.
+// Forward search (:209-301): one call = enter/continue one node (one dependent fetch of the node header + sequence
+// words, issued together). Fast mode compares up to 128 bases by counting mismatches only; when a node visit would
+// exceed its mismatch budget nothing is consumed and the lane switches to careful mode, which walks the same node 32
+// bases per call and locates the breaking base exactly as the reference's loop does (:236-255).
 template <bool TRACE = false>
 PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
-    const uint32_t K = ix.k;
-    const bool fresh = s.flags & F_FRESH;
-    const uint32_t ro0 = fresh ? s.off + K : s.ro;                  // ref_offset (:227)
-    uint32_t kp = fresh ? s.kp + K : s.kp;                          // kmer_pos += kmer_length (:215)
-    const Hdr hd = load_hdr(ix, s.h);                               // dbg.get_node (:210)
-    const uint64_t* sq = node_seq(ix, s.h) + (ro0 >> 5);
-    const uint64_t a0 = sq[0], a1 = sq[1], a2 = sq[2];
-    uint32_t rem = s.rem, snp = s.snp, ro = ro0;
+    const uint32_t K = ix.k, L = l_L(s);
+    const uint32_t fl = l_flags(s);
+    const bool fresh = fl & F_FRESH, careful = fl & F_CAREFUL;
+    const uint32_t ro0 = fresh ? l_off(s) + K : (s.rr & 0xFFFFFFu);   // ref_offset (:227)
+    const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
+    const Hdr hd = load_hdr(ix, s.h);                                 // dbg.get_node (:210)
+    const Q2* sq2 = reinterpret_cast<const Q2*>(node_seq(ix, s.h) + (ro0 >> 5));
+    const Q2 s01 = sq2[0], s23 = sq2[1], s45 = sq2[2];
+    const uint64_t a[5] = {s01.a, s01.b, s23.a, s23.b, s45.a};
+    uint32_t rem = s.rm & 0xFFFFu, snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
     if (fresh) {
-        s.cov += K;                                                 // :216
-        push_node<TRACE>(s, cols, hd.colour, hd.nid);                // nodes.push (:219)
-        rem = pa_min(s.L - kp, hd.len - ro);                        // max_matchable_pos (:222-231)
-        snp = 0;                                                    // :235
-        s.flags &= ~F_FRESH;
+        cov += K;                                                     // :216
+        push_node<TRACE>(s, cols, hd.ec_ref, hd.ec_len, hd.nid);      // nodes.push (:219)
+        rem = pa_min(L - kp0, hd.len - ro0);                          // max_matchable_pos (:222-231)
+        snp = 0;                                                      // :235
     }
+    const uint32_t sh_a = (ro0 & 31) * 2, sh_r = (kp0 & 31) * 2, rw = kp0 >> 5;
     bool premature = false;
-    const uint32_t n = pa_min(rem, 64u);
-    uint32_t matched = 0;
-    if (n > 0) {
-        const uint32_t sh = (ro & 31) * 2;
-        matched = compare_chunk(diff_mask(read_window(rd, kp) ^ funnel(a0, a1, sh)), pa_min(n, 32u), allowed, snp, s.mism, premature);
-        if (!premature && n > 32)
-            matched += compare_chunk(diff_mask(read_window(rd, kp + 32) ^ funnel(a1, a2, sh)), n - 32, allowed, snp, s.mism, premature);
-    }
-    kp += matched;                                                  // :257
-    s.cov += matched;                                               // :254
-    ro += matched;
-    rem -= matched;
-    s.kp = kp;
-    s.ro = ro;
-    s.rem = rem;
-    s.snp = snp;
-    if (!premature && rem > 0) return;                              // same node, next 64 bases
-    if (kp >= s.L) { s.st = ST_ISECT; return; }                     // :259-261
-    const uint32_t b = read_base(rd, kp);                           // :265
-    if (!premature && ((hd.exts >> b) & 1u)) {                      // :267
-        s.h = b == 0 ? hd.e0 : b == 1 ? hd.e1 : b == 2 ? hd.e2 : hd.e3;   // r_edges()[index].0 (:275-278)
-        s.off = 0;                                                  // :279
-        s.kp = kp - (K - 1);                                        // :282
-        s.cov -= K - 1;                                             // :283
-        s.flags |= F_FRESH;
-    } else if (kp > s.L - K) {                                      // :287-290
-        s.st = ST_ISECT;
+    uint32_t matched, nfl = fl & ~F_FRESH;
+    if (!careful) {
+        const uint32_t n = pa_min(rem, 128u);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t done = 32u * c;
+            if (n > done) cnt += pa_popc64(diff_mask(funnel(read_word(rd, rw + c), read_word(rd, rw + c + 1), sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u)));
+        }
+        if (snp + cnt <= allowed) {
+            matched = n;
+            snp += cnt;
+            mism += cnt;
+        } else {                                                      // over budget somewhere in these bases: redo carefully
+            matched = 0;
+            nfl |= F_CAREFUL;
+        }
     } else {
-        s.st = ST_SEEK;                                             // find_kmer_match(&mut kmer_pos) (:293)
+        const uint32_t n = pa_min(rem, 32u);
+        matched = compare_chunk(diff_mask(funnel(read_word(rd, rw), read_word(rd, rw + 1), sh_r) ^ funnel(a[0], a[1], sh_a), n), n, allowed, snp, mism, premature);
     }
+    const uint32_t kp = kp0 + matched;                                // :257
+    cov += matched;                                                   // :254
+    rem -= matched;
+    uint32_t st = ST_FWD, h = s.h, off = l_off(s), kp_out = kp;
+    if (!(nfl & F_CAREFUL) || careful) {
+        if (premature || rem == 0) {                                  // node visit finished
+            nfl &= ~F_CAREFUL;
+            if (kp >= L) st = ST_ISECT;                               // :259-261
+            else {
+                const uint32_t b = read_base(rd, kp);                 // :265
+                if (!premature && ((hd.exts >> b) & 1u)) {            // :267
+                    h = load_redge(ix, s.h, b);                       // r_edges()[index].0 (:275-278)
+                    off = 0;                                          // :279
+                    kp_out = kp - (K - 1);                            // :282
+                    cov -= K - 1;                                     // :283
+                    nfl |= F_FRESH;
+                } else if (kp > L - K) st = ST_ISECT;                 // :287-290
+                else st = ST_SEEK;                                    // find_kmer_match(&mut kmer_pos) (:293)
+            }
+        }
+    }
+    s.h = h;
+    s.lk = L | (kp_out << 16);
+    s.cm = cov | (mism << 16);
+    s.rr = (ro0 + matched) | (snp << 24);
+    s.rm = (s.rm & 0xFFFF0000u) | rem;
+    s.of = off | (st << 24) | (nfl << 27);
 }
 
 // ---------------------------------------------------------------------------------------------- LEFT
@@ -268,21 +346,22 @@ template <bool TRACE = false>
 PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
     const uint32_t K = ix.k;
     const Hdr hd = load_hdr(ix, s.ph);                              // dbg.get_node(prev_node_id) (:132)
-    uint32_t na = s.ro, rem = s.rem, snp = s.snp;
-    if (s.flags & F_FRESH) {
-        if (!(s.flags & F_LEFT_SEED)) {
-            push_node<TRACE>(s, cols, hd.colour, hd.nid);            // nodes.push(prev_node.node_id) (:199)
+    uint32_t na = s.rr & 0xFFFFFFu, snp = s.rr >> 24, rem = s.rm & 0xFFFFu, ra = s.rm >> 16, cov = l_cov(s), mism = l_mism(s);
+    const uint32_t fl = l_flags(s);
+    if (fl & F_FRESH) {
+        if (!(fl & F_LEFT_SEED)) {
+            push_node<TRACE>(s, cols, hd.ec_ref, hd.ec_len, hd.nid);   // nodes.push(prev_node.node_id) (:199)
             na = hd.len - K + 1;                                    // prev_kmer_offset = len - k (:196)
         }
-        rem = pa_min(s.ra, na);                                     // max_matchable_pos (:139-145)
+        rem = pa_min(ra, na);                                       // max_matchable_pos (:139-145)
         snp = 0;                                                    // :150
-        s.flags &= ~(F_FRESH | F_LEFT_SEED);
+        l_clr_flags(s, F_FRESH | F_LEFT_SEED);
     }
     bool premature = false;
     const uint32_t n = pa_min(rem, 32u);
     uint32_t matched = 0;
     if (n > 0) {
-        const uint32_t po = na - 1, lp = s.ra - 1;                  // ref_pos / read_offset of idx 0 (:152-153)
+        const uint32_t po = na - 1, lp = ra - 1;                    // ref_pos / read_offset of idx 0 (:152-153)
         const uint64_t* sq = node_seq(ix, s.ph);
         uint64_t sw;
         if (po >= 31) {
@@ -291,37 +370,42 @@ PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, u
         } else {
             sw = sq[0] << (2 * (31 - po));
         }
-        const uint64_t m = diff_mask(read_window_end(rd, lp) ^ sw);
-        matched = compare_chunk(pa_brev64(m) >> 1, n, allowed, snp, s.mism, premature);   // base idx 0 = top bits
+        // base idx 0 sits in the top bits: fold each base's two XOR bits onto its odd bit, then bit-reverse so that
+        // bit 2i = i-th base compared
+        const uint64_t x = read_window_end(rd, lp) ^ sw;
+        const uint64_t m = pa_brev64((x | (x << 1)) & 0xAAAAAAAAAAAAAAAAull);
+        const uint64_t keep = n >= 32 ? ~0ull : ((1ull << (2 * n)) - 1);
+        matched = compare_chunk(m & keep, n, allowed, snp, mism, premature);
     }
-    s.ra -= matched;                                                // last_pos -= matched_bases (:178)
+    ra -= matched;                                                  // last_pos -= matched_bases (:178)
     na -= matched;
     rem -= matched;
-    s.cov += matched;                                               // :169
-    s.ro = na;
-    s.rem = rem;
-    s.snp = snp;
+    cov += matched;                                                 // :169
+    s.cm = cov | (mism << 16);
+    s.rr = na | (snp << 24);
+    s.rm = rem | (ra << 16);
     if (!premature && rem > 0) return;
-    bool stop = s.ra == 0 || premature;                             // :173-175
-    if (!stop) {
-        const uint32_t b = read_base(rd, s.ra - 1);                 // next_base = read_seq.get(last_pos) (:182)
+    if (!(ra == 0 || premature)) {                                  // :173-175
+        const uint32_t b = read_base(rd, ra - 1);                   // next_base = read_seq.get(last_pos) (:182)
         if ((hd.exts >> (4 + b)) & 1u) {                            // has_ext(Dir::Left, b) (:183)
             s.ph = ix.ledge[4ull * hd.nid + b];                     // l_edges()[index].0 (:191-194)
-            s.flags |= F_FRESH;
+            l_or_flags(s, F_FRESH);
             return;
-        }
-        stop = true;                                                // :200-202
+        }                                                           // else :200-202
     }
-    s.st = ST_FWD;                                                  // forward search from the seed (:208)
-    s.flags |= F_FRESH;
+    l_set_st(s, ST_FWD);                                            // forward search from the seed (:208)
+    l_or_flags(s, F_FRESH);
 }
 
 // ---------------------------------------------------------------------------------------------- ISECT
-// nodes_to_eq_class (:323-356) + intersect (:389-418): the class is the intersection of the colour lists of every
-// visited node. Base list = a shortest one (what the stable sort at :331-334 puts first); survivors are tracked as a
-// 64-bit mask over the base list when it has <= 64 ids, else recomputed in the write pass.
+// nodes_to_eq_class (:323-356) + intersect (:389-418): the class is the intersection of the id lists of every visited
+// node's class. Base list = a shortest one (what the stable sort at :331-334 puts first). Regimes:
+//   register tier  <= 4 classes, base <= 7 ids: base ids in registers (two 16-byte loads of its record); other lists of
+//                  <= 7 ids are compared all-pairs in registers, longer ones by binary search
+//   generic tier   base <= 64 ids: survivors tracked as a 64-bit mask, membership by binary search; longer bases are
+//                  counted, then recomputed in the write pass
 struct Isect {
-    uint32_t base_start, base_len, base_colour, count;
+    uint32_t base_ref, base_len, base_colour, count;
     uint64_t alive;
 };
 
@@ -335,50 +419,116 @@ PA_HD bool list_contains(const uint32_t* v, uint32_t n, uint32_t key) {   // bin
     return lo < n && v[lo] == key;
 }
 
-PA_HD bool in_all_lists(const DevIndexView& ix, ColRef cols, uint32_t ncol, uint32_t base_colour, uint32_t v) {
+PA_HD const uint32_t* class_ids(const DevIndexView& ix, uint32_t ec_ref) { return ix.ec + 4ull * ec_ref + 1; }
+
+PA_HD void get_class(ColRef c, uint32_t i, uint32_t& ec_ref, uint32_t& ec_len) {
+    if (i < LDS_CLASSES) {
+        ec_ref = c.refs[i];
+        ec_len = c.lens[i];
+    } else {
+        ec_ref = c.spill[2 * (i - LDS_CLASSES)];
+        ec_len = c.spill[2 * (i - LDS_CLASSES) + 1];
+    }
+}
+
+PA_HD bool in_all_lists(const DevIndexView& ix, ColRef cols, uint32_t ncol, uint32_t base_ref, uint32_t v) {
     for (uint32_t i = 0; i < ncol; ++i) {
-        const uint32_t c = get_colour(cols, i);
-        if (c == base_colour) continue;
-        const uint32_t st = ix.ec_off[c], ln = ix.ec_off[c + 1] - st;
-        if (!list_contains(ix.ec_ids + st, ln, v)) return false;
+        uint32_t ref, len;
+        get_class(cols, i, ref, len);
+        if (ref == base_ref) continue;
+        if (!list_contains(class_ids(ix, ref), len, v)) return false;
     }
     return true;
 }
 
+PA_HD uint32_t eq_mask7(uint32_t v, const uint32_t (&b)[7]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) m |= (b[i] == v ? 1u : 0u) << i;
+    return m;
+}
+
 PA_HD Isect isect_count(const Lane& s, const DevIndexView& ix, ColRef cols) {
     Isect r{0, 0xFFFFFFFFu, 0, 0, 0};
-    for (uint32_t i = 0; i < s.ncol; ++i) {
-        const uint32_t c = get_colour(cols, i);
-        const uint32_t st = ix.ec_off[c], ln = ix.ec_off[c + 1] - st;
-        if (ln < r.base_len) { r.base_len = ln; r.base_start = st; r.base_colour = c; }
+    const uint32_t ncol = l_ncol(s);
+    const U4 refs = *reinterpret_cast<const U4*>(cols.refs), lens = *reinterpret_cast<const U4*>(cols.lens);
+    const uint32_t rf[4] = {refs.x, refs.y, refs.z, refs.w};
+    const uint32_t ln[4] = {lens.x, ncol > 1 ? lens.y : 0xFFFFFFFFu, ncol > 2 ? lens.z : 0xFFFFFFFFu, ncol > 3 ? lens.w : 0xFFFFFFFFu};
+    r.base_len = ln[0];
+    r.base_ref = rf[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (ln[i] < r.base_len) { r.base_len = ln[i]; r.base_ref = rf[i]; }
+    for (uint32_t i = LDS_CLASSES; i < ncol; ++i) {                 // spilled classes (rare)
+        uint32_t ref, len;
+        get_class(cols, i, ref, len);
+        if (len < r.base_len) { r.base_len = len; r.base_ref = ref; }
     }
+    const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * r.base_ref);
+    if (r.base_len <= 7 && ncol <= LDS_CLASSES) {
+        const U4 q0 = brec[0], q1 = brec[1];
+        r.base_colour = q0.x;
+        const uint32_t b[7] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        uint32_t alive = (1u << r.base_len) - 1;
+#pragma unroll 1
+        for (uint32_t i = 0; i < ncol && alive; ++i) {
+            const uint32_t ref = i == 0 ? rf[0] : i == 1 ? rf[1] : i == 2 ? rf[2] : rf[3];
+            const uint32_t len = i == 0 ? ln[0] : i == 1 ? ln[1] : i == 2 ? ln[2] : ln[3];
+            if (ref == r.base_ref) continue;
+            uint32_t m = 0;
+            if (len <= 7) {
+                const U4* orec = reinterpret_cast<const U4*>(ix.ec + 4ull * ref);
+                const U4 o0 = orec[0], o1 = orec[1];
+                const uint32_t o[7] = {o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+                for (int j = 0; j < 7; ++j)
+                    if ((uint32_t)j < len) m |= eq_mask7(o[j], b);
+            } else {
+                const uint32_t* ids = class_ids(ix, ref);
+                const uint32_t* bids = class_ids(ix, r.base_ref);
+#pragma unroll 1
+                for (uint32_t t = alive; t; t &= t - 1) {
+                    const uint32_t j = pa_ctz32(t);
+                    if (list_contains(ids, len, bids[j])) m |= 1u << j;
+                }
+            }
+            alive &= m;
+        }
+        r.alive = alive;
+        r.count = pa_popc32(alive);
+        return r;
+    }
+    r.base_colour = brec[0].x;
+    const uint32_t* bids = class_ids(ix, r.base_ref);
     if (r.base_len <= 64) {
         uint64_t alive = r.base_len == 64 ? ~0ull : ((1ull << r.base_len) - 1);
-        for (uint32_t i = 0; i < s.ncol && alive; ++i) {
-            const uint32_t c = get_colour(cols, i);
-            if (c == r.base_colour) continue;
-            const uint32_t st = ix.ec_off[c], ln = ix.ec_off[c + 1] - st;
+        for (uint32_t i = 0; i < ncol && alive; ++i) {
+            uint32_t ref, len;
+            get_class(cols, i, ref, len);
+            if (ref == r.base_ref) continue;
+            const uint32_t* ids = class_ids(ix, ref);
             for (uint64_t t = alive; t; t &= t - 1) {
                 const uint32_t j = pa_ctz64(t);
-                if (!list_contains(ix.ec_ids + st, ln, ix.ec_ids[r.base_start + j])) alive &= ~(1ull << j);
+                if (!list_contains(ids, len, bids[j])) alive &= ~(1ull << j);
             }
         }
         r.alive = alive;
         r.count = pa_popc64(alive);
     } else {
-        for (uint32_t j = 0; j < r.base_len; ++j)
-            r.count += in_all_lists(ix, cols, s.ncol, r.base_colour, ix.ec_ids[r.base_start + j]) ? 1u : 0u;
+        for (uint32_t j = 0; j < r.base_len; ++j) r.count += in_all_lists(ix, cols, ncol, r.base_ref, bids[j]) ? 1u : 0u;
     }
     return r;
 }
 
 PA_HD void isect_write(const Lane& s, const DevIndexView& ix, ColRef cols, const Isect& r, uint32_t* dst) {
+    const uint32_t* bids = class_ids(ix, r.base_ref);
     if (r.base_len <= 64) {
-        for (uint64_t t = r.alive; t; t &= t - 1) *dst++ = ix.ec_ids[r.base_start + pa_ctz64(t)];
+        for (uint64_t t = r.alive; t; t &= t - 1) *dst++ = bids[pa_ctz64(t)];
     } else {
+        const uint32_t ncol = l_ncol(s);
         for (uint32_t j = 0; j < r.base_len; ++j) {
-            const uint32_t v = ix.ec_ids[r.base_start + j];
-            if (in_all_lists(ix, cols, s.ncol, r.base_colour, v)) *dst++ = v;
+            const uint32_t v = bids[j];
+            if (in_all_lists(ix, cols, ncol, r.base_ref, v)) *dst++ = v;
         }
     }
 }

@@ -48,40 +48,42 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
     const DevIndexView ix = e->fd.host_view();
     std::vector<uint32_t> all;
     std::vector<uint64_t> rd(wpr + 2);
-    std::vector<uint32_t> cols(col_cap ? col_cap : 1), spill, trace;
+    alignas(16) uint32_t refs[4], lens4[4];
+    std::vector<uint32_t> spill, trace;
+    (void)col_cap;
     uint64_t st_seek = 0, st_fwd = 0, st_left = 0, st_spill = 0;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t t = i >> 6, r = i & 63;
         for (uint32_t w = 0; w < wpr; ++w) rd[w] = tiles[(t * wpr + w) * 64 + r];
         rd[wpr] = rd[wpr + 1] = 0;
         const uint32_t L = lens[i];
-        spill.assign(2 * (size_t)L + 2, 0);
-        trace.assign(2 * (size_t)L + 2, 0);
+        spill.assign(4 * (size_t)L + 4, 0);
+        trace.assign(4 * (size_t)L + 4, 0);
         Lane s;
         lane_start(s, (uint32_t)i, L, ix.k);
-        const ReadRef rr{rd.data(), 1};
-        const ColRef cr{cols.data(), 1, col_cap, spill.data(), (uint32_t)spill.size(), trace.data()};
-        while (s.st == ST_SEEK || s.st == ST_FWD || s.st == ST_LEFT) {
-            if (s.st == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
-            else if (s.st == ST_FWD) { fwd_step<true>(s, ix, rr, cr, allowed); ++st_fwd; }
+        const ReadRef rr{rd.data(), 1, wpr};
+        const ColRef cr{refs, lens4, spill.data(), (uint32_t)spill.size(), trace.data()};
+        while (l_st(s) == ST_SEEK || l_st(s) == ST_FWD || l_st(s) == ST_LEFT) {
+            if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
+            else if (l_st(s) == ST_FWD) { fwd_step<true>(s, ix, rr, cr, allowed); ++st_fwd; }
             else { left_step<true>(s, ix, rr, cr, allowed); ++st_left; }
         }
-        if (s.flags & F_SPILL_OVERFLOW) return PA_ERR_INTERNAL;
-        if (s.ncol > col_cap) ++st_spill;
+        if (l_flags(s) & F_SPILL_OVERFLOW) return PA_ERR_INTERNAL;
+        if (l_ncol(s) > LDS_CLASSES) ++st_spill;
         if (nodes_out) {
-            nodes_len[i] = s.ntrace;
-            for (uint32_t j = 0; j < s.ntrace && j < nodes_stride; ++j) nodes_out[i * nodes_stride + j] = trace[j];
+            nodes_len[i] = l_ntrace(s);
+            for (uint32_t j = 0; j < l_ntrace(s) && j < nodes_stride; ++j) nodes_out[i * nodes_stride + j] = trace[j];
         }
         class_offsets[i] = all.size();
         pa_read_result res{0, 0, 0, 0};
         uint32_t colour = 0xFFFFFFFFu;
-        if (s.st == ST_ISECT) {
+        if (l_st(s) == ST_ISECT) {
             const Isect is = isect_count(s, ix, cr);
             const size_t o = all.size();
             all.resize(o + is.count);
             isect_write(s, ix, cr, is, all.data() + o);
-            res.coverage = s.cov;
-            res.mismatches = s.mism | PA_MAPPED_BIT;
+            res.coverage = l_cov(s);
+            res.mismatches = l_mism(s) | PA_MAPPED_BIT;
             res.class_off = (uint32_t)o;
             res.class_len = is.count;
             if (is.count == is.base_len) colour = is.base_colour;
