@@ -96,6 +96,7 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
     const uint32_t topshift = 2 * (k - 1);
 
     // ---- classes: 16-byte aligned records {class id, id0, id1, ...} ----
+    if (f.num_transcripts >= 0xFFFFFFFFu) return fail(PA_ERR_UNSUPPORTED, "too many transcripts");   // 0xFFFFFFFF pads the records
     out.class_ref.resize(f.num_classes);
     out.class_len.resize(f.num_classes);
     for (uint32_t c = 0; c < f.num_classes; ++c) {
@@ -106,7 +107,7 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
         out.max_class_len = std::max(out.max_class_len, (uint32_t)len);
         out.ec.push_back(c);
         out.ec.insert(out.ec.end(), f.ec_ids + f.ec_offset[c], f.ec_ids + f.ec_offset[c + 1]);
-        while (out.ec.size() % 4) out.ec.push_back(0xFFFFFFFFu);
+        while (out.ec.size() % 4 || out.ec.size() - 4ull * out.class_ref[c] < 8) out.ec.push_back(0xFFFFFFFFu);   // >= 8 words, 0xFFFFFFFF padded
     }
     out.ec.resize(out.ec.size() + 8, 0xFFFFFFFFu);   // tail pad: records are read two 16-byte words at a time
 

@@ -186,7 +186,7 @@ static int env_int(const char* name, int dflt) {   // tuning knobs for A/B runs 
 
 static int map_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t* grid, size_t* lds, int* waves) {
     *waves = env_int("PA_MAP_WAVES", PA_DEFAULT_MAP_WAVES);
-    const size_t wave_bytes = 64 + (size_t)(wpr + 1) * 512 + 2 * LDS_CLASSES * 256;
+    const size_t wave_bytes = 448 + (size_t)(wpr + 1) * 512 + 2 * LDS_CLASSES * 256;
     *lds = (sizeof(MapParams) + 15) / 16 * 16 + wave_bytes * (PA_MAP_BLOCK / 64);
     if (*lds > 160 * 1024) return fail(PA_ERR_UNSUPPORTED, "reads of %u words need %zu bytes of LDS per workgroup (> 160 KiB)", wpr, *lds);
     int per_cu = 0;
@@ -237,6 +237,7 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.counts = reinterpret_cast<unsigned long long*>(d_counts);
     p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
     p.class_table_size = idx->class_table_size;
+    p.ablate = (uint32_t)env_int("PA_MAP_ABLATE", 0);
     p.dbg = env_int("PA_MAP_STATS", 0) ? idx->ctl.as<unsigned long long>() + 2 : nullptr;
     p.trace = d_nodes ? idx->trace.as<uint32_t>() : nullptr;
     p.nodes_out = d_nodes;
@@ -253,11 +254,15 @@ static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_
     struct { unsigned long long top; uint32_t status; uint32_t pad; } ctl;
     HIP_TRY(hipMemcpy(&ctl, idx->ctl.p, 16, hipMemcpyDeviceToHost));
     if (env_int("PA_MAP_STATS", 0)) {
-        unsigned long long d[10];
+        unsigned long long d[20];
         HIP_TRY(hipMemcpy(d, idx->ctl.as<unsigned long long>() + 2, sizeof d, hipMemcpyDeviceToHost));
         static const char* names[5] = {"refill", "seek", "fwd", "finish", "left"};
         fprintf(stderr, "[pa map stats] grid=%u", idx->last_grid);
-        for (int i = 0; i < 5; ++i) fprintf(stderr, " %s: %llu iters x %.1f lanes", names[i], d[i], d[i] ? (double)d[5 + i] / (double)d[i] : 0.0);
+        for (int i = 0; i < 5; ++i)
+            fprintf(stderr, " %s: %llu iters x %.1f lanes, %.0f ticks/iter;", names[i], d[i], d[i] ? (double)d[5 + i] / (double)d[i] : 0.0,
+                    d[i] ? (double)d[10 + i] / (double)d[i] : 0.0);
+        fprintf(stderr, " finish stages (ticks/iter): pick %.0f, light %.0f, scan+alloc %.0f, class ids %.0f, record+counts %.0f", (double)d[19] / (double)(d[3] ? d[3] : 1), (double)d[15] / (double)(d[3] ? d[3] : 1),
+                (double)d[16] / (double)(d[3] ? d[3] : 1), (double)d[17] / (double)(d[3] ? d[3] : 1), (double)d[18] / (double)(d[3] ? d[3] : 1));
         fprintf(stderr, "\n");
     }
     if (arena_used) *arena_used = ctl.top;

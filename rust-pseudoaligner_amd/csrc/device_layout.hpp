@@ -20,9 +20,9 @@
 //               next node needs no further lookup (the reference re-derives every edge by hashing: SURVEY.md §3.2) and
 //               the colour's id list is addressable without an offsets table.
 //   ledge       u32[4*num_nodes] handles by node id (Node::l_edges), only touched by the left extension
-//   ec          class records, 16-byte aligned: record r = words [4r, ...) = {class id, id0, id1, ...} — the sorted
-//               transcript-id lists of eq_classes: Vec<Vec<u32>> (src/pseudoaligner.rs:29); a class of <= 3 ids is one
-//               16-byte load, <= 7 ids two.
+//   ec          class records, 16-byte aligned, at least 32 bytes, padded with 0xFFFFFFFF: record r = words [4r, ...) =
+//               {class id, id0, id1, ...} — the sorted transcript-id lists of eq_classes: Vec<Vec<u32>>
+//               (src/pseudoaligner.rs:29); a class of <= 7 ids is two 16-byte loads and needs no length checks.
 //   class_ref/class_len  u32[num_classes] record ref and length by class id (only the count table's content lookup)
 #pragma once
 #include <cstdint>

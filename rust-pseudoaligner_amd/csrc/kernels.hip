@@ -27,12 +27,15 @@ namespace pa {
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if ((int)lane >= d) v += t;
-    }
+// wave64 inclusive prefix sum with DPP (no LDS traffic): row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15
+// into rows 1 and 3 and row_bcast:31 into the upper half (gfx9 DPP controls; row/bank masks as in LLVM's buildScan)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 
@@ -67,17 +70,20 @@ __device__ __forceinline__ uint32_t class_of_list(const uint32_t* v, uint32_t n,
 // passed with their address space so that the callee emits ds_* (not flat_*) accesses.
 typedef __attribute__((address_space(3))) uint64_t* lds_u64;
 typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+typedef __attribute__((address_space(1))) const uint8_t* glb_u8;     // global pointers keep their address space across the
+typedef __attribute__((address_space(1))) const uint32_t* glb_u32;   // call so that the callee emits global_* (not flat_*) loads
+typedef __attribute__((address_space(1))) uint32_t* glb_u32w;
 
 __device__ __forceinline__ ReadRef make_read_ref(lds_u64 rdp, uint32_t wmax) { return ReadRef{(const uint64_t*)rdp, 64, wmax}; }
-__device__ __forceinline__ ColRef make_col_ref(lds_u32 refs, uint32_t* spill_base, uint32_t slot, uint32_t spill_cap, uint32_t* trace_base) {
-    return ColRef{(uint32_t*)refs, (uint32_t*)(refs + 64 * LDS_CLASSES), spill_base + (uint64_t)slot * spill_cap, spill_cap,
-                  trace_base ? trace_base + (uint64_t)slot * spill_cap : nullptr};
+__device__ __forceinline__ ColRef make_col_ref(lds_u32 refs, glb_u32w spill_base, uint32_t slot, uint32_t spill_cap, glb_u32w trace_base) {
+    return ColRef{(uint32_t*)refs, (uint32_t*)(refs + 64 * LDS_CLASSES), (uint32_t*)(spill_base + (uint64_t)slot * spill_cap), spill_cap,
+                  trace_base ? (uint32_t*)(trace_base + (uint64_t)slot * spill_cap) : nullptr};
 }
 
-__device__ __attribute__((noinline)) Lane seek_call(Lane s, const uint32_t* table, uint32_t nbuckets, uint64_t kmask, uint32_t k, lds_u64 rdp,
+__device__ __attribute__((noinline)) Lane seek_call(Lane s, glb_u32 table, uint32_t nbuckets, uint64_t kmask, uint32_t k, lds_u64 rdp,
                                                     uint32_t wmax) {
     DevIndexView ix{};
-    ix.table = table;
+    ix.table = (const uint32_t*)table;
     ix.nbuckets = nbuckets;
     ix.kmask = kmask;
     ix.k = k;
@@ -85,24 +91,24 @@ __device__ __attribute__((noinline)) Lane seek_call(Lane s, const uint32_t* tabl
     return s;
 }
 
-template <bool TRACE>
-__device__ __attribute__((noinline)) Lane fwd_call(Lane s, const uint8_t* blobs, uint32_t k, lds_u64 rdp, uint32_t wmax, lds_u32 refs,
-                                                   uint32_t* spill_base, uint32_t slot, uint32_t spill_cap, uint32_t* trace_base,
+template <bool TRACE, int EXP = 0>
+__device__ __attribute__((noinline)) Lane fwd_call(Lane s, glb_u8 blobs, uint32_t k, lds_u64 rdp, uint32_t wmax, lds_u32 refs,
+                                                   glb_u32w spill_base, uint32_t slot, uint32_t spill_cap, glb_u32w trace_base,
                                                    uint32_t allowed) {
     DevIndexView ix{};
-    ix.blobs = blobs;
+    ix.blobs = (const uint8_t*)blobs;
     ix.k = k;
-    fwd_step<TRACE>(s, ix, make_read_ref(rdp, wmax), make_col_ref(refs, spill_base, slot, spill_cap, trace_base), allowed);
+    fwd_step<TRACE, EXP>(s, ix, make_read_ref(rdp, wmax), make_col_ref(refs, spill_base, slot, spill_cap, trace_base), allowed);
     return s;
 }
 
 template <bool TRACE>
-__device__ __attribute__((noinline)) Lane left_call(Lane s, const uint8_t* blobs, const uint32_t* ledge, uint32_t k, lds_u64 rdp, uint32_t wmax,
-                                                    lds_u32 refs, uint32_t* spill_base, uint32_t slot, uint32_t spill_cap,
-                                                    uint32_t* trace_base, uint32_t allowed) {
+__device__ __attribute__((noinline)) Lane left_call(Lane s, glb_u8 blobs, glb_u32 ledge, uint32_t k, lds_u64 rdp, uint32_t wmax,
+                                                    lds_u32 refs, glb_u32w spill_base, uint32_t slot, uint32_t spill_cap,
+                                                    glb_u32w trace_base, uint32_t allowed) {
     DevIndexView ix{};
-    ix.blobs = blobs;
-    ix.ledge = ledge;
+    ix.blobs = (const uint8_t*)blobs;
+    ix.ledge = (const uint32_t*)ledge;
     ix.k = k;
     left_step<TRACE>(s, ix, make_read_ref(rdp, wmax), make_col_ref(refs, spill_base, slot, spill_cap, trace_base), allowed);
     return s;
@@ -114,82 +120,224 @@ __device__ __attribute__((noinline)) Lane left_call(Lane s, const uint8_t* blobs
 typedef __attribute__((address_space(3))) const MapParams* lds_params;
 typedef __attribute__((address_space(3))) unsigned long long* lds_u64w;
 
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src) {
+    return ((uint64_t)(uint32_t)__shfl((int)(v >> 32), (int)src, 64) << 32) | (uint32_t)__shfl((int)v, (int)src, 64);
+}
+
+// Cooperative intersection of the reads in `mask` (one bit per lane whose read needs it): G lanes work on one read, lane
+// e of a group owns base ids e, e+G, ... and binary-searches every other list of that read; the survivors of a group are
+// compacted with a wave ballot and written straight to the read's arena slice (an upper bound, base_len entries, was
+// reserved for it). This is the wave-level AND-reduce of the class lists: one pass costs (classes x log2 len) dependent
+// L1/L2 hits for 64/G reads at once instead of base_len times that for a single lane.
+template <int G>
+__device__ __forceinline__ void coop_intersect(uint64_t mask, uint32_t lane, uint32_t ncol_mine, const Isect& is, uint64_t my_off,
+                                               lds_u32 wave_refs, lds_u32 wave_tmp, glb_u32 ec, glb_u32w spill_base, uint32_t wave_slot0,
+                                               uint32_t spill_cap, glb_u32w arena, uint64_t arena_cap) {
+    const uint32_t g = lane / G, e = lane % G;
+    while (mask) {
+        uint32_t L = 64;
+        for (int t = 0; t < 64 / G; ++t) {   // the g-th set bit of mask goes to group g (uniform scalar loop)
+            const uint32_t bit = mask ? (uint32_t)(__ffsll((unsigned long long)mask) - 1) : 64u;
+            if ((uint32_t)t == g) L = bit;
+            mask &= mask - 1;
+        }
+        const bool have = L < 64;
+        const uint32_t Ls = have ? L : 0u;
+        // cross-lane reads happen with EVERY lane active (a source lane that sat out a branch would return garbage)
+        const uint32_t bref = (uint32_t)__shfl((int)is.base_ref, (int)Ls, 64);
+        const uint32_t blen_any = (uint32_t)__shfl((int)is.base_len, (int)Ls, 64);
+        const uint32_t ncol_any = (uint32_t)__shfl((int)ncol_mine, (int)Ls, 64);
+        const uint64_t off = shfl64(my_off, Ls);
+        const uint32_t blen = have ? blen_any : 0u;
+        const uint32_t ncolL = have ? ncol_any : 0u;
+        const bool fits = off + blen <= arena_cap;
+        const lds_u32 refsL = wave_refs + Ls * LDS_CLASSES;
+        uint32_t total = 0;
+        for (uint32_t c = 0; __any(c < blen); c += G) {
+            const uint32_t j = c + e;
+            const bool valid = j < blen;
+            const uint32_t v = valid ? ec[4ull * bref + 1 + j] : 0u;
+            bool ok = valid;
+            for (uint32_t i = 0; __any(i < ncolL); ++i) {
+                if (i < ncolL && ok) {
+                    uint32_t ref, len;
+                    if (i < LDS_CLASSES) {
+                        ref = refsL[i];
+                        len = refsL[64 * LDS_CLASSES + i];
+                    } else {
+                        const glb_u32w sp = spill_base + (uint64_t)(wave_slot0 + Ls) * spill_cap + 2 * (i - LDS_CLASSES);
+                        ref = sp[0];
+                        len = sp[1];
+                    }
+                    if (ref != bref) {   // membership of v in the other (sorted) list: 16-byte loads, every address known up front
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        typedef __attribute__((address_space(1))) const u32x4* glb_v4;
+                        const glb_v4 rec = (glb_v4)(ec + 4ull * ref);   // words: {class id, id0, id1, id2}, {id3..id6}, ... 0xFFFFFFFF padded
+                        bool hit = false;
+                        if (len <= 64) {          // short list: scan it, no dependent loads
+                            const uint32_t nchunks = (len + 4) >> 2;
+#pragma unroll 4
+                            for (uint32_t q = 0; q < nchunks; ++q) {
+                                const u32x4 w = rec[q];
+                                hit |= (q != 0 && w.x == v) | (w.y == v) | (w.z == v) | (w.w == v);
+                            }
+                        } else {                  // long list: binary_search (:404)
+                            const glb_u32 ids = ec + 4ull * ref + 1;
+                            uint32_t lo = 0, hi = len;
+                            while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (ids[mid] < v) lo = mid + 1; else hi = mid;
+                            }
+                            hit = lo < len && ids[lo] == v;
+                        }
+                        ok = hit;
+                    }
+                }
+            }
+            const uint64_t bm = __ballot(ok);
+            const uint64_t gbits = G == 64 ? bm : ((bm >> (g * G)) & ((1ull << G) - 1));
+            if (ok && fits) arena[off + total + (uint32_t)__popcll(gbits & ((1ull << e) - 1))] = v;
+            total += (uint32_t)__popcll(gbits);
+        }
+        if (have && e == 0) wave_tmp[L] = total;   // handed back to lane L through LDS
+    }
+}
+
 template <bool TRACE>
-__device__ __attribute__((noinline)) void finish_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk) {
+__device__ __attribute__((noinline)) void finish_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk,
+                                                      glb_u32 ec, glb_u32w arena_g, glb_u32w results_g, glb_u32w counts_g) {
+    const bool prof = pp->dbg != nullptr;
+    const lds_u64w fclk = chunk + 8 + 5;   // finish stage clocks live after the 5 section clocks
+    unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull;
     const uint32_t st = l_st(s);
     const bool fin = st == ST_ISECT || st == ST_NONE;
     DevIndexView ix{};
-    ix.ec = pp->ix.ec;
-    uint32_t* const spill_base = pp->spill;
+    ix.ec = (const uint32_t*)ec;
+    const glb_u32w spill_base = (glb_u32w)pp->spill;
     const uint32_t spill_cap = pp->spill_cap;
     const ColRef cols = make_col_ref(refs_lane, spill_base, slot, spill_cap, nullptr);
-    Isect is{0, 0, 0, 0, 0};
-    if (st == ST_ISECT) is = isect_count(s, ix, cols);
-    const uint32_t cnt = fin ? is.count : 0;
-    const uint32_t incl = wave_incl_scan(cnt, lane);
-    const uint32_t total = __shfl(incl, 63, 64);
+    Isect is;
+    is.count = 0;
+    is.base_len = 0xFFFFFFFFu;
+    is.base_ref = 0;
+    is.base_colour = 0;
+    is.alive = 0;
+    is.in_regs = false;
+    uint32_t tier = 0;
+    if (st == ST_ISECT && !(pp->ablate & 1u)) {
+        tier = isect_pick(s, cols, is);
+    }
+    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[4] += t - t0; t0 = t; }
+    if (st == ST_ISECT && !(pp->ablate & 1u)) {
+        if (tier == 0) isect_light(s, ix, cols, is);
+        else {
+            is.base_colour = ec[4ull * is.base_ref];
+            if (tier == 3) is.count = is.base_len;   // a single class: the result is the class itself
+        }
+    }
+    const bool coop = st == ST_ISECT && (tier == 1 || tier == 2);
+    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[0] += t - t0; t0 = t; }
+    const uint32_t cnt_alloc = !fin ? 0u : coop ? is.base_len : is.count;   // cooperative reads reserve an upper bound
+    const uint32_t incl = wave_incl_scan(cnt_alloc);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     unsigned long long chunk_cur = chunk[0];
     if (total > 0) {
         if (chunk_cur + total > chunk[1]) {   // wave-uniform branch: take a new private slice of the class arena
             const unsigned long long want = total > PA_ARENA_CHUNK ? total : PA_ARENA_CHUNK;
             unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(pp->arena_top, want);
-            base = __shfl(base, 0, 64);
+            if (lane == 0) base = atomicAdd((unsigned long long*)pp->arena_top, want);
+            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             chunk_cur = base;
             if (lane == 0) chunk[1] = base + want;
         }
         if (lane == 0) chunk[0] = chunk_cur + total;
     }
+    const uint64_t my_off = chunk_cur + (incl - cnt_alloc);
+    const uint64_t arena_cap = pp->arena_cap;
+    uint32_t* const arena = (uint32_t*)arena_g;
+    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[1] += t - t0; t0 = t; }
+    // ---- cooperative tiers (wave-uniform branches: every lane takes part) ----
+    const uint64_t m1 = __ballot(coop && tier == 1), m2 = __ballot(coop && tier == 2);
+    if (m1 | m2) {
+        const lds_u32 wave_refs = refs_lane - lane * LDS_CLASSES;
+        const lds_u32 wave_tmp = (lds_u32)(chunk) + 48;   // 64 x u32 inside the per-wave fixed area
+        if (m1) coop_intersect<8>(m1, lane, l_ncol(s), is, my_off, wave_refs, wave_tmp, ec, spill_base, slot - lane, spill_cap, arena_g, arena_cap);
+        if (m2) coop_intersect<64>(m2, lane, l_ncol(s), is, my_off, wave_refs, wave_tmp, ec, spill_base, slot - lane, spill_cap, arena_g, arena_cap);
+        if (coop) is.count = wave_tmp[lane];
+    }
     if (!fin) return;
-    const uint64_t my_off = chunk_cur + (incl - cnt);
+    const uint32_t cnt = is.count;
     pa_read_result r{0, 0, 0, 0};
     uint32_t colour = 0xFFFFFFFFu;
-    const uint64_t arena_cap = pp->arena_cap;
-    uint32_t* const arena = pp->arena;
     if (st == ST_ISECT) {
         r.coverage = l_cov(s);
         r.mismatches = l_mism(s) | PA_MAPPED_BIT;
         r.class_len = cnt;
         r.class_off = (uint32_t)my_off;
-        if (cnt) {
-            if (my_off + cnt <= arena_cap) isect_write(s, ix, cols, is, arena + my_off);
-            else atomicOr(pp->status, PA_STATUS_ARENA_FULL);
-        }
+        if (my_off + cnt_alloc > arena_cap) atomicOr(pp->status, PA_STATUS_ARENA_FULL);
+        else if (tier == 3) {
+            // copy of one class record: 16-byte loads (record words 1..cnt), four in flight per round trip
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(1))) const u32x4* glb_v4;
+            const glb_v4 rec = (glb_v4)(ec + 4ull * is.base_ref);
+            const uint32_t nchunks = (cnt + 4) >> 2;
+            for (uint32_t q0 = 0; q0 < nchunks; q0 += 4) {
+                u32x4 w[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) w[t] = rec[q0 + t < nchunks ? q0 + t : q0];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint32_t q = q0 + t;
+                    if (q < nchunks) {
+                        const uint32_t j = 4 * q;   // record word index of w[t].x; id index = word - 1
+                        if (j >= 1 && j - 1 < cnt) arena_g[my_off + j - 1] = w[t].x;
+                        if (j < cnt) arena_g[my_off + j] = w[t].y;
+                        if (j + 1 < cnt) arena_g[my_off + j + 1] = w[t].z;
+                        if (j + 2 < cnt) arena_g[my_off + j + 2] = w[t].w;
+                    }
+                }
+            }
+        } else if (cnt && !coop) isect_write(s, ix, cols, is, arena + my_off);
         if (cnt == is.base_len) colour = is.base_colour;
         if (l_flags(s) & F_SPILL_OVERFLOW) atomicOr(pp->status, PA_STATUS_SPILL_OVERFLOW);
     }
-    reinterpret_cast<U4*>(pp->results)[s.rid] = U4{r.coverage, r.mismatches, r.class_off, r.class_len};
-    uint32_t* const colour_out = pp->colour_out;
+    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[2] += t - t0; t0 = t; }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) u32x4* glb_v4w;
+    ((glb_v4w)results_g)[s.rid] = u32x4{r.coverage, r.mismatches, r.class_off, r.class_len};
+    const glb_u32w colour_out = (glb_u32w)pp->colour_out;
     if (colour_out) colour_out[s.rid] = colour;
-    unsigned long long* const counts = pp->counts;
+    typedef __attribute__((address_space(1))) unsigned long long* glb_u64w;
+    unsigned long long* const counts = (unsigned long long*)(glb_u64w)counts_g;
     if (counts) {   // fused class-count table: fire-and-forget atomics overlap the other lanes' walks
         const uint32_t num_classes = pp->ix.num_classes;
         uint32_t cslot = num_classes + 2;                              // unmapped
         if (st == ST_ISECT) {
             if (cnt == 0) cslot = num_classes + 1;                     // mapped, empty class
             else {
-                if (colour == 0xFFFFFFFFu && my_off + cnt <= arena_cap) {   // strict subset of every visited class
-                    ix.class_ref = pp->ix.class_ref;
-                    ix.class_len = pp->ix.class_len;
-                    colour = class_of_list(arena + my_off, cnt, ix, pp->class_table, pp->class_table_size);
+                if (colour == 0xFFFFFFFFu && my_off + cnt_alloc <= arena_cap) {   // strict subset of every visited class
+                    ix.class_ref = (const uint32_t*)(glb_u32)pp->ix.class_ref;
+                    ix.class_len = (const uint32_t*)(glb_u32)pp->ix.class_len;
+                    colour = class_of_list(arena + my_off, cnt, ix, (const uint32_t*)(glb_u32)pp->class_table, pp->class_table_size);
                 }
                 cslot = colour == 0xFFFFFFFFu ? num_classes : colour;
             }
         }
         atomicAdd(counts + cslot, 1ull);
     }
+    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[3] += t - t0; t0 = t; }
     if (TRACE) {   // node lists, read-major, stride spill_cap (map_read_to_nodes test surface)
         const uint32_t nt = l_ntrace(s);
         const uint32_t nn = st == ST_ISECT ? (nt < spill_cap ? nt : spill_cap) : 0;
-        pp->nodes_len[s.rid] = st == ST_ISECT ? nt : 0;
-        const uint32_t* tr = pp->trace + (uint64_t)slot * spill_cap;
-        uint32_t* out = pp->nodes_out + (uint64_t)s.rid * spill_cap;
+        ((glb_u32w)pp->nodes_len)[s.rid] = st == ST_ISECT ? nt : 0;
+        const glb_u32w tr = (glb_u32w)pp->trace + (uint64_t)slot * spill_cap;
+        const glb_u32w out = (glb_u32w)pp->nodes_out + (uint64_t)s.rid * spill_cap;
         for (uint32_t j = 0; j < nn; ++j) out[j] = tr[j];
     }
 }
 
 constexpr uint32_t PA_LDS_PARAMS_BYTES = (sizeof(MapParams) + 15) / 16 * 16;
-constexpr uint32_t PA_LDS_WAVE_FIXED = 64;   // per-wave: arena chunk state {cur, end}, scheduler statistics [10] u32
+constexpr uint32_t PA_LDS_WAVE_FIXED = 448;  // per-wave: arena chunk state {cur, end}, scheduler statistics [10] u32, section clocks [5] u64
 
 template <bool TRACE, int WAVES>
 __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapParams p) {
@@ -226,7 +374,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
     Lane s;
     s.rid = s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0;   // state ST_EMPTY
     const lds_u32 dbg = (lds_u32)(wbase + 16);   // scheduler statistics (only kept when p.dbg)
-    if (lane < 10) dbg[lane] = 0;
+    if (lane < 44) dbg[lane] = 0;
+    const lds_u64w dbg_clk = (lds_u64w)(wbase + 64);   // wall clocks spent per section (s_memtime ticks)
 
     for (;;) {
         const uint32_t st = l_st(s);
@@ -249,6 +398,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
             dbg[sel] += 1;
             dbg[5 + sel] += best;
         }
+        const unsigned long long t_sec = p.dbg ? __builtin_readcyclecounter() : 0ull;
 
         if (sel == 0) {   // ---- REFILL: empty lanes take the next reads of this wave's range (coalesced by rank)
             const uint32_t rank = __popcll(mE & ((1ull << lane) - 1));
@@ -263,17 +413,24 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
             }
             next += nR;
         } else if (sel == 1) {
-            if (st == ST_SEEK) s = seek_call(s, p.ix.table, (uint32_t)p.ix.nbuckets, p.ix.kmask, p.ix.k, rd_lane, p.wpr);
+            if (st == ST_SEEK && (p.ablate & 4u)) { s.nc |= 1; l_set_st(s, (p.ablate & 2u) ? ST_ISECT : ST_FWD); s.h = s.rid & 1023u; l_or_flags(s, F_FRESH); }
+            else if (st == ST_SEEK) s = seek_call(s, (glb_u32)p.ix.table, (uint32_t)p.ix.nbuckets, p.ix.kmask, p.ix.k, rd_lane, p.wpr);
         } else if (sel == 2) {
-            if (st == ST_FWD) s = fwd_call<TRACE>(s, p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, p.spill, slot, p.spill_cap, TRACE ? p.trace : nullptr, p.allowed);
+            if (st == ST_FWD && (p.ablate & 2u)) l_set_st(s, ST_ISECT);
+            else if (st == ST_FWD && !TRACE && (p.ablate & 8u)) s = fwd_call<false, 1>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
+            else if (st == ST_FWD && !TRACE && (p.ablate & 16u)) s = fwd_call<false, 2>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
+            else if (st == ST_FWD && !TRACE && (p.ablate & 32u)) s = fwd_call<false, 3>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
+            else if (st == ST_FWD) s = fwd_call<TRACE>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, TRACE ? (glb_u32w)p.trace : nullptr, p.allowed);
         } else if (sel == 4) {
-            if (st == ST_LEFT) s = left_call<TRACE>(s, p.ix.blobs, p.ix.ledge, p.ix.k, rd_lane, p.wpr, refs_lane, p.spill, slot, p.spill_cap, TRACE ? p.trace : nullptr, p.allowed);
+            if (st == ST_LEFT) s = left_call<TRACE>(s, (glb_u8)p.ix.blobs, (glb_u32)p.ix.ledge, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, TRACE ? (glb_u32w)p.trace : nullptr, p.allowed);
         } else {          // ---- FINISH: nodes_to_eq_class + output (whole wave enters: the scan inside needs every lane)
-            finish_call<TRACE>(s, lane, slot, refs_lane, pp, chunk);
+            finish_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, (glb_u32)p.ix.ec, (glb_u32w)p.arena, (glb_u32w)p.results, (glb_u32w)p.counts);
             if (st == ST_ISECT || st == ST_NONE) s.of = 0;   // ST_EMPTY
         }
+        if (p.dbg && lane == 0) dbg_clk[sel] += __builtin_readcyclecounter() - t_sec;
     }
     if (p.dbg && lane < 10) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
+    if (p.dbg && lane < 10) atomicAdd(p.dbg + 10 + lane, dbg_clk[lane]);
 }
 
 // ---------------------------------------------------------------------------------------------- encode

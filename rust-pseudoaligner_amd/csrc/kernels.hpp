@@ -31,6 +31,9 @@ struct MapParams {
     unsigned long long* counts;
     const uint32_t* class_table;
     uint64_t class_table_size;
+    // timing experiments only (PA_MAP_ABLATE; results are WRONG when non-zero): 1 = skip the intersection, 2 = skip the
+    // forward walk, 4 = skip the dictionary probe
+    uint32_t ablate;
     // optional scheduler statistics: [0..4] iterations of refill/seek/fwd/finish/left, [5..9] lanes served by them
     unsigned long long* dbg;
     // trace launches only (pa_map_read_to_nodes): per-lane scratch, per-read node lists (stride spill_cap) and lengths

@@ -64,8 +64,8 @@ struct ColRef {    // the lane's list of distinct classes seen: the first LDS_CL
     uint32_t* trace;      // TRACE builds only: node ids in visit order (map_read_to_nodes, :54-61), capacity spill_cap
 };
 
-struct Hdr {   // first 16 bytes of a node blob; the edge handles (+16) are fetched only when a hop is taken
-    uint32_t len, exts, nid, ec_ref, ec_len;
+struct Hdr {   // the 32-byte header of a node blob
+    uint32_t len, exts, nid, ec_ref, ec_len, e0, e1, e2, e3;
 };
 
 // ---------------------------------------------------------------------------------------------- helpers
@@ -150,11 +150,8 @@ PA_HD uint32_t read_base(ReadRef r, uint32_t pos) { return (uint32_t)(r.p[(pos >
 
 PA_HD Hdr load_hdr(const DevIndexView& ix, uint32_t h) {
     const U4* p = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)h * BLOB_GRANULE);
-    const U4 a = p[0];
-    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, a.z, a.w};
-}
-PA_HD uint32_t load_redge(const DevIndexView& ix, uint32_t h, uint32_t base) {
-    return reinterpret_cast<const uint32_t*>(ix.blobs + (uint64_t)h * BLOB_GRANULE + 16)[base];
+    const U4 a = p[0], b = p[1];
+    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 }
 PA_HD const uint64_t* node_seq(const DevIndexView& ix, uint32_t h) {
     return reinterpret_cast<const uint64_t*>(ix.blobs + (uint64_t)h * BLOB_GRANULE + 32);
@@ -166,9 +163,8 @@ PA_HD uint64_t diff_mask(uint64_t x, uint32_t n) {
     uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
     lo = (lo | (lo >> 1)) & 0x55555555u;
     hi = (hi | (hi >> 1)) & 0x55555555u;
-    const uint32_t mlo = n >= 16 ? 0xFFFFFFFFu : ((1u << (2 * n)) - 1);
-    const uint32_t mhi = n >= 32 ? 0xFFFFFFFFu : (n > 16 ? ((1u << (2 * n - 32)) - 1) : 0u);
-    return (uint64_t)(lo & mlo) | ((uint64_t)(hi & mhi) << 32);
+    const uint64_t keep = n >= 32 ? ~0ull : ((1ull << (2 * n)) - 1);
+    return ((uint64_t)lo | ((uint64_t)hi << 32)) & keep;
 }
 
 // The body of the compare loops (:151-170 / :236-255) over n <= 32 bases given their mismatch mask (bit 2i = i-th base
@@ -270,7 +266,7 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
 // words, issued together). Fast mode compares up to 128 bases by counting mismatches only; when a node visit would
 // exceed its mismatch budget nothing is consumed and the lane switches to careful mode, which walks the same node 32
 // bases per call and locates the breaking base exactly as the reference's loop does (:236-255).
-template <bool TRACE = false>
+template <bool TRACE = false, int EXP = 0>   // EXP != 0: timing experiments only (wrong results)
 PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
     const uint32_t K = ix.k, L = l_L(s);
     const uint32_t fl = l_flags(s);
@@ -279,7 +275,8 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
     const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
     const Hdr hd = load_hdr(ix, s.h);                                 // dbg.get_node (:210)
     const Q2* sq2 = reinterpret_cast<const Q2*>(node_seq(ix, s.h) + (ro0 >> 5));
-    const Q2 s01 = sq2[0], s23 = sq2[1], s45 = sq2[2];
+    const Q2 zero2{0, 0};
+    const Q2 s01 = EXP == 2 ? zero2 : sq2[0], s23 = (EXP == 1 || EXP == 2) ? zero2 : sq2[1], s45 = (EXP == 1 || EXP == 2) ? zero2 : sq2[2];
     const uint64_t a[5] = {s01.a, s01.b, s23.a, s23.b, s45.a};
     uint32_t rem = s.rm & 0xFFFFu, snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
     if (fresh) {
@@ -289,6 +286,9 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
         snp = 0;                                                      // :235
     }
     const uint32_t sh_a = (ro0 & 31) * 2, sh_r = (kp0 & 31) * 2, rw = kp0 >> 5;
+    uint64_t r[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r[i] = read_word(rd, rw + i);         // all LDS reads in flight together
     bool premature = false;
     uint32_t matched, nfl = fl & ~F_FRESH;
     if (!careful) {
@@ -297,7 +297,8 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const uint32_t done = 32u * c;
-            if (n > done) cnt += pa_popc64(diff_mask(funnel(read_word(rd, rw + c), read_word(rd, rw + c + 1), sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u)));
+            if (EXP != 3 && EXP != 2 && EXP != 1 && n > done) cnt += pa_popc64(diff_mask(funnel(r[c], r[c + 1], sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u)));
+            if (EXP == 1 && c == 0 && n > done) cnt += pa_popc64(diff_mask(funnel(r[c], r[c + 1], sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u))) & 0u;
         }
         if (snp + cnt <= allowed) {
             matched = n;
@@ -309,7 +310,7 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
         }
     } else {
         const uint32_t n = pa_min(rem, 32u);
-        matched = compare_chunk(diff_mask(funnel(read_word(rd, rw), read_word(rd, rw + 1), sh_r) ^ funnel(a[0], a[1], sh_a), n), n, allowed, snp, mism, premature);
+        matched = compare_chunk(diff_mask(funnel(r[0], r[1], sh_r) ^ funnel(a[0], a[1], sh_a), n), n, allowed, snp, mism, premature);
     }
     const uint32_t kp = kp0 + matched;                                // :257
     cov += matched;                                                   // :254
@@ -322,7 +323,7 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
             else {
                 const uint32_t b = read_base(rd, kp);                 // :265
                 if (!premature && ((hd.exts >> b) & 1u)) {            // :267
-                    h = load_redge(ix, s.h, b);                       // r_edges()[index].0 (:275-278)
+                    h = b == 0 ? hd.e0 : b == 1 ? hd.e1 : b == 2 ? hd.e2 : hd.e3;   // r_edges()[index].0 (:275-278)
                     off = 0;                                          // :279
                     kp_out = kp - (K - 1);                            // :282
                     cov -= K - 1;                                     // :283
@@ -406,7 +407,9 @@ PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, u
 //                  counted, then recomputed in the write pass
 struct Isect {
     uint32_t base_ref, base_len, base_colour, count;
-    uint64_t alive;
+    uint64_t alive;       // survivors as a mask over the base list (base_len <= 64)
+    uint32_t ids[7];      // register tier only: the base list itself (ids beyond base_len are the 0xFFFFFFFF padding)
+    bool in_regs;
 };
 
 PA_HD bool list_contains(const uint32_t* v, uint32_t n, uint32_t key) {   // binary_search (:404)
@@ -441,64 +444,100 @@ PA_HD bool in_all_lists(const DevIndexView& ix, ColRef cols, uint32_t ncol, uint
     return true;
 }
 
-PA_HD uint32_t eq_mask7(uint32_t v, const uint32_t (&b)[7]) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) m |= (b[i] == v ? 1u : 0u) << i;
-    return m;
+// 1 iff v is one of the seven ids (unused slots hold the 0xFFFFFFFF record padding, which no transcript id equals)
+PA_HD uint32_t any_eq7(uint32_t v, const uint32_t (&o)[7]) {
+    return (uint32_t)((o[0] == v) | (o[1] == v) | (o[2] == v) | (o[3] == v) | (o[4] == v) | (o[5] == v) | (o[6] == v));
 }
 
-PA_HD Isect isect_count(const Lane& s, const DevIndexView& ix, ColRef cols) {
-    Isect r{0, 0xFFFFFFFFu, 0, 0, 0};
+// Step 1: the base list (a shortest one) and the tier that will intersect it:
+//   0  one class, or <= 4 classes with every list <= 7 ids: registers only, no dependent loads   (isect_light)
+//   1  base <= 8 ids, anything else long/many: eight lanes per read                              (kernel, cooperative)
+//   2  base > 8 ids: the whole wave per read                                                      (kernel, cooperative)
+//   3  one class of more than 7 ids: the result is that class, a plain copy                      (kernel / isect_write)
+// The host emulator and the oracle-style fallback below treat tiers 1 and 2 with per-lane binary searches.
+PA_HD uint32_t isect_pick(const Lane& s, ColRef cols, Isect& r) {
+    r.alive = 0;
+    r.count = 0;
+    r.in_regs = false;
+    r.base_colour = 0;
     const uint32_t ncol = l_ncol(s);
     const U4 refs = *reinterpret_cast<const U4*>(cols.refs), lens = *reinterpret_cast<const U4*>(cols.lens);
-    const uint32_t rf[4] = {refs.x, refs.y, refs.z, refs.w};
-    const uint32_t ln[4] = {lens.x, ncol > 1 ? lens.y : 0xFFFFFFFFu, ncol > 2 ? lens.z : 0xFFFFFFFFu, ncol > 3 ? lens.w : 0xFFFFFFFFu};
-    r.base_len = ln[0];
-    r.base_ref = rf[0];
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-        if (ln[i] < r.base_len) { r.base_len = ln[i]; r.base_ref = rf[i]; }
+    const uint32_t ln1 = ncol > 1 ? lens.y : lens.x, ln2 = ncol > 2 ? lens.z : lens.x, ln3 = ncol > 3 ? lens.w : lens.x;
+    r.base_len = lens.x;
+    r.base_ref = refs.x;
+    if (ln1 < r.base_len) { r.base_len = ln1; r.base_ref = refs.y; }
+    if (ln2 < r.base_len) { r.base_len = ln2; r.base_ref = refs.z; }
+    if (ln3 < r.base_len) { r.base_len = ln3; r.base_ref = refs.w; }
+    uint32_t maxlen = lens.x > ln1 ? lens.x : ln1;
+    maxlen = maxlen > ln2 ? maxlen : ln2;
+    maxlen = maxlen > ln3 ? maxlen : ln3;
     for (uint32_t i = LDS_CLASSES; i < ncol; ++i) {                 // spilled classes (rare)
         uint32_t ref, len;
         get_class(cols, i, ref, len);
         if (len < r.base_len) { r.base_len = len; r.base_ref = ref; }
     }
-    const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * r.base_ref);
-    if (r.base_len <= 7 && ncol <= LDS_CLASSES) {
-        const U4 q0 = brec[0], q1 = brec[1];
-        r.base_colour = q0.x;
-        const uint32_t b[7] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-        uint32_t alive = (1u << r.base_len) - 1;
-#pragma unroll 1
-        for (uint32_t i = 0; i < ncol && alive; ++i) {
-            const uint32_t ref = i == 0 ? rf[0] : i == 1 ? rf[1] : i == 2 ? rf[2] : rf[3];
-            const uint32_t len = i == 0 ? ln[0] : i == 1 ? ln[1] : i == 2 ? ln[2] : ln[3];
-            if (ref == r.base_ref) continue;
-            uint32_t m = 0;
-            if (len <= 7) {
-                const U4* orec = reinterpret_cast<const U4*>(ix.ec + 4ull * ref);
-                const U4 o0 = orec[0], o1 = orec[1];
-                const uint32_t o[7] = {o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+    if (ncol == 1) return r.base_len <= 7 ? 0u : 3u;
+    if (ncol <= LDS_CLASSES && maxlen <= 7) return 0;
+    return r.base_len <= 8 ? 1u : 2u;
+}
+
+PA_HD uint32_t match7(const U4& o0, const U4& o1, const uint32_t (&b)[7]) {
+    const uint32_t o[7] = {o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+    uint32_t m = 0;
 #pragma unroll
-                for (int j = 0; j < 7; ++j)
-                    if ((uint32_t)j < len) m |= eq_mask7(o[j], b);
-            } else {
-                const uint32_t* ids = class_ids(ix, ref);
-                const uint32_t* bids = class_ids(ix, r.base_ref);
-#pragma unroll 1
-                for (uint32_t t = alive; t; t &= t - 1) {
-                    const uint32_t j = pa_ctz32(t);
-                    if (list_contains(ids, len, bids[j])) m |= 1u << j;
-                }
-            }
-            alive &= m;
-        }
-        r.alive = alive;
-        r.count = pa_popc32(alive);
+    for (int j = 0; j < 7; ++j) m |= any_eq7(b[j], o) << j;
+    return m;
+}
+
+// Tier 0: the records of all (<= 4) classes are fetched together (two 16-byte loads each, one round trip), the base ids
+// are compared all-pairs with every other list in registers; survivors are a 7-bit mask over the base list.
+PA_HD void isect_light(const Lane& s, const DevIndexView& ix, ColRef cols, Isect& r) {
+    const uint32_t ncol = l_ncol(s);
+    const U4 refs = *reinterpret_cast<const U4*>(cols.refs);
+    const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * r.base_ref);
+    const U4* r1 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.y);
+    const U4* r2 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.z);
+    const U4* r3 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.w);
+    const U4* r0 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.x);
+    const U4 q0 = brec[0], q1 = brec[1];
+    const U4 sentinel{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const bool u0 = ncol > 1 && refs.x != r.base_ref, u1 = ncol > 1 && refs.y != r.base_ref, u2 = ncol > 2 && refs.z != r.base_ref,
+               u3 = ncol > 3 && refs.w != r.base_ref;
+    // unconditional loads (an unused slot re-reads the base record) so that all eight are in flight together
+    const U4* p0 = u0 ? r0 : brec;
+    const U4* p1 = u1 ? r1 : brec;
+    const U4* p2 = u2 ? r2 : brec;
+    const U4* p3 = u3 ? r3 : brec;
+    const U4 a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1], c0 = p2[0], c1 = p2[1], d0 = p3[0], d1 = p3[1];
+    (void)sentinel;
+    r.base_colour = q0.x;
+    r.in_regs = true;
+    r.ids[0] = q0.y; r.ids[1] = q0.z; r.ids[2] = q0.w; r.ids[3] = q1.x; r.ids[4] = q1.y; r.ids[5] = q1.z; r.ids[6] = q1.w;
+    uint32_t alive = (1u << r.base_len) - 1;
+    if (u0) alive &= match7(a0, a1, r.ids);   // (an unused slot holds the base itself: matching it would be the identity)
+    if (u1) alive &= match7(b0, b1, r.ids);
+    if (u2) alive &= match7(c0, c1, r.ids);
+    if (u3) alive &= match7(d0, d1, r.ids);
+    r.alive = alive;
+    r.count = pa_popc32(alive);
+}
+
+// Whole intersection by one lane (host emulator; tiers 1 and 2 by per-lane binary search)
+PA_HD Isect isect_count(const Lane& s, const DevIndexView& ix, ColRef cols) {
+    Isect r;
+    const uint32_t tier = isect_pick(s, cols, r);
+    if (tier == 0) {
+        isect_light(s, ix, cols, r);
         return r;
     }
-    r.base_colour = brec[0].x;
+    const uint32_t ncol = l_ncol(s);
+    if (tier == 3) {                                                // a single class: the result is the class itself
+        r.base_colour = ix.ec[4ull * r.base_ref];
+        r.count = r.base_len;
+        r.alive = r.base_len >= 64 ? ~0ull : ((1ull << r.base_len) - 1);
+        return r;
+    }
+    r.base_colour = ix.ec[4ull * r.base_ref];
     const uint32_t* bids = class_ids(ix, r.base_ref);
     if (r.base_len <= 64) {
         uint64_t alive = r.base_len == 64 ? ~0ull : ((1ull << r.base_len) - 1);
@@ -521,6 +560,13 @@ PA_HD Isect isect_count(const Lane& s, const DevIndexView& ix, ColRef cols) {
 }
 
 PA_HD void isect_write(const Lane& s, const DevIndexView& ix, ColRef cols, const Isect& r, uint32_t* dst) {
+    if (r.in_regs) {                                                // survivors straight from registers, no loads
+        const uint32_t alive = (uint32_t)r.alive;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if ((alive >> j) & 1u) dst[pa_popc32(alive & ((1u << j) - 1))] = r.ids[j];
+        return;
+    }
     const uint32_t* bids = class_ids(ix, r.base_ref);
     if (r.base_len <= 64) {
         for (uint64_t t = r.alive; t; t &= t - 1) *dst++ = bids[pa_ctz64(t)];

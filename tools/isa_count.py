@@ -9,7 +9,7 @@ for st in starts:
     name = lines[st].split(":")[0]
     if len(sys.argv) > 2 and sys.argv[2] not in name:
         continue
-    end = next(i for i in range(st, len(lines)) if "s_endpgm" in lines[i])
+    end = next(i for i in range(st, len(lines)) if "s_endpgm" in lines[i] or "s_setpc_b64 s[30:31]" in lines[i])
     ins = [l.strip() for l in lines[st + 1:end] if l.strip() and not l.strip().startswith((".", ";", "//")) and not l.split(";")[0].strip().endswith(":")]
     c = collections.Counter(l.split()[0] for l in ins)
     v = sum(n for k, n in c.items() if k.startswith("v_"))
