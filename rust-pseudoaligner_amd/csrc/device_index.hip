@@ -135,7 +135,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     if (rc == PA_OK) rc = upload(fd.class_ref.data(), fd.class_ref.size() * 4, &idx->d_class_ref);
     if (rc == PA_OK) rc = upload(fd.class_len.data(), fd.class_len.size() * 4, &idx->d_class_len);
     if (rc == PA_OK) rc = upload(ctab.data(), ctab.size() * 4, &idx->d_class_table);
-    if (rc == PA_OK) rc = idx->ctl.ensure(256);
+    if (rc == PA_OK) rc = idx->ctl.ensure(1024);
     if (rc != PA_OK) { pa_index_destroy(idx); return rc; }
     idx->class_table_size = ctab.size();
     idx->dv = fd.host_view();
@@ -186,7 +186,7 @@ static int env_int(const char* name, int dflt) {   // tuning knobs for A/B runs 
 
 static int map_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t* grid, size_t* lds, int* waves) {
     *waves = env_int("PA_MAP_WAVES", PA_DEFAULT_MAP_WAVES);
-    const size_t wave_bytes = 448 + (size_t)(wpr + 1) * 512 + 2 * LDS_CLASSES * 256;
+    const size_t wave_bytes = 256 + (size_t)(wpr + 1) * 512 + 2 * LDS_CLASSES * 256;
     *lds = (sizeof(MapParams) + 15) / 16 * 16 + wave_bytes * (PA_MAP_BLOCK / 64);
     if (*lds > 160 * 1024) return fail(PA_ERR_UNSUPPORTED, "reads of %u words need %zu bytes of LDS per workgroup (> 160 KiB)", wpr, *lds);
     int per_cu = 0;
@@ -218,7 +218,7 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     rc = idx->spill.ensure(lanes * spill_cap * 4);
     if (rc != PA_OK) return rc;
     if (d_nodes) { rc = idx->trace.ensure(lanes * spill_cap * 4); if (rc != PA_OK) return rc; }
-    HIP_TRY(hipMemsetAsync(idx->ctl.p, 0, 128, stream));
+    HIP_TRY(hipMemsetAsync(idx->ctl.p, 0, 512, stream));
     MapParams p{};
     p.ix = idx->dv;
     p.tiles = d_tiles;
@@ -254,15 +254,14 @@ static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_
     struct { unsigned long long top; uint32_t status; uint32_t pad; } ctl;
     HIP_TRY(hipMemcpy(&ctl, idx->ctl.p, 16, hipMemcpyDeviceToHost));
     if (env_int("PA_MAP_STATS", 0)) {
-        unsigned long long d[20];
+        unsigned long long d[3 * ST_COUNT];
         HIP_TRY(hipMemcpy(d, idx->ctl.as<unsigned long long>() + 2, sizeof d, hipMemcpyDeviceToHost));
-        static const char* names[5] = {"refill", "seek", "fwd", "finish", "left"};
+        static const char* names[ST_COUNT] = {"refill", "seek", "fwd", "left", "-", "fin_none", "fin_light", "fin_scan", "fin_coop", "fin_copy", "fin_novel"};
         fprintf(stderr, "[pa map stats] grid=%u", idx->last_grid);
-        for (int i = 0; i < 5; ++i)
-            fprintf(stderr, " %s: %llu iters x %.1f lanes, %.0f ticks/iter;", names[i], d[i], d[i] ? (double)d[5 + i] / (double)d[i] : 0.0,
-                    d[i] ? (double)d[10 + i] / (double)d[i] : 0.0);
-        fprintf(stderr, " finish stages (ticks/iter): pick %.0f, light %.0f, scan+alloc %.0f, class ids %.0f, record+counts %.0f", (double)d[19] / (double)(d[3] ? d[3] : 1), (double)d[15] / (double)(d[3] ? d[3] : 1),
-                (double)d[16] / (double)(d[3] ? d[3] : 1), (double)d[17] / (double)(d[3] ? d[3] : 1), (double)d[18] / (double)(d[3] ? d[3] : 1));
+        for (uint32_t i = 0; i < ST_COUNT; ++i)
+            if (d[i])
+                fprintf(stderr, " %s: %llu iters x %.1f lanes, %.0f ticks/iter;", names[i], d[i], (double)d[ST_COUNT + i] / (double)d[i],
+                        (double)d[2 * ST_COUNT + i] / (double)d[i]);
         fprintf(stderr, "\n");
     }
     if (arena_used) *arena_used = ctl.top;

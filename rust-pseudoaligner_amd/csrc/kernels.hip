@@ -114,135 +114,30 @@ __device__ __attribute__((noinline)) Lane left_call(Lane s, glb_u8 blobs, glb_u3
     return s;
 }
 
-// FINISH section: nodes_to_eq_class + output for the lanes whose walk has ended. Runs with the whole wave active (the
-// caller's branch is wave-uniform); kernel parameters and the wave's arena chunk live in LDS so that the call carries
-// almost no arguments.
+// ---- finishing states: nodes_to_eq_class + output -------------------------------------------------------------------
+// A lane whose walk has ended is sorted into one of five finishing states by what its intersection needs (isect_pick):
+// LIGHT (registers only), SCAN (base in registers, other lists streamed), COOP (whole wave per read), COPY (single
+// class) or NONE (unmapped). Like the walk states they are scheduled by population, so a rare expensive case (a long
+// class list, a strict-subset result that needs the class hash table) never stalls 63 cheap lanes: its lane simply
+// waits until enough lanes of the same kind have gathered. Every finishing call runs with the whole wave active.
 typedef __attribute__((address_space(3))) const MapParams* lds_params;
 typedef __attribute__((address_space(3))) unsigned long long* lds_u64w;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4* glb_v4w;
+typedef __attribute__((address_space(1))) const u32x4* glb_v4;
+typedef __attribute__((address_space(1))) unsigned long long* glb_u64w;
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src) {
     return ((uint64_t)(uint32_t)__shfl((int)(v >> 32), (int)src, 64) << 32) | (uint32_t)__shfl((int)v, (int)src, 64);
 }
 
-// Cooperative intersection of the reads in `mask` (one bit per lane whose read needs it): G lanes work on one read, lane
-// e of a group owns base ids e, e+G, ... and binary-searches every other list of that read; the survivors of a group are
-// compacted with a wave ballot and written straight to the read's arena slice (an upper bound, base_len entries, was
-// reserved for it). This is the wave-level AND-reduce of the class lists: one pass costs (classes x log2 len) dependent
-// L1/L2 hits for 64/G reads at once instead of base_len times that for a single lane.
-template <int G>
-__device__ __forceinline__ void coop_intersect(uint64_t mask, uint32_t lane, uint32_t ncol_mine, const Isect& is, uint64_t my_off,
-                                               lds_u32 wave_refs, lds_u32 wave_tmp, glb_u32 ec, glb_u32w spill_base, uint32_t wave_slot0,
-                                               uint32_t spill_cap, glb_u32w arena, uint64_t arena_cap) {
-    const uint32_t g = lane / G, e = lane % G;
-    while (mask) {
-        uint32_t L = 64;
-        for (int t = 0; t < 64 / G; ++t) {   // the g-th set bit of mask goes to group g (uniform scalar loop)
-            const uint32_t bit = mask ? (uint32_t)(__ffsll((unsigned long long)mask) - 1) : 64u;
-            if ((uint32_t)t == g) L = bit;
-            mask &= mask - 1;
-        }
-        const bool have = L < 64;
-        const uint32_t Ls = have ? L : 0u;
-        // cross-lane reads happen with EVERY lane active (a source lane that sat out a branch would return garbage)
-        const uint32_t bref = (uint32_t)__shfl((int)is.base_ref, (int)Ls, 64);
-        const uint32_t blen_any = (uint32_t)__shfl((int)is.base_len, (int)Ls, 64);
-        const uint32_t ncol_any = (uint32_t)__shfl((int)ncol_mine, (int)Ls, 64);
-        const uint64_t off = shfl64(my_off, Ls);
-        const uint32_t blen = have ? blen_any : 0u;
-        const uint32_t ncolL = have ? ncol_any : 0u;
-        const bool fits = off + blen <= arena_cap;
-        const lds_u32 refsL = wave_refs + Ls * LDS_CLASSES;
-        uint32_t total = 0;
-        for (uint32_t c = 0; __any(c < blen); c += G) {
-            const uint32_t j = c + e;
-            const bool valid = j < blen;
-            const uint32_t v = valid ? ec[4ull * bref + 1 + j] : 0u;
-            bool ok = valid;
-            for (uint32_t i = 0; __any(i < ncolL); ++i) {
-                if (i < ncolL && ok) {
-                    uint32_t ref, len;
-                    if (i < LDS_CLASSES) {
-                        ref = refsL[i];
-                        len = refsL[64 * LDS_CLASSES + i];
-                    } else {
-                        const glb_u32w sp = spill_base + (uint64_t)(wave_slot0 + Ls) * spill_cap + 2 * (i - LDS_CLASSES);
-                        ref = sp[0];
-                        len = sp[1];
-                    }
-                    if (ref != bref) {   // membership of v in the other (sorted) list: 16-byte loads, every address known up front
-                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                        typedef __attribute__((address_space(1))) const u32x4* glb_v4;
-                        const glb_v4 rec = (glb_v4)(ec + 4ull * ref);   // words: {class id, id0, id1, id2}, {id3..id6}, ... 0xFFFFFFFF padded
-                        bool hit = false;
-                        if (len <= 64) {          // short list: scan it, no dependent loads
-                            const uint32_t nchunks = (len + 4) >> 2;
-#pragma unroll 4
-                            for (uint32_t q = 0; q < nchunks; ++q) {
-                                const u32x4 w = rec[q];
-                                hit |= (q != 0 && w.x == v) | (w.y == v) | (w.z == v) | (w.w == v);
-                            }
-                        } else {                  // long list: binary_search (:404)
-                            const glb_u32 ids = ec + 4ull * ref + 1;
-                            uint32_t lo = 0, hi = len;
-                            while (lo < hi) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if (ids[mid] < v) lo = mid + 1; else hi = mid;
-                            }
-                            hit = lo < len && ids[lo] == v;
-                        }
-                        ok = hit;
-                    }
-                }
-            }
-            const uint64_t bm = __ballot(ok);
-            const uint64_t gbits = G == 64 ? bm : ((bm >> (g * G)) & ((1ull << G) - 1));
-            if (ok && fits) arena[off + total + (uint32_t)__popcll(gbits & ((1ull << e) - 1))] = v;
-            total += (uint32_t)__popcll(gbits);
-        }
-        if (have && e == 0) wave_tmp[L] = total;   // handed back to lane L through LDS
-    }
-}
-
-template <bool TRACE>
-__device__ __attribute__((noinline)) void finish_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk,
-                                                      glb_u32 ec, glb_u32w arena_g, glb_u32w results_g, glb_u32w counts_g) {
-    const bool prof = pp->dbg != nullptr;
-    const lds_u64w fclk = chunk + 8 + 5;   // finish stage clocks live after the 5 section clocks
-    unsigned long long t0 = prof ? __builtin_readcyclecounter() : 0ull;
-    const uint32_t st = l_st(s);
-    const bool fin = st == ST_ISECT || st == ST_NONE;
-    DevIndexView ix{};
-    ix.ec = (const uint32_t*)ec;
-    const glb_u32w spill_base = (glb_u32w)pp->spill;
-    const uint32_t spill_cap = pp->spill_cap;
-    const ColRef cols = make_col_ref(refs_lane, spill_base, slot, spill_cap, nullptr);
-    Isect is;
-    is.count = 0;
-    is.base_len = 0xFFFFFFFFu;
-    is.base_ref = 0;
-    is.base_colour = 0;
-    is.alive = 0;
-    is.in_regs = false;
-    uint32_t tier = 0;
-    if (st == ST_ISECT && !(pp->ablate & 1u)) {
-        tier = isect_pick(s, cols, is);
-    }
-    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[4] += t - t0; t0 = t; }
-    if (st == ST_ISECT && !(pp->ablate & 1u)) {
-        if (tier == 0) isect_light(s, ix, cols, is);
-        else {
-            is.base_colour = ec[4ull * is.base_ref];
-            if (tier == 3) is.count = is.base_len;   // a single class: the result is the class itself
-        }
-    }
-    const bool coop = st == ST_ISECT && (tier == 1 || tier == 2);
-    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[0] += t - t0; t0 = t; }
-    const uint32_t cnt_alloc = !fin ? 0u : coop ? is.base_len : is.count;   // cooperative reads reserve an upper bound
+// wave-uniform: reserve cnt_alloc arena entries per lane out of the wave's private chunk; returns this lane's offset
+__device__ __forceinline__ uint64_t arena_alloc(uint32_t cnt_alloc, uint32_t lane, lds_params pp, lds_u64w chunk) {
     const uint32_t incl = wave_incl_scan(cnt_alloc);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     unsigned long long chunk_cur = chunk[0];
     if (total > 0) {
-        if (chunk_cur + total > chunk[1]) {   // wave-uniform branch: take a new private slice of the class arena
+        if (chunk_cur + total > chunk[1]) {   // take a new private slice of the class arena (one global atomic per chunk)
             const unsigned long long want = total > PA_ARENA_CHUNK ? total : PA_ARENA_CHUNK;
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd((unsigned long long*)pp->arena_top, want);
@@ -252,33 +147,85 @@ __device__ __attribute__((noinline)) void finish_call(Lane s, uint32_t lane, uin
         }
         if (lane == 0) chunk[0] = chunk_cur + total;
     }
-    const uint64_t my_off = chunk_cur + (incl - cnt_alloc);
-    const uint64_t arena_cap = pp->arena_cap;
-    uint32_t* const arena = (uint32_t*)arena_g;
-    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[1] += t - t0; t0 = t; }
-    // ---- cooperative tiers (wave-uniform branches: every lane takes part) ----
-    const uint64_t m1 = __ballot(coop && tier == 1), m2 = __ballot(coop && tier == 2);
-    if (m1 | m2) {
-        const lds_u32 wave_refs = refs_lane - lane * LDS_CLASSES;
-        const lds_u32 wave_tmp = (lds_u32)(chunk) + 48;   // 64 x u32 inside the per-wave fixed area
-        if (m1) coop_intersect<8>(m1, lane, l_ncol(s), is, my_off, wave_refs, wave_tmp, ec, spill_base, slot - lane, spill_cap, arena_g, arena_cap);
-        if (m2) coop_intersect<64>(m2, lane, l_ncol(s), is, my_off, wave_refs, wave_tmp, ec, spill_base, slot - lane, spill_cap, arena_g, arena_cap);
-        if (coop) is.count = wave_tmp[lane];
-    }
-    if (!fin) return;
-    const uint32_t cnt = is.count;
+    return chunk_cur + (incl - cnt_alloc);
+}
+
+// record + class-count update of one finished read; returns the lane's next state (EMPTY, or F_NOVEL when the class of a
+// strict-subset result still has to be looked up by content before it can be counted)
+template <bool TRACE>
+__device__ __forceinline__ Lane emit_record(Lane s, bool mapped, uint32_t cnt, uint32_t cnt_alloc, uint64_t my_off, uint32_t base_len,
+                                            uint32_t base_colour, uint32_t slot, lds_params pp, glb_u32w results_g, glb_u32w counts_g) {
     pa_read_result r{0, 0, 0, 0};
     uint32_t colour = 0xFFFFFFFFu;
-    if (st == ST_ISECT) {
+    bool novel = false;
+    if (mapped) {
         r.coverage = l_cov(s);
         r.mismatches = l_mism(s) | PA_MAPPED_BIT;
         r.class_len = cnt;
         r.class_off = (uint32_t)my_off;
-        if (my_off + cnt_alloc > arena_cap) atomicOr(pp->status, PA_STATUS_ARENA_FULL);
-        else if (tier == 3) {
-            // copy of one class record: 16-byte loads (record words 1..cnt), four in flight per round trip
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            typedef __attribute__((address_space(1))) const u32x4* glb_v4;
+        if (my_off + cnt_alloc > pp->arena_cap) atomicOr(pp->status, PA_STATUS_ARENA_FULL);
+        if (cnt == base_len) colour = base_colour;
+        else novel = cnt != 0;
+        if (l_flags(s) & F_SPILL_OVERFLOW) atomicOr(pp->status, PA_STATUS_SPILL_OVERFLOW);
+    }
+    ((glb_v4w)results_g)[s.rid] = u32x4{r.coverage, r.mismatches, r.class_off, r.class_len};
+    if (TRACE) {   // node lists, read-major, stride spill_cap (map_read_to_nodes test surface)
+        const uint32_t spill_cap = pp->spill_cap;
+        const uint32_t nt = l_ntrace(s);
+        const uint32_t nn = mapped ? (nt < spill_cap ? nt : spill_cap) : 0;
+        ((glb_u32w)pp->nodes_len)[s.rid] = mapped ? nt : 0;
+        const glb_u32w tr = (glb_u32w)pp->trace + (uint64_t)slot * spill_cap;
+        const glb_u32w out = (glb_u32w)pp->nodes_out + (uint64_t)s.rid * spill_cap;
+        for (uint32_t j = 0; j < nn; ++j) out[j] = tr[j];
+    }
+    const glb_u32w colour_out = (glb_u32w)pp->colour_out;
+    const bool want_class = counts_g != nullptr || colour_out != nullptr;
+    if (novel && want_class && my_off + cnt_alloc <= pp->arena_cap) {   // defer the content lookup to the F_NOVEL state
+        s.h = (uint32_t)my_off;
+        s.rr = cnt;
+        l_set_st(s, ST_F_NOVEL);
+        return s;
+    }
+    if (colour_out) colour_out[s.rid] = colour;
+    if (counts_g) {   // fused class-count table: fire-and-forget atomic
+        const uint32_t num_classes = pp->ix.num_classes;
+        const uint32_t cslot = !mapped ? num_classes + 2 : cnt == 0 ? num_classes + 1 : colour == 0xFFFFFFFFu ? num_classes : colour;
+        atomicAdd((unsigned long long*)(glb_u64w)counts_g + cslot, 1ull);
+    }
+    s.lk = 0;   // ST_EMPTY
+    return s;
+}
+
+// LIGHT / SCAN / COPY / NONE: one lane = one read
+template <bool TRACE>
+__device__ __attribute__((noinline)) Lane fin_lane_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk,
+                                                        glb_u32 ec, glb_u32w arena_g, glb_u32w results_g, glb_u32w counts_g, uint32_t which) {
+    const uint32_t st = l_st(s);
+    const bool mine = st == which;
+    DevIndexView ix{};
+    ix.ec = (const uint32_t*)ec;
+    const ColRef cols = make_col_ref(refs_lane, (glb_u32w)pp->spill, slot, pp->spill_cap, nullptr);
+    Isect is;
+    is.count = 0;
+    is.base_len = 0xFFFFFFFFu;
+    is.base_ref = 0;
+    is.base_colour = 0;
+    is.alive = 0;
+    is.in_regs = false;
+    if (mine && which != ST_NONE && !(pp->ablate & 1u)) {
+        isect_pick(s, cols, is);
+        if (which == ST_F_LIGHT) isect_light(s, ix, cols, is);
+        else if (which == ST_F_SCAN) isect_scan(s, ix, cols, is);
+        else {   // ST_F_COPY: a single class, the result is the class itself
+            is.base_colour = ec[4ull * is.base_ref];
+            is.count = is.base_len;
+        }
+    }
+    const uint32_t cnt = mine ? is.count : 0u;
+    const uint64_t my_off = arena_alloc(cnt, lane, pp, chunk);
+    if (!mine) return s;
+    if (cnt && my_off + cnt <= pp->arena_cap) {
+        if (which == ST_F_COPY) {   // 16-byte loads of the record (words 1..cnt are the ids), four in flight per round trip
             const glb_v4 rec = (glb_v4)(ec + 4ull * is.base_ref);
             const uint32_t nchunks = (cnt + 4) >> 2;
             for (uint32_t q0 = 0; q0 < nchunks; q0 += 4) {
@@ -297,47 +244,114 @@ __device__ __attribute__((noinline)) void finish_call(Lane s, uint32_t lane, uin
                     }
                 }
             }
-        } else if (cnt && !coop) isect_write(s, ix, cols, is, arena + my_off);
-        if (cnt == is.base_len) colour = is.base_colour;
-        if (l_flags(s) & F_SPILL_OVERFLOW) atomicOr(pp->status, PA_STATUS_SPILL_OVERFLOW);
+        } else {
+            isect_write(s, ix, cols, is, (uint32_t*)arena_g + my_off);
+        }
     }
-    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[2] += t - t0; t0 = t; }
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(1))) u32x4* glb_v4w;
-    ((glb_v4w)results_g)[s.rid] = u32x4{r.coverage, r.mismatches, r.class_off, r.class_len};
+    return emit_record<TRACE>(s, which != ST_NONE, cnt, cnt, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
+}
+
+// COOP: the whole wave works on one read at a time (base list of more than 8 ids and at least two classes). Lane e owns
+// base ids e, e+64, ...; membership in every other list is a scan of 16-byte loads (short lists) or a binary search;
+// survivors are compacted with a wave ballot straight into the read's arena slice (base_len entries were reserved).
+template <bool TRACE>
+__device__ __attribute__((noinline)) Lane fin_coop_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk,
+                                                        glb_u32 ec, glb_u32w arena_g, glb_u32w results_g, glb_u32w counts_g) {
+    const bool mine = l_st(s) == ST_F_COOP;
+    const glb_u32w spill_base = (glb_u32w)pp->spill;
+    const uint32_t spill_cap = pp->spill_cap;
+    const ColRef cols = make_col_ref(refs_lane, spill_base, slot, spill_cap, nullptr);
+    Isect is;
+    is.count = 0;
+    is.base_len = 0;
+    is.base_ref = 0;
+    is.base_colour = 0;
+    if (mine) {
+        isect_pick(s, cols, is);
+        is.base_colour = ec[4ull * is.base_ref];
+    }
+    const uint32_t cnt_alloc = mine ? is.base_len : 0u;   // upper bound: the survivors are a subset of the base list
+    const uint64_t my_off = arena_alloc(cnt_alloc, lane, pp, chunk);
+    const uint64_t arena_cap = pp->arena_cap;
+    const lds_u32 wave_refs = refs_lane - lane * LDS_CLASSES;
+    const uint32_t ncol_mine = l_ncol(s);
+    uint32_t my_count = 0;
+    uint64_t mask = __ballot(mine);
+    while (mask) {
+        const uint32_t L = (uint32_t)(__ffsll((unsigned long long)mask) - 1);
+        mask &= mask - 1;
+        // cross-lane reads with every lane active
+        const uint32_t bref = (uint32_t)__shfl((int)is.base_ref, (int)L, 64);
+        const uint32_t blen = (uint32_t)__shfl((int)is.base_len, (int)L, 64);
+        const uint32_t ncolL = (uint32_t)__shfl((int)ncol_mine, (int)L, 64);
+        const uint64_t off = shfl64(my_off, L);
+        const bool fits = off + blen <= arena_cap;
+        const lds_u32 refsL = wave_refs + L * LDS_CLASSES;
+        uint32_t total = 0;
+        for (uint32_t c = 0; c < blen; c += 64) {   // uniform bounds: every lane sees the same read
+            const uint32_t j = c + lane;
+            const bool valid = j < blen;
+            const uint32_t v = valid ? ec[4ull * bref + 1 + j] : 0u;
+            bool ok = valid;
+            for (uint32_t i = 0; i < ncolL; ++i) {
+                uint32_t ref, len;
+                if (i < LDS_CLASSES) {
+                    ref = refsL[i];
+                    len = refsL[64 * LDS_CLASSES + i];
+                } else {
+                    const glb_u32w sp = spill_base + (uint64_t)(slot - lane + L) * spill_cap + 2 * (i - LDS_CLASSES);
+                    ref = sp[0];
+                    len = sp[1];
+                }
+                if (ref == bref) continue;   // uniform
+                bool hit = false;
+                if (len <= 64) {             // short list: scan it, no dependent loads
+                    const glb_v4 rec = (glb_v4)(ec + 4ull * ref);
+                    const uint32_t nchunks = (len + 4) >> 2;
+#pragma unroll 4
+                    for (uint32_t q = 0; q < nchunks; ++q) {
+                        const u32x4 w = rec[q];
+                        hit |= (q != 0 && w.x == v) | (w.y == v) | (w.z == v) | (w.w == v);
+                    }
+                } else {                     // long list: binary_search (:404)
+                    const glb_u32 ids = ec + 4ull * ref + 1;
+                    uint32_t lo = 0, hi = len;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (ids[mid] < v) lo = mid + 1; else hi = mid;
+                    }
+                    hit = lo < len && ids[lo] == v;
+                }
+                ok = ok && hit;
+            }
+            const uint64_t bm = __ballot(ok);
+            if (ok && fits) arena_g[off + total + (uint32_t)__popcll(bm & ((1ull << lane) - 1))] = v;
+            total += (uint32_t)__popcll(bm);
+        }
+        if (lane == L) my_count = total;
+    }
+    if (!mine) return s;
+    return emit_record<TRACE>(s, true, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
+}
+
+// NOVEL: the result is a strict subset of every visited class; find out whether it equals some index class (content
+// lookup in the class-list hash table), then count it
+__device__ __attribute__((noinline)) Lane fin_novel_call(Lane s, lds_params pp, glb_u32 ec, glb_u32w arena_g, glb_u32w counts_g) {
+    if (l_st(s) != ST_F_NOVEL) return s;
+    DevIndexView ix{};
+    ix.ec = (const uint32_t*)ec;
+    ix.class_ref = (const uint32_t*)(glb_u32)pp->ix.class_ref;
+    ix.class_len = (const uint32_t*)(glb_u32)pp->ix.class_len;
+    const uint32_t colour = class_of_list((const uint32_t*)arena_g + s.h, s.rr, ix, (const uint32_t*)(glb_u32)pp->class_table, pp->class_table_size);
     const glb_u32w colour_out = (glb_u32w)pp->colour_out;
     if (colour_out) colour_out[s.rid] = colour;
-    typedef __attribute__((address_space(1))) unsigned long long* glb_u64w;
-    unsigned long long* const counts = (unsigned long long*)(glb_u64w)counts_g;
-    if (counts) {   // fused class-count table: fire-and-forget atomics overlap the other lanes' walks
-        const uint32_t num_classes = pp->ix.num_classes;
-        uint32_t cslot = num_classes + 2;                              // unmapped
-        if (st == ST_ISECT) {
-            if (cnt == 0) cslot = num_classes + 1;                     // mapped, empty class
-            else {
-                if (colour == 0xFFFFFFFFu && my_off + cnt_alloc <= arena_cap) {   // strict subset of every visited class
-                    ix.class_ref = (const uint32_t*)(glb_u32)pp->ix.class_ref;
-                    ix.class_len = (const uint32_t*)(glb_u32)pp->ix.class_len;
-                    colour = class_of_list(arena + my_off, cnt, ix, (const uint32_t*)(glb_u32)pp->class_table, pp->class_table_size);
-                }
-                cslot = colour == 0xFFFFFFFFu ? num_classes : colour;
-            }
-        }
-        atomicAdd(counts + cslot, 1ull);
-    }
-    if (prof) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) fclk[3] += t - t0; t0 = t; }
-    if (TRACE) {   // node lists, read-major, stride spill_cap (map_read_to_nodes test surface)
-        const uint32_t nt = l_ntrace(s);
-        const uint32_t nn = st == ST_ISECT ? (nt < spill_cap ? nt : spill_cap) : 0;
-        ((glb_u32w)pp->nodes_len)[s.rid] = st == ST_ISECT ? nt : 0;
-        const glb_u32w tr = (glb_u32w)pp->trace + (uint64_t)slot * spill_cap;
-        const glb_u32w out = (glb_u32w)pp->nodes_out + (uint64_t)s.rid * spill_cap;
-        for (uint32_t j = 0; j < nn; ++j) out[j] = tr[j];
-    }
+    if (counts_g) atomicAdd((unsigned long long*)(glb_u64w)counts_g + (colour == 0xFFFFFFFFu ? pp->ix.num_classes : colour), 1ull);
+    s.lk = 0;   // ST_EMPTY
+    return s;
 }
 
 constexpr uint32_t PA_LDS_PARAMS_BYTES = (sizeof(MapParams) + 15) / 16 * 16;
-constexpr uint32_t PA_LDS_WAVE_FIXED = 448;  // per-wave: arena chunk state {cur, end}, scheduler statistics [10] u32, section clocks [5] u64
+constexpr uint32_t PA_LDS_WAVE_FIXED = 256;   // per-wave: arena chunk state {cur, end} (16 B), scheduler statistics [2*ST_COUNT] u32 + section clocks [ST_COUNT] u64
 
 template <bool TRACE, int WAVES>
 __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapParams p) {
@@ -349,7 +363,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
     const uint32_t nwaves = gridDim.x * waves_per_block;
     const uint32_t slot = wave * 64 + lane;   // this lane's slice of the spill / trace scratch
 
-    // LDS: [kernel parameters][per wave: arena chunk state | read tile (wpr+1 words x 64 lanes) | class refs | class lens]
+    // LDS: [kernel parameters][per wave: arena chunk state + statistics | read tile (wpr+1 words x 64 lanes) | class refs | class lens]
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&p);
         uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
@@ -361,7 +375,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
     const lds_u64 rd_lane = (lds_u64)(wbase + PA_LDS_WAVE_FIXED) + lane;
     const lds_u32 refs_lane = (lds_u32)(wbase + PA_LDS_WAVE_FIXED + (p.wpr + 1) * 512) + lane * LDS_CLASSES;
     const lds_params pp = (lds_params)smem;
-    if (lane == 0) { chunk[0] = 0; chunk[1] = 0; }
+    const lds_u32 dbg = (lds_u32)(wbase + 16);                            // [0..ST_COUNT) iterations, [ST_COUNT..2*ST_COUNT) lanes served
+    const lds_u64w dbg_clk = (lds_u64w)(wbase + 16 + 8 * ST_COUNT + 8);   // wall ticks per state (8-byte aligned)
+    if (lane < 60) ((lds_u32)wbase)[lane] = 0;
     __syncthreads();
 
     // static partition of the tiles over the waves (no global work queue: one hot atomic would cap the rate)
@@ -371,36 +387,34 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
     if (end > p.n_reads) end = p.n_reads;
     if (next > end) next = end;
 
+    const glb_u32 ec = (glb_u32)p.ix.ec;
+    const glb_u32w arena_g = (glb_u32w)p.arena, results_g = (glb_u32w)p.results, counts_g = (glb_u32w)p.counts;
+
     Lane s;
     s.rid = s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0;   // state ST_EMPTY
-    const lds_u32 dbg = (lds_u32)(wbase + 16);   // scheduler statistics (only kept when p.dbg)
-    if (lane < 44) dbg[lane] = 0;
-    const lds_u64w dbg_clk = (lds_u64w)(wbase + 64);   // wall clocks spent per section (s_memtime ticks)
 
     for (;;) {
         const uint32_t st = l_st(s);
+        // population of every state; the most populated one runs (EMPTY counts only as far as reads remain)
         const uint64_t mE = __ballot(st == ST_EMPTY);
-        const uint64_t mS = __ballot(st == ST_SEEK);
-        const uint64_t mF = __ballot(st == ST_FWD);
-        const uint64_t mL = __ballot(st == ST_LEFT);
-        const uint32_t nS = __popcll(mS), nF = __popcll(mF), nL = __popcll(mL);
-        const uint32_t nFin = 64 - __popcll(mE) - nS - nF - nL;
         const uint64_t left = end - next;
-        const uint32_t nR = (uint32_t)(left < (uint64_t)__popcll(mE) ? left : (uint64_t)__popcll(mE));
-        // pick the state with the most lanes (ties: refill, seek, fwd, finish, left)
-        uint32_t best = nR, sel = 0;
-        if (nS > best) { best = nS; sel = 1; }
-        if (nF > best) { best = nF; sel = 2; }
-        if (nFin > best) { best = nFin; sel = 3; }
-        if (nL > best) { best = nL; sel = 4; }
+        const uint32_t nE = __popcll(mE);
+        uint32_t best = (uint32_t)(left < (uint64_t)nE ? left : (uint64_t)nE), sel = ST_EMPTY;
+        const uint32_t nR = best;
+#pragma unroll
+        for (uint32_t q = ST_SEEK; q < ST_COUNT; ++q) {
+            if (q == ST_ISECT) continue;   // transient: resolved right after the walk step that produced it
+            const uint32_t n = __popcll(__ballot(st == q));
+            if (n > best) { best = n; sel = q; }
+        }
         if (best == 0) break;
         if (p.dbg && lane == 0) {
             dbg[sel] += 1;
-            dbg[5 + sel] += best;
+            dbg[ST_COUNT + sel] += best;
         }
         const unsigned long long t_sec = p.dbg ? __builtin_readcyclecounter() : 0ull;
 
-        if (sel == 0) {   // ---- REFILL: empty lanes take the next reads of this wave's range (coalesced by rank)
+        if (sel == ST_EMPTY) {   // ---- REFILL: empty lanes take the next reads of this wave's range (coalesced by rank)
             const uint32_t rank = __popcll(mE & ((1ull << lane) - 1));
             if (st == ST_EMPTY && rank < nR) {
                 const uint64_t rid = next + rank;
@@ -412,25 +426,31 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
                 lane_start(s, (uint32_t)rid, L, p.ix.k);
             }
             next += nR;
-        } else if (sel == 1) {
+        } else if (sel == ST_SEEK) {
             if (st == ST_SEEK && (p.ablate & 4u)) { s.nc |= 1; l_set_st(s, (p.ablate & 2u) ? ST_ISECT : ST_FWD); s.h = s.rid & 1023u; l_or_flags(s, F_FRESH); }
             else if (st == ST_SEEK) s = seek_call(s, (glb_u32)p.ix.table, (uint32_t)p.ix.nbuckets, p.ix.kmask, p.ix.k, rd_lane, p.wpr);
-        } else if (sel == 2) {
+        } else if (sel == ST_FWD) {
             if (st == ST_FWD && (p.ablate & 2u)) l_set_st(s, ST_ISECT);
-            else if (st == ST_FWD && !TRACE && (p.ablate & 8u)) s = fwd_call<false, 1>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
-            else if (st == ST_FWD && !TRACE && (p.ablate & 16u)) s = fwd_call<false, 2>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
-            else if (st == ST_FWD && !TRACE && (p.ablate & 32u)) s = fwd_call<false, 3>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
             else if (st == ST_FWD) s = fwd_call<TRACE>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, TRACE ? (glb_u32w)p.trace : nullptr, p.allowed);
-        } else if (sel == 4) {
+        } else if (sel == ST_LEFT) {
             if (st == ST_LEFT) s = left_call<TRACE>(s, (glb_u8)p.ix.blobs, (glb_u32)p.ix.ledge, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, TRACE ? (glb_u32w)p.trace : nullptr, p.allowed);
-        } else {          // ---- FINISH: nodes_to_eq_class + output (whole wave enters: the scan inside needs every lane)
-            finish_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, (glb_u32)p.ix.ec, (glb_u32w)p.arena, (glb_u32w)p.results, (glb_u32w)p.counts);
-            if (st == ST_ISECT || st == ST_NONE) s.of = 0;   // ST_EMPTY
+        } else if (sel == ST_F_COOP) {
+            s = fin_coop_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g);
+        } else if (sel == ST_F_NOVEL) {
+            s = fin_novel_call(s, pp, ec, arena_g, counts_g);
+        } else {   // ST_NONE, ST_F_LIGHT, ST_F_SCAN, ST_F_COPY (whole wave enters: the allocation scan needs every lane)
+            s = fin_lane_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g, sel);
+        }
+        if (l_st(s) == ST_ISECT) {   // the walk just ended: choose how this read's classes will be intersected (LDS only)
+            Isect tmp;
+            const ColRef cols = make_col_ref(refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr);
+            const uint32_t tier = (p.ablate & 1u) ? 0u : isect_pick(s, cols, tmp);
+            l_set_st(s, tier == 0 ? ST_F_LIGHT : tier == 1 ? ST_F_SCAN : tier == 2 ? ST_F_COOP : ST_F_COPY);
         }
         if (p.dbg && lane == 0) dbg_clk[sel] += __builtin_readcyclecounter() - t_sec;
     }
-    if (p.dbg && lane < 10) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
-    if (p.dbg && lane < 10) atomicAdd(p.dbg + 10 + lane, dbg_clk[lane]);
+    if (p.dbg && lane < 2 * ST_COUNT) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
+    if (p.dbg && lane < ST_COUNT) atomicAdd(p.dbg + 2 * ST_COUNT + lane, dbg_clk[lane]);
 }
 
 // ---------------------------------------------------------------------------------------------- encode

@@ -18,32 +18,35 @@
 
 namespace pa {
 
-enum : uint32_t { ST_EMPTY = 0, ST_SEEK = 1, ST_FWD = 2, ST_LEFT = 3, ST_ISECT = 4, ST_NONE = 5 };
+// walk states, then the finishing states the kernel schedules separately (ST_ISECT = walk ended, tier not yet chosen)
+enum : uint32_t { ST_EMPTY = 0, ST_SEEK = 1, ST_FWD = 2, ST_LEFT = 3, ST_ISECT = 4, ST_NONE = 5,
+                  ST_F_LIGHT = 6, ST_F_SCAN = 7, ST_F_COOP = 8, ST_F_COPY = 9, ST_F_NOVEL = 10, ST_COUNT = 11 };
 enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_CAREFUL = 16u };
 constexpr uint32_t LDS_CLASSES = 4;   // distinct classes per lane kept in LDS (one 16-byte vector of refs + one of lengths)
 
-// Packed lane state (9 VGPRs). Limits: read length <= 2048 (PA_MAX_READ_LEN), node length < 2^24.
+// Packed lane state (9 VGPRs). Limits: read length <= 2048 (PA_MAX_READ_LEN; 12 bits hold 0..4095), node length < 2^24.
 struct Lane {
     uint32_t rid;
-    uint32_t lk;    // L (bits 0..15) | kmer_pos (16..31)                                   (:70, :79)
+    uint32_t lk;    // L (bits 0..11) | kmer_pos (12..23) | state (24..27)                  (:70, :79)
     uint32_t cm;    // read_coverage (0..15) | mismatch_count (16..31)                      (:71-72)
     uint32_t h;     // node_id of the forward search as a blob handle                       (:118-121)
-    uint32_t of;    // kmer_offset (0..23) | state (24..26) | flags (27..31)
+    uint32_t of;    // kmer_offset (0..23) | flags (24..31)
     uint32_t rr;    // FWD: ref offset in the node, LEFT: node bases still to the left (0..23) | seen_snp (24..31)
     uint32_t rm;    // bases of max_matchable_pos not yet compared (0..15) | LEFT: read bases still to the left (16..31)
     uint32_t ph;    // LEFT: prev_node_id as a blob handle                                  (:128)
     uint32_t nc;    // distinct classes collected (0..11) | dictionary probe index (12..15) | TRACE: nodes.len() (16..31)
 };
 
-PA_HD uint32_t l_st(const Lane& s) { return (s.of >> 24) & 7u; }
-PA_HD void l_set_st(Lane& s, uint32_t st) { s.of = (s.of & ~(7u << 24)) | (st << 24); }
-PA_HD uint32_t l_flags(const Lane& s) { return s.of >> 27; }
-PA_HD void l_or_flags(Lane& s, uint32_t f) { s.of |= f << 27; }
-PA_HD void l_clr_flags(Lane& s, uint32_t f) { s.of &= ~(f << 27); }
+PA_HD uint32_t l_st(const Lane& s) { return (s.lk >> 24) & 15u; }
+PA_HD void l_set_st(Lane& s, uint32_t st) { s.lk = (s.lk & 0x00FFFFFFu) | (st << 24); }
+PA_HD uint32_t l_flags(const Lane& s) { return s.of >> 24; }
+PA_HD void l_or_flags(Lane& s, uint32_t f) { s.of |= f << 24; }
+PA_HD void l_clr_flags(Lane& s, uint32_t f) { s.of &= ~(f << 24); }
 PA_HD uint32_t l_off(const Lane& s) { return s.of & 0xFFFFFFu; }
-PA_HD uint32_t l_L(const Lane& s) { return s.lk & 0xFFFFu; }
-PA_HD uint32_t l_kp(const Lane& s) { return s.lk >> 16; }
-PA_HD void l_set_kp(Lane& s, uint32_t kp) { s.lk = (s.lk & 0xFFFFu) | (kp << 16); }
+PA_HD uint32_t l_L(const Lane& s) { return s.lk & 0xFFFu; }
+PA_HD uint32_t l_kp(const Lane& s) { return (s.lk >> 12) & 0xFFFu; }
+PA_HD void l_set_kp(Lane& s, uint32_t kp) { s.lk = (s.lk & 0xFF000FFFu) | (kp << 12); }
+PA_HD uint32_t l_pack_lk(uint32_t L, uint32_t kp, uint32_t st) { return L | (kp << 12) | (st << 24); }
 PA_HD uint32_t l_cov(const Lane& s) { return s.cm & 0xFFFFu; }
 PA_HD uint32_t l_mism(const Lane& s) { return s.cm >> 16; }
 PA_HD uint32_t l_ncol(const Lane& s) { return s.nc & 0xFFFu; }
@@ -210,10 +213,10 @@ PA_HD void push_node(Lane& s, ColRef c, uint32_t ec_ref, uint32_t ec_len, uint32
 
 PA_HD void lane_start(Lane& s, uint32_t rid, uint32_t L, uint32_t k) {
     s.rid = rid;
-    s.lk = L;
+    s.lk = l_pack_lk(L, 0, L < k ? ST_NONE : ST_SEEK);                   // :82-84
     s.cm = 0;
     s.h = s.rr = s.rm = s.ph = s.nc = 0;
-    s.of = ((L < k ? ST_NONE : ST_SEEK) << 24) | (F_FIRST_SEEK << 27);   // :82-84
+    s.of = F_FIRST_SEEK << 24;
 }
 
 // ---------------------------------------------------------------------------------------------- SEEK
@@ -245,9 +248,11 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
             s.rm = (s.rm & 0xFFFFu) | (kp << 16);                   // last_pos + 1 (:127)
             s.ph = h;                                               // :128
             s.rr = (off > 0 ? off - 1 : 0) + 1;                     // prev_kmer_offset + 1 (:129, quirk Q1 kept); snp = 0
-            s.of = off | (ST_LEFT << 24) | (((fl & ~F_FIRST_SEEK) | F_FRESH | F_LEFT_SEED) << 27);
+            s.of = off | (((fl & ~F_FIRST_SEEK) | F_FRESH | F_LEFT_SEED) << 24);
+            l_set_st(s, ST_LEFT);
         } else {
-            s.of = off | (ST_FWD << 24) | (((fl & ~F_FIRST_SEEK) | F_FRESH) << 27);
+            s.of = off | (((fl & ~F_FIRST_SEEK) | F_FRESH) << 24);
+            l_set_st(s, ST_FWD);
         }
         return;
     }
@@ -334,11 +339,11 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
         }
     }
     s.h = h;
-    s.lk = L | (kp_out << 16);
+    s.lk = l_pack_lk(L, kp_out, st);
     s.cm = cov | (mism << 16);
     s.rr = (ro0 + matched) | (snp << 24);
     s.rm = (s.rm & 0xFFFF0000u) | rem;
-    s.of = off | (st << 24) | (nfl << 27);
+    s.of = off | (nfl << 24);
 }
 
 // ---------------------------------------------------------------------------------------------- LEFT
@@ -451,10 +456,11 @@ PA_HD uint32_t any_eq7(uint32_t v, const uint32_t (&o)[7]) {
 
 // Step 1: the base list (a shortest one) and the tier that will intersect it:
 //   0  one class, or <= 4 classes with every list <= 7 ids: registers only, no dependent loads   (isect_light)
-//   1  base <= 8 ids, anything else long/many: eight lanes per read                              (kernel, cooperative)
-//   2  base > 8 ids: the whole wave per read                                                      (kernel, cooperative)
+//   1  base <= 8 ids, other lists long and/or more than 4 classes: base in registers, the other lists are scanned
+//      with 16-byte loads whose addresses are all known up front                                (isect_scan)
+//   2  base > 8 ids: the whole wave works on one read                                            (kernel, cooperative)
 //   3  one class of more than 7 ids: the result is that class, a plain copy                      (kernel / isect_write)
-// The host emulator and the oracle-style fallback below treat tiers 1 and 2 with per-lane binary searches.
+// The host emulator treats tier 2 with per-lane binary searches (isect_count).
 PA_HD uint32_t isect_pick(const Lane& s, ColRef cols, Isect& r) {
     r.alive = 0;
     r.count = 0;
@@ -522,6 +528,52 @@ PA_HD void isect_light(const Lane& s, const DevIndexView& ix, ColRef cols, Isect
     r.count = pa_popc32(alive);
 }
 
+PA_HD uint32_t eq_mask8(uint32_t v, const uint32_t (&b)[8]) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m |= (b[i] == v ? 1u : 0u) << i;
+    return m;
+}
+
+// Tier 1: base list of <= 8 ids in registers; every other list is streamed through 16-byte loads (record words
+// {class id, id0, id1, id2}, {id3..id6}, ..., 0xFFFFFFFF padded) and each word is compared with the eight base ids.
+PA_HD void isect_scan(const Lane& s, const DevIndexView& ix, ColRef cols, Isect& r) {
+    const uint32_t ncol = l_ncol(s);
+    const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * r.base_ref);
+    const U4 q0 = brec[0], q1 = brec[1], q2 = brec[2];
+    r.base_colour = q0.x;
+    const uint32_t b[8] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, r.base_len > 7 ? q2.x : 0xFFFFFFFFu};
+    uint32_t alive = (1u << r.base_len) - 1;
+#pragma unroll 1
+    for (uint32_t i = 0; i < ncol && alive; ++i) {
+        uint32_t ref, len;
+        get_class(cols, i, ref, len);
+        if (ref == r.base_ref) continue;
+        uint32_t m = 0;
+        if (len <= 64) {
+            const U4* rec = reinterpret_cast<const U4*>(ix.ec + 4ull * ref);
+            const uint32_t nchunks = (len + 4) >> 2;
+#pragma unroll 2
+            for (uint32_t q = 0; q < nchunks; ++q) {
+                const U4 w = rec[q];
+                if (q != 0) m |= eq_mask8(w.x, b);                  // word 0 of the record is the class id, not a member
+                m |= eq_mask8(w.y, b) | eq_mask8(w.z, b) | eq_mask8(w.w, b);
+            }
+        } else {
+            const uint32_t* ids = class_ids(ix, ref);
+#pragma unroll 1
+            for (uint32_t t = alive; t; t &= t - 1) {
+                const uint32_t j = pa_ctz32(t);
+                const uint32_t v = j == 0 ? b[0] : j == 1 ? b[1] : j == 2 ? b[2] : j == 3 ? b[3] : j == 4 ? b[4] : j == 5 ? b[5] : j == 6 ? b[6] : b[7];
+                if (list_contains(ids, len, v)) m |= 1u << j;
+            }
+        }
+        alive &= m;
+    }
+    r.alive = alive;
+    r.count = pa_popc32(alive);
+}
+
 // Whole intersection by one lane (host emulator; tiers 1 and 2 by per-lane binary search)
 PA_HD Isect isect_count(const Lane& s, const DevIndexView& ix, ColRef cols) {
     Isect r;
@@ -535,6 +587,10 @@ PA_HD Isect isect_count(const Lane& s, const DevIndexView& ix, ColRef cols) {
         r.base_colour = ix.ec[4ull * r.base_ref];
         r.count = r.base_len;
         r.alive = r.base_len >= 64 ? ~0ull : ((1ull << r.base_len) - 1);
+        return r;
+    }
+    if (tier == 1) {
+        isect_scan(s, ix, cols, r);
         return r;
     }
     r.base_colour = ix.ec[4ull * r.base_ref];
