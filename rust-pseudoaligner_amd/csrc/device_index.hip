@@ -59,7 +59,7 @@ struct pa_index {
     // per-launch scratch (one batch in flight per index handle; calls are serialised by `mu`)
     std::mutex mu;
     DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status
-    DevBuf spill, trace;
+    DevBuf spill, trace, slow;
     uint32_t last_grid = 0;
     // host-buffer convenience path
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
@@ -97,7 +97,7 @@ void pa_index_destroy(pa_index* idx) {
     (void)hipSetDevice(idx->device);
     for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table})
         if (p) (void)hipFree(p);
-    for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
+    for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->slow, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
                       &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})
         b->release();
     delete idx;
@@ -218,6 +218,8 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     rc = idx->spill.ensure(lanes * spill_cap * 4);
     if (rc != PA_OK) return rc;
     if (d_nodes) { rc = idx->trace.ensure(lanes * spill_cap * 4); if (rc != PA_OK) return rc; }
+    rc = idx->slow.ensure((n_reads + 64) * 4);
+    if (rc != PA_OK) return rc;
     HIP_TRY(hipMemsetAsync(idx->ctl.p, 0, 512, stream));
     MapParams p{};
     p.ix = idx->dv;
@@ -237,6 +239,12 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.counts = reinterpret_cast<unsigned long long*>(d_counts);
     p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
     p.class_table_size = idx->class_table_size;
+    p.slow = idx->slow.as<uint32_t>();
+    p.fast_steps = (uint32_t)env_int("PA_MAP_FAST_STEPS", 0);
+    p.thr_scan = (uint32_t)env_int("PA_MAP_THR_SCAN", 12);
+    p.thr_coop = (uint32_t)env_int("PA_MAP_THR_COOP", 4);
+    p.thr_novel = (uint32_t)env_int("PA_MAP_THR_NOVEL", 12);
+    p.thr_idle = (uint32_t)env_int("PA_MAP_THR_IDLE", 16);
     p.ablate = (uint32_t)env_int("PA_MAP_ABLATE", 0);
     p.dbg = env_int("PA_MAP_STATS", 0) ? idx->ctl.as<unsigned long long>() + 2 : nullptr;
     p.trace = d_nodes ? idx->trace.as<uint32_t>() : nullptr;

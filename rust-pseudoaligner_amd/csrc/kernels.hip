@@ -201,7 +201,8 @@ template <bool TRACE>
 __device__ __attribute__((noinline)) Lane fin_lane_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk,
                                                         glb_u32 ec, glb_u32w arena_g, glb_u32w results_g, glb_u32w counts_g, uint32_t which) {
     const uint32_t st = l_st(s);
-    const bool mine = st == which;
+    // which == ST_F_LIGHT runs the three cheap kinds together (NONE, LIGHT, COPY); ST_F_SCAN runs alone
+    const bool mine = which == ST_F_SCAN ? st == ST_F_SCAN : (st == ST_NONE || st == ST_F_LIGHT || st == ST_F_COPY);
     DevIndexView ix{};
     ix.ec = (const uint32_t*)ec;
     const ColRef cols = make_col_ref(refs_lane, (glb_u32w)pp->spill, slot, pp->spill_cap, nullptr);
@@ -212,10 +213,10 @@ __device__ __attribute__((noinline)) Lane fin_lane_call(Lane s, uint32_t lane, u
     is.base_colour = 0;
     is.alive = 0;
     is.in_regs = false;
-    if (mine && which != ST_NONE && !(pp->ablate & 1u)) {
+    if (mine && st != ST_NONE && !(pp->ablate & 1u)) {
         isect_pick(s, cols, is);
-        if (which == ST_F_LIGHT) isect_light(s, ix, cols, is);
-        else if (which == ST_F_SCAN) isect_scan(s, ix, cols, is);
+        if (st == ST_F_LIGHT) isect_light(s, ix, cols, is);
+        else if (st == ST_F_SCAN) isect_scan(s, ix, cols, is);
         else {   // ST_F_COPY: a single class, the result is the class itself
             is.base_colour = ec[4ull * is.base_ref];
             is.count = is.base_len;
@@ -225,7 +226,7 @@ __device__ __attribute__((noinline)) Lane fin_lane_call(Lane s, uint32_t lane, u
     const uint64_t my_off = arena_alloc(cnt, lane, pp, chunk);
     if (!mine) return s;
     if (cnt && my_off + cnt <= pp->arena_cap) {
-        if (which == ST_F_COPY) {   // 16-byte loads of the record (words 1..cnt are the ids), four in flight per round trip
+        if (st == ST_F_COPY) {   // 16-byte loads of the record (words 1..cnt are the ids), four in flight per round trip
             const glb_v4 rec = (glb_v4)(ec + 4ull * is.base_ref);
             const uint32_t nchunks = (cnt + 4) >> 2;
             for (uint32_t q0 = 0; q0 < nchunks; q0 += 4) {
@@ -248,7 +249,7 @@ __device__ __attribute__((noinline)) Lane fin_lane_call(Lane s, uint32_t lane, u
             isect_write(s, ix, cols, is, (uint32_t*)arena_g + my_off);
         }
     }
-    return emit_record<TRACE>(s, which != ST_NONE, cnt, cnt, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
+    return emit_record<TRACE>(s, st != ST_NONE, cnt, cnt, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
 }
 
 // COOP: the whole wave works on one read at a time (base list of more than 8 ids and at least two classes). Lane e owns
@@ -334,6 +335,38 @@ __device__ __attribute__((noinline)) Lane fin_coop_call(Lane s, uint32_t lane, u
     return emit_record<TRACE>(s, true, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
 }
 
+// Fast-phase finish: the lanes whose walk ended (ISECT / NONE) and whose classes need registers only are emitted at
+// once; every other finished lane comes back in state ST_SEEK, which the fast phase reads as "hand over".
+template <bool TRACE>
+__device__ __attribute__((noinline)) Lane fast_finish_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk,
+                                                           glb_u32 ec, glb_u32w arena_g, glb_u32w results_g, glb_u32w counts_g) {
+    const uint32_t st = l_st(s);
+    DevIndexView ix{};
+    ix.ec = (const uint32_t*)ec;
+    const ColRef cols = make_col_ref(refs_lane, (glb_u32w)pp->spill, slot, pp->spill_cap, nullptr);
+    Isect is;
+    is.count = 0;
+    is.base_len = 0xFFFFFFFFu;
+    is.base_ref = 0;
+    is.base_colour = 0;
+    is.alive = 0;
+    is.in_regs = false;
+    bool mine = st == ST_NONE;
+    if (st == ST_ISECT) {
+        if (isect_pick(s, cols, is) == 0) {
+            isect_light(s, ix, cols, is);
+            const bool want_class = counts_g != nullptr || pp->colour_out != nullptr;
+            mine = !(want_class && is.count != 0 && is.count != is.base_len);   // a strict subset needs the class hash table
+        }
+        if (!mine) l_set_st(s, ST_SEEK);
+    }
+    const uint32_t cnt = mine ? is.count : 0u;
+    const uint64_t my_off = arena_alloc(cnt, lane, pp, chunk);
+    if (!mine) return s;
+    if (cnt && my_off + cnt <= pp->arena_cap) isect_write(s, ix, cols, is, (uint32_t*)arena_g + my_off);
+    return emit_record<TRACE>(s, st == ST_ISECT, cnt, cnt, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
+}
+
 // NOVEL: the result is a strict subset of every visited class; find out whether it equals some index class (content
 // lookup in the class-list hash table), then count it
 __device__ __attribute__((noinline)) Lane fin_novel_call(Lane s, lds_params pp, glb_u32 ec, glb_u32w arena_g, glb_u32w counts_g) {
@@ -393,19 +426,65 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
     Lane s;
     s.rid = s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0;   // state ST_EMPTY
 
+    // ---- phase 1: lock-step fast path ---------------------------------------------------------------------------------
+    // One tile at a time, every lane in the same state: one dictionary probe at position 0, up to fast_steps forward
+    // steps, register-only intersection. No scheduler, no refill, one memory round trip per stage for all 64 reads. A read
+    // that leaves this envelope (probe miss, re-seek, careful mode, more nodes, a long or many-class intersection, a
+    // strict-subset result) is not emitted; its id goes to this wave's slice of p.slow and phase 2 maps it from scratch.
+    const glb_u32w slow_seg = (glb_u32w)p.slow + next;
+    uint32_t nslow = 0;
+    if (p.fast_steps && !TRACE) {
+        for (uint64_t base = next; base < end; base += 64) {
+            const uint64_t rid = base + lane;
+            s.lk = 0;
+            if (rid < end) {
+                uint32_t L = p.lens[rid];
+                if (L > p.wpr * 32) L = p.wpr * 32;
+                const uint64_t* src = p.tiles + ((rid >> 6) * p.wpr) * 64 + (rid & 63);
+                for (uint32_t w = 0; w < p.wpr; ++w) rd_lane[w * 64] = src[(uint64_t)w * 64];
+                rd_lane[p.wpr * 64] = 0;
+                lane_start(s, (uint32_t)rid, L, p.ix.k);
+            }
+            if (l_st(s) == ST_SEEK) s = seek_call(s, (glb_u32)p.ix.table, (uint32_t)p.ix.nbuckets, p.ix.kmask, p.ix.k, rd_lane, p.wpr);
+            for (uint32_t step = 0; step < p.fast_steps && __any(l_st(s) == ST_FWD && !(l_flags(s) & F_CAREFUL)); ++step)
+                if (l_st(s) == ST_FWD && !(l_flags(s) & F_CAREFUL))
+                    s = fwd_call<false>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
+            if (__any(l_st(s) == ST_ISECT || l_st(s) == ST_NONE))
+                s = fast_finish_call<false>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g);
+            const uint64_t ms = __ballot(l_st(s) != ST_EMPTY);   // everything not emitted is handed over
+            if (l_st(s) != ST_EMPTY) slow_seg[nslow + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = s.rid;
+            nslow += (uint32_t)__popcll(ms);
+        }
+        s.rid = s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0;
+        end = next + nslow;   // phase 2 walks this wave's slice of the slow list
+    }
+    const bool from_list = p.fast_steps && !TRACE;
+
+    // ---- phase 2: general state machine (population-scheduled) -------------------------------------------------------
     for (;;) {
         const uint32_t st = l_st(s);
-        // population of every state; the most populated one runs (EMPTY counts only as far as reads remain)
+        // population of every state. The cheap finishing states (NONE, LIGHT, COPY) are one section; the common states
+        // compete by population; the rare expensive ones (SCAN, COOP, NOVEL) wait until enough of their kind have gathered
+        // (or nothing else can run), so that they neither stall cheap lanes nor starve.
         const uint64_t mE = __ballot(st == ST_EMPTY);
         const uint64_t left = end - next;
         const uint32_t nE = __popcll(mE);
-        uint32_t best = (uint32_t)(left < (uint64_t)nE ? left : (uint64_t)nE), sel = ST_EMPTY;
-        const uint32_t nR = best;
-#pragma unroll
-        for (uint32_t q = ST_SEEK; q < ST_COUNT; ++q) {
-            if (q == ST_ISECT) continue;   // transient: resolved right after the walk step that produced it
-            const uint32_t n = __popcll(__ballot(st == q));
-            if (n > best) { best = n; sel = q; }
+        const uint32_t nR = (uint32_t)(left < (uint64_t)nE ? left : (uint64_t)nE);
+        const uint32_t nS = __popcll(__ballot(st == ST_SEEK)), nF = __popcll(__ballot(st == ST_FWD)), nL = __popcll(__ballot(st == ST_LEFT));
+        const uint32_t nFast = __popcll(__ballot(st == ST_NONE || st == ST_F_LIGHT || st == ST_F_COPY));
+        const uint32_t nScan = __popcll(__ballot(st == ST_F_SCAN)), nCoop = __popcll(__ballot(st == ST_F_COOP)), nNovel = __popcll(__ballot(st == ST_F_NOVEL));
+        uint32_t best = nR, sel = ST_EMPTY;
+        if (nS > best) { best = nS; sel = ST_SEEK; }
+        if (nF > best) { best = nF; sel = ST_FWD; }
+        if (nFast > best) { best = nFast; sel = ST_F_LIGHT; }
+        if (nL > best) { best = nL; sel = ST_LEFT; }
+        if (nCoop >= p.thr_coop) { best = nCoop; sel = ST_F_COOP; }
+        else if (nScan >= p.thr_scan) { best = nScan; sel = ST_F_SCAN; }
+        else if (nNovel >= p.thr_novel) { best = nNovel; sel = ST_F_NOVEL; }
+        else if (best < p.thr_idle) {   // little common work left: drain the rare states
+            if (nScan > best) { best = nScan; sel = ST_F_SCAN; }
+            if (nNovel > best) { best = nNovel; sel = ST_F_NOVEL; }
+            if (nCoop > best) { best = nCoop; sel = ST_F_COOP; }
         }
         if (best == 0) break;
         if (p.dbg && lane == 0) {
@@ -417,7 +496,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
         if (sel == ST_EMPTY) {   // ---- REFILL: empty lanes take the next reads of this wave's range (coalesced by rank)
             const uint32_t rank = __popcll(mE & ((1ull << lane) - 1));
             if (st == ST_EMPTY && rank < nR) {
-                const uint64_t rid = next + rank;
+                const uint64_t rid = from_list ? (uint64_t)((glb_u32w)p.slow)[next + rank] : next + rank;
                 uint32_t L = p.lens[rid];
                 if (L > p.wpr * 32) L = p.wpr * 32;
                 const uint64_t* src = p.tiles + ((rid >> 6) * p.wpr) * 64 + (rid & 63);
@@ -438,7 +517,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
             s = fin_coop_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g);
         } else if (sel == ST_F_NOVEL) {
             s = fin_novel_call(s, pp, ec, arena_g, counts_g);
-        } else {   // ST_NONE, ST_F_LIGHT, ST_F_SCAN, ST_F_COPY (whole wave enters: the allocation scan needs every lane)
+        } else {   // ST_F_LIGHT (= NONE + LIGHT + COPY) or ST_F_SCAN (whole wave enters: the allocation scan needs every lane)
             s = fin_lane_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g, sel);
         }
         if (l_st(s) == ST_ISECT) {   // the walk just ended: choose how this read's classes will be intersected (LDS only)

@@ -8,7 +8,8 @@ namespace pa {
 
 constexpr uint32_t PA_MAP_BLOCK = 256;          // 4 independent waves per workgroup, no barriers
 constexpr uint32_t PA_ARENA_CHUNK = 1024;       // u32 entries a wave reserves per global atomic
-constexpr int PA_DEFAULT_MAP_WAVES = 6;         // launch-bounds variant of the map kernel (waves per SIMD)
+constexpr int PA_DEFAULT_MAP_WAVES = 6;
+constexpr uint32_t PA_DEFAULT_FAST_STEPS = 4;   // forward steps of the lock-step fast phase         // launch-bounds variant of the map kernel (waves per SIMD)
 constexpr uint32_t PA_STATUS_ARENA_FULL = 1u;
 constexpr uint32_t PA_STATUS_SPILL_OVERFLOW = 2u;
 
@@ -27,6 +28,9 @@ struct MapParams {
     uint32_t* status;
     uint32_t* spill;
     uint32_t spill_cap;
+    uint32_t* slow;            // [n_reads] ids of the reads the lock-step fast phase hands to the general state machine
+    uint32_t thr_scan, thr_coop, thr_novel, thr_idle;   // scheduler thresholds of the rare finishing states
+    uint32_t fast_steps;       // forward steps the fast phase gives a read before handing it over (0 = no fast phase)
     // optional fused class-count table (pa_counts_len entries) and the class-list hash table it needs for novel subsets
     unsigned long long* counts;
     const uint32_t* class_table;

@@ -553,11 +553,18 @@ PA_HD void isect_scan(const Lane& s, const DevIndexView& ix, ColRef cols, Isect&
         if (len <= 64) {
             const U4* rec = reinterpret_cast<const U4*>(ix.ec + 4ull * ref);
             const uint32_t nchunks = (len + 4) >> 2;
-#pragma unroll 2
-            for (uint32_t q = 0; q < nchunks; ++q) {
-                const U4 w = rec[q];
-                if (q != 0) m |= eq_mask8(w.x, b);                  // word 0 of the record is the class id, not a member
-                m |= eq_mask8(w.y, b) | eq_mask8(w.z, b) | eq_mask8(w.w, b);
+#pragma unroll 1
+            for (uint32_t q0 = 0; q0 < nchunks; q0 += 4) {          // four 16-byte loads in flight per round trip
+                U4 w[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) w[t] = rec[q0 + t < nchunks ? q0 + t : q0];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (q0 + t < nchunks) {
+                        if (q0 + t != 0) m |= eq_mask8(w[t].x, b);  // word 0 of the record is the class id, not a member
+                        m |= eq_mask8(w[t].y, b) | eq_mask8(w[t].z, b) | eq_mask8(w[t].w, b);
+                    }
+                }
             }
         } else {
             const uint32_t* ids = class_ids(ix, ref);
