@@ -137,10 +137,13 @@ void pa_index_destroy(pa_index* idx);
 typedef struct pa_read_result {   /* one per read, same order as the input */
     uint32_t coverage;            /* map_read .1 (bases aligned); 0 when unmapped */
     uint32_t mismatches;          /* map_read_with_mismatch .2; bit 31 = mapped (Some vs None) */
-    uint32_t class_off;           /* offset of the class in the arena (u32 units) */
+    uint32_t class_off;           /* where the class (map_read .0) is: bit 31 set = it IS index class (class_off & 0x7FFFFFFF),
+                                     i.e. eq_classes[id] of the flat index, returned by reference; bit 31 clear = offset of
+                                     the ids in the arena (u32 units): an intersection that is no single visited class */
     uint32_t class_len;           /* number of transcript ids */
 } pa_read_result;
 #define PA_MAPPED_BIT 0x80000000u
+#define PA_CLASS_REF 0x80000000u
 
 size_t pa_tiles_words(uint64_t n_reads, uint32_t words_per_read);   /* u64 words in the tile buffer */
 uint32_t pa_words_per_read(uint32_t max_read_len);
@@ -155,7 +158,7 @@ int pa_encode_reads_host(const uint8_t* ascii, const uint64_t* offsets, uint64_t
 
 /* The hot path. map_read_with_mismatch for every read of a device-resident batch.
  *   d_results  [n_reads] pa_read_result
- *   d_arena    [arena_cap] u32: class ids, referenced by (class_off, class_len)
+ *   d_arena    [arena_cap] u32: ids of the classes that are not index classes, referenced by (class_off, class_len)
  *   d_colour   optional [n_reads] u32: equivalence-class id of the result when it equals an index class
  *              reached by the read, 0xFFFFFFFF otherwise (input of pa_counts_accumulate_device); may be NULL
  * Asynchronous on `stream`; completion status is fetched with pa_map_finish (which synchronises the stream). */

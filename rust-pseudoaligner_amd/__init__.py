@@ -22,8 +22,9 @@ from ._ffi import (PA_DEFAULT_ALLOWED_MISMATCHES, PA_MAPPED_BIT, PA_READ_COVERAG
 
 __all__ = ["HostIndex", "Txome", "Pseudoaligner", "build_index", "process_reads", "PaError", "lib", "concat_reads",
            "gather_classes", "unpack_tiles", "RESULT_DTYPE", "PA_MAPPED_BIT", "PA_DEFAULT_ALLOWED_MISMATCHES",
-           "PA_READ_COVERAGE_THRESHOLD"]
+           "PA_READ_COVERAGE_THRESHOLD", "PA_CLASS_REF"]
 
+PA_CLASS_REF = 0x80000000
 RESULT_DTYPE = np.dtype([("coverage", "<u4"), ("mismatches", "<u4"), ("class_off", "<u4"), ("class_len", "<u4")])
 
 
@@ -340,14 +341,23 @@ def process_reads(fastq_path: str, index: Pseudoaligner, out_path: str = "-", nu
     return n.value, flagged.value
 
 
-def gather_classes(results: np.ndarray, arena: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """(results with arena offsets, arena) -> (class_offsets[n+1], class_ids) in read order (vectorised)."""
+def gather_classes(results: np.ndarray, arena: np.ndarray, index: "HostIndex") -> Tuple[np.ndarray, np.ndarray]:
+    """Device-format results -> (class_offsets[n+1], class_ids) in read order (vectorised). A class is either given by
+    reference (class_off has PA_CLASS_REF set: it is eq_classes[class_off & 0x7FFFFFFF] of the flat index) or by its
+    offset in the arena."""
+    a = index.arrays()
     lens = results["class_len"].astype(np.int64)
     coff = np.zeros(len(results) + 1, dtype=np.uint64)
     coff[1:] = np.cumsum(lens)
     total = int(coff[-1])
     if total == 0:
         return coff, np.zeros(0, np.uint32)
-    starts = np.repeat(results["class_off"].astype(np.int64), lens)
+    off = results["class_off"].astype(np.int64)
+    is_ref = (off & 0x80000000) != 0
+    ec_offset = a["ec_offset"].astype(np.int64)
+    src = np.concatenate([np.asarray(arena, dtype=np.uint32), a["ec_ids"]])
+    cid = np.where(is_ref & (lens > 0), off & 0x7FFFFFFF, 0)
+    start = np.where(is_ref, len(arena) + ec_offset[cid], off)
+    starts = np.repeat(start, lens)
     within = np.arange(total, dtype=np.int64) - np.repeat(coff[:-1].astype(np.int64), lens)
-    return coff, arena[starts + within].astype(np.uint32)
+    return coff, src[starts + within].astype(np.uint32)

@@ -20,6 +20,7 @@ DevIndexView FlatDevice::host_view() const {
     v.nbuckets = nbuckets;
     v.blobs = blobs.data();
     v.ledge = ledge.data();
+    v.nid_of_handle = nid_of_handle.data();
     v.ec = ec.data();
     v.class_ref = class_ref.data();
     v.class_len = class_len.data();
@@ -156,7 +157,9 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
     if (bad.load() != NO_HANDLE) return fail(PA_ERR_FORMAT, "a k-mer of node %u occurs twice in the graph", bad.load());
 
     // ---- blobs + edges ----
-    out.ledge.assign(4ull * N + 4, NO_HANDLE);
+    const uint64_t granules = out.blobs.size() / BLOB_GRANULE;
+    out.ledge.assign(4ull * granules + 4, NO_HANDLE);
+    out.nid_of_handle.assign(granules + 1, 0xFFFFFFFFu);
     std::atomic<uint32_t> dangling{NO_HANDLE};
     par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
         for (uint64_t i = a; i < b; ++i) {
@@ -166,7 +169,8 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
             const uint32_t len = f.node_len[i];
             const uint64_t s = f.node_start[i];
             hd[0] = len | ((uint32_t)f.node_exts[i] << 24);
-            hd[1] = (uint32_t)i;
+            hd[1] = f.node_colour[i];
+            out.nid_of_handle[out.handle[i]] = (uint32_t)i;
             hd[2] = out.class_ref[f.node_colour[i]];
             hd[3] = out.class_len[f.node_colour[i]];
             for (uint32_t w = 0; w < (len + 31) / 32; ++w) {
@@ -202,7 +206,7 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
                     if (le == NO_HANDLE) dangling.store((uint32_t)i);
                 }
                 hd[4 + base] = re;
-                out.ledge[4 * i + base] = le;
+                out.ledge[4ull * out.handle[i] + base] = le;
             }
         }
     });

@@ -11,7 +11,8 @@ struct FlatDevice {
     uint64_t nbuckets = 0;
     std::vector<uint8_t> blobs;
     std::vector<uint32_t> handle;   // node id -> blob handle
-    std::vector<uint32_t> ledge;
+    std::vector<uint32_t> ledge;           // by handle
+    std::vector<uint32_t> nid_of_handle;
     std::vector<uint32_t> ec;                      // class records (16-byte aligned)
     std::vector<uint32_t> class_ref, class_len;    // by class id
     uint64_t num_kmers = 0;

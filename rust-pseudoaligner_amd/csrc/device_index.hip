@@ -52,7 +52,7 @@ struct pa_index {
     int device = 0;
     int num_cus = 0;
     DevIndexView dv{};
-    void *d_table = nullptr, *d_blobs = nullptr, *d_ledge = nullptr, *d_ec = nullptr, *d_class_ref = nullptr, *d_class_len = nullptr,
+    void *d_table = nullptr, *d_blobs = nullptr, *d_ledge = nullptr, *d_nid = nullptr, *d_ec = nullptr, *d_class_ref = nullptr, *d_class_len = nullptr,
          *d_class_table = nullptr;
     uint64_t class_table_size = 0;
     pa_index_stats stats{};
@@ -64,6 +64,7 @@ struct pa_index {
     // host-buffer convenience path
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
     std::vector<uint32_t> h_class_ids;
+    std::vector<uint32_t> h_ec, h_class_ref;
     std::vector<uint32_t> h_arena;
 };
 
@@ -95,7 +96,7 @@ static int upload(const void* src, size_t bytes, void** dst) {
 void pa_index_destroy(pa_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
-    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table})
+    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table})
         if (p) (void)hipFree(p);
     for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->slow, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
                       &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})
@@ -131,6 +132,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     rc = upload(fd.table.data(), fd.table.size() * 4, &idx->d_table);
     if (rc == PA_OK) rc = upload(fd.blobs.data(), fd.blobs.size(), &idx->d_blobs);
     if (rc == PA_OK) rc = upload(fd.ledge.data(), fd.ledge.size() * 4, &idx->d_ledge);
+    if (rc == PA_OK) rc = upload(fd.nid_of_handle.data(), fd.nid_of_handle.size() * 4, &idx->d_nid);
     if (rc == PA_OK) rc = upload(fd.ec.data(), fd.ec.size() * 4, &idx->d_ec);
     if (rc == PA_OK) rc = upload(fd.class_ref.data(), fd.class_ref.size() * 4, &idx->d_class_ref);
     if (rc == PA_OK) rc = upload(fd.class_len.data(), fd.class_len.size() * 4, &idx->d_class_len);
@@ -142,6 +144,9 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     idx->dv.table = static_cast<const uint32_t*>(idx->d_table);
     idx->dv.blobs = static_cast<const uint8_t*>(idx->d_blobs);
     idx->dv.ledge = static_cast<const uint32_t*>(idx->d_ledge);
+    idx->dv.nid_of_handle = static_cast<const uint32_t*>(idx->d_nid);
+    idx->h_ec = fd.ec;   // host copy of the class table: pa_map_batch resolves by-reference classes from it
+    idx->h_class_ref = fd.class_ref;
     idx->dv.ec = static_cast<const uint32_t*>(idx->d_ec);
     idx->dv.class_ref = static_cast<const uint32_t*>(idx->d_class_ref);
     idx->dv.class_len = static_cast<const uint32_t*>(idx->d_class_len);
@@ -149,7 +154,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     s.num_kmers = fd.num_kmers;
     s.table_slots = fd.nbuckets * SLOTS_PER_BUCKET;
     s.bytes_table = fd.table.size() * 4;
-    s.bytes_graph = fd.blobs.size() + fd.ledge.size() * 4;
+    s.bytes_graph = fd.blobs.size() + fd.ledge.size() * 4 + fd.nid_of_handle.size() * 4;
     s.bytes_classes = (fd.ec.size() + fd.class_ref.size() + fd.class_len.size() + ctab.size()) * 4;
     s.bytes_total = s.bytes_table + s.bytes_graph + s.bytes_classes;
     s.num_nodes = fd.num_nodes;
@@ -186,7 +191,7 @@ static int env_int(const char* name, int dflt) {   // tuning knobs for A/B runs 
 
 static int map_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t* grid, size_t* lds, int* waves) {
     *waves = env_int("PA_MAP_WAVES", PA_DEFAULT_MAP_WAVES);
-    const size_t wave_bytes = 256 + (size_t)(wpr + 1) * 512 + 2 * LDS_CLASSES * 256;
+    const size_t wave_bytes = 256 + (size_t)(wpr + 1) * 512 + 3 * LDS_CLASSES * 256;
     *lds = (sizeof(MapParams) + 15) / 16 * 16 + wave_bytes * (PA_MAP_BLOCK / 64);
     if (*lds > 160 * 1024) return fail(PA_ERR_UNSUPPORTED, "reads of %u words need %zu bytes of LDS per workgroup (> 160 KiB)", wpr, *lds);
     int per_cu = 0;
@@ -213,7 +218,7 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     int waves = 0;
     int rc = map_geometry(idx, n_reads, wpr, &grid, &lds, &waves);
     if (rc != PA_OK) return rc;
-    const uint32_t spill_cap = 128 * wpr + 4;   // u32 words: (ref, len) pairs for >= 2 * max read length + 2 node visits
+    const uint32_t spill_cap = 256 * wpr + 8;   // u32 words: (ref, len, class id, -) quads for >= 2 * max read length + 2 node visits
     const size_t lanes = (size_t)grid * PA_MAP_BLOCK;
     rc = idx->spill.ensure(lanes * spill_cap * 4);
     if (rc != PA_OK) return rc;
@@ -241,9 +246,9 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.class_table_size = idx->class_table_size;
     p.slow = idx->slow.as<uint32_t>();
     p.fast_steps = (uint32_t)env_int("PA_MAP_FAST_STEPS", 0);
-    p.thr_scan = (uint32_t)env_int("PA_MAP_THR_SCAN", 12);
-    p.thr_coop = (uint32_t)env_int("PA_MAP_THR_COOP", 4);
-    p.thr_novel = (uint32_t)env_int("PA_MAP_THR_NOVEL", 12);
+    p.thr_scan = (uint32_t)env_int("PA_MAP_THR_SCAN", 4);
+    p.thr_coop = (uint32_t)env_int("PA_MAP_THR_COOP", 1);
+    p.thr_novel = (uint32_t)env_int("PA_MAP_THR_NOVEL", 4);
     p.thr_idle = (uint32_t)env_int("PA_MAP_THR_IDLE", 16);
     p.ablate = (uint32_t)env_int("PA_MAP_ABLATE", 0);
     p.dbg = env_int("PA_MAP_STATS", 0) ? idx->ctl.as<unsigned long long>() + 2 : nullptr;
@@ -341,7 +346,7 @@ static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* o
     int e = launch_encode(idx->b_ascii.as<uint8_t>(), idx->b_offsets.as<uint64_t>(), n, wpr, idx->b_tiles.as<uint64_t>(),
                           idx->b_lens.as<uint32_t>(), st);
     if (e) return fail(PA_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
-    const uint32_t spill_cap = 128 * wpr + 4;
+    const uint32_t spill_cap = 256 * wpr + 8;
     uint32_t *d_nodes = nullptr, *d_nodes_len = nullptr;
     if (nodes_flat) {
         if ((rc = idx->b_nodes.ensure(n * spill_cap * 4)) || (rc = idx->b_nodes_len.ensure(n * 4))) return rc;
@@ -369,7 +374,12 @@ static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* o
         uint64_t o = 0;
         for (uint64_t i = 0; i < n; ++i) {
             if (class_offsets) class_offsets[i] = o;
-            if (results[i].class_len) memcpy(idx->h_class_ids.data() + o, idx->h_arena.data() + results[i].class_off, results[i].class_len * 4ull);
+            if (results[i].class_len) {
+                const uint32_t* src = (results[i].class_off & PA_CLASS_REF)
+                                          ? idx->h_ec.data() + 4ull * idx->h_class_ref[results[i].class_off & ~PA_CLASS_REF] + 1
+                                          : idx->h_arena.data() + results[i].class_off;
+                memcpy(idx->h_class_ids.data() + o, src, results[i].class_len * 4ull);
+            }
             results[i].class_off = (uint32_t)o;
             o += results[i].class_len;
         }

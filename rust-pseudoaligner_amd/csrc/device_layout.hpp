@@ -13,13 +13,14 @@
 //               96-107) no node sequence has to be fetched to confirm a hit.
 //   node blobs  one blob per unitig, 32-byte granules, addressed by handle = byte offset / 32:
 //                 +0  u32 len (bits 0..23) | debruijn::Exts byte (bits 24..31)
-//                 +4  u32 node id          +8  u32 class record ref      +12 u32 class length (ids)
+//                 +4  u32 class id         +8  u32 class record ref      +12 u32 class length (ids)
 //                 +16 u32 redge[4]      handle of the node reached by right-extending with base b (Node::r_edges)
 //                 +32 u64 seq[ceil(len/32)]  2-bit packed, LSB-first
 //               so a node visit is ONE dependent fetch (header + sequence share a line for len <= 128), the hop to the
 //               next node needs no further lookup (the reference re-derives every edge by hashing: SURVEY.md §3.2) and
 //               the colour's id list is addressable without an offsets table.
-//   ledge       u32[4*num_nodes] handles by node id (Node::l_edges), only touched by the left extension
+//   ledge       u32[4*granules] left-edge handles by blob handle (Node::l_edges), only touched by the left extension
+//   nid_of_handle  u32[granules] node id by blob handle (only the node-trace test surface reads it)
 //   ec          class records, 16-byte aligned, at least 32 bytes, padded with 0xFFFFFFFF: record r = words [4r, ...) =
 //               {class id, id0, id1, ...} — the sorted transcript-id lists of eq_classes: Vec<Vec<u32>>
 //               (src/pseudoaligner.rs:29); a class of <= 7 ids is two 16-byte loads and needs no length checks.
@@ -58,7 +59,8 @@ struct DevIndexView {
     const uint32_t* table;    // nbuckets * 16 words
     uint64_t nbuckets;
     const uint8_t* blobs;     // node blobs
-    const uint32_t* ledge;    // [4 * num_nodes]
+    const uint32_t* ledge;    // [4 * granules], by handle
+    const uint32_t* nid_of_handle;   // [granules]
     const uint32_t* ec;       // class records (16-byte aligned records of u32)
     const uint32_t* class_ref;   // [num_classes]
     const uint32_t* class_len;   // [num_classes]

@@ -76,7 +76,8 @@ typedef __attribute__((address_space(1))) uint32_t* glb_u32w;
 
 __device__ __forceinline__ ReadRef make_read_ref(lds_u64 rdp, uint32_t wmax) { return ReadRef{(const uint64_t*)rdp, 64, wmax}; }
 __device__ __forceinline__ ColRef make_col_ref(lds_u32 refs, glb_u32w spill_base, uint32_t slot, uint32_t spill_cap, glb_u32w trace_base) {
-    return ColRef{(uint32_t*)refs, (uint32_t*)(refs + 64 * LDS_CLASSES), (uint32_t*)(spill_base + (uint64_t)slot * spill_cap), spill_cap,
+    return ColRef{(uint32_t*)refs, (uint32_t*)(refs + 64 * LDS_CLASSES), (uint32_t*)(refs + 128 * LDS_CLASSES),
+                  (uint32_t*)(spill_base + (uint64_t)slot * spill_cap), spill_cap,
                   trace_base ? (uint32_t*)(trace_base + (uint64_t)slot * spill_cap) : nullptr};
 }
 
@@ -92,23 +93,25 @@ __device__ __attribute__((noinline)) Lane seek_call(Lane s, glb_u32 table, uint3
 }
 
 template <bool TRACE, int EXP = 0>
-__device__ __attribute__((noinline)) Lane fwd_call(Lane s, glb_u8 blobs, uint32_t k, lds_u64 rdp, uint32_t wmax, lds_u32 refs,
+__device__ __attribute__((noinline)) Lane fwd_call(Lane s, glb_u8 blobs, glb_u32 nid_of_handle, uint32_t k, lds_u64 rdp, uint32_t wmax, lds_u32 refs,
                                                    glb_u32w spill_base, uint32_t slot, uint32_t spill_cap, glb_u32w trace_base,
                                                    uint32_t allowed) {
     DevIndexView ix{};
     ix.blobs = (const uint8_t*)blobs;
+    ix.nid_of_handle = (const uint32_t*)nid_of_handle;
     ix.k = k;
     fwd_step<TRACE, EXP>(s, ix, make_read_ref(rdp, wmax), make_col_ref(refs, spill_base, slot, spill_cap, trace_base), allowed);
     return s;
 }
 
 template <bool TRACE>
-__device__ __attribute__((noinline)) Lane left_call(Lane s, glb_u8 blobs, glb_u32 ledge, uint32_t k, lds_u64 rdp, uint32_t wmax,
+__device__ __attribute__((noinline)) Lane left_call(Lane s, glb_u8 blobs, glb_u32 ledge, glb_u32 nid_of_handle, uint32_t k, lds_u64 rdp, uint32_t wmax,
                                                     lds_u32 refs, glb_u32w spill_base, uint32_t slot, uint32_t spill_cap,
                                                     glb_u32w trace_base, uint32_t allowed) {
     DevIndexView ix{};
     ix.blobs = (const uint8_t*)blobs;
     ix.ledge = (const uint32_t*)ledge;
+    ix.nid_of_handle = (const uint32_t*)nid_of_handle;
     ix.k = k;
     left_step<TRACE>(s, ix, make_read_ref(rdp, wmax), make_col_ref(refs, spill_base, slot, spill_cap, trace_base), allowed);
     return s;
@@ -164,8 +167,10 @@ __device__ __forceinline__ Lane emit_record(Lane s, bool mapped, uint32_t cnt, u
         r.class_len = cnt;
         r.class_off = (uint32_t)my_off;
         if (my_off + cnt_alloc > pp->arena_cap) atomicOr(pp->status, PA_STATUS_ARENA_FULL);
-        if (cnt == base_len) colour = base_colour;
-        else novel = cnt != 0;
+        if (cnt == base_len) {   // the class IS index class base_colour: returned by reference, nothing was written to the arena
+            colour = base_colour;
+            r.class_off = PA_CLASS_REF | base_colour;
+        } else novel = cnt != 0;
         if (l_flags(s) & F_SPILL_OVERFLOW) atomicOr(pp->status, PA_STATUS_SPILL_OVERFLOW);
     }
     ((glb_v4w)results_g)[s.rid] = u32x4{r.coverage, r.mismatches, r.class_off, r.class_len};
@@ -201,8 +206,8 @@ template <bool TRACE>
 __device__ __attribute__((noinline)) Lane fin_lane_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk,
                                                         glb_u32 ec, glb_u32w arena_g, glb_u32w results_g, glb_u32w counts_g, uint32_t which) {
     const uint32_t st = l_st(s);
-    // which == ST_F_LIGHT runs the three cheap kinds together (NONE, LIGHT, COPY); ST_F_SCAN runs alone
-    const bool mine = which == ST_F_SCAN ? st == ST_F_SCAN : (st == ST_NONE || st == ST_F_LIGHT || st == ST_F_COPY);
+    // which == ST_F_LIGHT runs the two cheap kinds together (NONE, LIGHT); ST_F_SCAN runs alone
+    const bool mine = which == ST_F_SCAN ? st == ST_F_SCAN : (st == ST_NONE || st == ST_F_LIGHT);
     DevIndexView ix{};
     ix.ec = (const uint32_t*)ec;
     const ColRef cols = make_col_ref(refs_lane, (glb_u32w)pp->spill, slot, pp->spill_cap, nullptr);
@@ -216,40 +221,14 @@ __device__ __attribute__((noinline)) Lane fin_lane_call(Lane s, uint32_t lane, u
     if (mine && st != ST_NONE && !(pp->ablate & 1u)) {
         isect_pick(s, cols, is);
         if (st == ST_F_LIGHT) isect_light(s, ix, cols, is);
-        else if (st == ST_F_SCAN) isect_scan(s, ix, cols, is);
-        else {   // ST_F_COPY: a single class, the result is the class itself
-            is.base_colour = ec[4ull * is.base_ref];
-            is.count = is.base_len;
-        }
+        else isect_scan(s, ix, cols, is);
     }
     const uint32_t cnt = mine ? is.count : 0u;
-    const uint64_t my_off = arena_alloc(cnt, lane, pp, chunk);
+    const uint32_t cnt_alloc = cnt == is.base_len ? 0u : cnt;   // a result that is an index class is returned by reference
+    const uint64_t my_off = arena_alloc(cnt_alloc, lane, pp, chunk);
     if (!mine) return s;
-    if (cnt && my_off + cnt <= pp->arena_cap) {
-        if (st == ST_F_COPY) {   // 16-byte loads of the record (words 1..cnt are the ids), four in flight per round trip
-            const glb_v4 rec = (glb_v4)(ec + 4ull * is.base_ref);
-            const uint32_t nchunks = (cnt + 4) >> 2;
-            for (uint32_t q0 = 0; q0 < nchunks; q0 += 4) {
-                u32x4 w[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) w[t] = rec[q0 + t < nchunks ? q0 + t : q0];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint32_t q = q0 + t;
-                    if (q < nchunks) {
-                        const uint32_t j = 4 * q;   // record word index of w[t].x; id index = word - 1
-                        if (j >= 1 && j - 1 < cnt) arena_g[my_off + j - 1] = w[t].x;
-                        if (j < cnt) arena_g[my_off + j] = w[t].y;
-                        if (j + 1 < cnt) arena_g[my_off + j + 1] = w[t].z;
-                        if (j + 2 < cnt) arena_g[my_off + j + 2] = w[t].w;
-                    }
-                }
-            }
-        } else {
-            isect_write(s, ix, cols, is, (uint32_t*)arena_g + my_off);
-        }
-    }
-    return emit_record<TRACE>(s, st != ST_NONE, cnt, cnt, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
+    if (cnt_alloc && my_off + cnt_alloc <= pp->arena_cap) isect_write(s, ix, cols, is, (uint32_t*)arena_g + my_off);
+    return emit_record<TRACE>(s, st != ST_NONE, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
 }
 
 // COOP: the whole wave works on one read at a time (base list of more than 8 ids and at least two classes). Lane e owns
@@ -267,10 +246,7 @@ __device__ __attribute__((noinline)) Lane fin_coop_call(Lane s, uint32_t lane, u
     is.base_len = 0;
     is.base_ref = 0;
     is.base_colour = 0;
-    if (mine) {
-        isect_pick(s, cols, is);
-        is.base_colour = ec[4ull * is.base_ref];
-    }
+    if (mine) isect_pick(s, cols, is);
     const uint32_t cnt_alloc = mine ? is.base_len : 0u;   // upper bound: the survivors are a subset of the base list
     const uint64_t my_off = arena_alloc(cnt_alloc, lane, pp, chunk);
     const uint64_t arena_cap = pp->arena_cap;
@@ -300,7 +276,7 @@ __device__ __attribute__((noinline)) Lane fin_coop_call(Lane s, uint32_t lane, u
                     ref = refsL[i];
                     len = refsL[64 * LDS_CLASSES + i];
                 } else {
-                    const glb_u32w sp = spill_base + (uint64_t)(slot - lane + L) * spill_cap + 2 * (i - LDS_CLASSES);
+                    const glb_u32w sp = spill_base + (uint64_t)(slot - lane + L) * spill_cap + 4 * (i - LDS_CLASSES);
                     ref = sp[0];
                     len = sp[1];
                 }
@@ -361,10 +337,11 @@ __device__ __attribute__((noinline)) Lane fast_finish_call(Lane s, uint32_t lane
         if (!mine) l_set_st(s, ST_SEEK);
     }
     const uint32_t cnt = mine ? is.count : 0u;
-    const uint64_t my_off = arena_alloc(cnt, lane, pp, chunk);
+    const uint32_t cnt_alloc = cnt == is.base_len ? 0u : cnt;
+    const uint64_t my_off = arena_alloc(cnt_alloc, lane, pp, chunk);
     if (!mine) return s;
-    if (cnt && my_off + cnt <= pp->arena_cap) isect_write(s, ix, cols, is, (uint32_t*)arena_g + my_off);
-    return emit_record<TRACE>(s, st == ST_ISECT, cnt, cnt, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
+    if (cnt_alloc && my_off + cnt_alloc <= pp->arena_cap) isect_write(s, ix, cols, is, (uint32_t*)arena_g + my_off);
+    return emit_record<TRACE>(s, st == ST_ISECT, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
 }
 
 // NOVEL: the result is a strict subset of every visited class; find out whether it equals some index class (content
@@ -402,7 +379,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
         uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
         for (uint32_t i = threadIdx.x; i < sizeof(MapParams) / 4; i += PA_MAP_BLOCK) dst[i] = src[i];
     }
-    const uint32_t wave_bytes = PA_LDS_WAVE_FIXED + (p.wpr + 1) * 512 + 2 * LDS_CLASSES * 256;
+    const uint32_t wave_bytes = PA_LDS_WAVE_FIXED + (p.wpr + 1) * 512 + 3 * LDS_CLASSES * 256;
     uint8_t* const wbase = smem + PA_LDS_PARAMS_BYTES + wave_in_block * wave_bytes;
     const lds_u64w chunk = (lds_u64w)wbase;
     const lds_u64 rd_lane = (lds_u64)(wbase + PA_LDS_WAVE_FIXED) + lane;
@@ -448,7 +425,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
             if (l_st(s) == ST_SEEK) s = seek_call(s, (glb_u32)p.ix.table, (uint32_t)p.ix.nbuckets, p.ix.kmask, p.ix.k, rd_lane, p.wpr);
             for (uint32_t step = 0; step < p.fast_steps && __any(l_st(s) == ST_FWD && !(l_flags(s) & F_CAREFUL)); ++step)
                 if (l_st(s) == ST_FWD && !(l_flags(s) & F_CAREFUL))
-                    s = fwd_call<false>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
+                    s = fwd_call<false>(s, (glb_u8)p.ix.blobs, nullptr, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
             if (__any(l_st(s) == ST_ISECT || l_st(s) == ST_NONE))
                 s = fast_finish_call<false>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g);
             const uint64_t ms = __ballot(l_st(s) != ST_EMPTY);   // everything not emitted is handed over
@@ -471,7 +448,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
         const uint32_t nE = __popcll(mE);
         const uint32_t nR = (uint32_t)(left < (uint64_t)nE ? left : (uint64_t)nE);
         const uint32_t nS = __popcll(__ballot(st == ST_SEEK)), nF = __popcll(__ballot(st == ST_FWD)), nL = __popcll(__ballot(st == ST_LEFT));
-        const uint32_t nFast = __popcll(__ballot(st == ST_NONE || st == ST_F_LIGHT || st == ST_F_COPY));
+        const uint32_t nFast = __popcll(__ballot(st == ST_NONE || st == ST_F_LIGHT));
         const uint32_t nScan = __popcll(__ballot(st == ST_F_SCAN)), nCoop = __popcll(__ballot(st == ST_F_COOP)), nNovel = __popcll(__ballot(st == ST_F_NOVEL));
         uint32_t best = nR, sel = ST_EMPTY;
         if (nS > best) { best = nS; sel = ST_SEEK; }
@@ -510,9 +487,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
             else if (st == ST_SEEK) s = seek_call(s, (glb_u32)p.ix.table, (uint32_t)p.ix.nbuckets, p.ix.kmask, p.ix.k, rd_lane, p.wpr);
         } else if (sel == ST_FWD) {
             if (st == ST_FWD && (p.ablate & 2u)) l_set_st(s, ST_ISECT);
-            else if (st == ST_FWD) s = fwd_call<TRACE>(s, (glb_u8)p.ix.blobs, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, TRACE ? (glb_u32w)p.trace : nullptr, p.allowed);
+            else if (st == ST_FWD) s = fwd_call<TRACE>(s, (glb_u8)p.ix.blobs, (glb_u32)p.ix.nid_of_handle, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, TRACE ? (glb_u32w)p.trace : nullptr, p.allowed);
         } else if (sel == ST_LEFT) {
-            if (st == ST_LEFT) s = left_call<TRACE>(s, (glb_u8)p.ix.blobs, (glb_u32)p.ix.ledge, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, TRACE ? (glb_u32w)p.trace : nullptr, p.allowed);
+            if (st == ST_LEFT) s = left_call<TRACE>(s, (glb_u8)p.ix.blobs, (glb_u32)p.ix.ledge, (glb_u32)p.ix.nid_of_handle, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, TRACE ? (glb_u32w)p.trace : nullptr, p.allowed);
         } else if (sel == ST_F_COOP) {
             s = fin_coop_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g);
         } else if (sel == ST_F_NOVEL) {
@@ -524,7 +501,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
             Isect tmp;
             const ColRef cols = make_col_ref(refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr);
             const uint32_t tier = (p.ablate & 1u) ? 0u : isect_pick(s, cols, tmp);
-            l_set_st(s, tier == 0 ? ST_F_LIGHT : tier == 1 ? ST_F_SCAN : tier == 2 ? ST_F_COOP : ST_F_COPY);
+            l_set_st(s, tier == 0 ? ST_F_LIGHT : tier == 1 ? ST_F_SCAN : ST_F_COOP);
         }
         if (p.dbg && lane == 0) dbg_clk[sel] += __builtin_readcyclecounter() - t_sec;
     }
@@ -599,7 +576,7 @@ __global__ __launch_bounds__(256) void pa_count_kernel(const pa_read_result* __r
     if (!(r.mismatches & PA_MAPPED_BIT)) slot = num_classes + 2;
     else if (r.class_len == 0) slot = num_classes + 1;
     else {
-        uint32_t c = colour ? colour[i] : 0xFFFFFFFFu;
+        uint32_t c = (r.class_off & PA_CLASS_REF) ? (r.class_off & ~PA_CLASS_REF) : colour ? colour[i] : 0xFFFFFFFFu;
         if (c == 0xFFFFFFFFu) c = class_of_list(arena + r.class_off, r.class_len, ix, class_table, class_table_size);
         slot = c == 0xFFFFFFFFu ? num_classes : c;
     }

@@ -59,16 +59,17 @@ struct ReadRef {   // the lane's packed read: word w at p[w * stride]; words 0..
     uint32_t wmax;
 };
 
-struct ColRef {    // the lane's list of distinct classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] (LDS, each one
-    uint32_t* refs;   // 16-byte vector), the rest as (ref, len) pairs in `spill` (HBM)
+struct ColRef {    // the lane's list of distinct classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] / cids[0..3]
+    uint32_t* refs;   // (LDS, each one 16-byte vector), the rest as (ref, len, class id, -) quads in `spill` (HBM)
     uint32_t* lens;
+    uint32_t* cids;
     uint32_t* spill;
     uint32_t spill_cap;   // u32 words
     uint32_t* trace;      // TRACE builds only: node ids in visit order (map_read_to_nodes, :54-61), capacity spill_cap
 };
 
 struct Hdr {   // the 32-byte header of a node blob
-    uint32_t len, exts, nid, ec_ref, ec_len, e0, e1, e2, e3;
+    uint32_t len, exts, cid, ec_ref, ec_len, e0, e1, e2, e3;
 };
 
 // ---------------------------------------------------------------------------------------------- helpers
@@ -189,24 +190,26 @@ PA_HD uint32_t compare_chunk(uint64_t m, uint32_t n, uint32_t allowed, uint32_t&
 
 // nodes.push(node_id) (:199, :219): record the node's class unless already present
 template <bool TRACE>
-PA_HD void push_node(Lane& s, ColRef c, uint32_t ec_ref, uint32_t ec_len, uint32_t nid) {
+PA_HD void push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, uint32_t handle) {
     if (TRACE) {
         const uint32_t nt = l_ntrace(s);
-        if (nt < c.spill_cap) c.trace[nt] = nid;
+        if (nt < c.spill_cap) c.trace[nt] = ix.nid_of_handle[handle];
         s.nc += 1u << 16;
     }
     const uint32_t n = l_ncol(s);
     const U4 r = *reinterpret_cast<const U4*>(c.refs);
-    const bool dup = (n > 0 && r.x == ec_ref) | (n > 1 && r.y == ec_ref) | (n > 2 && r.z == ec_ref) | (n > 3 && r.w == ec_ref);
+    const bool dup = (n > 0 && r.x == hd.ec_ref) | (n > 1 && r.y == hd.ec_ref) | (n > 2 && r.z == hd.ec_ref) | (n > 3 && r.w == hd.ec_ref);
     if (dup) return;
     if (n < LDS_CLASSES) {
-        c.refs[n] = ec_ref;
-        c.lens[n] = ec_len;
+        c.refs[n] = hd.ec_ref;
+        c.lens[n] = hd.ec_len;
+        c.cids[n] = hd.cid;
     } else {
-        const uint32_t o = 2 * (n - LDS_CLASSES);
-        if (o + 1 >= c.spill_cap) { l_or_flags(s, F_SPILL_OVERFLOW); return; }
-        c.spill[o] = ec_ref;
-        c.spill[o + 1] = ec_len;
+        const uint32_t o = 4 * (n - LDS_CLASSES);
+        if (o + 3 >= c.spill_cap) { l_or_flags(s, F_SPILL_OVERFLOW); return; }
+        c.spill[o] = hd.ec_ref;
+        c.spill[o + 1] = hd.ec_len;
+        c.spill[o + 2] = hd.cid;
     }
     s.nc += 1;
 }
@@ -286,7 +289,7 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
     uint32_t rem = s.rm & 0xFFFFu, snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
     if (fresh) {
         cov += K;                                                     // :216
-        push_node<TRACE>(s, cols, hd.ec_ref, hd.ec_len, hd.nid);      // nodes.push (:219)
+        push_node<TRACE>(s, cols, ix, hd, s.h);                       // nodes.push (:219)
         rem = pa_min(L - kp0, hd.len - ro0);                          // max_matchable_pos (:222-231)
         snp = 0;                                                      // :235
     }
@@ -356,7 +359,7 @@ PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, u
     const uint32_t fl = l_flags(s);
     if (fl & F_FRESH) {
         if (!(fl & F_LEFT_SEED)) {
-            push_node<TRACE>(s, cols, hd.ec_ref, hd.ec_len, hd.nid);   // nodes.push(prev_node.node_id) (:199)
+            push_node<TRACE>(s, cols, ix, hd, s.ph);                // nodes.push(prev_node.node_id) (:199)
             na = hd.len - K + 1;                                    // prev_kmer_offset = len - k (:196)
         }
         rem = pa_min(ra, na);                                       // max_matchable_pos (:139-145)
@@ -394,7 +397,7 @@ PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, u
     if (!(ra == 0 || premature)) {                                  // :173-175
         const uint32_t b = read_base(rd, ra - 1);                   // next_base = read_seq.get(last_pos) (:182)
         if ((hd.exts >> (4 + b)) & 1u) {                            // has_ext(Dir::Left, b) (:183)
-            s.ph = ix.ledge[4ull * hd.nid + b];                     // l_edges()[index].0 (:191-194)
+            s.ph = ix.ledge[4ull * s.ph + b];                       // l_edges()[index].0 (:191-194)
             l_or_flags(s, F_FRESH);
             return;
         }                                                           // else :200-202
@@ -434,10 +437,11 @@ PA_HD void get_class(ColRef c, uint32_t i, uint32_t& ec_ref, uint32_t& ec_len) {
         ec_ref = c.refs[i];
         ec_len = c.lens[i];
     } else {
-        ec_ref = c.spill[2 * (i - LDS_CLASSES)];
-        ec_len = c.spill[2 * (i - LDS_CLASSES) + 1];
+        ec_ref = c.spill[4 * (i - LDS_CLASSES)];
+        ec_len = c.spill[4 * (i - LDS_CLASSES) + 1];
     }
 }
+PA_HD uint32_t get_class_id(ColRef c, uint32_t i) { return i < LDS_CLASSES ? c.cids[i] : c.spill[4 * (i - LDS_CLASSES) + 2]; }
 
 PA_HD bool in_all_lists(const DevIndexView& ix, ColRef cols, uint32_t ncol, uint32_t base_ref, uint32_t v) {
     for (uint32_t i = 0; i < ncol; ++i) {
@@ -455,34 +459,38 @@ PA_HD uint32_t any_eq7(uint32_t v, const uint32_t (&o)[7]) {
 }
 
 // Step 1: the base list (a shortest one) and the tier that will intersect it:
-//   0  one class, or <= 4 classes with every list <= 7 ids: registers only, no dependent loads   (isect_light)
+//   0  one class (the result IS that class: nothing to load), or <= 4 classes with every list <= 7 ids: registers only,
+//      no dependent loads                                                                       (isect_light)
 //   1  base <= 8 ids, other lists long and/or more than 4 classes: base in registers, the other lists are scanned
 //      with 16-byte loads whose addresses are all known up front                                (isect_scan)
-//   2  base > 8 ids: the whole wave works on one read                                            (kernel, cooperative)
-//   3  one class of more than 7 ids: the result is that class, a plain copy                      (kernel / isect_write)
+//   2  base > 8 ids and at least two classes: the whole wave works on one read                   (kernel, cooperative)
 // The host emulator treats tier 2 with per-lane binary searches (isect_count).
 PA_HD uint32_t isect_pick(const Lane& s, ColRef cols, Isect& r) {
     r.alive = 0;
     r.count = 0;
     r.in_regs = false;
-    r.base_colour = 0;
     const uint32_t ncol = l_ncol(s);
-    const U4 refs = *reinterpret_cast<const U4*>(cols.refs), lens = *reinterpret_cast<const U4*>(cols.lens);
+    const U4 refs = *reinterpret_cast<const U4*>(cols.refs), lens = *reinterpret_cast<const U4*>(cols.lens),
+             cids = *reinterpret_cast<const U4*>(cols.cids);
     const uint32_t ln1 = ncol > 1 ? lens.y : lens.x, ln2 = ncol > 2 ? lens.z : lens.x, ln3 = ncol > 3 ? lens.w : lens.x;
     r.base_len = lens.x;
     r.base_ref = refs.x;
-    if (ln1 < r.base_len) { r.base_len = ln1; r.base_ref = refs.y; }
-    if (ln2 < r.base_len) { r.base_len = ln2; r.base_ref = refs.z; }
-    if (ln3 < r.base_len) { r.base_len = ln3; r.base_ref = refs.w; }
+    r.base_colour = cids.x;
+    if (ln1 < r.base_len) { r.base_len = ln1; r.base_ref = refs.y; r.base_colour = cids.y; }
+    if (ln2 < r.base_len) { r.base_len = ln2; r.base_ref = refs.z; r.base_colour = cids.z; }
+    if (ln3 < r.base_len) { r.base_len = ln3; r.base_ref = refs.w; r.base_colour = cids.w; }
     uint32_t maxlen = lens.x > ln1 ? lens.x : ln1;
     maxlen = maxlen > ln2 ? maxlen : ln2;
     maxlen = maxlen > ln3 ? maxlen : ln3;
     for (uint32_t i = LDS_CLASSES; i < ncol; ++i) {                 // spilled classes (rare)
         uint32_t ref, len;
         get_class(cols, i, ref, len);
-        if (len < r.base_len) { r.base_len = len; r.base_ref = ref; }
+        if (len < r.base_len) { r.base_len = len; r.base_ref = ref; r.base_colour = get_class_id(cols, i); }
     }
-    if (ncol == 1) return r.base_len <= 7 ? 0u : 3u;
+    if (ncol == 1) {                                                // eq_class = eq_classes[colour] (:346-350), no intersection
+        r.count = r.base_len;
+        return 0;
+    }
     if (ncol <= LDS_CLASSES && maxlen <= 7) return 0;
     return r.base_len <= 8 ? 1u : 2u;
 }
@@ -499,6 +507,7 @@ PA_HD uint32_t match7(const U4& o0, const U4& o1, const uint32_t (&b)[7]) {
 // are compared all-pairs with every other list in registers; survivors are a 7-bit mask over the base list.
 PA_HD void isect_light(const Lane& s, const DevIndexView& ix, ColRef cols, Isect& r) {
     const uint32_t ncol = l_ncol(s);
+    if (ncol == 1) return;                                          // the class itself, returned by reference
     const U4 refs = *reinterpret_cast<const U4*>(cols.refs);
     const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * r.base_ref);
     const U4* r1 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.y);
@@ -516,7 +525,6 @@ PA_HD void isect_light(const Lane& s, const DevIndexView& ix, ColRef cols, Isect
     const U4* p3 = u3 ? r3 : brec;
     const U4 a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1], c0 = p2[0], c1 = p2[1], d0 = p3[0], d1 = p3[1];
     (void)sentinel;
-    r.base_colour = q0.x;
     r.in_regs = true;
     r.ids[0] = q0.y; r.ids[1] = q0.z; r.ids[2] = q0.w; r.ids[3] = q1.x; r.ids[4] = q1.y; r.ids[5] = q1.z; r.ids[6] = q1.w;
     uint32_t alive = (1u << r.base_len) - 1;
@@ -541,7 +549,6 @@ PA_HD void isect_scan(const Lane& s, const DevIndexView& ix, ColRef cols, Isect&
     const uint32_t ncol = l_ncol(s);
     const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * r.base_ref);
     const U4 q0 = brec[0], q1 = brec[1], q2 = brec[2];
-    r.base_colour = q0.x;
     const uint32_t b[8] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, r.base_len > 7 ? q2.x : 0xFFFFFFFFu};
     uint32_t alive = (1u << r.base_len) - 1;
 #pragma unroll 1
@@ -590,17 +597,10 @@ PA_HD Isect isect_count(const Lane& s, const DevIndexView& ix, ColRef cols) {
         return r;
     }
     const uint32_t ncol = l_ncol(s);
-    if (tier == 3) {                                                // a single class: the result is the class itself
-        r.base_colour = ix.ec[4ull * r.base_ref];
-        r.count = r.base_len;
-        r.alive = r.base_len >= 64 ? ~0ull : ((1ull << r.base_len) - 1);
-        return r;
-    }
     if (tier == 1) {
         isect_scan(s, ix, cols, r);
         return r;
     }
-    r.base_colour = ix.ec[4ull * r.base_ref];
     const uint32_t* bids = class_ids(ix, r.base_ref);
     if (r.base_len <= 64) {
         uint64_t alive = r.base_len == 64 ? ~0ull : ((1ull << r.base_len) - 1);

@@ -48,7 +48,7 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
     const DevIndexView ix = e->fd.host_view();
     std::vector<uint32_t> all;
     std::vector<uint64_t> rd(wpr + 2);
-    alignas(16) uint32_t refs[4], lens4[4];
+    alignas(16) uint32_t refs[4], lens4[4], cids4[4];
     std::vector<uint32_t> spill, trace;
     (void)col_cap;
     uint64_t st_seek = 0, st_fwd = 0, st_left = 0, st_spill = 0;
@@ -57,12 +57,12 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
         for (uint32_t w = 0; w < wpr; ++w) rd[w] = tiles[(t * wpr + w) * 64 + r];
         rd[wpr] = rd[wpr + 1] = 0;
         const uint32_t L = lens[i];
-        spill.assign(4 * (size_t)L + 4, 0);
-        trace.assign(4 * (size_t)L + 4, 0);
+        spill.assign(8 * (size_t)L + 8, 0);
+        trace.assign(8 * (size_t)L + 8, 0);
         Lane s;
         lane_start(s, (uint32_t)i, L, ix.k);
         const ReadRef rr{rd.data(), 1, wpr};
-        const ColRef cr{refs, lens4, spill.data(), (uint32_t)spill.size(), trace.data()};
+        const ColRef cr{refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), trace.data()};
         while (l_st(s) == ST_SEEK || l_st(s) == ST_FWD || l_st(s) == ST_LEFT) {
             if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
             else if (l_st(s) == ST_FWD) { fwd_step<true>(s, ix, rr, cr, allowed); ++st_fwd; }
@@ -81,12 +81,19 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
             const Isect is = isect_count(s, ix, cr);
             const size_t o = all.size();
             all.resize(o + is.count);
-            isect_write(s, ix, cr, is, all.data() + o);
             res.coverage = l_cov(s);
             res.mismatches = l_mism(s) | PA_MAPPED_BIT;
-            res.class_off = (uint32_t)o;
             res.class_len = is.count;
-            if (is.count == is.base_len) colour = is.base_colour;
+            if (is.count == is.base_len) {   // the class is index class base_colour: returned by reference; the CSR the
+                colour = is.base_colour;     // tests compare is resolved from the class table like a host would
+                res.class_off = PA_CLASS_REF | colour;
+                const uint32_t* cls = pa::class_ids(ix, ix.class_ref[colour]);
+                for (uint32_t j = 0; j < is.count; ++j) all[o + j] = cls[j];
+                if (ix.class_len[colour] != is.count || ix.class_ref[colour] != is.base_ref) return PA_ERR_INTERNAL;
+            } else {
+                isect_write(s, ix, cr, is, all.data() + o);
+                res.class_off = (uint32_t)o;
+            }
         }
         results[i] = res;
         if (colour_out) colour_out[i] = colour;

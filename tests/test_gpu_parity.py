@@ -77,7 +77,7 @@ def test_simulated_reads_device_batches(aligners, k, read_len, ppm, allowed, n):
     a.map_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, allowed, d_col.data_ptr())
     used, _ = a.map_finish()
     res = d_res.cpu().numpy().view(pa.RESULT_DTYPE)
-    coff, cids = pa.gather_classes(res, d_arena[: max(used, 1)].cpu().numpy().view(np.uint32))
+    coff, cids = pa.gather_classes(res, d_arena[: max(used, 1)].cpu().numpy().view(np.uint32), a.host)
     o_res, o_coff, o_ids, ctr = helpers.Oracle(a.host).map_tiles(h_tiles, h_lens, wpr, allowed, 8)
     helpers.assert_same_as_oracle(res, coff, cids, o_res, o_coff, o_ids, "simulated k=%d" % k)
     # the count kernel against its numpy definition
@@ -240,7 +240,7 @@ def test_full_size_batch_properties(aligners):
     # checksum of the class ids, independent of arena placement
     host_res = d_res.cpu().numpy().view(pa.RESULT_DTYPE)
     sample = host_res[:200000]
-    coff, cids = pa.gather_classes(sample, d_arena[: max(used, 1)].cpu().numpy().view(np.uint32))
+    coff, cids = pa.gather_classes(sample, d_arena[: max(used, 1)].cpu().numpy().view(np.uint32), a.host)
     h_tiles, h_lens = tx.simulate_host(100, 1, 200000, 0, 0, wpr)
     o_res, o_coff, o_ids, _ = helpers.Oracle(a.host).map_tiles(h_tiles, h_lens, wpr, 2, 8)
     helpers.assert_same_as_oracle(sample, coff, cids, o_res, o_coff, o_ids, "10M batch sample")
