@@ -246,9 +246,9 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.class_table_size = idx->class_table_size;
     p.slow = idx->slow.as<uint32_t>();
     p.fast_steps = (uint32_t)env_int("PA_MAP_FAST_STEPS", 0);
-    p.thr_scan = (uint32_t)env_int("PA_MAP_THR_SCAN", 4);
-    p.thr_coop = (uint32_t)env_int("PA_MAP_THR_COOP", 1);
-    p.thr_novel = (uint32_t)env_int("PA_MAP_THR_NOVEL", 4);
+    p.thr_scan = (uint32_t)env_int("PA_MAP_THR_SCAN", 8);
+    p.thr_coop = (uint32_t)env_int("PA_MAP_THR_COOP", 2);
+    p.thr_novel = (uint32_t)env_int("PA_MAP_THR_NOVEL", 8);
     p.thr_idle = (uint32_t)env_int("PA_MAP_THR_IDLE", 16);
     p.ablate = (uint32_t)env_int("PA_MAP_ABLATE", 0);
     p.dbg = env_int("PA_MAP_STATS", 0) ? idx->ctl.as<unsigned long long>() + 2 : nullptr;

@@ -185,7 +185,7 @@ __device__ __forceinline__ Lane emit_record(Lane s, bool mapped, uint32_t cnt, u
     }
     const glb_u32w colour_out = (glb_u32w)pp->colour_out;
     const bool want_class = counts_g != nullptr || colour_out != nullptr;
-    if (novel && want_class && my_off + cnt_alloc <= pp->arena_cap) {   // defer the content lookup to the F_NOVEL state
+    if (novel && want_class && !(pp->ablate & 128u) && my_off + cnt_alloc <= pp->arena_cap) {   // defer the content lookup to the F_NOVEL state
         s.h = (uint32_t)my_off;
         s.rr = cnt;
         l_set_st(s, ST_F_NOVEL);
@@ -201,34 +201,59 @@ __device__ __forceinline__ Lane emit_record(Lane s, bool mapped, uint32_t cnt, u
     return s;
 }
 
-// LIGHT / SCAN / COPY / NONE: one lane = one read
-template <bool TRACE>
-__device__ __attribute__((noinline)) Lane fin_lane_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk,
-                                                        glb_u32 ec, glb_u32w arena_g, glb_u32w results_g, glb_u32w counts_g, uint32_t which) {
-    const uint32_t st = l_st(s);
-    // which == ST_F_LIGHT runs the two cheap kinds together (NONE, LIGHT); ST_F_SCAN runs alone
-    const bool mine = which == ST_F_SCAN ? st == ST_F_SCAN : (st == ST_NONE || st == ST_F_LIGHT);
+// LIGHT / SCAN intersections and the emit step are three separate calls so that each stays within the caller-saved
+// VGPRs (<= 56 at 6 waves per SIMD): a callee that needs more must save/restore callee-saved registers through scratch
+// on EVERY call, which measured as 5 GB of extra HBM writes per 10 M reads.
+__device__ __attribute__((noinline)) Isect light_call(uint32_t nc, lds_u32 refs_lane, glb_u32 ec) {
     DevIndexView ix{};
     ix.ec = (const uint32_t*)ec;
-    const ColRef cols = make_col_ref(refs_lane, (glb_u32w)pp->spill, slot, pp->spill_cap, nullptr);
+    Lane s{};
+    s.nc = nc;
+    const ColRef cols = make_col_ref(refs_lane, nullptr, 0, 0, nullptr);   // LIGHT never touches spilled classes
     Isect is;
-    is.count = 0;
-    is.base_len = 0xFFFFFFFFu;
-    is.base_ref = 0;
-    is.base_colour = 0;
-    is.alive = 0;
-    is.in_regs = false;
-    if (mine && st != ST_NONE && !(pp->ablate & 1u)) {
-        isect_pick(s, cols, is);
-        if (st == ST_F_LIGHT) isect_light(s, ix, cols, is);
-        else isect_scan(s, ix, cols, is);
-    }
-    const uint32_t cnt = mine ? is.count : 0u;
-    const uint32_t cnt_alloc = cnt == is.base_len ? 0u : cnt;   // a result that is an index class is returned by reference
+    isect_pick(s, cols, is);
+    isect_light(s, ix, cols, is);
+    return is;
+}
+
+__device__ __attribute__((noinline)) Isect scan_call(uint32_t nc, lds_u32 refs_lane, glb_u32w spill_base, uint32_t slot, uint32_t spill_cap,
+                                                     glb_u32 ec) {
+    DevIndexView ix{};
+    ix.ec = (const uint32_t*)ec;
+    Lane s{};
+    s.nc = nc;
+    const ColRef cols = make_col_ref(refs_lane, spill_base, slot, spill_cap, nullptr);
+    Isect is;
+    isect_pick(s, cols, is);
+    isect_scan(s, ix, cols, is);
+    return is;
+}
+
+// arena allocation + class ids + record + count for the lanes in `mine` (whole wave enters: the scan needs every lane)
+template <bool TRACE>
+__device__ __attribute__((noinline)) Lane emit_call(Lane s, bool mine, bool mapped, uint32_t count, uint32_t base_len, uint32_t base_colour,
+                                                    uint32_t base_ref, uint32_t alive, bool in_regs, uint32_t id0, uint32_t id1, uint32_t id2,
+                                                    uint32_t id3, uint32_t id4, uint32_t id5, uint32_t id6, uint32_t lane, uint32_t slot,
+                                                    lds_params pp, lds_u64w chunk) {
+    const uint32_t cnt = mine ? count : 0u;
+    const uint32_t cnt_alloc = cnt == base_len ? 0u : cnt;   // a result that is an index class is returned by reference
     const uint64_t my_off = arena_alloc(cnt_alloc, lane, pp, chunk);
     if (!mine) return s;
-    if (cnt_alloc && my_off + cnt_alloc <= pp->arena_cap) isect_write(s, ix, cols, is, (uint32_t*)arena_g + my_off);
-    return emit_record<TRACE>(s, st != ST_NONE, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
+    const glb_u32w arena_g = (glb_u32w)pp->arena;
+    if (cnt_alloc && my_off + cnt_alloc <= pp->arena_cap) {
+        const glb_u32w dst = arena_g + my_off;
+        if (in_regs) {   // survivors straight from registers
+            const uint32_t ids[7] = {id0, id1, id2, id3, id4, id5, id6};
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if ((alive >> j) & 1u) dst[__popc(alive & ((1u << j) - 1))] = ids[j];
+        } else {         // SCAN tier: base of <= 8 ids, re-read from its record
+            const glb_u32 bids = (glb_u32)pp->ix.ec + 4ull * base_ref + 1;
+            uint32_t k = 0;
+            for (uint32_t t = alive; t; t &= t - 1) dst[k++] = bids[__ffs((int)t) - 1];
+        }
+    }
+    return emit_record<TRACE>(s, mapped, cnt, cnt_alloc, my_off, base_len, base_colour, slot, pp, (glb_u32w)pp->results, (glb_u32w)pp->counts);
 }
 
 // COOP: the whole wave works on one read at a time (base list of more than 8 ids and at least two classes). Lane e owns
@@ -285,7 +310,7 @@ __device__ __attribute__((noinline)) Lane fin_coop_call(Lane s, uint32_t lane, u
                 if (len <= 64) {             // short list: scan it, no dependent loads
                     const glb_v4 rec = (glb_v4)(ec + 4ull * ref);
                     const uint32_t nchunks = (len + 4) >> 2;
-#pragma unroll 4
+#pragma unroll 2
                     for (uint32_t q = 0; q < nchunks; ++q) {
                         const u32x4 w = rec[q];
                         hit |= (q != 0 && w.x == v) | (w.y == v) | (w.z == v) | (w.w == v);
@@ -309,39 +334,6 @@ __device__ __attribute__((noinline)) Lane fin_coop_call(Lane s, uint32_t lane, u
     }
     if (!mine) return s;
     return emit_record<TRACE>(s, true, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
-}
-
-// Fast-phase finish: the lanes whose walk ended (ISECT / NONE) and whose classes need registers only are emitted at
-// once; every other finished lane comes back in state ST_SEEK, which the fast phase reads as "hand over".
-template <bool TRACE>
-__device__ __attribute__((noinline)) Lane fast_finish_call(Lane s, uint32_t lane, uint32_t slot, lds_u32 refs_lane, lds_params pp, lds_u64w chunk,
-                                                           glb_u32 ec, glb_u32w arena_g, glb_u32w results_g, glb_u32w counts_g) {
-    const uint32_t st = l_st(s);
-    DevIndexView ix{};
-    ix.ec = (const uint32_t*)ec;
-    const ColRef cols = make_col_ref(refs_lane, (glb_u32w)pp->spill, slot, pp->spill_cap, nullptr);
-    Isect is;
-    is.count = 0;
-    is.base_len = 0xFFFFFFFFu;
-    is.base_ref = 0;
-    is.base_colour = 0;
-    is.alive = 0;
-    is.in_regs = false;
-    bool mine = st == ST_NONE;
-    if (st == ST_ISECT) {
-        if (isect_pick(s, cols, is) == 0) {
-            isect_light(s, ix, cols, is);
-            const bool want_class = counts_g != nullptr || pp->colour_out != nullptr;
-            mine = !(want_class && is.count != 0 && is.count != is.base_len);   // a strict subset needs the class hash table
-        }
-        if (!mine) l_set_st(s, ST_SEEK);
-    }
-    const uint32_t cnt = mine ? is.count : 0u;
-    const uint32_t cnt_alloc = cnt == is.base_len ? 0u : cnt;
-    const uint64_t my_off = arena_alloc(cnt_alloc, lane, pp, chunk);
-    if (!mine) return s;
-    if (cnt_alloc && my_off + cnt_alloc <= pp->arena_cap) isect_write(s, ix, cols, is, (uint32_t*)arena_g + my_off);
-    return emit_record<TRACE>(s, st == ST_ISECT, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, slot, pp, results_g, counts_g);
 }
 
 // NOVEL: the result is a strict subset of every visited class; find out whether it equals some index class (content
@@ -403,41 +395,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
     Lane s;
     s.rid = s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0;   // state ST_EMPTY
 
-    // ---- phase 1: lock-step fast path ---------------------------------------------------------------------------------
-    // One tile at a time, every lane in the same state: one dictionary probe at position 0, up to fast_steps forward
-    // steps, register-only intersection. No scheduler, no refill, one memory round trip per stage for all 64 reads. A read
-    // that leaves this envelope (probe miss, re-seek, careful mode, more nodes, a long or many-class intersection, a
-    // strict-subset result) is not emitted; its id goes to this wave's slice of p.slow and phase 2 maps it from scratch.
-    const glb_u32w slow_seg = (glb_u32w)p.slow + next;
-    uint32_t nslow = 0;
-    if (p.fast_steps && !TRACE) {
-        for (uint64_t base = next; base < end; base += 64) {
-            const uint64_t rid = base + lane;
-            s.lk = 0;
-            if (rid < end) {
-                uint32_t L = p.lens[rid];
-                if (L > p.wpr * 32) L = p.wpr * 32;
-                const uint64_t* src = p.tiles + ((rid >> 6) * p.wpr) * 64 + (rid & 63);
-                for (uint32_t w = 0; w < p.wpr; ++w) rd_lane[w * 64] = src[(uint64_t)w * 64];
-                rd_lane[p.wpr * 64] = 0;
-                lane_start(s, (uint32_t)rid, L, p.ix.k);
-            }
-            if (l_st(s) == ST_SEEK) s = seek_call(s, (glb_u32)p.ix.table, (uint32_t)p.ix.nbuckets, p.ix.kmask, p.ix.k, rd_lane, p.wpr);
-            for (uint32_t step = 0; step < p.fast_steps && __any(l_st(s) == ST_FWD && !(l_flags(s) & F_CAREFUL)); ++step)
-                if (l_st(s) == ST_FWD && !(l_flags(s) & F_CAREFUL))
-                    s = fwd_call<false>(s, (glb_u8)p.ix.blobs, nullptr, p.ix.k, rd_lane, p.wpr, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr, p.allowed);
-            if (__any(l_st(s) == ST_ISECT || l_st(s) == ST_NONE))
-                s = fast_finish_call<false>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g);
-            const uint64_t ms = __ballot(l_st(s) != ST_EMPTY);   // everything not emitted is handed over
-            if (l_st(s) != ST_EMPTY) slow_seg[nslow + (uint32_t)__popcll(ms & ((1ull << lane) - 1))] = s.rid;
-            nslow += (uint32_t)__popcll(ms);
-        }
-        s.rid = s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0;
-        end = next + nslow;   // phase 2 walks this wave's slice of the slow list
-    }
-    const bool from_list = p.fast_steps && !TRACE;
+    const bool from_list = false;
 
-    // ---- phase 2: general state machine (population-scheduled) -------------------------------------------------------
+    // ---- population-scheduled state machine ----------------------------------------------------------------------------
     for (;;) {
         const uint32_t st = l_st(s);
         // population of every state. The cheap finishing states (NONE, LIGHT, COPY) are one section; the common states
@@ -494,14 +454,27 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
             s = fin_coop_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g);
         } else if (sel == ST_F_NOVEL) {
             s = fin_novel_call(s, pp, ec, arena_g, counts_g);
-        } else {   // ST_F_LIGHT (= NONE + LIGHT + COPY) or ST_F_SCAN (whole wave enters: the allocation scan needs every lane)
-            s = fin_lane_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g, sel);
+        } else {   // ST_F_LIGHT (= NONE + LIGHT) or ST_F_SCAN
+            const bool mine = sel == ST_F_SCAN ? st == ST_F_SCAN : (st == ST_NONE || st == ST_F_LIGHT);
+            Isect is;
+            is.count = 0;
+            is.base_len = 0xFFFFFFFFu;
+            is.base_ref = is.base_colour = 0;
+            is.alive = 0;
+            is.in_regs = false;
+            for (int j = 0; j < 7; ++j) is.ids[j] = 0;
+            if (!(p.ablate & 1u)) {
+                if (st == ST_F_LIGHT && sel == ST_F_LIGHT) is = light_call(s.nc, refs_lane, ec);
+                else if (st == ST_F_SCAN && sel == ST_F_SCAN) is = scan_call(s.nc, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, ec);
+            }
+            s = emit_call<TRACE>(s, mine, st != ST_NONE, is.count, is.base_len, is.base_colour, is.base_ref, (uint32_t)is.alive, is.in_regs,
+                                 is.ids[0], is.ids[1], is.ids[2], is.ids[3], is.ids[4], is.ids[5], is.ids[6], lane, slot, pp, chunk);
         }
         if (l_st(s) == ST_ISECT) {   // the walk just ended: choose how this read's classes will be intersected (LDS only)
             Isect tmp;
             const ColRef cols = make_col_ref(refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr);
             const uint32_t tier = (p.ablate & 1u) ? 0u : isect_pick(s, cols, tmp);
-            l_set_st(s, tier == 0 ? ST_F_LIGHT : tier == 1 ? ST_F_SCAN : ST_F_COOP);
+            l_set_st(s, (tier == 0 || (p.ablate & 64u)) ? ST_F_LIGHT : tier == 1 ? ST_F_SCAN : ST_F_COOP);   // ablate 64: everything LIGHT (wrong)
         }
         if (p.dbg && lane == 0) dbg_clk[sel] += __builtin_readcyclecounter() - t_sec;
     }
@@ -596,22 +569,19 @@ static int launch_map_variant(const MapParams& p, uint32_t grid, size_t lds_byte
     return (int)hipGetLastError();
 }
 
+// Only ONE launch-bounds variant of the production kernel is instantiated: the state functions are shared by every kernel
+// that calls them and are register-allocated for the most restrictive caller (an 8-waves variant forces them into 64
+// VGPRs and ~150 bytes/lane of scratch, which showed up as 5 GB of HBM writes per 10 M reads).
 int launch_map(const MapParams& p, uint32_t grid, size_t lds_bytes, int waves, hipStream_t stream) {
+    (void)waves;
     if (p.trace) return launch_map_variant<true, 4>(p, grid, lds_bytes, stream);
-    switch (waves) {
-        case 8: return launch_map_variant<false, 8>(p, grid, lds_bytes, stream);
-        case 6: return launch_map_variant<false, 6>(p, grid, lds_bytes, stream);
-        case 5: return launch_map_variant<false, 5>(p, grid, lds_bytes, stream);
-        default: return launch_map_variant<false, 4>(p, grid, lds_bytes, stream);
-    }
+    return launch_map_variant<false, PA_DEFAULT_MAP_WAVES>(p, grid, lds_bytes, stream);
 }
 
 int map_kernel_occupancy(size_t lds_bytes, int waves, int* blocks_per_cu) {
-    const void* fn = waves == 8 ? reinterpret_cast<const void*>(&pa_map_kernel<false, 8>)
-                   : waves == 6 ? reinterpret_cast<const void*>(&pa_map_kernel<false, 6>)
-                   : waves == 5 ? reinterpret_cast<const void*>(&pa_map_kernel<false, 5>)
-                                : reinterpret_cast<const void*>(&pa_map_kernel<false, 4>);
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, fn, PA_MAP_BLOCK, lds_bytes);
+    (void)waves;
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(&pa_map_kernel<false, PA_DEFAULT_MAP_WAVES>),
+                                                             PA_MAP_BLOCK, lds_bytes);
 }
 
 int launch_encode(const uint8_t* ascii, const uint64_t* offsets, uint64_t n, uint32_t wpr, uint64_t* tiles, uint32_t* lens,

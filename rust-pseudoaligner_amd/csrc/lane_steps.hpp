@@ -415,6 +415,7 @@ PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, u
 //                  counted, then recomputed in the write pass
 struct Isect {
     uint32_t base_ref, base_len, base_colour, count;
+    uint32_t base_slot;   // which of the lane's LDS class slots holds the base list (tier 0)
     uint64_t alive;       // survivors as a mask over the base list (base_len <= 64)
     uint32_t ids[7];      // register tier only: the base list itself (ids beyond base_len are the 0xFFFFFFFF padding)
     bool in_regs;
@@ -459,7 +460,7 @@ PA_HD uint32_t any_eq7(uint32_t v, const uint32_t (&o)[7]) {
 }
 
 // Step 1: the base list (a shortest one) and the tier that will intersect it:
-//   0  one class (the result IS that class: nothing to load), or <= 4 classes with every list <= 7 ids: registers only,
+//   0  one class (the result IS that class: nothing to load), or <= 3 classes with every list <= 7 ids: registers only,
 //      no dependent loads                                                                       (isect_light)
 //   1  base <= 8 ids, other lists long and/or more than 4 classes: base in registers, the other lists are scanned
 //      with 16-byte loads whose addresses are all known up front                                (isect_scan)
@@ -476,9 +477,10 @@ PA_HD uint32_t isect_pick(const Lane& s, ColRef cols, Isect& r) {
     r.base_len = lens.x;
     r.base_ref = refs.x;
     r.base_colour = cids.x;
-    if (ln1 < r.base_len) { r.base_len = ln1; r.base_ref = refs.y; r.base_colour = cids.y; }
-    if (ln2 < r.base_len) { r.base_len = ln2; r.base_ref = refs.z; r.base_colour = cids.z; }
-    if (ln3 < r.base_len) { r.base_len = ln3; r.base_ref = refs.w; r.base_colour = cids.w; }
+    r.base_slot = 0;
+    if (ln1 < r.base_len) { r.base_len = ln1; r.base_ref = refs.y; r.base_colour = cids.y; r.base_slot = 1; }
+    if (ln2 < r.base_len) { r.base_len = ln2; r.base_ref = refs.z; r.base_colour = cids.z; r.base_slot = 2; }
+    if (ln3 < r.base_len) { r.base_len = ln3; r.base_ref = refs.w; r.base_colour = cids.w; r.base_slot = 3; }
     uint32_t maxlen = lens.x > ln1 ? lens.x : ln1;
     maxlen = maxlen > ln2 ? maxlen : ln2;
     maxlen = maxlen > ln3 ? maxlen : ln3;
@@ -491,7 +493,7 @@ PA_HD uint32_t isect_pick(const Lane& s, ColRef cols, Isect& r) {
         r.count = r.base_len;
         return 0;
     }
-    if (ncol <= LDS_CLASSES && maxlen <= 7) return 0;
+    if (ncol <= 3 && maxlen <= 7) return 0;
     return r.base_len <= 8 ? 1u : 2u;
 }
 
@@ -503,35 +505,24 @@ PA_HD uint32_t match7(const U4& o0, const U4& o1, const uint32_t (&b)[7]) {
     return m;
 }
 
-// Tier 0: the records of all (<= 4) classes are fetched together (two 16-byte loads each, one round trip), the base ids
-// are compared all-pairs with every other list in registers; survivors are a 7-bit mask over the base list.
+// Tier 0: the records of the (<= 3) classes are fetched together (two 16-byte loads each, one round trip); the base ids
+// are compared all-pairs with the other lists in registers; survivors are a 7-bit mask over the base list.
 PA_HD void isect_light(const Lane& s, const DevIndexView& ix, ColRef cols, Isect& r) {
     const uint32_t ncol = l_ncol(s);
     if (ncol == 1) return;                                          // the class itself, returned by reference
     const U4 refs = *reinterpret_cast<const U4*>(cols.refs);
-    const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * r.base_ref);
-    const U4* r1 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.y);
-    const U4* r2 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.z);
-    const U4* r3 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.w);
-    const U4* r0 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.x);
-    const U4 q0 = brec[0], q1 = brec[1];
-    const U4 sentinel{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    const bool u0 = ncol > 1 && refs.x != r.base_ref, u1 = ncol > 1 && refs.y != r.base_ref, u2 = ncol > 2 && refs.z != r.base_ref,
-               u3 = ncol > 3 && refs.w != r.base_ref;
-    // unconditional loads (an unused slot re-reads the base record) so that all eight are in flight together
-    const U4* p0 = u0 ? r0 : brec;
-    const U4* p1 = u1 ? r1 : brec;
-    const U4* p2 = u2 ? r2 : brec;
-    const U4* p3 = u3 ? r3 : brec;
-    const U4 a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1], c0 = p2[0], c1 = p2[1], d0 = p3[0], d1 = p3[1];
-    (void)sentinel;
+    const U4* p0 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.x);
+    const U4* p1 = reinterpret_cast<const U4*>(ix.ec + 4ull * refs.y);
+    const U4* p2 = reinterpret_cast<const U4*>(ix.ec + 4ull * (ncol > 2 ? refs.z : refs.x));   // unused slot: re-read slot 0
+    const U4 a0 = p0[0], a1 = p0[1], b0 = p1[0], b1 = p1[1], c0 = p2[0], c1 = p2[1];           // six loads in flight together
+    const uint32_t bs = r.base_slot;
+    const U4 q0 = bs == 0 ? a0 : bs == 1 ? b0 : c0, q1 = bs == 0 ? a1 : bs == 1 ? b1 : c1;
     r.in_regs = true;
     r.ids[0] = q0.y; r.ids[1] = q0.z; r.ids[2] = q0.w; r.ids[3] = q1.x; r.ids[4] = q1.y; r.ids[5] = q1.z; r.ids[6] = q1.w;
     uint32_t alive = (1u << r.base_len) - 1;
-    if (u0) alive &= match7(a0, a1, r.ids);   // (an unused slot holds the base itself: matching it would be the identity)
-    if (u1) alive &= match7(b0, b1, r.ids);
-    if (u2) alive &= match7(c0, c1, r.ids);
-    if (u3) alive &= match7(d0, d1, r.ids);
+    if (bs != 0) alive &= match7(a0, a1, r.ids);
+    if (bs != 1) alive &= match7(b0, b1, r.ids);
+    if (bs != 2 && ncol > 2) alive &= match7(c0, c1, r.ids);
     r.alive = alive;
     r.count = pa_popc32(alive);
 }
@@ -545,44 +536,78 @@ PA_HD uint32_t eq_mask8(uint32_t v, const uint32_t (&b)[8]) {
 
 // Tier 1: base list of <= 8 ids in registers; every other list is streamed through 16-byte loads (record words
 // {class id, id0, id1, id2}, {id3..id6}, ..., 0xFFFFFFFF padded) and each word is compared with the eight base ids.
+// The first 11 ids of the classes held in LDS are fetched two classes at a time (six loads in flight); longer lists and
+// classes spilled to HBM take the sequential tail loop.
+PA_HD uint32_t scan_words(const U4& w, bool first, const uint32_t (&b)[8]) {
+    return (first ? 0u : eq_mask8(w.x, b)) | eq_mask8(w.y, b) | eq_mask8(w.z, b) | eq_mask8(w.w, b);   // word 0 of a record is its class id
+}
+
+PA_HD uint32_t scan_tail(const DevIndexView& ix, uint32_t ref, uint32_t len, uint32_t from_chunk, uint32_t alive, const uint32_t (&b)[8]) {
+    uint32_t m = 0;
+    if (len <= 64) {
+        const U4* rec = reinterpret_cast<const U4*>(ix.ec + 4ull * ref);
+        const uint32_t nchunks = (len + 4) >> 2;
+#pragma unroll 1
+        for (uint32_t q0 = from_chunk; q0 < nchunks; q0 += 2) {      // two 16-byte loads in flight per round trip
+            const U4 w0 = rec[q0], w1 = rec[q0 + 1 < nchunks ? q0 + 1 : q0];
+            m |= scan_words(w0, q0 == 0, b);
+            if (q0 + 1 < nchunks) m |= scan_words(w1, false, b);
+        }
+    } else {                                                         // long list: binary_search (:404) per surviving base id
+        const uint32_t* ids = class_ids(ix, ref);
+#pragma unroll 1
+        for (uint32_t t = alive; t; t &= t - 1) {
+            const uint32_t j = pa_ctz32(t);
+            const uint32_t v = j == 0 ? b[0] : j == 1 ? b[1] : j == 2 ? b[2] : j == 3 ? b[3] : j == 4 ? b[4] : j == 5 ? b[5] : j == 6 ? b[6] : b[7];
+            if (list_contains(ids, len, v)) m |= 1u << j;
+        }
+    }
+    return m;
+}
+
+// membership mask of the base ids in the (<= 64 ids) lists of two LDS slots, first three chunks of each fetched together
+PA_HD void scan_pair(const DevIndexView& ix, uint32_t refA, uint32_t lenA, bool useA, uint32_t refB, uint32_t lenB, bool useB,
+                     uint32_t base_ref, const uint32_t (&b)[8], uint32_t& alive) {
+    const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * base_ref);
+    const U4* ra = useA ? reinterpret_cast<const U4*>(ix.ec + 4ull * refA) : brec;   // an unused slot re-reads the base record
+    const U4* rb = useB ? reinterpret_cast<const U4*>(ix.ec + 4ull * refB) : brec;
+    const uint32_t na = useA && lenA <= 64 ? (lenA + 4) >> 2 : 0, nb = useB && lenB <= 64 ? (lenB + 4) >> 2 : 0;
+    U4 wa[3], wb[3];
+#pragma unroll
+    for (uint32_t q = 0; q < 3; ++q) {
+        wa[q] = ra[q < na ? q : 0];
+        wb[q] = rb[q < nb ? q : 0];
+    }
+    uint32_t ma = 0, mb = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 3; ++q) {
+        if (q < na) ma |= scan_words(wa[q], q == 0, b);
+        if (q < nb) mb |= scan_words(wb[q], q == 0, b);
+    }
+    if (useA) {
+        if (na == 0 || na > 3) ma |= scan_tail(ix, refA, lenA, na == 0 ? 0 : 3, alive, b);
+        alive &= ma;
+    }
+    if (useB) {
+        if (nb == 0 || nb > 3) mb |= scan_tail(ix, refB, lenB, nb == 0 ? 0 : 3, alive, b);
+        alive &= mb;
+    }
+}
+
 PA_HD void isect_scan(const Lane& s, const DevIndexView& ix, ColRef cols, Isect& r) {
     const uint32_t ncol = l_ncol(s);
+    const U4 refs = *reinterpret_cast<const U4*>(cols.refs), lens = *reinterpret_cast<const U4*>(cols.lens);
     const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * r.base_ref);
     const U4 q0 = brec[0], q1 = brec[1], q2 = brec[2];
     const uint32_t b[8] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, r.base_len > 7 ? q2.x : 0xFFFFFFFFu};
     uint32_t alive = (1u << r.base_len) - 1;
+    scan_pair(ix, refs.x, lens.x, refs.x != r.base_ref, refs.y, lens.y, ncol > 1 && refs.y != r.base_ref, r.base_ref, b, alive);
+    if (ncol > 2) scan_pair(ix, refs.z, lens.z, refs.z != r.base_ref, refs.w, lens.w, ncol > 3 && refs.w != r.base_ref, r.base_ref, b, alive);
 #pragma unroll 1
-    for (uint32_t i = 0; i < ncol && alive; ++i) {
+    for (uint32_t i = LDS_CLASSES; i < ncol && alive; ++i) {         // classes spilled to HBM (rare)
         uint32_t ref, len;
         get_class(cols, i, ref, len);
-        if (ref == r.base_ref) continue;
-        uint32_t m = 0;
-        if (len <= 64) {
-            const U4* rec = reinterpret_cast<const U4*>(ix.ec + 4ull * ref);
-            const uint32_t nchunks = (len + 4) >> 2;
-#pragma unroll 1
-            for (uint32_t q0 = 0; q0 < nchunks; q0 += 4) {          // four 16-byte loads in flight per round trip
-                U4 w[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) w[t] = rec[q0 + t < nchunks ? q0 + t : q0];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (q0 + t < nchunks) {
-                        if (q0 + t != 0) m |= eq_mask8(w[t].x, b);  // word 0 of the record is the class id, not a member
-                        m |= eq_mask8(w[t].y, b) | eq_mask8(w[t].z, b) | eq_mask8(w[t].w, b);
-                    }
-                }
-            }
-        } else {
-            const uint32_t* ids = class_ids(ix, ref);
-#pragma unroll 1
-            for (uint32_t t = alive; t; t &= t - 1) {
-                const uint32_t j = pa_ctz32(t);
-                const uint32_t v = j == 0 ? b[0] : j == 1 ? b[1] : j == 2 ? b[2] : j == 3 ? b[3] : j == 4 ? b[4] : j == 5 ? b[5] : j == 6 ? b[6] : b[7];
-                if (list_contains(ids, len, v)) m |= 1u << j;
-            }
-        }
-        alive &= m;
+        if (ref != r.base_ref) alive &= scan_tail(ix, ref, len, 0, alive, b);
     }
     r.alive = alive;
     r.count = pa_popc32(alive);
