@@ -238,8 +238,15 @@ def main() -> None:
             out["parity_sample"] = {"reads": sample_n, "bit_exact_vs_oracle": True}
         bytes_per_read = algorithmic_bytes_per_read(ctr, read_len, k)
         achieved = bytes_per_read * B / (kernel_avg_ms * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from committed rocprofv3 PMC passes of this same workload (bench.py cannot run PMC itself)
+        try:
+            pmc = json.load(open(ROOT / "profiles" / "latest_pmc.json"))
+            if pmc.get("workload") == args.workload and pmc.get("reads_per_launch") == B:
+                traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                           "traffic": None, "kernel": "pa_map_kernel", "kernel_ms": kernel_avg_ms,
+                           "traffic": traffic, "kernel": "pa_map_kernel", "kernel_ms": kernel_avg_ms,
                            "algorithmic_bytes_per_read": bytes_per_read, "reads_per_launch": B}
         if n_gpus == 1 and not args.no_cpu_baseline:
             rate = sample_n / max(1e-9, _time_oracle(oracle, s_tiles, s_lens, wpr, ncpu))
