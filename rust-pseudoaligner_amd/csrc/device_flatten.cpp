@@ -111,17 +111,25 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
         while (out.ec.size() % 4 || out.ec.size() - 4ull * out.class_ref[c] < 8) out.ec.push_back(0xFFFFFFFFu);   // >= 8 words, 0xFFFFFFFF padded
     }
     out.ec.resize(out.ec.size() + 8, 0xFFFFFFFFu);   // tail pad: records are read two 16-byte words at a time
+    // class windows: {cmin, cmask} when every id lies in [cmin, cmin + 32), else cmask = 0
+    std::vector<uint32_t> cmin(f.num_classes, 0), cmask(f.num_classes, 0);
+    for (uint32_t c = 0; c < f.num_classes; ++c) {
+        const uint32_t* ids = f.ec_ids + f.ec_offset[c];
+        const uint64_t len = f.ec_offset[c + 1] - f.ec_offset[c];
+        if (len == 0 || ids[len - 1] - ids[0] >= CLASS_WINDOW) continue;
+        cmin[c] = ids[0];
+        for (uint64_t j = 0; j < len; ++j) cmask[c] |= 1u << (ids[j] - ids[0]);
+    }
 
-    // ---- blob placement: 32-byte granules; a blob that fits one 64-byte line does not straddle two ----
+    // ---- blob placement: every blob starts on a 64-byte line ----
     out.handle.resize(N);
     uint64_t cursor = 0, nk = 0;
     for (uint32_t i = 0; i < N; ++i) {
         if (f.node_len[i] < k) return fail(PA_ERR_FORMAT, "node %u shorter than k", i);
         if (f.node_len[i] >= (1u << 24)) return fail(PA_ERR_UNSUPPORTED, "node %u longer than 2^24 bases", i);
         if (f.node_colour[i] >= f.num_classes) return fail(PA_ERR_FORMAT, "node %u: colour out of range", i);
-        const uint64_t size = (32 + 8ull * ((f.node_len[i] + 31) / 32) + 31) / 32 * 32;
-        if (size <= 64 && (cursor & 63) + size > 64) cursor = (cursor + 63) & ~63ull;
-        if (cursor / BLOB_GRANULE >= NO_HANDLE) return fail(PA_ERR_UNSUPPORTED, "graph exceeds the 128 GiB blob address space");
+        const uint64_t size = (BLOB_HDR_BYTES + 8ull * ((f.node_len[i] + 31) / 32) + BLOB_GRANULE - 1) / BLOB_GRANULE * BLOB_GRANULE;
+        if (cursor / BLOB_GRANULE >= NO_HANDLE) return fail(PA_ERR_UNSUPPORTED, "graph exceeds the 256 GiB blob address space");
         out.handle[i] = (uint32_t)(cursor / BLOB_GRANULE);
         cursor += size;
         nk += f.node_len[i] - k + 1;
@@ -165,7 +173,7 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
         for (uint64_t i = a; i < b; ++i) {
             uint8_t* blob = out.blobs.data() + (uint64_t)out.handle[i] * BLOB_GRANULE;
             uint32_t* hd = reinterpret_cast<uint32_t*>(blob);
-            uint64_t* sq = reinterpret_cast<uint64_t*>(blob + 32);
+            uint64_t* sq = reinterpret_cast<uint64_t*>(blob + BLOB_HDR_BYTES);
             const uint32_t len = f.node_len[i];
             const uint64_t s = f.node_start[i];
             hd[0] = len | ((uint32_t)f.node_exts[i] << 24);
@@ -173,6 +181,8 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
             out.nid_of_handle[out.handle[i]] = (uint32_t)i;
             hd[2] = out.class_ref[f.node_colour[i]];
             hd[3] = out.class_len[f.node_colour[i]];
+            hd[8] = cmin[f.node_colour[i]];
+            hd[9] = cmask[f.node_colour[i]];
             for (uint32_t w = 0; w < (len + 31) / 32; ++w) {
                 uint64_t v = window32(f.node_seq, s + 32ull * w);
                 const uint32_t rem = len - 32 * w;

@@ -11,14 +11,18 @@
 //               dependent 12-byte load from the same line that both returns (handle, off) and VERIFIES the remaining
 //               33 key bits — the dictionary stores whole keys, so unlike the reference's MPHF (src/pseudoaligner.rs:
 //               96-107) no node sequence has to be fetched to confirm a hit.
-//   node blobs  one blob per unitig, 32-byte granules, addressed by handle = byte offset / 32:
+//   node blobs  one blob per unitig, 64-byte aligned (one HBM line), addressed by handle = byte offset / 64:
 //                 +0  u32 len (bits 0..23) | debruijn::Exts byte (bits 24..31)
 //                 +4  u32 class id         +8  u32 class record ref      +12 u32 class length (ids)
 //                 +16 u32 redge[4]      handle of the node reached by right-extending with base b (Node::r_edges)
-//                 +32 u64 seq[ceil(len/32)]  2-bit packed, LSB-first
-//               so a node visit is ONE dependent fetch (header + sequence share a line for len <= 128), the hop to the
-//               next node needs no further lookup (the reference re-derives every edge by hashing: SURVEY.md §3.2) and
-//               the colour's id list is addressable without an offsets table.
+//                 +32 u32 cmin, u32 cmask   the class as a WINDOW: transcript ids {cmin + i : bit i of cmask}; cmask = 0
+//                                           when the class does not fit a 32-id window (then only the id list describes it)
+//                 +40 u64 seq[ceil(len/32)]  2-bit packed, LSB-first
+//               so a node visit is ONE dependent fetch (header and the first 96 bases share a line), the hop to the
+//               next node needs no further lookup (the reference re-derives every edge by hashing: SURVEY.md §3.2),
+//               the colour's id list is addressable without an offsets table, and for window classes (transcripts of
+//               one gene are neighbours in the FASTA) the intersection of nodes_to_eq_class is an AND of masks that
+//               never touches the id lists.
 //   ledge       u32[4*granules] left-edge handles by blob handle (Node::l_edges), only touched by the left extension
 //   nid_of_handle  u32[granules] node id by blob handle (only the node-trace test surface reads it)
 //   ec          class records, 16-byte aligned, at least 32 bytes, padded with 0xFFFFFFFF: record r = words [4r, ...) =
@@ -40,7 +44,9 @@
 namespace pa {
 
 constexpr uint32_t NO_HANDLE = 0xFFFFFFFFu;
-constexpr uint32_t BLOB_GRANULE = 32;
+constexpr uint32_t BLOB_GRANULE = 64;
+constexpr uint32_t BLOB_HDR_BYTES = 40;
+constexpr uint32_t CLASS_WINDOW = 32;   // ids per class window (one mask word)
 constexpr uint32_t SLOTS_PER_BUCKET = 4;
 constexpr uint32_t BUCKET_WORDS = 16;
 constexpr uint32_t FP_EMPTY = 0xFFFFFFFFu;

@@ -232,7 +232,7 @@ __device__ __attribute__((noinline)) Isect scan_call(uint32_t nc, lds_u32 refs_l
 // arena allocation + class ids + record + count for the lanes in `mine` (whole wave enters: the scan needs every lane)
 template <bool TRACE>
 __device__ __attribute__((noinline)) Lane emit_call(Lane s, bool mine, bool mapped, uint32_t count, uint32_t base_len, uint32_t base_colour,
-                                                    uint32_t base_ref, uint32_t alive, bool in_regs, uint32_t id0, uint32_t id1, uint32_t id2,
+                                                    uint32_t base_ref, uint32_t alive, uint32_t mode, uint32_t id0, uint32_t id1, uint32_t id2,
                                                     uint32_t id3, uint32_t id4, uint32_t id5, uint32_t id6, uint32_t lane, uint32_t slot,
                                                     lds_params pp, lds_u64w chunk) {
     const uint32_t cnt = mine ? count : 0u;
@@ -242,7 +242,10 @@ __device__ __attribute__((noinline)) Lane emit_call(Lane s, bool mine, bool mapp
     const glb_u32w arena_g = (glb_u32w)pp->arena;
     if (cnt_alloc && my_off + cnt_alloc <= pp->arena_cap) {
         const glb_u32w dst = arena_g + my_off;
-        if (in_regs) {   // survivors straight from registers
+        if (mode == 2) {   // window mode: ids = window base + bit positions
+            uint32_t k = 0;
+            for (uint32_t t = alive; t; t &= t - 1) dst[k++] = id0 + (uint32_t)(__ffs((int)t) - 1);
+        } else if (mode == 1) {   // LIGHT tier: survivors straight from registers
             const uint32_t ids[7] = {id0, id1, id2, id3, id4, id5, id6};
 #pragma unroll
             for (int j = 0; j < 7; ++j)
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
         const uint32_t nE = __popcll(mE);
         const uint32_t nR = (uint32_t)(left < (uint64_t)nE ? left : (uint64_t)nE);
         const uint32_t nS = __popcll(__ballot(st == ST_SEEK)), nF = __popcll(__ballot(st == ST_FWD)), nL = __popcll(__ballot(st == ST_LEFT));
-        const uint32_t nFast = __popcll(__ballot(st == ST_NONE || st == ST_F_LIGHT));
+        const uint32_t nFast = __popcll(__ballot(st == ST_NONE || st == ST_F_LIGHT || st == ST_F_BITS));
         const uint32_t nScan = __popcll(__ballot(st == ST_F_SCAN)), nCoop = __popcll(__ballot(st == ST_F_COOP)), nNovel = __popcll(__ballot(st == ST_F_NOVEL));
         uint32_t best = nR, sel = ST_EMPTY;
         if (nS > best) { best = nS; sel = ST_SEEK; }
@@ -454,8 +457,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
             s = fin_coop_call<TRACE>(s, lane, slot, refs_lane, pp, chunk, ec, arena_g, results_g, counts_g);
         } else if (sel == ST_F_NOVEL) {
             s = fin_novel_call(s, pp, ec, arena_g, counts_g);
-        } else {   // ST_F_LIGHT (= NONE + LIGHT) or ST_F_SCAN
-            const bool mine = sel == ST_F_SCAN ? st == ST_F_SCAN : (st == ST_NONE || st == ST_F_LIGHT);
+        } else {   // ST_F_LIGHT (= NONE + BITS + LIGHT) or ST_F_SCAN
+            const bool mine = sel == ST_F_SCAN ? st == ST_F_SCAN : (st == ST_NONE || st == ST_F_LIGHT || st == ST_F_BITS);
             Isect is;
             is.count = 0;
             is.base_len = 0xFFFFFFFFu;
@@ -463,18 +466,31 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, WAVES) void pa_map_kernel(const MapPa
             is.alive = 0;
             is.in_regs = false;
             for (int j = 0; j < 7; ++j) is.ids[j] = 0;
+            uint32_t mode = 0;
+            if (st == ST_F_BITS && sel == ST_F_LIGHT) {   // window mode: the class is already in LDS as {base, mask, class id}
+                const u32x4 w = *(__attribute__((address_space(3))) const u32x4*)refs_lane;
+                is.count = (uint32_t)__popc(w.y);
+                is.base_len = w.z != NO_CLASS ? is.count : 0xFFFFFFFFu;   // by reference iff the window IS a class that was seen
+                is.base_colour = w.z;
+                is.alive = w.y;
+                is.ids[0] = w.x;
+                mode = 2;
+            }
             if (!(p.ablate & 1u)) {
                 if (st == ST_F_LIGHT && sel == ST_F_LIGHT) is = light_call(s.nc, refs_lane, ec);
                 else if (st == ST_F_SCAN && sel == ST_F_SCAN) is = scan_call(s.nc, refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, ec);
             }
-            s = emit_call<TRACE>(s, mine, st != ST_NONE, is.count, is.base_len, is.base_colour, is.base_ref, (uint32_t)is.alive, is.in_regs,
+            s = emit_call<TRACE>(s, mine, st != ST_NONE, is.count, is.base_len, is.base_colour, is.base_ref, (uint32_t)is.alive, mode == 2 ? 2u : is.in_regs ? 1u : 0u,
                                  is.ids[0], is.ids[1], is.ids[2], is.ids[3], is.ids[4], is.ids[5], is.ids[6], lane, slot, pp, chunk);
         }
         if (l_st(s) == ST_ISECT) {   // the walk just ended: choose how this read's classes will be intersected (LDS only)
-            Isect tmp;
-            const ColRef cols = make_col_ref(refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr);
-            const uint32_t tier = (p.ablate & 1u) ? 0u : isect_pick(s, cols, tmp);
-            l_set_st(s, (tier == 0 || (p.ablate & 64u)) ? ST_F_LIGHT : tier == 1 ? ST_F_SCAN : ST_F_COOP);   // ablate 64: everything LIGHT (wrong)
+            if (!(l_flags(s) & F_LISTS)) l_set_st(s, ST_F_BITS);   // window mode: nothing left to intersect
+            else {
+                Isect tmp;
+                const ColRef cols = make_col_ref(refs_lane, (glb_u32w)p.spill, slot, p.spill_cap, nullptr);
+                const uint32_t tier = (p.ablate & 1u) ? 0u : isect_pick(s, cols, tmp);
+                l_set_st(s, (tier == 0 || (p.ablate & 64u)) ? ST_F_LIGHT : tier == 1 ? ST_F_SCAN : ST_F_COOP);   // ablate 64: everything LIGHT (wrong)
+            }
         }
         if (p.dbg && lane == 0) dbg_clk[sel] += __builtin_readcyclecounter() - t_sec;
     }

@@ -20,8 +20,9 @@ namespace pa {
 
 // walk states, then the finishing states the kernel schedules separately (ST_ISECT = walk ended, tier not yet chosen)
 enum : uint32_t { ST_EMPTY = 0, ST_SEEK = 1, ST_FWD = 2, ST_LEFT = 3, ST_ISECT = 4, ST_NONE = 5,
-                  ST_F_LIGHT = 6, ST_F_SCAN = 7, ST_F_COOP = 8, ST_F_COPY = 9, ST_F_NOVEL = 10, ST_COUNT = 11 };
-enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_CAREFUL = 16u };
+                  ST_F_LIGHT = 6, ST_F_SCAN = 7, ST_F_COOP = 8, ST_F_BITS = 9, ST_F_NOVEL = 10, ST_COUNT = 11 };
+enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_CAREFUL = 16u, F_LISTS = 32u };
+constexpr uint32_t NO_CLASS = 0xFFFFFFFFu;
 constexpr uint32_t LDS_CLASSES = 4;   // distinct classes per lane kept in LDS (one 16-byte vector of refs + one of lengths)
 
 // Packed lane state (9 VGPRs). Limits: read length <= 2048 (PA_MAX_READ_LEN; 12 bits hold 0..4095), node length < 2^24.
@@ -59,8 +60,15 @@ struct ReadRef {   // the lane's packed read: word w at p[w * stride]; words 0..
     uint32_t wmax;
 };
 
-struct ColRef {    // the lane's list of distinct classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] / cids[0..3]
-    uint32_t* refs;   // (LDS, each one 16-byte vector), the rest as (ref, len, class id, -) quads in `spill` (HBM)
+// The lane's record of the classes seen, in one of two modes:
+//   window mode (default)  refs[0..2] = {base id, mask, class id or NO_CLASS}: the running intersection of the classes of
+//                          every node pushed so far as a 32-id window (bit i = transcript base + i) and, when that
+//                          intersection IS one of the classes seen, its id. Nothing else is kept.
+//   list mode (F_LISTS)    the distinct classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] / cids[0..3]
+//                          (LDS, each one 16-byte vector), the rest as (ref, len, class id, -) quads in `spill` (HBM).
+// A read starts in window mode; the first node whose class has no window (cmask == 0) restarts the read in list mode.
+struct ColRef {
+    uint32_t* refs;
     uint32_t* lens;
     uint32_t* cids;
     uint32_t* spill;
@@ -69,7 +77,10 @@ struct ColRef {    // the lane's list of distinct classes seen: the first LDS_CL
 };
 
 struct Hdr {   // the 32-byte header of a node blob
-    uint32_t len, exts, cid, ec_ref, ec_len, e0, e1, e2, e3;
+    uint32_t len, exts, cid, ec_ref, ec_len, e0, e1, e2, e3, cmin, cmask;
+};
+struct alignas(8) U2 {
+    uint32_t x, y;
 };
 
 // ---------------------------------------------------------------------------------------------- helpers
@@ -155,10 +166,11 @@ PA_HD uint32_t read_base(ReadRef r, uint32_t pos) { return (uint32_t)(r.p[(pos >
 PA_HD Hdr load_hdr(const DevIndexView& ix, uint32_t h) {
     const U4* p = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)h * BLOB_GRANULE);
     const U4 a = p[0], b = p[1];
-    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const U2 c = *reinterpret_cast<const U2*>(p + 2);
+    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y};
 }
 PA_HD const uint64_t* node_seq(const DevIndexView& ix, uint32_t h) {
-    return reinterpret_cast<const uint64_t*>(ix.blobs + (uint64_t)h * BLOB_GRANULE + 32);
+    return reinterpret_cast<const uint64_t*>(ix.blobs + (uint64_t)h * BLOB_GRANULE + BLOB_HDR_BYTES);
 }
 
 // mismatch mask of a 32-base XOR restricted to its first n bases (1 <= n <= 32): bit 2i set <=> base i differs.
@@ -188,30 +200,51 @@ PA_HD uint32_t compare_chunk(uint64_t m, uint32_t n, uint32_t allowed, uint32_t&
     return pa_ctz64(m) >> 1;
 }
 
-// nodes.push(node_id) (:199, :219): record the node's class unless already present
+// nodes.push(node_id) (:199, :219): fold the node's class into the lane's record. Returns true when the read has to
+// restart in list mode (the caller resets the lane with restart_lists).
 template <bool TRACE>
-PA_HD void push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, uint32_t handle) {
+PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, uint32_t handle) {
     if (TRACE) {
         const uint32_t nt = l_ntrace(s);
         if (nt < c.spill_cap) c.trace[nt] = ix.nid_of_handle[handle];
         s.nc += 1u << 16;
     }
     const uint32_t n = l_ncol(s);
+    if (!(l_flags(s) & F_LISTS)) {                                   // window mode: AND of masks
+        if (hd.cmask == 0) return true;
+        U4 w = *reinterpret_cast<const U4*>(c.refs);                 // {base, mask, class id, -}
+        if (n == 0) {
+            w.x = hd.cmin;
+            w.y = hd.cmask;
+            w.z = hd.cid;
+        } else {
+            const uint32_t up = hd.cmin - w.x, down = w.x - hd.cmin; // ids outside the running window cannot survive
+            const uint32_t m = up < CLASS_WINDOW ? hd.cmask << up : down < CLASS_WINDOW ? hd.cmask >> down : 0u;
+            const uint32_t nm = w.y & m;
+            if (pa_popc32(nm) == pa_popc32(hd.cmask)) w.z = hd.cid;  // this class is a subset of all before: it IS the result
+            else if (nm != w.y) w.z = NO_CLASS;                      // strict subset of everything seen so far
+            w.y = nm;
+        }
+        *reinterpret_cast<U4*>(c.refs) = w;
+        s.nc = (s.nc & ~0xFFFu) | 1u;
+        return false;
+    }
     const U4 r = *reinterpret_cast<const U4*>(c.refs);
     const bool dup = (n > 0 && r.x == hd.ec_ref) | (n > 1 && r.y == hd.ec_ref) | (n > 2 && r.z == hd.ec_ref) | (n > 3 && r.w == hd.ec_ref);
-    if (dup) return;
+    if (dup) return false;
     if (n < LDS_CLASSES) {
         c.refs[n] = hd.ec_ref;
         c.lens[n] = hd.ec_len;
         c.cids[n] = hd.cid;
     } else {
         const uint32_t o = 4 * (n - LDS_CLASSES);
-        if (o + 3 >= c.spill_cap) { l_or_flags(s, F_SPILL_OVERFLOW); return; }
+        if (o + 3 >= c.spill_cap) { l_or_flags(s, F_SPILL_OVERFLOW); return false; }
         c.spill[o] = hd.ec_ref;
         c.spill[o + 1] = hd.ec_len;
         c.spill[o + 2] = hd.cid;
     }
     s.nc += 1;
+    return false;
 }
 
 PA_HD void lane_start(Lane& s, uint32_t rid, uint32_t L, uint32_t k) {
@@ -220,6 +253,11 @@ PA_HD void lane_start(Lane& s, uint32_t rid, uint32_t L, uint32_t k) {
     s.cm = 0;
     s.h = s.rr = s.rm = s.ph = s.nc = 0;
     s.of = F_FIRST_SEEK << 24;
+}
+// a class without a window was met: map the read again from its first base, this time collecting class lists
+PA_HD void restart_lists(Lane& s, uint32_t k) {
+    lane_start(s, s.rid, l_L(s), k);
+    l_or_flags(s, F_LISTS);
 }
 
 // ---------------------------------------------------------------------------------------------- SEEK
@@ -289,7 +327,10 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
     uint32_t rem = s.rm & 0xFFFFu, snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
     if (fresh) {
         cov += K;                                                     // :216
-        push_node<TRACE>(s, cols, ix, hd, s.h);                       // nodes.push (:219)
+        if (push_node<TRACE>(s, cols, ix, hd, s.h)) {                 // nodes.push (:219)
+            restart_lists(s, K);
+            return;
+        }
         rem = pa_min(L - kp0, hd.len - ro0);                          // max_matchable_pos (:222-231)
         snp = 0;                                                      // :235
     }
@@ -359,7 +400,10 @@ PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, u
     const uint32_t fl = l_flags(s);
     if (fl & F_FRESH) {
         if (!(fl & F_LEFT_SEED)) {
-            push_node<TRACE>(s, cols, ix, hd, s.ph);                // nodes.push(prev_node.node_id) (:199)
+            if (push_node<TRACE>(s, cols, ix, hd, s.ph)) {          // nodes.push(prev_node.node_id) (:199)
+                restart_lists(s, K);
+                return;
+            }
             na = hd.len - K + 1;                                    // prev_kmer_offset = len - k (:196)
         }
         rem = pa_min(ra, na);                                       // max_matchable_pos (:139-145)

@@ -77,7 +77,26 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
         class_offsets[i] = all.size();
         pa_read_result res{0, 0, 0, 0};
         uint32_t colour = 0xFFFFFFFFu;
-        if (l_st(s) == ST_ISECT) {
+        if (l_st(s) == ST_ISECT && !(l_flags(s) & F_LISTS)) {   // window mode: {base, mask, class id or NO_CLASS}
+            const uint32_t base = refs[0], mask = refs[1], cand = refs[2];
+            const uint32_t count = (uint32_t)__builtin_popcount(mask);
+            const size_t o = all.size();
+            all.resize(o + count);
+            uint32_t j = 0;
+            for (uint32_t t = mask; t; t &= t - 1) all[o + j++] = base + (uint32_t)__builtin_ctz(t);
+            res.coverage = l_cov(s);
+            res.mismatches = l_mism(s) | PA_MAPPED_BIT;
+            res.class_len = count;
+            res.class_off = (uint32_t)o;
+            if (cand != NO_CLASS) {   // returned by reference: must be exactly that index class
+                colour = cand;
+                res.class_off = PA_CLASS_REF | colour;
+                if (colour >= ix.num_classes || ix.class_len[colour] != count) return PA_ERR_INTERNAL;
+                const uint32_t* cls = pa::class_ids(ix, ix.class_ref[colour]);
+                for (uint32_t q = 0; q < count; ++q)
+                    if (cls[q] != all[o + q]) return PA_ERR_INTERNAL;
+            }
+        } else if (l_st(s) == ST_ISECT) {
             const Isect is = isect_count(s, ix, cr);
             const size_t o = all.size();
             all.resize(o + is.count);
