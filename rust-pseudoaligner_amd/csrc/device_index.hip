@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <thread>
 
@@ -59,7 +60,7 @@ struct pa_index {
     // per-launch scratch (one batch in flight per index handle; calls are serialised by `mu`)
     std::mutex mu;
     DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status
-    DevBuf spill, trace, slow;
+    DevBuf spill, trace, slow, xcd_counts;
     uint32_t last_grid = 0;
     // host-buffer convenience path
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
@@ -98,7 +99,7 @@ void pa_index_destroy(pa_index* idx) {
     (void)hipSetDevice(idx->device);
     for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table})
         if (p) (void)hipFree(p);
-    for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->slow, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
+    for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->slow, &idx->xcd_counts, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
                       &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})
         b->release();
     delete idx;
@@ -208,6 +209,40 @@ static int map_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t*
     return PA_OK;
 }
 
+// u32 words of a slot's row in the spill / trace scratch: list-mode header + (ref, len, class id, -) quads for >= 2 * max
+// read length + 2 node visits; also the stride of the node lists of pa_map_batch_nodes
+static uint32_t spill_cap_of(uint32_t wpr) { return 256 * wpr + 24; }
+
+// pooled kernel: slots per wave such that `per_cu` workgroups share the 160 KiB of LDS of a CU
+static int pool_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t* grid, size_t* lds, uint32_t* slots) {
+    const size_t cu_lds = 160 * 1024;
+    int per_cu = env_int("PA_MAP_BLOCKS_PER_CU", 3);
+    uint32_t S = 0;
+    for (; per_cu >= 1; --per_cu) {
+        const size_t per_wave = cu_lds / (size_t)per_cu / (PA_MAP_BLOCK / 64);
+        const size_t per_slot = 8 * (size_t)wpr + 48 + ST_COUNT;
+        if (per_wave < 256 + 64 * per_slot + 16) continue;
+        S = (uint32_t)((per_wave - 256 - 16) / per_slot) & ~7u;
+        break;
+    }
+    if (S < 64) return fail(PA_ERR_UNSUPPORTED, "reads of %u words do not fit the LDS of a compute unit", wpr);
+    if (S > 256) S = 256;
+    const int want = env_int("PA_POOL_SLOTS", 0);
+    if (want >= 64 && (uint32_t)want <= S) S = (uint32_t)want & ~7u;
+    *slots = S;
+    *lds = pool_lds_bytes(wpr, S);
+    int occ = 0;
+    if (pool_kernel_occupancy(*lds, &occ) == 0 && occ >= 1 && occ < per_cu) per_cu = occ;
+    const uint64_t ntiles = (n_reads + 63) / 64;
+    const uint64_t waves_wanted = (ntiles + 7) / 8;                      // >= 8 tiles per wave when the batch allows
+    uint64_t blocks = (waves_wanted + PA_MAP_BLOCK / 64 - 1) / (PA_MAP_BLOCK / 64);
+    const uint64_t cap = (uint64_t)idx->num_cus * per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    *grid = (uint32_t)blocks;
+    return PA_OK;
+}
+
 static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads, uint32_t wpr,
                              uint32_t allowed, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour,
                              uint64_t* d_counts, uint32_t* d_nodes, uint32_t* d_nodes_len, hipStream_t stream) {
@@ -216,10 +251,13 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     uint32_t grid = 0;
     size_t lds = 0;
     int waves = 0;
-    int rc = map_geometry(idx, n_reads, wpr, &grid, &lds, &waves);
+    const char* which = getenv("PA_MAP_KERNEL");
+    const bool pool = !(which && strcmp(which, "lanes") == 0);
+    uint32_t slots = 64;
+    int rc = pool ? pool_geometry(idx, n_reads, wpr, &grid, &lds, &slots) : map_geometry(idx, n_reads, wpr, &grid, &lds, &waves);
     if (rc != PA_OK) return rc;
-    const uint32_t spill_cap = 256 * wpr + 8;   // u32 words: (ref, len, class id, -) quads for >= 2 * max read length + 2 node visits
-    const size_t lanes = (size_t)grid * PA_MAP_BLOCK;
+    const uint32_t spill_cap = spill_cap_of(wpr);
+    const size_t lanes = (size_t)grid * (PA_MAP_BLOCK / 64) * slots;
     rc = idx->spill.ensure(lanes * spill_cap * 4);
     if (rc != PA_OK) return rc;
     if (d_nodes) { rc = idx->trace.ensure(lanes * spill_cap * 4); if (rc != PA_OK) return rc; }
@@ -242,8 +280,21 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.spill = idx->spill.as<uint32_t>();
     p.spill_cap = spill_cap;
     p.counts = reinterpret_cast<unsigned long long*>(d_counts);
+    const uint64_t counts_len = (uint64_t)idx->stats.num_classes + 3;
+    const uint32_t xcd_stride = (uint32_t)((counts_len + 63) / 64 * 64);
+    if (pool && d_counts) {   // per-XCD replicas of the table, zero on entry (the fold kernel clears what it adds)
+        const size_t need = (size_t)PA_COUNT_REPLICAS * xcd_stride * 4;
+        if (idx->xcd_counts.bytes < need) {
+            rc = idx->xcd_counts.ensure(need);
+            if (rc != PA_OK) return rc;
+            HIP_TRY(hipMemsetAsync(idx->xcd_counts.p, 0, idx->xcd_counts.bytes, stream));
+        }
+        p.xcd_counts = idx->xcd_counts.as<uint32_t>();
+        p.xcd_stride = xcd_stride;
+    }
     p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
     p.class_table_size = idx->class_table_size;
+    p.pool_slots = slots;
     p.slow = idx->slow.as<uint32_t>();
     p.fast_steps = (uint32_t)env_int("PA_MAP_FAST_STEPS", 0);
     p.thr_scan = (uint32_t)env_int("PA_MAP_THR_SCAN", 8);
@@ -257,8 +308,12 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.nodes_len = d_nodes_len;
     idx->last_grid = grid;
     if (n_reads == 0) return PA_OK;
-    const int e = launch_map(p, grid, lds, waves, stream);
+    const int e = pool ? launch_map_pool(p, grid, lds, stream) : launch_map(p, grid, lds, waves, stream);
     if (e) return fail(PA_ERR_HIP, "map launch (grid %u, lds %zu): %s", grid, lds, hipGetErrorString((hipError_t)e));
+    if (pool && d_counts) {
+        const int e2 = launch_counts_fold(p.xcd_counts, p.xcd_stride, p.counts, counts_len, stream);
+        if (e2) return fail(PA_ERR_HIP, "count fold launch: %s", hipGetErrorString((hipError_t)e2));
+    }
     return PA_OK;
 }
 
@@ -269,7 +324,7 @@ static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_
     if (env_int("PA_MAP_STATS", 0)) {
         unsigned long long d[3 * ST_COUNT];
         HIP_TRY(hipMemcpy(d, idx->ctl.as<unsigned long long>() + 2, sizeof d, hipMemcpyDeviceToHost));
-        static const char* names[ST_COUNT] = {"refill", "seek", "fwd", "left", "-", "fin_none", "fin_light", "fin_scan", "fin_coop", "fin_copy", "fin_novel"};
+        static const char* names[ST_COUNT] = {"refill", "seek", "fwd", "left", "pick+pop", "store+push", "fin_light", "fin_scan", "fin_coop", "fin_bits", "fin_novel"};
         fprintf(stderr, "[pa map stats] grid=%u", idx->last_grid);
         for (uint32_t i = 0; i < ST_COUNT; ++i)
             if (d[i])
@@ -346,7 +401,7 @@ static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* o
     int e = launch_encode(idx->b_ascii.as<uint8_t>(), idx->b_offsets.as<uint64_t>(), n, wpr, idx->b_tiles.as<uint64_t>(),
                           idx->b_lens.as<uint32_t>(), st);
     if (e) return fail(PA_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
-    const uint32_t spill_cap = 256 * wpr + 8;
+    const uint32_t spill_cap = spill_cap_of(wpr);
     uint32_t *d_nodes = nullptr, *d_nodes_len = nullptr;
     if (nodes_flat) {
         if ((rc = idx->b_nodes.ensure(n * spill_cap * 4)) || (rc = idx->b_nodes_len.ensure(n * 4))) return rc;

@@ -54,20 +54,21 @@ PA_HD uint32_t l_ncol(const Lane& s) { return s.nc & 0xFFFu; }
 PA_HD uint32_t l_probe(const Lane& s) { return (s.nc >> 12) & 15u; }
 PA_HD uint32_t l_ntrace(const Lane& s) { return s.nc >> 16; }
 
-struct ReadRef {   // the lane's packed read: word w at p[w * stride]; words 0..wmax are readable (word wmax is zero pad)
+struct ReadRef {   // the lane's packed read: word w < wmax at p[w * stride]; words from wmax on read as zero
     const uint64_t* p;
     uint32_t stride;
     uint32_t wmax;
 };
 
 // The lane's record of the classes seen, in one of two modes:
-//   window mode (default)  refs[0..2] = {base id, mask, class id or NO_CLASS}: the running intersection of the classes of
+//   window mode (default)  win[0..2] = {base id, mask, class id or NO_CLASS} (win[3] is the caller's): the running intersection of the classes of
 //                          every node pushed so far as a 32-id window (bit i = transcript base + i) and, when that
 //                          intersection IS one of the classes seen, its id. Nothing else is kept.
 //   list mode (F_LISTS)    the distinct classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] / cids[0..3]
 //                          (LDS, each one 16-byte vector), the rest as (ref, len, class id, -) quads in `spill` (HBM).
 // A read starts in window mode; the first node whose class has no window (cmask == 0) restarts the read in list mode.
 struct ColRef {
+    uint32_t* win;    // window mode: one 16-byte vector
     uint32_t* refs;
     uint32_t* lens;
     uint32_t* cids;
@@ -152,7 +153,10 @@ PA_HD uint64_t funnel(uint64_t lo, uint64_t hi, uint32_t sh) {
 #endif
 }
 
-PA_HD uint64_t read_word(ReadRef r, uint32_t w) { return r.p[pa_min(w, r.wmax) * r.stride]; }
+PA_HD uint64_t read_word(ReadRef r, uint32_t w) {
+    const uint64_t v = r.p[pa_min(w, r.wmax - 1) * r.stride];
+    return w < r.wmax ? v : 0;
+}
 // 32 bases of the read starting at base `pos`
 PA_HD uint64_t read_window(ReadRef r, uint32_t pos) {
     const uint32_t w = pos >> 5;
@@ -212,7 +216,7 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
     const uint32_t n = l_ncol(s);
     if (!(l_flags(s) & F_LISTS)) {                                   // window mode: AND of masks
         if (hd.cmask == 0) return true;
-        U4 w = *reinterpret_cast<const U4*>(c.refs);                 // {base, mask, class id, -}
+        U4 w = *reinterpret_cast<const U4*>(c.win);                  // {base, mask, class id, -}
         if (n == 0) {
             w.x = hd.cmin;
             w.y = hd.cmask;
@@ -225,7 +229,7 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
             else if (nm != w.y) w.z = NO_CLASS;                      // strict subset of everything seen so far
             w.y = nm;
         }
-        *reinterpret_cast<U4*>(c.refs) = w;
+        *reinterpret_cast<U4*>(c.win) = w;
         s.nc = (s.nc & ~0xFFFu) | 1u;
         return false;
     }

@@ -1,0 +1,441 @@
+// pa_map_pool_kernel — the hot path (map_read_with_mismatch, src/pseudoaligner.rs:361-376) with POOLED scheduling.
+//
+// The per-read state machine of lane_steps.hpp has data-dependent length (node visits per read are heavy-tailed) and
+// several kinds of step (dictionary probe, node visit, left extension, class intersection, output). Running it with one
+// fixed read per lane leaves most lanes idle in every step: the lanes of a wave are never all in the same state.
+// Here a wave owns a POOL of S read slots (S > 64, typically 128) that lives in LDS — packed read, 32-byte lane state,
+// class window — and one byte queue per state. Each iteration the wave
+//     1. picks a queue (one that holds a full wave of 64 slots, preferring the states nearest to completion; otherwise
+//        the longest one), pops up to 64 slot ids from it and loads their lane state from LDS,
+//     2. runs that state's step for all of them (one dependent HBM round trip; every lane does the same thing),
+//     3. stores the lane state back and pushes every slot onto the queue of its new state.
+// Rare states simply wait in their queue until enough of them have gathered, so they are executed at full width too.
+// Nothing is shared between waves: no locks, no barriers, no atomics besides the arena chunk grab and the count table.
+//
+// LDS per wave (S slots, wpr words per read):   [256 B fixed | rd u64[wpr][S] | st {u32 x 8}[S] | win {u32 x 4}[S] | q u8[ST_COUNT][S]]
+// HBM per slot: a row of spill_cap u32 that holds the class lists of a read in list mode (lane_steps.hpp, ColRef) and,
+// in TRACE builds, a second row with the visited node ids.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "lane_steps.hpp"
+#include "kernel_utils.hpp"
+
+namespace pa {
+namespace {
+
+typedef __attribute__((address_space(3))) uint64_t* lds_u64;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+typedef __attribute__((address_space(3))) uint8_t* lds_u8;
+typedef __attribute__((address_space(3))) unsigned long long* lds_u64w;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4* lds_v4;
+typedef __attribute__((address_space(1))) u32x4* glb_v4w;
+typedef __attribute__((address_space(1))) const u32x4* glb_v4;
+typedef __attribute__((address_space(1))) uint32_t* glb_u32w;
+typedef __attribute__((address_space(1))) const uint32_t* glb_u32;
+typedef __attribute__((address_space(1))) unsigned long long* glb_u64w;
+
+typedef __attribute__((address_space(4))) const MapParams* karg_ptr;   // the kernel's parameter block in the kernarg segment
+
+__device__ __forceinline__ DevIndexView view_of(karg_ptr p) {   // member-wise: only the fields a step uses are actually loaded
+    DevIndexView v;
+    v.table = p->ix.table; v.nbuckets = p->ix.nbuckets; v.blobs = p->ix.blobs; v.ledge = p->ix.ledge;
+    v.nid_of_handle = p->ix.nid_of_handle; v.ec = p->ix.ec; v.class_ref = p->ix.class_ref; v.class_len = p->ix.class_len;
+    v.kmask = p->ix.kmask; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes;
+    return v;
+}
+
+constexpr uint32_t POOL_FIXED = 256;   // per wave: arena chunk {cur, end} (16 B) + statistics
+constexpr uint32_t LIST_ROW_HDR = 12;  // list mode row: refs[4], lens[4], cids[4], then (ref, len, class id, -) quads
+
+__device__ __forceinline__ uint32_t rank_in(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src) {
+    return ((uint64_t)(uint32_t)__shfl((int)(v >> 32), (int)src, 64) << 32) | (uint32_t)__shfl((int)v, (int)src, 64);
+}
+
+// wave-uniform: reserve cnt_alloc arena entries per lane out of the wave's private chunk; returns this lane's offset
+__device__ __forceinline__ uint64_t arena_alloc(uint32_t cnt_alloc, uint32_t lane, karg_ptr p, lds_u64w chunk) {
+    const uint32_t incl = wave_incl_scan(cnt_alloc);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    unsigned long long chunk_cur = chunk[0];
+    if (total > 0) {
+        if (chunk_cur + total > chunk[1]) {   // take a new private slice of the class arena (one global atomic per chunk)
+            const unsigned long long want = total > PA_ARENA_CHUNK ? total : PA_ARENA_CHUNK;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(p->arena_top, want);
+            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            chunk_cur = base;
+            if (lane == 0) chunk[1] = base + want;
+        }
+        if (lane == 0) chunk[0] = chunk_cur + total;
+    }
+    return chunk_cur + (incl - cnt_alloc);
+}
+
+// record + class-count update of one finished read; leaves the lane in ST_EMPTY, or in ST_F_NOVEL when the class of a
+// strict-subset result still has to be looked up by content before it can be counted
+template <bool TRACE>
+__device__ __forceinline__ void emit_record(Lane& s, bool mapped, uint32_t cnt, uint32_t cnt_alloc, uint64_t my_off, uint32_t base_len,
+                                            uint32_t base_colour, uint32_t gslot, karg_ptr p, glb_u32w xcounts) {
+    pa_read_result r{0, 0, 0, 0};
+    uint32_t colour = NO_CLASS;
+    bool novel = false;
+    if (mapped) {
+        r.coverage = l_cov(s);
+        r.mismatches = l_mism(s) | PA_MAPPED_BIT;
+        r.class_len = cnt;
+        r.class_off = (uint32_t)my_off;
+        if (my_off + cnt_alloc > p->arena_cap) atomicOr(p->status, PA_STATUS_ARENA_FULL);
+        if (cnt == base_len) {   // the class IS index class base_colour: returned by reference, nothing was written to the arena
+            colour = base_colour;
+            r.class_off = PA_CLASS_REF | base_colour;
+        } else novel = cnt != 0;
+        if (l_flags(s) & F_SPILL_OVERFLOW) atomicOr(p->status, PA_STATUS_SPILL_OVERFLOW);
+    }
+    ((glb_v4w)p->results)[s.rid] = u32x4{r.coverage, r.mismatches, r.class_off, r.class_len};
+    if (TRACE) {   // node lists, read-major, stride spill_cap (map_read_to_nodes test surface)
+        const uint32_t spill_cap = p->spill_cap;
+        const uint32_t nt = l_ntrace(s);
+        const uint32_t nn = mapped ? (nt < spill_cap ? nt : spill_cap) : 0;
+        ((glb_u32w)p->nodes_len)[s.rid] = mapped ? nt : 0;
+        const glb_u32w tr = (glb_u32w)p->trace + (uint64_t)gslot * spill_cap;
+        const glb_u32w out = (glb_u32w)p->nodes_out + (uint64_t)s.rid * spill_cap;
+        for (uint32_t j = 0; j < nn; ++j) out[j] = tr[j];
+    }
+    const glb_u32w colour_out = (glb_u32w)p->colour_out;
+    const glb_u32w counts_g = xcounts;
+    const bool want_class = counts_g != nullptr || colour_out != nullptr;
+    if (novel && want_class && my_off + cnt_alloc <= p->arena_cap) {   // defer the content lookup to the NOVEL state
+        s.h = (uint32_t)my_off;
+        s.rr = cnt;
+        l_set_st(s, ST_F_NOVEL);
+        return;
+    }
+    if (colour_out) colour_out[s.rid] = colour;
+    if (counts_g) {   // fused class-count table: fire-and-forget atomic
+        const uint32_t num_classes = p->ix.num_classes;
+        const uint32_t cslot = !mapped ? num_classes + 2 : cnt == 0 ? num_classes + 1 : colour == NO_CLASS ? num_classes : colour;
+        atomicAdd((uint32_t*)(counts_g + cslot), 1u);
+    }
+    s.lk = 0;   // ST_EMPTY
+}
+
+// the queue a slot goes to after a step
+__device__ __forceinline__ uint32_t queue_of(Lane& s) {
+    uint32_t st = l_st(s);
+    if (st == ST_ISECT) {   // the walk just ended: window mode has nothing left to intersect; list mode picks a tier later
+        st = (l_flags(s) & F_LISTS) ? ST_F_LIGHT : ST_F_BITS;
+        l_set_st(s, st);
+    }
+    return st == ST_NONE ? (uint32_t)ST_F_BITS : st;   // unmapped reads share the output queue
+}
+
+}  // namespace
+
+template <bool TRACE>
+__global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapParams p_arg) {
+    // The ~50 words of parameters are NOT kept in registers across the loop (the allocator would spill most of them to
+    // VGPR lanes and pay a v_readlane + hazard nops at every use): each iteration re-reads what its step needs from the
+    // kernarg segment with scalar loads (scalar cache hits). The empty asm makes the pointer opaque per iteration.
+    karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)p_arg;
+#define p (*kp)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t lane = lane_id();
+    const uint32_t wave_in_block = threadIdx.x >> 6;
+    const uint32_t waves_per_block = PA_MAP_BLOCK / 64;
+    const uint32_t wave = blockIdx.x * waves_per_block + wave_in_block;
+    const uint32_t nwaves = gridDim.x * waves_per_block;
+    const uint32_t S = p.pool_slots, wpr = p.wpr;
+
+    const uint32_t wave_bytes = (POOL_FIXED + S * (8 * wpr + 48 + ST_COUNT) + 15) & ~15u;
+    uint8_t* const wbase = smem + wave_in_block * wave_bytes;
+    const lds_u64w chunk = (lds_u64w)wbase;
+    const lds_u32 dbg = (lds_u32)(wbase + 16);                            // [0..ST_COUNT) iterations, [ST_COUNT..2*ST_COUNT) lanes served
+    const lds_u64w dbg_clk = (lds_u64w)(wbase + 16 + 8 * ST_COUNT + 8);   // wall ticks per state
+    const lds_u64 rd = (lds_u64)(wbase + POOL_FIXED);
+    const lds_v4 stv = (lds_v4)(wbase + POOL_FIXED + 8 * wpr * S);        // two vectors per slot
+    const lds_v4 win = (lds_v4)(wbase + POOL_FIXED + (8 * wpr + 32) * S); // {window base, mask, class id, read id}
+    const lds_u8 q = (lds_u8)(wbase + POOL_FIXED + (8 * wpr + 48) * S);
+    if (lane < 60) ((lds_u32)wbase)[lane] = 0;
+    for (uint32_t i = lane; i < S; i += 64) q[ST_EMPTY * S + i] = (uint8_t)i;
+
+    // static partition of the tiles over the waves (no global work queue: one hot atomic would cap the rate)
+    const uint64_t ntiles = (p.n_reads + 63) >> 6;
+    uint64_t next = (ntiles * wave / nwaves) << 6;
+    uint64_t end = (ntiles * (wave + 1) / nwaves) << 6;
+    if (end > p.n_reads) end = p.n_reads;
+    if (next > end) next = end;
+
+    // this XCD's replica of the count table (HW_REG_XCC_ID, bits 3:0)
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (PA_COUNT_REPLICAS - 1);
+    const glb_u32w xcounts = p.counts ? (glb_u32w)p.xcd_counts + (uint64_t)xcc * p.xcd_stride : (glb_u32w) nullptr;
+
+    uint32_t cntv = lane == ST_EMPTY ? S : 0u;   // queue lengths: lane t holds the length of queue t
+#define PA_CNT(t) ((uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)(t)))
+
+    for (;;) {
+        asm volatile("" : "+s"(kp));
+        const DevIndexView ix = view_of(kp);
+        const glb_u32 ec = (glb_u32)ix.ec;
+        const uint32_t K = ix.k, allowed = p.allowed, spill_cap = p.spill_cap;
+        // ---- 1. pick a queue: the first one (states nearest to completion first) that fills a wave, else the longest
+        const uint64_t left = end - next;
+        const uint32_t nempty = PA_CNT(ST_EMPTY);
+        const uint32_t nrefill = (uint32_t)(left < (uint64_t)nempty ? left : (uint64_t)nempty);
+        uint32_t best = 0, sel = ST_EMPTY;
+#define PA_CONSIDER(t, c) { const uint32_t c_ = (c); if (best < 64 && c_ > best) { best = c_; sel = (t); } }
+        PA_CONSIDER(ST_F_NOVEL, PA_CNT(ST_F_NOVEL))
+        PA_CONSIDER(ST_F_COOP, PA_CNT(ST_F_COOP))
+        PA_CONSIDER(ST_F_LIGHT, PA_CNT(ST_F_LIGHT))
+        PA_CONSIDER(ST_F_BITS, PA_CNT(ST_F_BITS))
+        PA_CONSIDER(ST_FWD, PA_CNT(ST_FWD))
+        PA_CONSIDER(ST_LEFT, PA_CNT(ST_LEFT))
+        PA_CONSIDER(ST_SEEK, PA_CNT(ST_SEEK))
+        PA_CONSIDER(ST_EMPTY, nrefill)
+#undef PA_CONSIDER
+        if (best == 0) break;
+        const uint32_t n = best < 64 ? best : 64;
+        if (p.dbg && lane == 0) {
+            dbg[sel] += 1;
+            dbg[ST_COUNT + sel] += n;
+        }
+        const unsigned long long t_sec = p.dbg ? __builtin_readcyclecounter() : 0ull;
+
+        // ---- 2. pop n slots
+        cntv -= lane == sel ? n : 0u;
+        const uint32_t qbase = PA_CNT(sel);
+        const bool active = lane < n;
+        const uint32_t slot = active ? (uint32_t)q[sel * S + qbase + lane] : 0u;
+        const uint32_t gslot = wave * S + slot;
+        Lane s;
+        {
+            const u32x4 a = stv[2 * slot], b = stv[2 * slot + 1];
+            s.lk = a.x; s.cm = a.y; s.h = a.z; s.of = a.w; s.rr = b.x; s.rm = b.y; s.ph = b.z; s.nc = b.w;
+            s.rid = win[slot].w;
+        }
+        const ReadRef rr{(const uint64_t*)(rd + slot), S, wpr};
+        const glb_u32w row = (glb_u32w)p.spill + (uint64_t)gslot * spill_cap;
+        const ColRef cols{(uint32_t*)&win[slot], (uint32_t*)row, (uint32_t*)(row + 4), (uint32_t*)(row + 8), (uint32_t*)(row + LIST_ROW_HDR),
+                          spill_cap - LIST_ROW_HDR, TRACE ? (uint32_t*)((glb_u32w)p.trace + (uint64_t)gslot * spill_cap) : nullptr};
+
+        const unsigned long long t_pop = p.dbg ? __builtin_readcyclecounter() : 0ull;
+        // ---- 3. the step
+        if (sel == ST_EMPTY) {   // REFILL: free slots take the next reads of this wave's range (coalesced: lane = consecutive read)
+            if (active) {
+                const uint64_t rid = next + lane;
+                uint32_t L = p.lens[rid];
+                if (L > wpr * 32) L = wpr * 32;
+                const uint64_t* src = p.tiles + ((rid >> 6) * wpr) * 64 + (rid & 63);
+                for (uint32_t w = 0; w < wpr; ++w) rd[w * S + slot] = src[(uint64_t)w * 64];
+                lane_start(s, (uint32_t)rid, L, K);
+                win[slot] = u32x4{0u, 0u, NO_CLASS, (uint32_t)rid};
+            }
+            next += n;
+        } else if (sel == ST_SEEK) {
+            if (active) seek_step(s, ix, rr);
+        } else if (sel == ST_FWD) {
+            if (active) fwd_step<TRACE>(s, ix, rr, cols, allowed);
+        } else if (sel == ST_LEFT) {
+            if (active) left_step<TRACE>(s, ix, rr, cols, allowed);
+        } else if (sel == ST_F_NOVEL) {
+            // the result is a strict subset of every visited class: does it equal some index class? (content lookup)
+            if (active) {
+                const uint32_t colour = class_of_list(p.arena + s.h, s.rr, ix, p.class_table, p.class_table_size);
+                const glb_u32w colour_out = (glb_u32w)p.colour_out;
+                if (colour_out) colour_out[s.rid] = colour;
+                if (xcounts) atomicAdd((uint32_t*)(xcounts + (colour == NO_CLASS ? ix.num_classes : colour)), 1u);
+                s.lk = 0;   // ST_EMPTY
+            }
+        } else if (sel == ST_F_COOP) {
+            // the whole wave works on one read at a time (list mode, base list of more than 8 ids). Lane e owns base ids
+            // e, e+64, ...; membership in every other list is a scan of 16-byte loads (short lists) or a binary search;
+            // survivors are compacted with a wave ballot straight into the read's arena slice.
+            Isect is;
+            is.count = 0;
+            is.base_len = is.base_ref = is.base_colour = 0;
+            if (active) isect_pick(s, cols, is);
+            const uint32_t cnt_alloc = active ? is.base_len : 0u;   // upper bound: the survivors are a subset of the base list
+            const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
+            const uint64_t arena_cap = p.arena_cap;
+            const glb_u32w arena_g = (glb_u32w)p.arena;
+            const uint32_t ncol_mine = l_ncol(s);
+            uint32_t my_count = 0;
+            for (uint32_t Lr = 0; Lr < n; ++Lr) {   // uniform: every lane sees the same read
+                const uint32_t bref = (uint32_t)__shfl((int)is.base_ref, (int)Lr, 64);
+                const uint32_t blen = (uint32_t)__shfl((int)is.base_len, (int)Lr, 64);
+                const uint32_t ncolL = (uint32_t)__shfl((int)ncol_mine, (int)Lr, 64);
+                const uint32_t slotL = (uint32_t)__shfl((int)slot, (int)Lr, 64);
+                const uint64_t off = shfl64(my_off, Lr);
+                const bool fits = off + blen <= arena_cap;
+                const glb_u32w rowL = (glb_u32w)p.spill + (uint64_t)(wave * S + slotL) * spill_cap;
+                uint32_t total = 0;
+                for (uint32_t c = 0; c < blen; c += 64) {
+                    const uint32_t j = c + lane;
+                    const bool valid = j < blen;
+                    const uint32_t v = valid ? ec[4ull * bref + 1 + j] : 0u;
+                    bool ok = valid;
+                    for (uint32_t i = 0; i < ncolL; ++i) {
+                        const glb_u32w e = i < LDS_CLASSES ? rowL + i : rowL + LIST_ROW_HDR + 4 * (i - LDS_CLASSES);
+                        const uint32_t ref = e[0], len = i < LDS_CLASSES ? e[4] : e[1];
+                        if (ref == bref) continue;   // uniform
+                        bool hit = false;
+                        if (len <= 64) {             // short list: scan it, no dependent loads
+                            const glb_v4 rec = (glb_v4)(ec + 4ull * ref);
+                            const uint32_t nchunks = (len + 4) >> 2;
+#pragma unroll 2
+                            for (uint32_t qq = 0; qq < nchunks; ++qq) {
+                                const u32x4 w = rec[qq];
+                                hit |= (qq != 0 && w.x == v) | (w.y == v) | (w.z == v) | (w.w == v);
+                            }
+                        } else {                     // long list: binary_search (:404)
+                            const glb_u32 ids = ec + 4ull * ref + 1;
+                            uint32_t lo = 0, hi = len;
+                            while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (ids[mid] < v) lo = mid + 1; else hi = mid;
+                            }
+                            hit = lo < len && ids[lo] == v;
+                        }
+                        ok = ok && hit;
+                    }
+                    const uint64_t bm = __ballot(ok);
+                    if (ok && fits) arena_g[off + total + rank_in(bm)] = v;
+                    total += (uint32_t)__popcll(bm);
+                }
+                if (lane == Lr) my_count = total;
+            }
+            if (active) emit_record<TRACE>(s, true, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts);
+        } else {   // ST_F_BITS (window results and unmapped reads) or ST_F_LIGHT (list mode: pick a tier, intersect)
+            const bool mapped = l_st(s) != ST_NONE;
+            Isect is;
+            is.count = 0;
+            is.base_len = 0xFFFFFFFFu;
+            is.base_ref = is.base_colour = 0;
+            is.alive = 0;
+            is.in_regs = false;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) is.ids[j] = 0;
+            uint32_t mode = 0;   // where the surviving ids come from: 0 base record, 1 registers, 2 window
+            bool emit_now = active;
+            if (sel == ST_F_BITS) {
+                if (active && mapped) {   // {window base, mask, class id}
+                    const u32x4 w = win[slot];
+                    is.count = (uint32_t)__popc(w.y);
+                    is.base_len = w.z != NO_CLASS ? is.count : 0xFFFFFFFFu;   // by reference iff the window IS a class that was seen
+                    is.base_colour = w.z;
+                    is.alive = w.y;
+                    is.ids[0] = w.x;
+                }
+                mode = 2;
+            } else if (active) {
+                const uint32_t tier = isect_pick(s, cols, is);
+                if (tier == 0) {
+                    isect_light(s, ix, cols, is);
+                    mode = is.in_regs ? 1u : 0u;
+                } else if (tier == 1) {
+                    isect_scan(s, ix, cols, is);
+                } else {
+                    l_set_st(s, ST_F_COOP);
+                    emit_now = false;
+                }
+            }
+            const uint32_t cntv = emit_now ? is.count : 0u;
+            const uint32_t cnt_alloc = cntv == is.base_len ? 0u : cntv;   // a result that is an index class is returned by reference
+            const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
+            if (emit_now) {
+                if (cnt_alloc && my_off + cnt_alloc <= p.arena_cap) {
+                    const glb_u32w dst = (glb_u32w)p.arena + my_off;
+                    const uint32_t alive = (uint32_t)is.alive;
+                    if (mode == 2) {          // ids = window base + bit positions
+                        uint32_t k = 0;
+                        for (uint32_t t = alive; t; t &= t - 1) dst[k++] = is.ids[0] + (uint32_t)(__ffs((int)t) - 1);
+                    } else if (mode == 1) {   // survivors straight from registers
+#pragma unroll
+                        for (int j = 0; j < 7; ++j)
+                            if ((alive >> j) & 1u) dst[__popc(alive & ((1u << j) - 1))] = is.ids[j];
+                    } else {                  // base of <= 8 ids, re-read from its record
+                        const glb_u32 bids = ec + 4ull * is.base_ref + 1;
+                        uint32_t k = 0;
+                        for (uint32_t t = alive; t; t &= t - 1) dst[k++] = bids[__ffs((int)t) - 1];
+                    }
+                }
+                emit_record<TRACE>(s, mapped, cntv, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts);
+            }
+        }
+
+        const unsigned long long t_step = p.dbg ? __builtin_readcyclecounter() : 0ull;
+        // ---- 4. store the lane state, push every slot onto the queue of its new state
+        const uint32_t nq = active ? queue_of(s) : 0xFFu;
+        if (active) {
+            stv[2 * slot] = u32x4{s.lk, s.cm, s.h, s.of};
+            stv[2 * slot + 1] = u32x4{s.rr, s.rm, s.ph, s.nc};
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < ST_COUNT; ++t) {
+            if (t == ST_ISECT || t == ST_NONE || t == ST_F_SCAN) continue;   // never queued
+            const uint64_t m = __ballot(nq == t);
+            if (m) {
+                if (nq == t) q[t * S + PA_CNT(t) + rank_in(m)] = (uint8_t)slot;
+                cntv += lane == t ? (uint32_t)__popcll(m) : 0u;
+            }
+        }
+        if (p.dbg && lane == 0) {   // [ST_ISECT] = pick + pop, [ST_NONE] = store + push (statistics only)
+            const unsigned long long t_end = __builtin_readcyclecounter();
+            dbg_clk[sel] += t_end - t_sec;
+            dbg[ST_ISECT] += 1;
+            dbg_clk[ST_ISECT] += t_pop - t_sec;
+            dbg[ST_NONE] += 1;
+            dbg_clk[ST_NONE] += t_end - t_step;
+        }
+    }
+    if (p.dbg && lane < 2 * ST_COUNT) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
+    if (p.dbg && lane < ST_COUNT) atomicAdd(p.dbg + 2 * ST_COUNT + lane, dbg_clk[lane]);
+#undef PA_CNT
+#undef p
+}
+
+// counts[c] += sum of the per-XCD replicas, which are cleared for the next launch
+__global__ __launch_bounds__(256) void pa_counts_fold_kernel(uint32_t* __restrict__ rep, uint32_t stride, unsigned long long* __restrict__ counts,
+                                                             uint64_t len) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= len) return;
+    unsigned long long sum = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < PA_COUNT_REPLICAS; ++r) {
+        const uint32_t v = rep[(uint64_t)r * stride + c];
+        if (v) { sum += v; rep[(uint64_t)r * stride + c] = 0; }
+    }
+    if (sum) counts[c] += sum;
+}
+
+int launch_counts_fold(uint32_t* xcd_counts, uint32_t xcd_stride, unsigned long long* counts, uint64_t len, hipStream_t stream) {
+    if (len == 0) return 0;
+    hipLaunchKernelGGL(pa_counts_fold_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream, xcd_counts, xcd_stride, counts, len);
+    return (int)hipGetLastError();
+}
+
+size_t pool_lds_bytes(uint32_t wpr, uint32_t slots) {
+    const size_t wave_bytes = (POOL_FIXED + (size_t)slots * (8 * wpr + 48 + ST_COUNT) + 15) & ~(size_t)15;
+    return wave_bytes * (PA_MAP_BLOCK / 64);
+}
+
+int launch_map_pool(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
+    const void* fn = p.trace ? reinterpret_cast<const void*>(&pa_map_pool_kernel<true>) : reinterpret_cast<const void*>(&pa_map_pool_kernel<false>);
+    if (lds_bytes > 48 * 1024) {   // opt in to more than the default dynamic LDS limit
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (p.trace) hipLaunchKernelGGL((pa_map_pool_kernel<true>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
+    else hipLaunchKernelGGL((pa_map_pool_kernel<false>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
+    return (int)hipGetLastError();
+}
+
+int pool_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu) {
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(&pa_map_pool_kernel<false>),
+                                                             PA_MAP_BLOCK, lds_bytes);
+}
+
+}  // namespace pa

@@ -62,7 +62,7 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
         Lane s;
         lane_start(s, (uint32_t)i, L, ix.k);
         const ReadRef rr{rd.data(), 1, wpr};
-        const ColRef cr{refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), trace.data()};
+        const ColRef cr{refs, refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), trace.data()};
         while (l_st(s) == ST_SEEK || l_st(s) == ST_FWD || l_st(s) == ST_LEFT) {
             if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
             else if (l_st(s) == ST_FWD) { fwd_step<true>(s, ix, rr, cr, allowed); ++st_fwd; }

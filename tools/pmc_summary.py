@@ -5,7 +5,7 @@ import csv
 import glob
 import sys
 
-root, kernel = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "pa_map_kernel"
+root, kernel = sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "pa_map_"
 print("# rocprofv3 --pmc (one pass per directory) averages per launch of %s, launches with the full batch only" % kernel)
 for d in sorted(glob.glob(root + "/pmc_*")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
