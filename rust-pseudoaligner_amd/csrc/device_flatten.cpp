@@ -24,6 +24,8 @@ DevIndexView FlatDevice::host_view() const {
     v.ec = ec.data();
     v.class_ref = class_ref.data();
     v.class_len = class_len.data();
+    v.wtable = wtable.data();
+    v.wbuckets = wbuckets;
     v.kmask = kmer_mask(k);
     v.k = k;
     v.num_nodes = num_nodes;
@@ -111,14 +113,41 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
         while (out.ec.size() % 4 || out.ec.size() - 4ull * out.class_ref[c] < 8) out.ec.push_back(0xFFFFFFFFu);   // >= 8 words, 0xFFFFFFFF padded
     }
     out.ec.resize(out.ec.size() + 8, 0xFFFFFFFFu);   // tail pad: records are read two 16-byte words at a time
-    // class windows: {cmin, cmask} when every id lies in [cmin, cmin + 32), else cmask = 0
-    std::vector<uint32_t> cmin(f.num_classes, 0), cmask(f.num_classes, 0);
+    // class windows: ids in [cmin, cmin + 32) U [cmin2, cmin2 + 32), cmin2 = first id beyond window 1; cmask = 0 if it does not fit
+    std::vector<U4> cwin(f.num_classes, U4{0, 0, 0, 0});
+    uint64_t nwin = 0;
     for (uint32_t c = 0; c < f.num_classes; ++c) {
         const uint32_t* ids = f.ec_ids + f.ec_offset[c];
         const uint64_t len = f.ec_offset[c + 1] - f.ec_offset[c];
-        if (len == 0 || ids[len - 1] - ids[0] >= CLASS_WINDOW) continue;
-        cmin[c] = ids[0];
-        for (uint64_t j = 0; j < len; ++j) cmask[c] |= 1u << (ids[j] - ids[0]);
+        if (len == 0) continue;
+        U4 w{ids[0], 0, 0, 0};
+        uint64_t j = 0;
+        for (; j < len && ids[j] - w.x < CLASS_WINDOW; ++j) w.y |= 1u << (ids[j] - w.x);
+        if (j < len) {
+            w.z = ids[j];
+            for (; j < len && ids[j] - w.z < CLASS_WINDOW; ++j) w.w |= 1u << (ids[j] - w.z);
+        }
+        if (j < len) continue;   // three or more windows: list mode only
+        cwin[c] = w;
+        ++nwin;
+    }
+    // window table: canonical windows -> class id
+    out.wbuckets = (uint32_t)std::max<uint64_t>(1, (uint64_t)((double)nwin / (WT_ENTRIES * 0.5)) + 1);
+    out.wtable.assign((size_t)out.wbuckets * 16, 0);
+    for (uint64_t l = 0; l < out.wbuckets; ++l) out.wtable[l * 16 + 4] = out.wtable[l * 16 + 9] = out.wtable[l * 16 + 14] = NO_CLASS;
+    for (uint32_t c = 0; c < f.num_classes; ++c) {
+        const U4 w = cwin[c];
+        if (w.y == 0) continue;
+        uint64_t line = ((uint64_t)window_hash(w.x, w.y, w.z, w.w) * out.wbuckets) >> 32;
+        for (bool done = false; !done;) {
+            uint32_t* e = out.wtable.data() + line * 16;
+            for (uint32_t t = 0; t < WT_ENTRIES && !done; ++t)
+                if (e[5 * t + 4] == NO_CLASS) {
+                    e[5 * t] = w.x; e[5 * t + 1] = w.y; e[5 * t + 2] = w.z; e[5 * t + 3] = w.w; e[5 * t + 4] = c;
+                    done = true;
+                }
+            if (++line == out.wbuckets) line = 0;
+        }
     }
 
     // ---- blob placement: every blob starts on a 64-byte line ----
@@ -181,8 +210,8 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
             out.nid_of_handle[out.handle[i]] = (uint32_t)i;
             hd[2] = out.class_ref[f.node_colour[i]];
             hd[3] = out.class_len[f.node_colour[i]];
-            hd[8] = cmin[f.node_colour[i]];
-            hd[9] = cmask[f.node_colour[i]];
+            const U4 cw = cwin[f.node_colour[i]];
+            hd[8] = cw.x; hd[9] = cw.y; hd[10] = cw.z; hd[11] = cw.w;
             for (uint32_t w = 0; w < (len + 31) / 32; ++w) {
                 uint64_t v = window32(f.node_seq, s + 32ull * w);
                 const uint32_t rem = len - 32 * w;

@@ -15,6 +15,8 @@ struct FlatDevice {
     std::vector<uint32_t> nid_of_handle;
     std::vector<uint32_t> ec;                      // class records (16-byte aligned)
     std::vector<uint32_t> class_ref, class_len;    // by class id
+    std::vector<uint32_t> wtable;                  // window classes by content (wbuckets lines of 16 words)
+    uint32_t wbuckets = 0;
     uint64_t num_kmers = 0;
     uint32_t k = 0, num_nodes = 0, num_classes = 0, max_class_len = 0;
     DevIndexView host_view() const;   // pointers into the vectors above

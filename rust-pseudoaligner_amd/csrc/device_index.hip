@@ -54,13 +54,13 @@ struct pa_index {
     int num_cus = 0;
     DevIndexView dv{};
     void *d_table = nullptr, *d_blobs = nullptr, *d_ledge = nullptr, *d_nid = nullptr, *d_ec = nullptr, *d_class_ref = nullptr, *d_class_len = nullptr,
-         *d_class_table = nullptr;
+         *d_class_table = nullptr, *d_wtable = nullptr;
     uint64_t class_table_size = 0;
     pa_index_stats stats{};
     // per-launch scratch (one batch in flight per index handle; calls are serialised by `mu`)
     std::mutex mu;
     DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status
-    DevBuf spill, trace, slow, xcd_counts;
+    DevBuf spill, trace, xcd_counts;
     uint32_t last_grid = 0;
     // host-buffer convenience path
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
@@ -97,9 +97,9 @@ static int upload(const void* src, size_t bytes, void** dst) {
 void pa_index_destroy(pa_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
-    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table})
+    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table, idx->d_wtable})
         if (p) (void)hipFree(p);
-    for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->slow, &idx->xcd_counts, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
+    for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->xcd_counts, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
                       &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})
         b->release();
     delete idx;
@@ -138,6 +138,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     if (rc == PA_OK) rc = upload(fd.class_ref.data(), fd.class_ref.size() * 4, &idx->d_class_ref);
     if (rc == PA_OK) rc = upload(fd.class_len.data(), fd.class_len.size() * 4, &idx->d_class_len);
     if (rc == PA_OK) rc = upload(ctab.data(), ctab.size() * 4, &idx->d_class_table);
+    if (rc == PA_OK) rc = upload(fd.wtable.data(), fd.wtable.size() * 4, &idx->d_wtable);
     if (rc == PA_OK) rc = idx->ctl.ensure(1024);
     if (rc != PA_OK) { pa_index_destroy(idx); return rc; }
     idx->class_table_size = ctab.size();
@@ -151,12 +152,13 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     idx->dv.ec = static_cast<const uint32_t*>(idx->d_ec);
     idx->dv.class_ref = static_cast<const uint32_t*>(idx->d_class_ref);
     idx->dv.class_len = static_cast<const uint32_t*>(idx->d_class_len);
+    idx->dv.wtable = static_cast<const uint32_t*>(idx->d_wtable);
     pa_index_stats& s = idx->stats;
     s.num_kmers = fd.num_kmers;
     s.table_slots = fd.nbuckets * SLOTS_PER_BUCKET;
     s.bytes_table = fd.table.size() * 4;
     s.bytes_graph = fd.blobs.size() + fd.ledge.size() * 4 + fd.nid_of_handle.size() * 4;
-    s.bytes_classes = (fd.ec.size() + fd.class_ref.size() + fd.class_len.size() + ctab.size()) * 4;
+    s.bytes_classes = (fd.ec.size() + fd.class_ref.size() + fd.class_len.size() + ctab.size() + fd.wtable.size()) * 4;
     s.bytes_total = s.bytes_table + s.bytes_graph + s.bytes_classes;
     s.num_nodes = fd.num_nodes;
     s.num_classes = fd.num_classes;
@@ -184,29 +186,10 @@ int pa_encode_reads_device(const pa_index* idx, const uint8_t* d_ascii, const ui
     return PA_OK;
 }
 
-// ---- launch geometry: enough waves to fill the chip, few enough that each owns several tiles ----
+// ---- launch geometry ----
 static int env_int(const char* name, int dflt) {   // tuning knobs for A/B runs (documented in DESIGN.md); unset in production
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
-}
-
-static int map_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t* grid, size_t* lds, int* waves) {
-    *waves = env_int("PA_MAP_WAVES", PA_DEFAULT_MAP_WAVES);
-    const size_t wave_bytes = 256 + (size_t)(wpr + 1) * 512 + 3 * LDS_CLASSES * 256;
-    *lds = (sizeof(MapParams) + 15) / 16 * 16 + wave_bytes * (PA_MAP_BLOCK / 64);
-    if (*lds > 160 * 1024) return fail(PA_ERR_UNSUPPORTED, "reads of %u words need %zu bytes of LDS per workgroup (> 160 KiB)", wpr, *lds);
-    int per_cu = 0;
-    if (map_kernel_occupancy(*lds, *waves, &per_cu) != 0 || per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    per_cu = env_int("PA_MAP_BLOCKS_PER_CU", per_cu);
-    const uint64_t ntiles = (n_reads + 63) / 64;
-    const uint64_t waves_wanted = (ntiles + 3) / 4;                      // >= 4 tiles per wave when the batch allows
-    uint64_t blocks = (waves_wanted + PA_MAP_BLOCK / 64 - 1) / (PA_MAP_BLOCK / 64);
-    const uint64_t cap = (uint64_t)idx->num_cus * per_cu;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    *grid = (uint32_t)blocks;
-    return PA_OK;
 }
 
 // u32 words of a slot's row in the spill / trace scratch: list-mode header + (ref, len, class id, -) quads for >= 2 * max
@@ -220,7 +203,7 @@ static int pool_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t
     uint32_t S = 0;
     for (; per_cu >= 1; --per_cu) {
         const size_t per_wave = cu_lds / (size_t)per_cu / (PA_MAP_BLOCK / 64);
-        const size_t per_slot = 8 * (size_t)wpr + 48 + ST_COUNT;
+        const size_t per_slot = pool_slot_bytes(wpr);
         if (per_wave < 256 + 64 * per_slot + 16) continue;
         S = (uint32_t)((per_wave - 256 - 16) / per_slot) & ~7u;
         break;
@@ -250,19 +233,14 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     if (wpr == 0 || wpr > PA_MAX_READ_LEN / 32) return fail(PA_ERR_UNSUPPORTED, "words_per_read %u outside [1,%u]", wpr, PA_MAX_READ_LEN / 32);
     uint32_t grid = 0;
     size_t lds = 0;
-    int waves = 0;
-    const char* which = getenv("PA_MAP_KERNEL");
-    const bool pool = !(which && strcmp(which, "lanes") == 0);
     uint32_t slots = 64;
-    int rc = pool ? pool_geometry(idx, n_reads, wpr, &grid, &lds, &slots) : map_geometry(idx, n_reads, wpr, &grid, &lds, &waves);
+    int rc = pool_geometry(idx, n_reads, wpr, &grid, &lds, &slots);
     if (rc != PA_OK) return rc;
     const uint32_t spill_cap = spill_cap_of(wpr);
     const size_t lanes = (size_t)grid * (PA_MAP_BLOCK / 64) * slots;
     rc = idx->spill.ensure(lanes * spill_cap * 4);
     if (rc != PA_OK) return rc;
     if (d_nodes) { rc = idx->trace.ensure(lanes * spill_cap * 4); if (rc != PA_OK) return rc; }
-    rc = idx->slow.ensure((n_reads + 64) * 4);
-    if (rc != PA_OK) return rc;
     HIP_TRY(hipMemsetAsync(idx->ctl.p, 0, 512, stream));
     MapParams p{};
     p.ix = idx->dv;
@@ -282,7 +260,7 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.counts = reinterpret_cast<unsigned long long*>(d_counts);
     const uint64_t counts_len = (uint64_t)idx->stats.num_classes + 3;
     const uint32_t xcd_stride = (uint32_t)((counts_len + 63) / 64 * 64);
-    if (pool && d_counts) {   // per-XCD replicas of the table, zero on entry (the fold kernel clears what it adds)
+    if (d_counts) {   // per-XCD replicas of the table, zero on entry (the fold kernel clears what it adds)
         const size_t need = (size_t)PA_COUNT_REPLICAS * xcd_stride * 4;
         if (idx->xcd_counts.bytes < need) {
             rc = idx->xcd_counts.ensure(need);
@@ -295,22 +273,15 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
     p.class_table_size = idx->class_table_size;
     p.pool_slots = slots;
-    p.slow = idx->slow.as<uint32_t>();
-    p.fast_steps = (uint32_t)env_int("PA_MAP_FAST_STEPS", 0);
-    p.thr_scan = (uint32_t)env_int("PA_MAP_THR_SCAN", 8);
-    p.thr_coop = (uint32_t)env_int("PA_MAP_THR_COOP", 2);
-    p.thr_novel = (uint32_t)env_int("PA_MAP_THR_NOVEL", 8);
-    p.thr_idle = (uint32_t)env_int("PA_MAP_THR_IDLE", 16);
-    p.ablate = (uint32_t)env_int("PA_MAP_ABLATE", 0);
     p.dbg = env_int("PA_MAP_STATS", 0) ? idx->ctl.as<unsigned long long>() + 2 : nullptr;
     p.trace = d_nodes ? idx->trace.as<uint32_t>() : nullptr;
     p.nodes_out = d_nodes;
     p.nodes_len = d_nodes_len;
     idx->last_grid = grid;
     if (n_reads == 0) return PA_OK;
-    const int e = pool ? launch_map_pool(p, grid, lds, stream) : launch_map(p, grid, lds, waves, stream);
+    const int e = launch_map_pool(p, grid, lds, stream);
     if (e) return fail(PA_ERR_HIP, "map launch (grid %u, lds %zu): %s", grid, lds, hipGetErrorString((hipError_t)e));
-    if (pool && d_counts) {
+    if (d_counts) {
         const int e2 = launch_counts_fold(p.xcd_counts, p.xcd_stride, p.counts, counts_len, stream);
         if (e2) return fail(PA_ERR_HIP, "count fold launch: %s", hipGetErrorString((hipError_t)e2));
     }

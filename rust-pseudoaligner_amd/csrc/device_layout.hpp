@@ -15,20 +15,24 @@
 //                 +0  u32 len (bits 0..23) | debruijn::Exts byte (bits 24..31)
 //                 +4  u32 class id         +8  u32 class record ref      +12 u32 class length (ids)
 //                 +16 u32 redge[4]      handle of the node reached by right-extending with base b (Node::r_edges)
-//                 +32 u32 cmin, u32 cmask   the class as a WINDOW: transcript ids {cmin + i : bit i of cmask}; cmask = 0
-//                                           when the class does not fit a 32-id window (then only the id list describes it)
-//                 +40 u64 seq[ceil(len/32)]  2-bit packed, LSB-first
-//               so a node visit is ONE dependent fetch (header and the first 96 bases share a line), the hop to the
+//                 +32 u32 cmin, cmask, cmin2, cmask2   the class as two WINDOWS of 32 transcript ids: {cmin + i : bit i of
+//                                           cmask} U {cmin2 + i : bit i of cmask2}, cmin2 >= cmin + 32 (cmask2 = 0: one window);
+//                                           cmask = 0 when the class does not fit (then only the id list describes it)
+//                 +48 u64 seq[ceil(len/32)]  2-bit packed, LSB-first
+//               so a node visit is ONE dependent fetch (header and the first 64 bases share a line), the hop to the
 //               next node needs no further lookup (the reference re-derives every edge by hashing: SURVEY.md §3.2),
 //               the colour's id list is addressable without an offsets table, and for window classes (transcripts of
-//               one gene are neighbours in the FASTA) the intersection of nodes_to_eq_class is an AND of masks that
-//               never touches the id lists.
+//               one gene are neighbours in the FASTA; a second window covers a paralog or an overlapping gene) the
+//               intersection of nodes_to_eq_class is an AND of masks that never touches the id lists.
 //   ledge       u32[4*granules] left-edge handles by blob handle (Node::l_edges), only touched by the left extension
 //   nid_of_handle  u32[granules] node id by blob handle (only the node-trace test surface reads it)
 //   ec          class records, 16-byte aligned, at least 32 bytes, padded with 0xFFFFFFFF: record r = words [4r, ...) =
 //               {class id, id0, id1, ...} — the sorted transcript-id lists of eq_classes: Vec<Vec<u32>>
 //               (src/pseudoaligner.rs:29); a class of <= 7 ids is two 16-byte loads and needs no length checks.
 //   class_ref/class_len  u32[num_classes] record ref and length by class id (only the count table's content lookup)
+//   wtable      window classes by content: open addressing over 64-byte lines of three {cmin, cmask, cmin2, cmask2, class
+//               id} entries (class id 0xFFFFFFFF = empty), line = mulhi32(hash(windows), wbuckets), linear probing —
+//               tells in ONE fetch whether a window result that is a strict subset of every class seen is itself a class
 #pragma once
 #include <cstdint>
 
@@ -45,7 +49,7 @@ namespace pa {
 
 constexpr uint32_t NO_HANDLE = 0xFFFFFFFFu;
 constexpr uint32_t BLOB_GRANULE = 64;
-constexpr uint32_t BLOB_HDR_BYTES = 40;
+constexpr uint32_t BLOB_HDR_BYTES = 48;
 constexpr uint32_t CLASS_WINDOW = 32;   // ids per class window (one mask word)
 constexpr uint32_t SLOTS_PER_BUCKET = 4;
 constexpr uint32_t BUCKET_WORDS = 16;
@@ -61,6 +65,8 @@ struct alignas(8) Q2 {   // two sequence words, 8-byte aligned (global_load_dwor
     uint64_t a, b;
 };
 
+constexpr uint32_t WT_ENTRIES = 3;   // window-table entries per 64-byte line, 5 words each
+
 struct DevIndexView {
     const uint32_t* table;    // nbuckets * 16 words
     uint64_t nbuckets;
@@ -70,6 +76,8 @@ struct DevIndexView {
     const uint32_t* ec;       // class records (16-byte aligned records of u32)
     const uint32_t* class_ref;   // [num_classes]
     const uint32_t* class_len;   // [num_classes]
+    const uint32_t* wtable;      // wbuckets * 16 words
+    uint32_t wbuckets;
     uint64_t kmask;
     uint32_t k;
     uint32_t num_nodes, num_classes;

@@ -61,14 +61,17 @@ struct ReadRef {   // the lane's packed read: word w < wmax at p[w * stride]; wo
 };
 
 // The lane's record of the classes seen, in one of two modes:
-//   window mode (default)  win[0..2] = {base id, mask, class id or NO_CLASS} (win[3] is the caller's): the running intersection of the classes of
-//                          every node pushed so far as a 32-id window (bit i = transcript base + i) and, when that
-//                          intersection IS one of the classes seen, its id. Nothing else is kept.
+//   window mode (default)  win[0..3] = {base1, mask1, base2, mask2}: the running intersection of the classes of every
+//                          node pushed so far as two 32-id windows (bit i of mask w = transcript base w + i; base2 >=
+//                          base1 + 32) and wcand[0] = the class id when that intersection IS one of the classes seen,
+//                          else NO_CLASS. Nothing else is kept.
 //   list mode (F_LISTS)    the distinct classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] / cids[0..3]
 //                          (LDS, each one 16-byte vector), the rest as (ref, len, class id, -) quads in `spill` (HBM).
-// A read starts in window mode; the first node whose class has no window (cmask == 0) restarts the read in list mode.
+// A read starts in window mode; the first node whose class does not fit two windows (cmask == 0) restarts the read in
+// list mode.
 struct ColRef {
     uint32_t* win;    // window mode: one 16-byte vector
+    uint32_t* wcand;  // window mode: one word
     uint32_t* refs;
     uint32_t* lens;
     uint32_t* cids;
@@ -78,10 +81,7 @@ struct ColRef {
 };
 
 struct Hdr {   // the 32-byte header of a node blob
-    uint32_t len, exts, cid, ec_ref, ec_len, e0, e1, e2, e3, cmin, cmask;
-};
-struct alignas(8) U2 {
-    uint32_t x, y;
+    uint32_t len, exts, cid, ec_ref, ec_len, e0, e1, e2, e3, cmin, cmask, cmin2, cmask2;
 };
 
 // ---------------------------------------------------------------------------------------------- helpers
@@ -169,9 +169,8 @@ PA_HD uint32_t read_base(ReadRef r, uint32_t pos) { return (uint32_t)(r.p[(pos >
 
 PA_HD Hdr load_hdr(const DevIndexView& ix, uint32_t h) {
     const U4* p = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)h * BLOB_GRANULE);
-    const U4 a = p[0], b = p[1];
-    const U2 c = *reinterpret_cast<const U2*>(p + 2);
-    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y};
+    const U4 a = p[0], b = p[1], c = p[2];
+    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
 }
 PA_HD const uint64_t* node_seq(const DevIndexView& ix, uint32_t h) {
     return reinterpret_cast<const uint64_t*>(ix.blobs + (uint64_t)h * BLOB_GRANULE + BLOB_HDR_BYTES);
@@ -204,6 +203,57 @@ PA_HD uint32_t compare_chunk(uint64_t m, uint32_t n, uint32_t allowed, uint32_t&
     return pa_ctz64(m) >> 1;
 }
 
+// hash of a canonical two-window class (cmin is the smallest id, so bit 0 of m1 is set; b2/m2 = 0 when one window)
+PA_HD uint32_t window_hash(uint32_t b1, uint32_t m1, uint32_t b2, uint32_t m2) {
+    return (uint32_t)(pa_mix64(((uint64_t)b1 << 32 | m1) ^ pa_mix64((uint64_t)b2 << 32 | m2)) >> 32);
+}
+
+// canonical form of the id set {b1 + i : m1 bit i} U {b2 + i : m2 bit i} (b2 >= b1 + 32, not both empty): window 1 starts
+// at the smallest id, window 2 at the first id beyond window 1 — what the index stores for a class
+PA_HD void window_canon(uint32_t& b1, uint32_t& m1, uint32_t& b2, uint32_t& m2) {
+    if (m1 == 0) { b1 = b2; m1 = m2; m2 = 0; }
+    const uint32_t z = pa_ctz32(m1);
+    b1 += z;
+    m1 >>= z;
+    if (m2) {
+        const uint32_t gap = b2 - b1;                 // ids of window 2 that now fall inside window 1
+        if (gap < CLASS_WINDOW) {
+            m1 |= m2 << gap;
+            m2 = gap ? m2 >> (CLASS_WINDOW - gap) : 0u;
+            b2 = b1 + CLASS_WINDOW;
+        }
+    }
+    if (m2) {
+        const uint32_t z2 = pa_ctz32(m2);
+        b2 += z2;
+        m2 >>= z2;
+    } else b2 = 0;
+}
+
+// class whose windows are exactly (b1, m1, b2, m2) (canonical), or NO_CLASS
+PA_HD uint32_t window_class(const DevIndexView& ix, uint32_t b1, uint32_t m1, uint32_t b2, uint32_t m2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t line = __umulhi(window_hash(b1, m1, b2, m2), ix.wbuckets);
+#else
+    uint32_t line = (uint32_t)(((uint64_t)window_hash(b1, m1, b2, m2) * ix.wbuckets) >> 32);
+#endif
+    for (;;) {
+        const U4* p = reinterpret_cast<const U4*>(ix.wtable + (uint64_t)line * 16);
+        const U4 a = p[0], b = p[1], c = p[2], d = p[3];
+        if (a.x == b1 && a.y == m1 && a.z == b2 && a.w == m2 && b.x != NO_CLASS) return b.x;
+        if (b.y == b1 && b.z == m1 && b.w == b2 && c.x == m2 && c.y != NO_CLASS) return c.y;
+        if (c.z == b1 && c.w == m1 && d.x == b2 && d.y == m2 && d.z != NO_CLASS) return d.z;
+        if (b.x == NO_CLASS || c.y == NO_CLASS || d.z == NO_CLASS) return NO_CLASS;   // a line with a free entry ends the probe sequence
+        if (++line == ix.wbuckets) line = 0;
+    }
+}
+
+// mask of the window (base c, mask n) expressed relative to base b
+PA_HD uint32_t window_at(uint32_t b, uint32_t c, uint32_t n) {
+    const uint32_t up = c - b, down = b - c;
+    return up < CLASS_WINDOW ? n << up : down < CLASS_WINDOW ? n >> down : 0u;
+}
+
 // nodes.push(node_id) (:199, :219): fold the node's class into the lane's record. Returns true when the read has to
 // restart in list mode (the caller resets the lane with restart_lists).
 template <bool TRACE>
@@ -216,20 +266,21 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
     const uint32_t n = l_ncol(s);
     if (!(l_flags(s) & F_LISTS)) {                                   // window mode: AND of masks
         if (hd.cmask == 0) return true;
-        U4 w = *reinterpret_cast<const U4*>(c.win);                  // {base, mask, class id, -}
+        U4 w = *reinterpret_cast<const U4*>(c.win);                  // {base1, mask1, base2, mask2}
+        uint32_t cand = hd.cid;
         if (n == 0) {
-            w.x = hd.cmin;
-            w.y = hd.cmask;
-            w.z = hd.cid;
+            w = U4{hd.cmin, hd.cmask, hd.cmin2, hd.cmask2};
         } else {
-            const uint32_t up = hd.cmin - w.x, down = w.x - hd.cmin; // ids outside the running window cannot survive
-            const uint32_t m = up < CLASS_WINDOW ? hd.cmask << up : down < CLASS_WINDOW ? hd.cmask >> down : 0u;
-            const uint32_t nm = w.y & m;
-            if (pa_popc32(nm) == pa_popc32(hd.cmask)) w.z = hd.cid;  // this class is a subset of all before: it IS the result
-            else if (nm != w.y) w.z = NO_CLASS;                      // strict subset of everything seen so far
-            w.y = nm;
+            // the class's windows re-based onto each running window (ids outside a running window cannot survive)
+            const uint32_t m1 = w.y & (window_at(w.x, hd.cmin, hd.cmask) | window_at(w.x, hd.cmin2, hd.cmask2));
+            const uint32_t m2 = w.w & (window_at(w.z, hd.cmin, hd.cmask) | window_at(w.z, hd.cmin2, hd.cmask2));
+            if (pa_popc32(m1) + pa_popc32(m2) != pa_popc32(hd.cmask) + pa_popc32(hd.cmask2))   // else: this class is a subset of all before, it IS the result
+                cand = (m1 == w.y && m2 == w.w) ? c.wcand[0] : NO_CLASS;   // unchanged, or a strict subset of everything seen so far
+            w.y = m1;
+            w.w = m2;
         }
         *reinterpret_cast<U4*>(c.win) = w;
+        c.wcand[0] = cand;
         s.nc = (s.nc & ~0xFFFu) | 1u;
         return false;
     }
@@ -272,18 +323,15 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
     const uint32_t probe = l_probe(s);
     uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + probe;
     if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
-    const uint32_t* line = ix.table + (uint64_t)b * BUCKET_WORDS;
-    const U4 fp = *reinterpret_cast<const U4*>(line);
+    const U4* line = reinterpret_cast<const U4*>(ix.table + (uint64_t)b * BUCKET_WORDS);
+    const U4 fp = line[0], e0 = line[1], e1 = line[2], e2 = line[3];   // the whole 64-byte bucket, one round trip
     const uint32_t klo = (uint32_t)kmer, khi = (uint32_t)(kmer >> 32);
-    const uint32_t want = klo & 0x7FFFFFFFu;
-    uint32_t cand = (fp.x == want ? 1u : 0u) | (fp.y == want ? 2u : 0u) | (fp.z == want ? 4u : 0u) | (fp.w == want ? 8u : 0u);
-    uint32_t h = NO_HANDLE, off = 0;
-    while (cand) {                                                  // almost always exactly one candidate on a hit
-        const uint32_t j = pa_ctz32(cand);
-        cand &= cand - 1;
-        const U3 e = *reinterpret_cast<const U3*>(line + 4 + 3 * j);
-        if (e.x == khi && (e.z >> 31) == (klo >> 31)) { h = e.y; off = e.z & 0x7FFFFFFFu; cand = 0; }
-    }
+    const uint32_t want = klo & 0x7FFFFFFFu, top = klo >> 31;
+    // entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j
+    const bool h0 = fp.x == want && e0.x == khi && (e0.z >> 31) == top, h1 = fp.y == want && e0.w == khi && (e1.y >> 31) == top,
+               h2 = fp.z == want && e1.z == khi && (e2.x >> 31) == top, h3 = fp.w == want && e2.y == khi && (e2.w >> 31) == top;
+    const uint32_t h = h0 ? e0.y : h1 ? e1.x : h2 ? e1.w : h3 ? e2.z : NO_HANDLE;
+    const uint32_t off = (h0 ? e0.z : h1 ? e1.y : h2 ? e2.x : e2.w) & 0x7FFFFFFFu;
     s.nc &= ~(15u << 12);                                           // probe index back to 0
     if (h != NO_HANDLE) {                                           // Some((nid, offset)) (:106)
         s.h = h;

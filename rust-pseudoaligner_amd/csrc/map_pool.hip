@@ -42,7 +42,7 @@ __device__ __forceinline__ DevIndexView view_of(karg_ptr p) {   // member-wise: 
     DevIndexView v;
     v.table = p->ix.table; v.nbuckets = p->ix.nbuckets; v.blobs = p->ix.blobs; v.ledge = p->ix.ledge;
     v.nid_of_handle = p->ix.nid_of_handle; v.ec = p->ix.ec; v.class_ref = p->ix.class_ref; v.class_len = p->ix.class_len;
-    v.kmask = p->ix.kmask; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes;
+    v.wtable = p->ix.wtable; v.wbuckets = p->ix.wbuckets; v.kmask = p->ix.kmask; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes;
     return v;
 }
 
@@ -74,50 +74,45 @@ __device__ __forceinline__ uint64_t arena_alloc(uint32_t cnt_alloc, uint32_t lan
     return chunk_cur + (incl - cnt_alloc);
 }
 
-// record + class-count update of one finished read; leaves the lane in ST_EMPTY, or in ST_F_NOVEL when the class of a
-// strict-subset result still has to be looked up by content before it can be counted
+// node list of a finished read (TRACE builds: the map_read_to_nodes test surface), read-major, stride spill_cap
 template <bool TRACE>
-__device__ __forceinline__ void emit_record(Lane& s, bool mapped, uint32_t cnt, uint32_t cnt_alloc, uint64_t my_off, uint32_t base_len,
+__device__ __forceinline__ void trace_out(const Lane& s, bool mapped, uint32_t gslot, karg_ptr p) {
+    if (!TRACE) return;
+    const uint32_t spill_cap = p->spill_cap;
+    const uint32_t nt = l_ntrace(s);
+    const uint32_t nn = mapped ? (nt < spill_cap ? nt : spill_cap) : 0;
+    ((glb_u32w)p->nodes_len)[s.rid] = mapped ? nt : 0;
+    const glb_u32w tr = (glb_u32w)p->trace + (uint64_t)gslot * spill_cap;
+    const glb_u32w out = (glb_u32w)p->nodes_out + (uint64_t)s.rid * spill_cap;
+    for (uint32_t j = 0; j < nn; ++j) out[j] = tr[j];
+}
+
+// list mode: record + class-count update of one finished read; leaves the lane in ST_EMPTY, or in ST_F_NOVEL when the class
+// of a strict-subset result still has to be looked up by content before it can be counted
+template <bool TRACE>
+__device__ __forceinline__ void emit_record(Lane& s, uint32_t cnt, uint32_t cnt_alloc, uint64_t my_off, uint32_t base_len,
                                             uint32_t base_colour, uint32_t gslot, karg_ptr p, glb_u32w xcounts) {
-    pa_read_result r{0, 0, 0, 0};
-    uint32_t colour = NO_CLASS;
+    uint32_t colour = NO_CLASS, class_off = (uint32_t)my_off;
     bool novel = false;
-    if (mapped) {
-        r.coverage = l_cov(s);
-        r.mismatches = l_mism(s) | PA_MAPPED_BIT;
-        r.class_len = cnt;
-        r.class_off = (uint32_t)my_off;
-        if (my_off + cnt_alloc > p->arena_cap) atomicOr(p->status, PA_STATUS_ARENA_FULL);
-        if (cnt == base_len) {   // the class IS index class base_colour: returned by reference, nothing was written to the arena
-            colour = base_colour;
-            r.class_off = PA_CLASS_REF | base_colour;
-        } else novel = cnt != 0;
-        if (l_flags(s) & F_SPILL_OVERFLOW) atomicOr(p->status, PA_STATUS_SPILL_OVERFLOW);
-    }
-    ((glb_v4w)p->results)[s.rid] = u32x4{r.coverage, r.mismatches, r.class_off, r.class_len};
-    if (TRACE) {   // node lists, read-major, stride spill_cap (map_read_to_nodes test surface)
-        const uint32_t spill_cap = p->spill_cap;
-        const uint32_t nt = l_ntrace(s);
-        const uint32_t nn = mapped ? (nt < spill_cap ? nt : spill_cap) : 0;
-        ((glb_u32w)p->nodes_len)[s.rid] = mapped ? nt : 0;
-        const glb_u32w tr = (glb_u32w)p->trace + (uint64_t)gslot * spill_cap;
-        const glb_u32w out = (glb_u32w)p->nodes_out + (uint64_t)s.rid * spill_cap;
-        for (uint32_t j = 0; j < nn; ++j) out[j] = tr[j];
-    }
+    if (my_off + cnt_alloc > p->arena_cap) atomicOr(p->status, PA_STATUS_ARENA_FULL);
+    if (cnt == base_len) {   // the class IS index class base_colour: returned by reference, nothing was written to the arena
+        colour = base_colour;
+        class_off = PA_CLASS_REF | base_colour;
+    } else novel = cnt != 0;
+    if (l_flags(s) & F_SPILL_OVERFLOW) atomicOr(p->status, PA_STATUS_SPILL_OVERFLOW);
+    ((glb_v4w)p->results)[s.rid] = u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, class_off, cnt};
+    trace_out<TRACE>(s, true, gslot, p);
     const glb_u32w colour_out = (glb_u32w)p->colour_out;
-    const glb_u32w counts_g = xcounts;
-    const bool want_class = counts_g != nullptr || colour_out != nullptr;
-    if (novel && want_class && my_off + cnt_alloc <= p->arena_cap) {   // defer the content lookup to the NOVEL state
+    if (novel && (xcounts != nullptr || colour_out != nullptr) && my_off + cnt_alloc <= p->arena_cap) {   // content lookup: NOVEL state
         s.h = (uint32_t)my_off;
         s.rr = cnt;
         l_set_st(s, ST_F_NOVEL);
         return;
     }
     if (colour_out) colour_out[s.rid] = colour;
-    if (counts_g) {   // fused class-count table: fire-and-forget atomic
+    if (xcounts) {   // fused class-count table: fire-and-forget atomic
         const uint32_t num_classes = p->ix.num_classes;
-        const uint32_t cslot = !mapped ? num_classes + 2 : cnt == 0 ? num_classes + 1 : colour == NO_CLASS ? num_classes : colour;
-        atomicAdd((uint32_t*)(counts_g + cslot), 1u);
+        atomicAdd((uint32_t*)(xcounts + (cnt == 0 ? num_classes + 1 : colour == NO_CLASS ? num_classes : colour)), 1u);
     }
     s.lk = 0;   // ST_EMPTY
 }
@@ -131,6 +126,8 @@ __device__ __forceinline__ uint32_t queue_of(Lane& s) {
     }
     return st == ST_NONE ? (uint32_t)ST_F_BITS : st;   // unmapped reads share the output queue
 }
+
+constexpr uint32_t SLOT_FIXED_BYTES = 32 + 16 + 8 + ST_COUNT;   // lane state, class windows, {class id, read id}, one queue byte per state
 
 }  // namespace
 
@@ -150,15 +147,16 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     const uint32_t nwaves = gridDim.x * waves_per_block;
     const uint32_t S = p.pool_slots, wpr = p.wpr;
 
-    const uint32_t wave_bytes = (POOL_FIXED + S * (8 * wpr + 48 + ST_COUNT) + 15) & ~15u;
+    const uint32_t wave_bytes = (POOL_FIXED + S * (8 * wpr + SLOT_FIXED_BYTES) + 15) & ~15u;
     uint8_t* const wbase = smem + wave_in_block * wave_bytes;
     const lds_u64w chunk = (lds_u64w)wbase;
-    const lds_u32 dbg = (lds_u32)(wbase + 16);                            // [0..ST_COUNT) iterations, [ST_COUNT..2*ST_COUNT) lanes served
+    const lds_u32 dbg = (lds_u32)(wbase + 16);                            // [0..ST_COUNT) iterations, [ST_COUNT..2*ST_COUNT) slots served
     const lds_u64w dbg_clk = (lds_u64w)(wbase + 16 + 8 * ST_COUNT + 8);   // wall ticks per state
     const lds_u64 rd = (lds_u64)(wbase + POOL_FIXED);
     const lds_v4 stv = (lds_v4)(wbase + POOL_FIXED + 8 * wpr * S);        // two vectors per slot
-    const lds_v4 win = (lds_v4)(wbase + POOL_FIXED + (8 * wpr + 32) * S); // {window base, mask, class id, read id}
-    const lds_u8 q = (lds_u8)(wbase + POOL_FIXED + (8 * wpr + 48) * S);
+    const lds_v4 win = (lds_v4)(wbase + POOL_FIXED + (8 * wpr + 32) * S); // {base1, mask1, base2, mask2}
+    const lds_u32 wc = (lds_u32)(wbase + POOL_FIXED + (8 * wpr + 48) * S);   // {class id, read id} per slot
+    const lds_u8 q = (lds_u8)(wbase + POOL_FIXED + (8 * wpr + 56) * S);
     if (lane < 60) ((lds_u32)wbase)[lane] = 0;
     for (uint32_t i = lane; i < S; i += 64) q[ST_EMPTY * S + i] = (uint8_t)i;
 
@@ -214,12 +212,13 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         {
             const u32x4 a = stv[2 * slot], b = stv[2 * slot + 1];
             s.lk = a.x; s.cm = a.y; s.h = a.z; s.of = a.w; s.rr = b.x; s.rm = b.y; s.ph = b.z; s.nc = b.w;
-            s.rid = win[slot].w;
+            s.rid = wc[2 * slot + 1];
         }
         const ReadRef rr{(const uint64_t*)(rd + slot), S, wpr};
         const glb_u32w row = (glb_u32w)p.spill + (uint64_t)gslot * spill_cap;
-        const ColRef cols{(uint32_t*)&win[slot], (uint32_t*)row, (uint32_t*)(row + 4), (uint32_t*)(row + 8), (uint32_t*)(row + LIST_ROW_HDR),
-                          spill_cap - LIST_ROW_HDR, TRACE ? (uint32_t*)((glb_u32w)p.trace + (uint64_t)gslot * spill_cap) : nullptr};
+        const ColRef cols{(uint32_t*)&win[slot], (uint32_t*)(wc + 2 * slot), (uint32_t*)row, (uint32_t*)(row + 4), (uint32_t*)(row + 8),
+                          (uint32_t*)(row + LIST_ROW_HDR), spill_cap - LIST_ROW_HDR,
+                          TRACE ? (uint32_t*)((glb_u32w)p.trace + (uint64_t)gslot * spill_cap) : nullptr};
 
         const unsigned long long t_pop = p.dbg ? __builtin_readcyclecounter() : 0ull;
         // ---- 3. the step
@@ -229,9 +228,16 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 uint32_t L = p.lens[rid];
                 if (L > wpr * 32) L = wpr * 32;
                 const uint64_t* src = p.tiles + ((rid >> 6) * wpr) * 64 + (rid & 63);
-                for (uint32_t w = 0; w < wpr; ++w) rd[w * S + slot] = src[(uint64_t)w * 64];
+                for (uint32_t w0 = 0; w0 < wpr; w0 += 8) {   // eight words in flight per round trip
+                    uint64_t v[8];
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; ++i) v[i] = w0 + i < wpr ? src[(uint64_t)(w0 + i) * 64] : 0ull;
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; ++i)
+                        if (w0 + i < wpr) rd[(w0 + i) * S + slot] = v[i];
+                }
                 lane_start(s, (uint32_t)rid, L, K);
-                win[slot] = u32x4{0u, 0u, NO_CLASS, (uint32_t)rid};
+                wc[2 * slot + 1] = (uint32_t)rid;
             }
             next += n;
         } else if (sel == ST_SEEK) {
@@ -240,10 +246,60 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             if (active) fwd_step<TRACE>(s, ix, rr, cols, allowed);
         } else if (sel == ST_LEFT) {
             if (active) left_step<TRACE>(s, ix, rr, cols, allowed);
-        } else if (sel == ST_F_NOVEL) {
-            // the result is a strict subset of every visited class: does it equal some index class? (content lookup)
+        } else if (sel == ST_F_BITS) {
+            // output of window-mode reads and of unmapped reads: no loads. A non-empty window that is a strict subset of
+            // every class seen goes on to NOVEL (is it an index class all the same?) and is written there.
             if (active) {
-                const uint32_t colour = class_of_list(p.arena + s.h, s.rr, ix, p.class_table, p.class_table_size);
+                const bool mapped = l_st(s) != ST_NONE;
+                const u32x4 w = win[slot];
+                const uint32_t cand = wc[2 * slot];
+                const uint32_t count = mapped ? (uint32_t)(__popc(w.y) + __popc(w.w)) : 0u;
+                if (mapped && count != 0 && cand == NO_CLASS) {
+                    l_set_st(s, ST_F_NOVEL);
+                } else {
+                    const bool is_ref = mapped && count != 0;
+                    ((glb_v4w)p.results)[s.rid] = mapped ? u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, is_ref ? PA_CLASS_REF | cand : 0u, count}
+                                                         : u32x4{0u, 0u, 0u, 0u};
+                    trace_out<TRACE>(s, mapped, gslot, kp);
+                    const glb_u32w colour_out = (glb_u32w)p.colour_out;
+                    if (colour_out) colour_out[s.rid] = is_ref ? cand : NO_CLASS;
+                    if (xcounts) atomicAdd((uint32_t*)(xcounts + (!mapped ? ix.num_classes + 2 : count == 0 ? ix.num_classes + 1 : cand)), 1u);
+                    s.lk = 0;   // ST_EMPTY
+                }
+            }
+        } else if (sel == ST_F_NOVEL) {
+            // the result is a strict subset of every class seen: does it equal some index class all the same?
+            const bool lists = l_flags(s) & F_LISTS;
+            uint32_t colour = NO_CLASS, count = 0;
+            u32x4 w{0u, 0u, 0u, 0u};
+            if (active && lists) {          // list mode: ids are in the arena, the record is written: look the list up by content
+                colour = class_of_list(p.arena + s.h, s.rr, ix, p.class_table, p.class_table_size);
+            } else if (active) {            // window mode: one fetch of the window table
+                w = win[slot];
+                count = (uint32_t)(__popc(w.y) + __popc(w.w));
+                uint32_t b1 = w.x, m1 = w.y, b2 = w.z, m2 = w.w;
+                window_canon(b1, m1, b2, m2);
+                colour = window_class(ix, b1, m1, b2, m2);
+            }
+            const bool fresh = active && !lists && colour == NO_CLASS;   // a new class: its ids go to the arena
+            const uint32_t cnt_alloc = fresh ? count : 0u;
+            const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
+            if (active) {
+                if (!lists) {
+                    uint32_t class_off = PA_CLASS_REF | colour;
+                    if (fresh) {
+                        class_off = (uint32_t)my_off;
+                        if (my_off + cnt_alloc > p.arena_cap) atomicOr(p.status, PA_STATUS_ARENA_FULL);
+                        else {
+                            const glb_u32w dst = (glb_u32w)p.arena + my_off;
+                            uint32_t k = 0;
+                            for (uint32_t t = w.y; t; t &= t - 1) dst[k++] = w.x + (uint32_t)(__ffs((int)t) - 1);
+                            for (uint32_t t = w.w; t; t &= t - 1) dst[k++] = w.z + (uint32_t)(__ffs((int)t) - 1);
+                        }
+                    }
+                    ((glb_v4w)p.results)[s.rid] = u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, class_off, count};
+                    trace_out<TRACE>(s, true, gslot, kp);
+                }
                 const glb_u32w colour_out = (glb_u32w)p.colour_out;
                 if (colour_out) colour_out[s.rid] = colour;
                 if (xcounts) atomicAdd((uint32_t*)(xcounts + (colour == NO_CLASS ? ix.num_classes : colour)), 1u);
@@ -287,8 +343,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                             const uint32_t nchunks = (len + 4) >> 2;
 #pragma unroll 2
                             for (uint32_t qq = 0; qq < nchunks; ++qq) {
-                                const u32x4 w = rec[qq];
-                                hit |= (qq != 0 && w.x == v) | (w.y == v) | (w.z == v) | (w.w == v);
+                                const u32x4 x = rec[qq];
+                                hit |= (qq != 0 && x.x == v) | (x.y == v) | (x.z == v) | (x.w == v);
                             }
                         } else {                     // long list: binary_search (:404)
                             const glb_u32 ids = ec + 4ull * ref + 1;
@@ -307,9 +363,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 }
                 if (lane == Lr) my_count = total;
             }
-            if (active) emit_record<TRACE>(s, true, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts);
-        } else {   // ST_F_BITS (window results and unmapped reads) or ST_F_LIGHT (list mode: pick a tier, intersect)
-            const bool mapped = l_st(s) != ST_NONE;
+            if (active) emit_record<TRACE>(s, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts);
+        } else {   // ST_F_LIGHT: list mode — pick a tier, intersect, write
             Isect is;
             is.count = 0;
             is.base_len = 0xFFFFFFFFu;
@@ -318,51 +373,34 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             is.in_regs = false;
 #pragma unroll
             for (int j = 0; j < 7; ++j) is.ids[j] = 0;
-            uint32_t mode = 0;   // where the surviving ids come from: 0 base record, 1 registers, 2 window
             bool emit_now = active;
-            if (sel == ST_F_BITS) {
-                if (active && mapped) {   // {window base, mask, class id}
-                    const u32x4 w = win[slot];
-                    is.count = (uint32_t)__popc(w.y);
-                    is.base_len = w.z != NO_CLASS ? is.count : 0xFFFFFFFFu;   // by reference iff the window IS a class that was seen
-                    is.base_colour = w.z;
-                    is.alive = w.y;
-                    is.ids[0] = w.x;
-                }
-                mode = 2;
-            } else if (active) {
+            if (active) {
                 const uint32_t tier = isect_pick(s, cols, is);
-                if (tier == 0) {
-                    isect_light(s, ix, cols, is);
-                    mode = is.in_regs ? 1u : 0u;
-                } else if (tier == 1) {
-                    isect_scan(s, ix, cols, is);
-                } else {
+                if (tier == 0) isect_light(s, ix, cols, is);
+                else if (tier == 1) isect_scan(s, ix, cols, is);
+                else {
                     l_set_st(s, ST_F_COOP);
                     emit_now = false;
                 }
             }
-            const uint32_t cntv = emit_now ? is.count : 0u;
-            const uint32_t cnt_alloc = cntv == is.base_len ? 0u : cntv;   // a result that is an index class is returned by reference
+            const uint32_t cntv2 = emit_now ? is.count : 0u;
+            const uint32_t cnt_alloc = cntv2 == is.base_len ? 0u : cntv2;   // a result that is an index class is returned by reference
             const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
             if (emit_now) {
                 if (cnt_alloc && my_off + cnt_alloc <= p.arena_cap) {
                     const glb_u32w dst = (glb_u32w)p.arena + my_off;
                     const uint32_t alive = (uint32_t)is.alive;
-                    if (mode == 2) {          // ids = window base + bit positions
-                        uint32_t k = 0;
-                        for (uint32_t t = alive; t; t &= t - 1) dst[k++] = is.ids[0] + (uint32_t)(__ffs((int)t) - 1);
-                    } else if (mode == 1) {   // survivors straight from registers
+                    if (is.in_regs) {   // survivors straight from registers
 #pragma unroll
                         for (int j = 0; j < 7; ++j)
                             if ((alive >> j) & 1u) dst[__popc(alive & ((1u << j) - 1))] = is.ids[j];
-                    } else {                  // base of <= 8 ids, re-read from its record
+                    } else {            // base of <= 8 ids, re-read from its record
                         const glb_u32 bids = ec + 4ull * is.base_ref + 1;
                         uint32_t k = 0;
                         for (uint32_t t = alive; t; t &= t - 1) dst[k++] = bids[__ffs((int)t) - 1];
                     }
                 }
-                emit_record<TRACE>(s, mapped, cntv, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts);
+                emit_record<TRACE>(s, cntv2, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts);
             }
         }
 
@@ -373,14 +411,12 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             stv[2 * slot] = u32x4{s.lk, s.cm, s.h, s.of};
             stv[2 * slot + 1] = u32x4{s.rr, s.rm, s.ph, s.nc};
         }
-#pragma unroll
-        for (uint32_t t = 0; t < ST_COUNT; ++t) {
-            if (t == ST_ISECT || t == ST_NONE || t == ST_F_SCAN) continue;   // never queued
+        for (uint64_t todo = __ballot(active); todo;) {   // one round per queue that receives slots (usually two or three)
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)nq, (int)(__ffsll((unsigned long long)todo) - 1));
             const uint64_t m = __ballot(nq == t);
-            if (m) {
-                if (nq == t) q[t * S + PA_CNT(t) + rank_in(m)] = (uint8_t)slot;
-                cntv += lane == t ? (uint32_t)__popcll(m) : 0u;
-            }
+            if (nq == t) q[t * S + PA_CNT(t) + rank_in(m)] = (uint8_t)slot;
+            cntv += lane == t ? (uint32_t)__popcll(m) : 0u;
+            todo &= ~m;
         }
         if (p.dbg && lane == 0) {   // [ST_ISECT] = pick + pop, [ST_NONE] = store + push (statistics only)
             const unsigned long long t_end = __builtin_readcyclecounter();
@@ -417,8 +453,10 @@ int launch_counts_fold(uint32_t* xcd_counts, uint32_t xcd_stride, unsigned long 
     return (int)hipGetLastError();
 }
 
+size_t pool_slot_bytes(uint32_t wpr) { return 8 * (size_t)wpr + SLOT_FIXED_BYTES; }
+
 size_t pool_lds_bytes(uint32_t wpr, uint32_t slots) {
-    const size_t wave_bytes = (POOL_FIXED + (size_t)slots * (8 * wpr + 48 + ST_COUNT) + 15) & ~(size_t)15;
+    const size_t wave_bytes = (POOL_FIXED + (size_t)slots * pool_slot_bytes(wpr) + 15) & ~(size_t)15;
     return wave_bytes * (PA_MAP_BLOCK / 64);
 }
 

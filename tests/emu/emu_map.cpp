@@ -7,6 +7,7 @@
 // kernels.hip and are covered by the `-m gpu` tier. Nothing in the product links or loads this file.
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../../rust-pseudoaligner_amd/csrc/device_flatten.hpp"
@@ -17,6 +18,7 @@ using namespace pa;
 
 struct emu_index {
     FlatDevice fd;
+    std::map<std::vector<uint32_t>, uint32_t> by_list;   // id list -> class id: brute-force check of the window table
 };
 
 extern "C" {
@@ -25,6 +27,8 @@ int emu_index_new(const pa_flat_index* f, int threads, emu_index** out) {
     emu_index* e = new emu_index();
     int rc = flatten_for_device(*f, threads, e->fd);
     if (rc != PA_OK) { delete e; return rc; }
+    for (uint32_t c = 0; c < f->num_classes; ++c)
+        e->by_list[std::vector<uint32_t>(f->ec_ids + f->ec_offset[c], f->ec_ids + f->ec_offset[c + 1])] = c;
     *out = e;
     return PA_OK;
 }
@@ -48,7 +52,8 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
     const DevIndexView ix = e->fd.host_view();
     std::vector<uint32_t> all;
     std::vector<uint64_t> rd(wpr + 2);
-    alignas(16) uint32_t refs[4], lens4[4], cids4[4];
+    alignas(16) uint32_t refs[4], lens4[4], cids4[4], win4[4];
+    uint32_t wcand[2];
     std::vector<uint32_t> spill, trace;
     (void)col_cap;
     uint64_t st_seek = 0, st_fwd = 0, st_left = 0, st_spill = 0;
@@ -62,7 +67,7 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
         Lane s;
         lane_start(s, (uint32_t)i, L, ix.k);
         const ReadRef rr{rd.data(), 1, wpr};
-        const ColRef cr{refs, refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), trace.data()};
+        const ColRef cr{win4, wcand, refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), trace.data()};
         while (l_st(s) == ST_SEEK || l_st(s) == ST_FWD || l_st(s) == ST_LEFT) {
             if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
             else if (l_st(s) == ST_FWD) { fwd_step<true>(s, ix, rr, cr, allowed); ++st_fwd; }
@@ -77,24 +82,30 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
         class_offsets[i] = all.size();
         pa_read_result res{0, 0, 0, 0};
         uint32_t colour = 0xFFFFFFFFu;
-        if (l_st(s) == ST_ISECT && !(l_flags(s) & F_LISTS)) {   // window mode: {base, mask, class id or NO_CLASS}
-            const uint32_t base = refs[0], mask = refs[1], cand = refs[2];
-            const uint32_t count = (uint32_t)__builtin_popcount(mask);
+        if (l_st(s) == ST_ISECT && !(l_flags(s) & F_LISTS)) {   // window mode: {base1, mask1, base2, mask2} + class id or NO_CLASS
+            const uint32_t cand = wcand[0];
+            const uint32_t count = (uint32_t)(__builtin_popcount(win4[1]) + __builtin_popcount(win4[3]));
             const size_t o = all.size();
             all.resize(o + count);
             uint32_t j = 0;
-            for (uint32_t t = mask; t; t &= t - 1) all[o + j++] = base + (uint32_t)__builtin_ctz(t);
+            for (uint32_t t = win4[1]; t; t &= t - 1) all[o + j++] = win4[0] + (uint32_t)__builtin_ctz(t);
+            for (uint32_t t = win4[3]; t; t &= t - 1) all[o + j++] = win4[2] + (uint32_t)__builtin_ctz(t);
             res.coverage = l_cov(s);
             res.mismatches = l_mism(s) | PA_MAPPED_BIT;
             res.class_len = count;
             res.class_off = (uint32_t)o;
+            const std::vector<uint32_t> ids(all.begin() + o, all.end());
+            const auto it = e->by_list.find(ids);
+            const uint32_t truth = it == e->by_list.end() ? NO_CLASS : it->second;
             if (cand != NO_CLASS) {   // returned by reference: must be exactly that index class
                 colour = cand;
                 res.class_off = PA_CLASS_REF | colour;
-                if (colour >= ix.num_classes || ix.class_len[colour] != count) return PA_ERR_INTERNAL;
-                const uint32_t* cls = pa::class_ids(ix, ix.class_ref[colour]);
-                for (uint32_t q = 0; q < count; ++q)
-                    if (cls[q] != all[o + q]) return PA_ERR_INTERNAL;
+                if (colour != truth) return PA_ERR_INTERNAL;
+            } else if (count) {       // strict subset of every class seen: the window table says whether it is a class anyway
+                uint32_t b1 = win4[0], m1 = win4[1], b2 = win4[2], m2 = win4[3];
+                window_canon(b1, m1, b2, m2);
+                colour = window_class(ix, b1, m1, b2, m2);
+                if (colour != truth) return PA_ERR_INTERNAL;
             }
         } else if (l_st(s) == ST_ISECT) {
             const Isect is = isect_count(s, ix, cr);
