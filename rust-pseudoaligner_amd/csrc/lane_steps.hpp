@@ -323,15 +323,17 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
     const uint32_t probe = l_probe(s);
     uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + probe;
     if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
-    const U4* line = reinterpret_cast<const U4*>(ix.table + (uint64_t)b * BUCKET_WORDS);
-    const U4 fp = line[0], e0 = line[1], e1 = line[2], e2 = line[3];   // the whole 64-byte bucket, one round trip
+    const uint32_t* linew = ix.table + (uint64_t)b * BUCKET_WORDS;
+    const U4 fp = *reinterpret_cast<const U4*>(linew);
     const uint32_t klo = (uint32_t)kmer, khi = (uint32_t)(kmer >> 32);
     const uint32_t want = klo & 0x7FFFFFFFu, top = klo >> 31;
-    // entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j
-    const bool h0 = fp.x == want && e0.x == khi && (e0.z >> 31) == top, h1 = fp.y == want && e0.w == khi && (e1.y >> 31) == top,
-               h2 = fp.z == want && e1.z == khi && (e2.x >> 31) == top, h3 = fp.w == want && e2.y == khi && (e2.w >> 31) == top;
-    const uint32_t h = h0 ? e0.y : h1 ? e1.x : h2 ? e1.w : h3 ? e2.z : NO_HANDLE;
-    const uint32_t off = (h0 ? e0.z : h1 ? e1.y : h2 ? e2.x : e2.w) & 0x7FFFFFFFu;
+    // entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j: fetch the one whose fingerprint matches (same line)
+    const uint32_t j = fp.x == want ? 0u : fp.y == want ? 1u : fp.z == want ? 2u : 3u;
+    const U3 e = *reinterpret_cast<const U3*>(linew + 4 + 3 * j);
+    const bool anyfp = (fp.x == want) | (fp.y == want) | (fp.z == want) | (fp.w == want);
+    const bool hit = anyfp && e.x == khi && (e.z >> 31) == top;
+    const uint32_t h = hit ? e.y : NO_HANDLE;
+    const uint32_t off = e.z & 0x7FFFFFFFu;
     s.nc &= ~(15u << 12);                                           // probe index back to 0
     if (h != NO_HANDLE) {                                           // Some((nid, offset)) (:106)
         s.h = h;
