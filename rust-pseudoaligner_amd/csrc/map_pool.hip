@@ -59,6 +59,9 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src) {
 __device__ __forceinline__ uint64_t arena_alloc(uint32_t cnt_alloc, uint32_t lane, karg_ptr p, lds_u64w chunk) {
     const uint32_t incl = wave_incl_scan(cnt_alloc);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    // LDS that one lane writes and other lanes read later: the compiler reasons per thread and would otherwise reuse a value
+    // this lane loaded before another lane's store ("memory" = reload)
+    asm volatile("" ::: "memory");
     unsigned long long chunk_cur = chunk[0];
     if (total > 0) {
         if (chunk_cur + total > chunk[1]) {   // take a new private slice of the class arena (one global atomic per chunk)
@@ -71,6 +74,7 @@ __device__ __forceinline__ uint64_t arena_alloc(uint32_t cnt_alloc, uint32_t lan
         }
         if (lane == 0) chunk[0] = chunk_cur + total;
     }
+    asm volatile("" ::: "memory");
     return chunk_cur + (incl - cnt_alloc);
 }
 
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
 #define PA_CNT(t) ((uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)(t)))
 
     for (;;) {
-        asm volatile("" : "+s"(kp));
+        asm volatile("" : "+s"(kp) : : "memory");   // also: slots and queues in LDS change hands between lanes every iteration
         const DevIndexView ix = view_of(kp);
         const glb_u32 ec = (glb_u32)ix.ec;
         const uint32_t K = ix.k, allowed = p.allowed, spill_cap = p.spill_cap;

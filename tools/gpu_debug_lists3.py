@@ -1,0 +1,39 @@
+"""Debug aid: device API with a poisoned arena: are wrong class ids unwritten slices or overwritten ones? (GPU box)"""
+import importlib, sys
+import numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+pa = importlib.import_module("rust-pseudoaligner_amd")
+import helpers
+helpers.build_all()
+k, read_len, n = 24, 100, int(sys.argv[1]) if len(sys.argv) > 1 else 300000
+hi = pa.HostIndex.build_fasta(helpers.FASTA, k, 8)
+a = pa.Pseudoaligner(hi)
+tx = pa.Txome.from_host_index(hi)
+wpr = pa.lib().pa_words_per_read(read_len)
+dev = torch.device("cuda", 0)
+h_tiles, h_lens = tx.simulate_host(read_len, 4, n, 0, 0, wpr)
+d_tiles = torch.from_numpy(h_tiles.view(np.int64)).to(dev); d_lens = torch.from_numpy(h_lens.view(np.int32)).to(dev)
+cap = a.arena_hint(n)
+d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+d_arena = torch.full((cap,), -286331154, dtype=torch.int32, device=dev)   # 0xEEEEEEEE
+a.map_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, 2, 0)
+used, _ = a.map_finish()
+res = d_res.cpu().numpy().view(pa.RESULT_DTYPE)
+arena = d_arena.cpu().numpy().view(np.uint32)
+o_res, o_coff, o_ids, ctr = helpers.Oracle(hi).map_tiles(h_tiles, h_lens, wpr, 2, 8)
+bad = 0
+owners = {}
+for i in range(n):
+    if not (res["class_off"][i] >> 31) and res["class_len"][i]:
+        for q in range(int(res["class_off"][i]), int(res["class_off"][i]) + int(res["class_len"][i])):
+            owners.setdefault(q, []).append(i)
+dups = [(q, v) for q, v in owners.items() if len(v) > 1]
+print("arena used", used, "overlapping entries", len(dups), dups[:5])
+for i in range(n):
+    if res["class_off"][i] >> 31: continue
+    L = int(res["class_len"][i]); off = int(res["class_off"][i])
+    g = arena[off:off + L].tolist(); e = o_ids[int(o_coff[i]):int(o_coff[i + 1])].tolist()
+    if g != e:
+        if bad < 10: print("read", i, "off", off, "got", [hex(x) if x > 1 << 24 else x for x in g], "exp", e)
+        bad += 1
+print("bad", bad)
