@@ -94,6 +94,16 @@ static int upload(const void* src, size_t bytes, void** dst) {
     return PA_OK;
 }
 
+extern "C++" {
+namespace pa {
+void index_host_classes(const pa_index* idx, const uint32_t** ec, const uint32_t** class_ref, int* device) {
+    *ec = idx->h_ec.data();
+    *class_ref = idx->h_class_ref.data();
+    *device = idx->device;
+}
+}  // namespace pa
+}
+
 void pa_index_destroy(pa_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);

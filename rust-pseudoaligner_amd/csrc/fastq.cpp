@@ -1,9 +1,32 @@
-// Host driver mirroring process_reads (src/pseudoaligner.rs:420-514): FASTQ in, one Rust-Debug-formatted tuple per
-// read out. The reference's per-record mutex (src/utils.rs:152-157), bounded channel (:430,:464) and serial println
-// consumer (:490) are replaced by: parse a batch -> one pa_map_batch call (GPU) -> format in parallel -> write in INPUT
-// order. The flag rule of :455 is kept as is (true iff coverage >= 32 and the class is EMPTY).
+// Host ingest pipeline mirroring process_reads (src/pseudoaligner.rs:420-514): FASTQ in, one Rust-Debug-formatted tuple
+// per read out, in INPUT order. The reference's per-record mutex around the reader (src/utils.rs:152-157), bounded
+// channel (:430,:464) and serial println consumer (:490) become a batch pipeline whose stages overlap:
+//
+//   scan     the FASTQ file is memory-mapped; all host threads count line breaks in their byte range, then record the
+//            start of every 4-line record (no thread ever parses a byte twice, nobody takes a lock)
+//   pack     per batch: threads 2-bit pack their reads straight into pinned tiles (the layout the kernel reads)
+//   GPU      one stream: tiles H2D -> pa_map_batch_device -> results D2H; runs while the host formats the previous batch
+//            and packs the next one
+//   format   threads render "(flag, id, [ids], coverage)" (:455-461,:490) into per-thread buffers; classes returned by
+//            reference are read from the host copy of the class table
+//   write    a writer thread streams the buffers to the output in order
+//
+// The flag rule of :455 is kept as is (true iff coverage >= 32 and the class is EMPTY).
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "pa_common.hpp"
@@ -12,19 +35,103 @@ using namespace pa;
 
 namespace {
 
-constexpr size_t BATCH_READS = 1u << 20;
+constexpr uint64_t DEFAULT_BATCH_READS = 4u << 20;   // PA_INGEST_BATCH overrides (tests exercise the batch seams with small values)
 
-struct Batch {
-    std::vector<uint8_t> seq;
-    std::vector<uint64_t> off{0};
-    std::vector<std::string> ids;
-    void clear() { seq.clear(); off.assign(1, 0); ids.clear(); }
+// persistent worker threads; run(n, fn) executes fn(0..n-1) on them (and on the caller) and returns when all are done
+class Pool {
+public:
+    explicit Pool(int threads) : nthreads_(threads < 1 ? 1 : threads) {
+        for (int t = 1; t < nthreads_; ++t) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& w : workers_) w.join();
+    }
+    int size() const { return nthreads_; }
+    void run(int ntasks, const std::function<void(int)>& fn) {
+        if (ntasks <= 0) return;
+        { std::lock_guard<std::mutex> g(mu_); fn_ = &fn; ntasks_ = ntasks; next_ = 0; pending_ = ntasks; ++epoch_; }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void work() {
+        for (;;) {
+            int t;
+            const std::function<void(int)>* fn;
+            { std::lock_guard<std::mutex> g(mu_); if (!fn_ || next_ >= ntasks_) return; t = next_++; fn = fn_; }
+            (*fn)(t);
+            { std::lock_guard<std::mutex> g(mu_); if (--pending_ == 0) done_.notify_all(); }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> g(mu_); cv_.wait(g, [&] { return stop_ || epoch_ != seen; }); if (stop_) return; seen = epoch_; }
+            work();
+        }
+    }
+    int nthreads_;
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int ntasks_ = 0, next_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+
+// in-order writer: buffers handed over by the main thread are written by a dedicated thread
+class Writer {
+public:
+    explicit Writer(FILE* f) : f_(f), th_([this] { loop(); }) {}
+    void push(std::vector<std::string>&& parts) {
+        std::unique_lock<std::mutex> g(mu_);
+        room_.wait(g, [this] { return q_.size() < 2; });   // bounded: at most two batches of text in memory
+        q_.push_back(std::move(parts));
+        cv_.notify_one();
+    }
+    bool finish() {
+        { std::lock_guard<std::mutex> g(mu_); done_ = true; }
+        cv_.notify_one();
+        th_.join();
+        return ok_;
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            std::vector<std::string> parts;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [this] { return done_ || !q_.empty(); });
+                if (q_.empty()) return;
+                parts = std::move(q_.front());
+                q_.pop_front();
+                room_.notify_one();
+            }
+            for (const std::string& s : parts)
+                if (ok_ && !s.empty() && fwrite(s.data(), 1, s.size(), f_) != s.size()) ok_ = false;
+        }
+    }
+    FILE* f_;
+    std::mutex mu_;
+    std::condition_variable cv_, room_;
+    std::deque<std::vector<std::string>> q_;
+    bool done_ = false, ok_ = true;
+    std::thread th_;
 };
 
 // Rust `impl Debug for str`: quotes, backslash escapes for \t \r \n \\ \" and \u{..} for other control bytes
-void debug_str(std::string& out, const std::string& s) {
+void debug_str(std::string& out, const char* s, size_t n) {
     out.push_back('"');
-    for (unsigned char c : s) {
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = (unsigned char)s[i];
         switch (c) {
             case '\t': out += "\\t"; break;
             case '\r': out += "\\r"; break;
@@ -39,18 +146,45 @@ void debug_str(std::string& out, const std::string& s) {
     out.push_back('"');
 }
 
-bool read_line(FILE* f, std::string& line) {
-    line.clear();
-    int c;
-    bool any = false;
-    while ((c = fgetc_unlocked(f)) != EOF) {
-        any = true;
-        if (c == '\n') break;
-        line.push_back((char)c);
-    }
-    if (!line.empty() && line.back() == '\r') line.pop_back();
-    return any;
+void append_u32(std::string& out, uint32_t v) {
+    char b[10];
+    int n = 0;
+    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) out.push_back(b[--n]);
 }
+
+struct Record {   // one FASTQ record inside the mapped file
+    uint64_t id_off;
+    uint32_t id_len, seq_len;
+    uint64_t seq_off;
+};
+
+const char* line_end(const char* p, const char* end) {
+    const char* e = (const char*)memchr(p, '\n', (size_t)(end - p));
+    return e ? e : end;
+}
+
+struct BatchCtx {   // pinned host buffers + device buffers of one batch in flight
+    uint64_t* h_tiles = nullptr;
+    uint32_t* h_lens = nullptr;
+    pa_read_result* h_results = nullptr;
+    void *d_tiles = nullptr, *d_lens = nullptr, *d_results = nullptr, *d_arena = nullptr;
+    size_t tiles_bytes = 0, arena_entries = 0;
+    std::vector<uint32_t> h_arena;
+    std::vector<Record> recs;
+    uint64_t first = 0, n = 0;
+    uint32_t wpr = 1;
+    void release() {
+        if (h_tiles) (void)hipHostFree(h_tiles);
+        if (h_lens) (void)hipHostFree(h_lens);
+        if (h_results) (void)hipHostFree(h_results);
+        for (void* p : {d_tiles, d_lens, d_results, d_arena})
+            if (p) (void)hipFree(p);
+        *this = BatchCtx();
+    }
+};
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(PA_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
 }  // namespace
 
@@ -58,84 +192,277 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                                 uint64_t* n_flagged_out) {
     if (!idx || !fastq_path || !out_path) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (num_threads < 1) num_threads = 1;
-    FILE* in = fopen(fastq_path, "rb");
-    if (!in) return fail(PA_ERR_IO, "cannot open %s: %s", fastq_path, strerror(errno));
-    FILE* out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
-    if (!out) { fclose(in); return fail(PA_ERR_IO, "cannot create %s: %s", out_path, strerror(errno)); }
-    std::vector<char> iobuf(1 << 22);
-    setvbuf(in, iobuf.data(), _IOFBF, iobuf.size());
+    if (n_reads_out) *n_reads_out = 0;
+    if (n_flagged_out) *n_flagged_out = 0;
+    const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
+    int device = 0;
+    index_host_classes(idx, &h_ec, &h_class_ref, &device);
+    HIP_OK(hipSetDevice(device));
 
-    Batch b;
-    std::string l1, l2, l3, l4;
-    uint64_t read_counter = 0, flagged = 0, next_report = 1000000;
+    // ---- map the file ----
+    const int fd = open(fastq_path, O_RDONLY);
+    if (fd < 0) return fail(PA_ERR_IO, "cannot open %s: %s", fastq_path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return fail(PA_ERR_IO, "cannot stat %s: %s", fastq_path, strerror(errno)); }
+    const uint64_t fsize = (uint64_t)st.st_size;
+    const char* data = nullptr;
+    if (fsize) {
+        void* m = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); return fail(PA_ERR_IO, "cannot map %s: %s", fastq_path, strerror(errno)); }
+        (void)madvise(m, fsize, MADV_SEQUENTIAL);
+        data = (const char*)m;
+    }
+    close(fd);
+    FILE* out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
+    if (!out) { if (data) munmap((void*)data, fsize); return fail(PA_ERR_IO, "cannot create %s: %s", out_path, strerror(errno)); }
+    std::vector<char> obuf(1 << 22);
+    setvbuf(out, obuf.data(), _IOFBF, obuf.size());
+
+    uint64_t BATCH_READS = DEFAULT_BATCH_READS;
+    if (const char* v = getenv("PA_INGEST_BATCH")) { const long long x = atoll(v); if (x >= 64) BATCH_READS = (uint64_t)x / 64 * 64; }
+    Pool pool(num_threads);
+    const int T = pool.size();
     int rc = PA_OK;
-    bool eof = false;
-    std::vector<pa_read_result> results;
-    std::vector<uint64_t> coff;
-    while (!eof && rc == PA_OK) {
-        b.clear();
-        while (b.ids.size() < BATCH_READS) {
-            if (!read_line(in, l1)) { eof = true; break; }
-            if (l1.empty()) continue;
-            if (l1[0] != '@' || !read_line(in, l2) || !read_line(in, l3) || l3.empty() || l3[0] != '+' || !read_line(in, l4)) {
-                rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu", fastq_path, (unsigned long long)(read_counter + b.ids.size()));
-                break;
+    uint64_t nrec = 0;
+    std::vector<uint64_t> rec_start;
+
+    // ---- scan: line breaks per byte range, then the start of every fourth line ----
+    {
+        const int R = (int)std::min<uint64_t>((uint64_t)T * 4, fsize / (1 << 16) + 1);
+        std::vector<uint64_t> nl((size_t)R + 1, 0);
+        auto range = [&](int r, uint64_t& a, uint64_t& b) { a = fsize * (uint64_t)r / R; b = fsize * (uint64_t)(r + 1) / R; };
+        pool.run(R, [&](int r) {
+            uint64_t a, b, c = 0;
+            range(r, a, b);
+            for (const char* p = data + a; p < data + b;) {
+                const char* e = (const char*)memchr(p, '\n', (size_t)(data + b - p));
+                if (!e) break;
+                ++c;
+                p = e + 1;
             }
-            const size_t sp = l1.find_first_of(" \t");
-            b.ids.emplace_back(l1, 1, sp == std::string::npos ? std::string::npos : sp - 1);   // record.id() (:456)
-            b.seq.insert(b.seq.end(), l2.begin(), l2.end());
-            b.off.push_back(b.seq.size());
-        }
-        if (rc != PA_OK || b.ids.empty()) break;
-        const uint64_t n = b.ids.size();
-        results.resize(n);
-        coff.resize(n + 1);
-        const uint32_t* cids = nullptr;
-        rc = pa_map_batch(idx, b.seq.data(), b.off.data(), n, PA_DEFAULT_ALLOWED_MISMATCHES, results.data(), coff.data(), &cids);   // index.map_read (:451)
-        if (rc != PA_OK) break;
-        std::vector<std::string> parts((size_t)num_threads);
-        std::vector<uint64_t> flags((size_t)num_threads, 0);
-        auto fmt = [&](int t) {
-            std::string& o = parts[t];
-            char num[32];
-            for (uint64_t i = n * t / num_threads; i < n * (t + 1) / num_threads; ++i) {
-                const pa_read_result& r = results[i];
-                const bool mapped = r.mismatches & PA_MAPPED_BIT;
-                const bool flag = mapped && r.coverage >= PA_READ_COVERAGE_THRESHOLD && r.class_len == 0;   // :455
-                flags[t] += flag;
-                o += flag ? "(true, " : "(false, ";
-                debug_str(o, b.ids[i]);
-                o += ", [";
-                for (uint32_t j = 0; j < r.class_len; ++j) {
-                    if (j) o += ", ";
-                    snprintf(num, sizeof num, "%u", cids[coff[i] + j]);
-                    o += num;
+            nl[(size_t)r + 1] = c;
+        });
+        for (int r = 0; r < R; ++r) nl[(size_t)r + 1] += nl[(size_t)r];
+        // trailing empty lines are tolerated: lines = line breaks before the last content byte + 1
+        uint64_t tail = fsize, trailing_nl = 0;
+        while (tail > 0 && (data[tail - 1] == '\n' || data[tail - 1] == '\r')) { trailing_nl += data[tail - 1] == '\n'; --tail; }
+        const uint64_t content_lines = tail ? nl[(size_t)R] - trailing_nl + 1 : 0;
+        if (content_lines % 4 != 0)
+            rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu (file ends inside a record)", fastq_path, (unsigned long long)(content_lines / 4));
+        nrec = content_lines / 4;
+        if (rc == PA_OK && nrec) {
+            rec_start.assign(nrec, 0);
+            pool.run(R, [&](int r) {
+                uint64_t a, b;
+                range(r, a, b);
+                // index of the first line that STARTS in [a, b)
+                uint64_t li = nl[(size_t)r];
+                const char* p = data + a;
+                if (a > 0 && data[a - 1] != '\n') {
+                    const char* e = (const char*)memchr(p, '\n', (size_t)(data + fsize - p));
+                    if (!e) return;
+                    p = e + 1;
+                    li += 1;
                 }
-                snprintf(num, sizeof num, "], %u)\n", mapped ? r.coverage : 0u);   // None -> (false, id, [], 0) (:461)
-                o += num;
-            }
-        };
-        if (num_threads == 1) fmt(0);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < num_threads; ++t) th.emplace_back(fmt, t);
-            for (auto& t : th) t.join();
-        }
-        for (int t = 0; t < num_threads; ++t) {
-            if (fwrite(parts[t].data(), 1, parts[t].size(), out) != parts[t].size()) { rc = fail(PA_ERR_IO, "short write to %s", out_path); break; }
-            flagged += flags[t];
-        }
-        read_counter += n;
-        while (read_counter >= next_report) {   // :497-503
-            fprintf(stderr, "\rDone Mapping %llu reads w/ Rate: %g", (unsigned long long)next_report,
-                    (double)((float)flagged * 100.0f / (float)read_counter));
-            next_report += 1000000;
+                while (p < data + b && p < data + fsize) {
+                    if (li % 4 == 0 && li / 4 < nrec) rec_start[li / 4] = (uint64_t)(p - data);
+                    const char* e = (const char*)memchr(p, '\n', (size_t)(data + fsize - p));
+                    if (!e) break;
+                    p = e + 1;
+                    ++li;
+                }
+            });
         }
     }
-    fclose(in);
+
+    // ---- batches ----
+    BatchCtx ctx[2];
+    hipStream_t stream = nullptr;
+    if (rc == PA_OK && hipStreamCreate(&stream) != hipSuccess) rc = fail(PA_ERR_HIP, "hipStreamCreate failed");
+    Writer writer(out);
+    uint64_t flagged = 0, next_report = 1000000, reported = 0;
+    const uint64_t nb = (nrec + BATCH_READS - 1) / BATCH_READS;
+    std::atomic<uint64_t> bad_record{~0ull};
+
+    auto ensure = [&](BatchCtx& c, uint64_t n, uint32_t wpr) -> int {
+        const size_t tb = pa_tiles_words(n, wpr) * 8 + 8;
+        if (tb > c.tiles_bytes || !c.h_tiles) {
+            const size_t cap_reads = std::max<uint64_t>(n, std::min<uint64_t>(BATCH_READS, nrec));
+            const size_t want = pa_tiles_words(cap_reads, wpr) * 8 + 8;
+            if (c.h_tiles) (void)hipHostFree(c.h_tiles);
+            if (c.d_tiles) (void)hipFree(c.d_tiles);
+            c.h_tiles = nullptr; c.d_tiles = nullptr;
+            HIP_OK(hipHostMalloc((void**)&c.h_tiles, want, hipHostMallocDefault));
+            HIP_OK(hipMalloc(&c.d_tiles, want));
+            c.tiles_bytes = want;
+        }
+        if (!c.h_lens) {
+            const size_t cap_reads = std::min<uint64_t>(BATCH_READS, nrec) + 64;
+            HIP_OK(hipHostMalloc((void**)&c.h_lens, cap_reads * 4, hipHostMallocDefault));
+            HIP_OK(hipHostMalloc((void**)&c.h_results, cap_reads * sizeof(pa_read_result), hipHostMallocDefault));
+            HIP_OK(hipMalloc(&c.d_lens, cap_reads * 4));
+            HIP_OK(hipMalloc(&c.d_results, cap_reads * sizeof(pa_read_result)));
+        }
+        const uint64_t hint = pa_map_arena_hint(idx, n);
+        if (hint > c.arena_entries) {
+            if (c.d_arena) (void)hipFree(c.d_arena);
+            c.d_arena = nullptr;
+            HIP_OK(hipMalloc(&c.d_arena, hint * 4));
+            c.arena_entries = hint;
+        }
+        return PA_OK;
+    };
+
+    // parse + pack batch b (parallel over whole tiles)
+    auto pack = [&](BatchCtx& c, uint64_t b) -> int {
+        c.first = b * BATCH_READS;
+        c.n = std::min<uint64_t>(BATCH_READS, nrec - c.first);
+        c.recs.resize(c.n);
+        std::vector<uint32_t> tmax((size_t)T * 4, 0);
+        const int ntask = T * 4;
+        pool.run(ntask, [&](int t) {   // records + lengths
+            uint32_t mx = 0;
+            for (uint64_t i = c.n * (uint64_t)t / ntask; i < c.n * (uint64_t)(t + 1) / ntask; ++i) {
+                const char* end = data + fsize;
+                const char* p = data + rec_start[c.first + i];
+                const char* l1e = line_end(p, end);
+                const char* l2 = l1e < end ? l1e + 1 : end;
+                const char* l2e = line_end(l2, end);
+                const char* l3 = l2e < end ? l2e + 1 : end;
+                if (*p != '@' || l3 >= end || *l3 != '+') {
+                    uint64_t cur = bad_record.load();
+                    while (c.first + i < cur && !bad_record.compare_exchange_weak(cur, c.first + i)) {}
+                    continue;
+                }
+                const char* ide = p + 1;
+                while (ide < l1e && *ide != ' ' && *ide != '\t' && *ide != '\r') ++ide;   // record.id() (:456): up to the first blank
+                const char* se = l2e;
+                if (se > l2 && se[-1] == '\r') --se;
+                Record& rec = c.recs[i];
+                rec.id_off = (uint64_t)(p + 1 - data);
+                rec.id_len = (uint32_t)(ide - (p + 1));
+                rec.seq_off = (uint64_t)(l2 - data);
+                rec.seq_len = (uint32_t)std::min<uint64_t>((uint64_t)(se - l2), 0xFFFFFFFFull);
+                mx = std::max(mx, rec.seq_len);
+            }
+            tmax[(size_t)t] = mx;
+        });
+        if (bad_record.load() != ~0ull)
+            return fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu", fastq_path, (unsigned long long)bad_record.load());
+        uint32_t maxlen = 1;
+        for (uint32_t m : tmax) maxlen = std::max(maxlen, m);
+        if (maxlen > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
+        c.wpr = pa_words_per_read(maxlen);
+        const int e = ensure(c, c.n, c.wpr);
+        if (e != PA_OK) return e;
+        const uint64_t ntiles = (c.n + 63) / 64;
+        const uint32_t wpr = c.wpr;
+        pool.run(ntask, [&](int t) {   // DnaString::from_dna_string (:450): A0 C1 G2 T3, anything else A, either case
+            for (uint64_t tile = ntiles * (uint64_t)t / ntask; tile < ntiles * (uint64_t)(t + 1) / ntask; ++tile) {
+                uint64_t* tw = c.h_tiles + tile * wpr * 64;
+                for (uint32_t r = 0; r < 64; ++r) {
+                    const uint64_t i = tile * 64 + r;
+                    if (i >= c.n) {
+                        for (uint32_t w = 0; w < wpr; ++w) tw[(uint64_t)w * 64 + r] = 0;
+                        continue;
+                    }
+                    const Record& rec = c.recs[i];
+                    const uint8_t* sq = (const uint8_t*)data + rec.seq_off;
+                    c.h_lens[i] = rec.seq_len;
+                    for (uint32_t w = 0; w < wpr; ++w) {
+                        uint64_t v = 0;
+                        const uint32_t b0 = 32 * w, nbases = rec.seq_len > b0 ? std::min<uint32_t>(32, rec.seq_len - b0) : 0;
+                        for (uint32_t j = 0; j < nbases; ++j) {
+                            const uint8_t ch = sq[b0 + j] & 0xDF;
+                            const uint64_t code = ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0u;
+                            v |= code << (2 * j);
+                        }
+                        tw[(uint64_t)w * 64 + r] = v;
+                    }
+                }
+            }
+        });
+        return PA_OK;
+    };
+
+    auto launch = [&](BatchCtx& c) -> int {
+        HIP_OK(hipMemcpyAsync(c.d_tiles, c.h_tiles, pa_tiles_words(c.n, c.wpr) * 8, hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(c.d_lens, c.h_lens, c.n * 4, hipMemcpyHostToDevice, stream));
+        const int e = pa_map_batch_device(idx, (const uint64_t*)c.d_tiles, (const uint32_t*)c.d_lens, c.n, c.wpr, PA_DEFAULT_ALLOWED_MISMATCHES,
+                                          (pa_read_result*)c.d_results, (uint32_t*)c.d_arena, c.arena_entries, nullptr, stream);   // index.map_read (:451)
+        if (e != PA_OK) return e;
+        HIP_OK(hipMemcpyAsync(c.h_results, c.d_results, c.n * sizeof(pa_read_result), hipMemcpyDeviceToHost, stream));
+        return PA_OK;
+    };
+
+    auto finish = [&](BatchCtx& c) -> int {
+        uint64_t used = 0, need = 0;
+        int e = pa_map_finish(idx, stream, &used, &need);
+        for (int attempt = 0; e == PA_ERR_ARENA_FULL && attempt < 3; ++attempt) {   // grow the class arena and map the batch again
+            if (c.d_arena) (void)hipFree(c.d_arena);
+            c.d_arena = nullptr;
+            c.arena_entries = need + need / 8 + 4096;
+            HIP_OK(hipMalloc(&c.d_arena, c.arena_entries * 4));
+            e = launch(c);
+            if (e == PA_OK) e = pa_map_finish(idx, stream, &used, &need);
+        }
+        if (e != PA_OK) return e;
+        c.h_arena.resize(used + 1);
+        if (used) HIP_OK(hipMemcpy(c.h_arena.data(), c.d_arena, used * 4, hipMemcpyDeviceToHost));
+        return PA_OK;
+    };
+
+    auto format = [&](BatchCtx& c) {
+        std::vector<std::string> parts((size_t)T);
+        std::vector<uint64_t> flags((size_t)T, 0);
+        pool.run(T, [&](int t) {
+            std::string& o = parts[(size_t)t];
+            const uint64_t a = c.n * (uint64_t)t / T, b = c.n * (uint64_t)(t + 1) / T;
+            o.reserve((size_t)(b - a) * 64);
+            for (uint64_t i = a; i < b; ++i) {
+                const pa_read_result& r = c.h_results[i];
+                const bool mapped = r.mismatches & PA_MAPPED_BIT;
+                const bool flag = mapped && r.coverage >= PA_READ_COVERAGE_THRESHOLD && r.class_len == 0;   // :455
+                flags[(size_t)t] += flag;
+                o += flag ? "(true, " : "(false, ";
+                debug_str(o, data + c.recs[i].id_off, c.recs[i].id_len);
+                o += ", [";
+                const uint32_t* ids = (r.class_off & PA_CLASS_REF) ? h_ec + 4ull * h_class_ref[r.class_off & ~PA_CLASS_REF] + 1
+                                                                   : c.h_arena.data() + r.class_off;
+                for (uint32_t j = 0; j < r.class_len; ++j) {
+                    if (j) o += ", ";
+                    append_u32(o, ids[j]);
+                }
+                o += "], ";
+                append_u32(o, mapped ? r.coverage : 0u);   // None -> (false, id, [], 0) (:461)
+                o += ")\n";
+            }
+        });
+        for (uint64_t f : flags) flagged += f;
+        reported += c.n;
+        while (reported >= next_report) {   // :497-503
+            fprintf(stderr, "\rDone Mapping %llu reads w/ Rate: %g", (unsigned long long)next_report,
+                    (double)((float)flagged * 100.0f / (float)reported));
+            next_report += 1000000;
+        }
+        writer.push(std::move(parts));
+    };
+
+    // pack(b) overlaps GPU(b-1); format(b-1) overlaps GPU(b)
+    for (uint64_t b = 0; rc == PA_OK && b <= nb && nb > 0; ++b) {
+        if (b < nb) rc = pack(ctx[b & 1], b);
+        if (rc == PA_OK && b >= 1) rc = finish(ctx[(b - 1) & 1]);
+        if (rc == PA_OK && b < nb) rc = launch(ctx[b & 1]);
+        if (rc == PA_OK && b >= 1) format(ctx[(b - 1) & 1]);
+    }
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    const bool wrote = writer.finish();
+    if (rc == PA_OK && !wrote) rc = fail(PA_ERR_IO, "short write to %s", out_path);
+    for (BatchCtx& c : ctx) c.release();
+    if (data) munmap((void*)data, fsize);
     if (out != stdout) { if (fclose(out) != 0 && rc == PA_OK) rc = fail(PA_ERR_IO, "close %s: %s", out_path, strerror(errno)); }
     else fflush(stdout);
-    if (n_reads_out) *n_reads_out = read_counter;
+    if (n_reads_out) *n_reads_out = reported;
     if (n_flagged_out) *n_flagged_out = flagged;
     return rc;
 }

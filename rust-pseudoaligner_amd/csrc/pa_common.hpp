@@ -15,6 +15,10 @@ namespace pa {
 std::string& last_error_ref();
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// host copy of the class records of a device index (device_index.hip): class c = ec[4 * class_ref[c] + 1 ...]; used to
+// resolve results returned by reference (PA_CLASS_REF) without a device round trip
+void index_host_classes(const pa_index* idx, const uint32_t** ec, const uint32_t** class_ref, int* device);
+
 // ---- 2-bit packed sequences, LSB-first (base j -> bits 2*(j%32) of word j/32) ----
 static inline uint64_t kmer_mask(uint32_t k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1); }
 

@@ -212,6 +212,54 @@ def test_process_reads_output_format(aligners, tmp_path):
         pa.process_reads(str(bad), a, str(out))
 
 
+def _expected_lines(a, ids, seqs):
+    res, coff, cids, _ = helpers.Oracle(a.host).map_reads(seqs, 2, 4)
+    want = []
+    for i, rid in enumerate(ids):
+        cl = cids[int(coff[i]):int(coff[i + 1])].tolist()
+        flag = bool(res["mapped"][i]) and res["coverage"][i] >= 32 and not cl
+        want.append('(%s, "%s", [%s], %d)' % ("true" if flag else "false", rid, ", ".join(map(str, cl)), res["coverage"][i] if res["mapped"][i] else 0))
+    return want
+
+
+def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
+    """the ingest pipeline of process_reads: many small batches, every thread count, CRLF, no final newline, trailing
+    blank lines, ragged read lengths (words per read change between batches), lower case and N, empty input"""
+    a = aligners(24)
+    ids, seqs = helpers.read_fastq()
+    rng = np.random.default_rng(5)
+    ids, seqs = list(ids[:3000]), list(seqs[:3000])
+    for i in range(0, 3000, 7):                       # ragged: truncate, extend with a second read, lower-case, N
+        s = seqs[i]
+        kind = i % 4
+        seqs[i] = s[: int(rng.integers(1, len(s)))] if kind == 0 else (s + seqs[(i + 1) % 3000] + s)[: int(rng.integers(61, 181))] if kind == 1 else \
+            s.lower() if kind == 2 else s[:20] + "N" + s[21:]
+    want = _expected_lines(a, ids, [s.upper().replace("N", "A") for s in seqs])
+    out = tmp_path / "o.txt"
+    variants = {
+        "plain": "".join("@%s extra words\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in zip(ids, seqs)),
+        "crlf": "".join("@%s\r\n%s\r\n+\r\n%s\r\n" % (i, s, "I" * len(s)) for i, s in zip(ids, seqs)),
+    }
+    variants["no_final_newline"] = variants["plain"][:-1]
+    variants["trailing_blank_lines"] = variants["plain"] + "\n\n\n"
+    for name, text in variants.items():
+        fq = tmp_path / (name + ".fq")
+        fq.write_text(text, newline="")
+        for batch, threads in ((64, 1), (192, 3), (1024, 8), (1 << 22, 5)):
+            monkeypatch.setenv("PA_INGEST_BATCH", str(batch))
+            n, flagged = pa.process_reads(str(fq), a, str(out), threads)
+            got = out.read_text().splitlines()
+            assert n == len(ids) and got == want, (name, batch, threads)
+            assert flagged == sum(1 for w in want if w.startswith("(true"))
+    empty = tmp_path / "empty.fq"
+    empty.write_text("")
+    assert pa.process_reads(str(empty), a, str(out), 4) == (0, 0) and out.read_text() == ""
+    trunc = tmp_path / "trunc.fq"
+    trunc.write_text("@r1\nACGT\n+\nIIII\n@r2\nACGT\n")
+    with pytest.raises(pa.PaError):
+        pa.process_reads(str(trunc), a, str(out), 2)
+
+
 def test_full_size_batch_properties(aligners):
     """BASELINE.json configs[1] size (10 M x 100 bp on gencode_small, K=24) through size-independent properties:
     every error-free read maps over its full length with 0 mismatches and a non-empty class; the count table adds up;

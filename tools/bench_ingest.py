@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""End-to-end rate of pa_process_reads: FASTQ text in page cache -> tuples to /dev/null, reads/s.
+
+Run on the GPU box: python tools/bench_ingest.py [--reads N] [--index-cache PATH]. Config-3 index, 150 bp reads."""
+import argparse, importlib, json, os, sys, time
+from pathlib import Path
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+pa = importlib.import_module("rust-pseudoaligner_amd")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=16_000_000)
+    ap.add_argument("--index-cache", default="/tmp/g.idx")
+    ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+    ap.add_argument("--threads", default="")
+    args = ap.parse_args()
+    t0 = time.time()
+    tx = pa.Txome.synthesize(58000, 203000, 7)
+    if os.path.exists(args.index_cache):
+        hi = pa.HostIndex.load(args.index_cache)
+    else:
+        hi = pa.HostIndex.from_txome(tx, 24, 0)
+        hi.save(args.index_cache)
+    al = pa.Pseudoaligner(hi)
+    print("[ingest] index ready %.1f s" % (time.time() - t0), file=sys.stderr)
+    n, L, wpr = args.reads, 150, 5
+    fq = Path(args.dir) / "pa_ingest_bench.fq"
+    t0 = time.time()
+    with open(fq, "wb") as f:   # "@r%09d\n" + seq + "\n+\n" + qual + "\n", written in chunks of 1 M reads
+        lut = np.frombuffer(b"ACGT", np.uint8)
+        for first in range(0, n, 1 << 20):
+            m = min(1 << 20, n - first)
+            tiles, lens = tx.simulate_host(L, 2, m, 0, first, wpr)
+            t = tiles.reshape(-1, wpr, 64)                       # [tile][word][read]
+            words = t.transpose(0, 2, 1).reshape(-1, wpr)[:m]    # [read][word]
+            shifts = (2 * np.arange(32, dtype=np.uint64))[None, None, :]
+            bases = ((words[:, :, None] >> shifts) & np.uint64(3)).astype(np.uint8).reshape(m, wpr * 32)[:, :L]
+            rec = np.empty((m, 16 + 2 * L), np.uint8)
+            ids = np.char.zfill(np.arange(first, first + m).astype("U9"), 9)
+            rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+            rec[:, 2:11] = np.frombuffer("".join(ids).encode(), np.uint8).reshape(m, 9)
+            rec[:, 11] = 10
+            rec[:, 12:12 + L] = lut[bases]
+            rec[:, 12 + L:12 + L + 3] = np.frombuffer(b"\n+\n", np.uint8)
+            rec[:, 15 + L:15 + 2 * L] = ord("I")
+            rec[:, 15 + 2 * L] = 10
+            f.write(rec.tobytes())
+    size = fq.stat().st_size
+    print("[ingest] %d reads, %.2f GB FASTQ written in %.1f s" % (n, size / 1e9, time.time() - t0), file=sys.stderr)
+    ncpu = os.cpu_count() or 1
+    threads = [int(x) for x in args.threads.split(",") if x] or sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(16, ncpu)}, reverse=True)
+    pa.process_reads(str(fq), al, "/dev/null", ncpu)   # warm-up (page cache, pinned buffers, kernels)
+    for t in threads:
+        t0 = time.time()
+        got, flagged = pa.process_reads(str(fq), al, "/dev/null", t)
+        dt = time.time() - t0
+        assert got == n
+        print(json.dumps({"metric": "reads/sec FASTQ text -> Debug tuples (pa_process_reads, /dev/null)", "value": n / dt, "unit": "reads/s",
+                          "threads": t, "reads": n, "seconds": dt, "fastq_GBps": size / dt / 1e9, "flagged": flagged}))
+    fq.unlink()
+
+
+if __name__ == "__main__":
+    main()
