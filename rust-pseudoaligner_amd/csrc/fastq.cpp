@@ -23,9 +23,11 @@
 #include <cerrno>
 #include <condition_variable>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -86,14 +88,35 @@ private:
     bool stop_ = false;
 };
 
-// in-order writer: buffers handed over by the main thread are written by a dedicated thread
+// text of one batch: one growable byte buffer per formatting thread, reused from batch to batch (fresh memory would be
+// page-faulted in again every time)
+struct TextBuf {
+    std::vector<char> mem;
+    size_t len = 0;
+    char* room(size_t need) {   // at least `need` more bytes
+        if (len + need > mem.size()) mem.resize(std::max(mem.size() * 2, len + need + (1 << 16)));
+        return mem.data() + len;
+    }
+};
+typedef std::vector<TextBuf> TextSet;
+
+// in-order writer: buffers handed over by the main thread are written by a dedicated thread and then recycled
 class Writer {
 public:
     explicit Writer(FILE* f) : f_(f), th_([this] { loop(); }) {}
-    void push(std::vector<std::string>&& parts) {
+    TextSet* acquire(size_t nbuf) {   // a free set (at most three exist: being filled, queued, being written)
         std::unique_lock<std::mutex> g(mu_);
-        room_.wait(g, [this] { return q_.size() < 2; });   // bounded: at most two batches of text in memory
-        q_.push_back(std::move(parts));
+        room_.wait(g, [this] { return !free_.empty() || made_ < 3; });
+        TextSet* s;
+        if (!free_.empty()) { s = free_.back(); free_.pop_back(); }
+        else { sets_.emplace_back(new TextSet()); s = sets_.back().get(); ++made_; }
+        s->resize(nbuf);
+        for (TextBuf& b : *s) b.len = 0;
+        return s;
+    }
+    void push(TextSet* parts) {
+        std::lock_guard<std::mutex> g(mu_);
+        q_.push_back(parts);
         cv_.notify_one();
     }
     bool finish() {
@@ -106,52 +129,71 @@ public:
 private:
     void loop() {
         for (;;) {
-            std::vector<std::string> parts;
+            TextSet* parts;
             {
                 std::unique_lock<std::mutex> g(mu_);
                 cv_.wait(g, [this] { return done_ || !q_.empty(); });
                 if (q_.empty()) return;
-                parts = std::move(q_.front());
+                parts = q_.front();
                 q_.pop_front();
-                room_.notify_one();
             }
-            for (const std::string& s : parts)
-                if (ok_ && !s.empty() && fwrite(s.data(), 1, s.size(), f_) != s.size()) ok_ = false;
+            for (const TextBuf& b : *parts)
+                if (ok_ && b.len && fwrite(b.mem.data(), 1, b.len, f_) != b.len) ok_ = false;
+            { std::lock_guard<std::mutex> g(mu_); free_.push_back(parts); }
+            room_.notify_one();
         }
     }
     FILE* f_;
     std::mutex mu_;
     std::condition_variable cv_, room_;
-    std::deque<std::vector<std::string>> q_;
+    std::deque<TextSet*> q_;
+    std::vector<TextSet*> free_;
+    std::vector<std::unique_ptr<TextSet>> sets_;
+    int made_ = 0;
     bool done_ = false, ok_ = true;
     std::thread th_;
 };
 
-// Rust `impl Debug for str`: quotes, backslash escapes for \t \r \n \\ \" and \u{..} for other control bytes
-void debug_str(std::string& out, const char* s, size_t n) {
-    out.push_back('"');
+// Rust `impl Debug for str`: quotes, backslash escapes for \t \r \n \\ \" and \u{..} for other control bytes; at most
+// 6 * n + 2 bytes
+char* debug_str(char* o, const char* s, size_t n) {
+    *o++ = '"';
     for (size_t i = 0; i < n; ++i) {
         const unsigned char c = (unsigned char)s[i];
+        if (c >= 0x20 && c != 0x7f && c != '\\' && c != '"') { *o++ = (char)c; continue; }
+        *o++ = '\\';
         switch (c) {
-            case '\t': out += "\\t"; break;
-            case '\r': out += "\\r"; break;
-            case '\n': out += "\\n"; break;
-            case '\\': out += "\\\\"; break;
-            case '"': out += "\\\""; break;
-            default:
-                if (c < 0x20 || c == 0x7f) { char b[16]; snprintf(b, sizeof b, "\\u{%x}", c); out += b; }
-                else out.push_back((char)c);
+            case '\t': *o++ = 't'; break;
+            case '\r': *o++ = 'r'; break;
+            case '\n': *o++ = 'n'; break;
+            case '\\': *o++ = '\\'; break;
+            case '"': *o++ = '"'; break;
+            default: o += snprintf(o, 8, "u{%x}", c);
         }
     }
-    out.push_back('"');
+    *o++ = '"';
+    return o;
 }
 
-void append_u32(std::string& out, uint32_t v) {
+char* put_u32(char* o, uint32_t v) {
     char b[10];
     int n = 0;
     do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) out.push_back(b[--n]);
+    while (n) *o++ = b[--n];
+    return o;
 }
+
+char* put_str(char* o, const char* s) {
+    while (*s) *o++ = *s++;
+    return o;
+}
+
+// DnaString::from_dna_string (:450) as a table: A0 C1 G2 T3 in either case, anything else A
+struct BaseLut {
+    uint8_t v[256];
+    BaseLut() { memset(v, 0, sizeof v); v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; }
+};
+const BaseLut BASE_LUT;
 
 struct Record {   // one FASTQ record inside the mapped file
     uint64_t id_off;
@@ -220,6 +262,10 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
 
     uint64_t BATCH_READS = DEFAULT_BATCH_READS;
     if (const char* v = getenv("PA_INGEST_BATCH")) { const long long x = atoll(v); if (x >= 64) BATCH_READS = (uint64_t)x / 64 * 64; }
+    const bool verbose = getenv("PA_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_scan = 0, t_pack = 0, t_finish = 0, t_launch = 0, t_format = 0, t_pack_rec = 0, t_pack_alloc = 0, t_pack_tiles = 0, t_push = 0;
+    const double t_begin = now();
     Pool pool(num_threads);
     const int T = pool.size();
     int rc = PA_OK;
@@ -275,6 +321,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         }
     }
 
+    t_scan = now() - t_begin;
     // ---- batches ----
     BatchCtx ctx[2];
     hipStream_t stream = nullptr;
@@ -317,6 +364,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     auto pack = [&](BatchCtx& c, uint64_t b) -> int {
         c.first = b * BATCH_READS;
         c.n = std::min<uint64_t>(BATCH_READS, nrec - c.first);
+        double t0 = now();
         c.recs.resize(c.n);
         std::vector<uint32_t> tmax((size_t)T * 4, 0);
         const int ntask = T * 4;
@@ -353,8 +401,10 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         for (uint32_t m : tmax) maxlen = std::max(maxlen, m);
         if (maxlen > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
         c.wpr = pa_words_per_read(maxlen);
+        t_pack_rec += now() - t0; t0 = now();
         const int e = ensure(c, c.n, c.wpr);
         if (e != PA_OK) return e;
+        t_pack_alloc += now() - t0; t0 = now();
         const uint64_t ntiles = (c.n + 63) / 64;
         const uint32_t wpr = c.wpr;
         pool.run(ntask, [&](int t) {   // DnaString::from_dna_string (:450): A0 C1 G2 T3, anything else A, either case
@@ -372,16 +422,13 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                     for (uint32_t w = 0; w < wpr; ++w) {
                         uint64_t v = 0;
                         const uint32_t b0 = 32 * w, nbases = rec.seq_len > b0 ? std::min<uint32_t>(32, rec.seq_len - b0) : 0;
-                        for (uint32_t j = 0; j < nbases; ++j) {
-                            const uint8_t ch = sq[b0 + j] & 0xDF;
-                            const uint64_t code = ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0u;
-                            v |= code << (2 * j);
-                        }
+                        for (uint32_t j = 0; j < nbases; ++j) v |= (uint64_t)BASE_LUT.v[sq[b0 + j]] << (2 * j);
                         tw[(uint64_t)w * 64 + r] = v;
                     }
                 }
             }
         });
+        t_pack_tiles += now() - t0;
         return PA_OK;
     };
 
@@ -413,30 +460,35 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     };
 
     auto format = [&](BatchCtx& c) {
-        std::vector<std::string> parts((size_t)T);
+        TextSet* parts = writer.acquire((size_t)T);
         std::vector<uint64_t> flags((size_t)T, 0);
         pool.run(T, [&](int t) {
-            std::string& o = parts[(size_t)t];
+            TextBuf buf = std::move((*parts)[(size_t)t]);   // thread-local while filling: neighbours share cache lines in the set
+            uint64_t nflag = 0;
             const uint64_t a = c.n * (uint64_t)t / T, b = c.n * (uint64_t)(t + 1) / T;
-            o.reserve((size_t)(b - a) * 64);
             for (uint64_t i = a; i < b; ++i) {
                 const pa_read_result& r = c.h_results[i];
                 const bool mapped = r.mismatches & PA_MAPPED_BIT;
                 const bool flag = mapped && r.coverage >= PA_READ_COVERAGE_THRESHOLD && r.class_len == 0;   // :455
-                flags[(size_t)t] += flag;
-                o += flag ? "(true, " : "(false, ";
-                debug_str(o, data + c.recs[i].id_off, c.recs[i].id_len);
-                o += ", [";
+                nflag += flag;
+                char* const base = buf.room(6 * (size_t)c.recs[i].id_len + 12 * (size_t)r.class_len + 64);
+                char* o = put_str(base, flag ? "(true, " : "(false, ");
+                o = debug_str(o, data + c.recs[i].id_off, c.recs[i].id_len);
+                o = put_str(o, ", [");
                 const uint32_t* ids = (r.class_off & PA_CLASS_REF) ? h_ec + 4ull * h_class_ref[r.class_off & ~PA_CLASS_REF] + 1
                                                                    : c.h_arena.data() + r.class_off;
                 for (uint32_t j = 0; j < r.class_len; ++j) {
-                    if (j) o += ", ";
-                    append_u32(o, ids[j]);
+                    if (j) { *o++ = ','; *o++ = ' '; }
+                    o = put_u32(o, ids[j]);
                 }
-                o += "], ";
-                append_u32(o, mapped ? r.coverage : 0u);   // None -> (false, id, [], 0) (:461)
-                o += ")\n";
+                o = put_str(o, "], ");
+                o = put_u32(o, mapped ? r.coverage : 0u);   // None -> (false, id, [], 0) (:461)
+                *o++ = ')';
+                *o++ = '\n';
+                buf.len += (size_t)(o - base);
             }
+            flags[(size_t)t] = nflag;
+            (*parts)[(size_t)t] = std::move(buf);
         });
         for (uint64_t f : flags) flagged += f;
         reported += c.n;
@@ -445,16 +497,26 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                     (double)((float)flagged * 100.0f / (float)reported));
             next_report += 1000000;
         }
-        writer.push(std::move(parts));
+        const double t0 = now();
+        writer.push(parts);
+        t_push += now() - t0;
     };
 
     // pack(b) overlaps GPU(b-1); format(b-1) overlaps GPU(b)
     for (uint64_t b = 0; rc == PA_OK && b <= nb && nb > 0; ++b) {
+        double t0 = now();
         if (b < nb) rc = pack(ctx[b & 1], b);
+        t_pack += now() - t0; t0 = now();
         if (rc == PA_OK && b >= 1) rc = finish(ctx[(b - 1) & 1]);
+        t_finish += now() - t0; t0 = now();
         if (rc == PA_OK && b < nb) rc = launch(ctx[b & 1]);
+        t_launch += now() - t0; t0 = now();
         if (rc == PA_OK && b >= 1) format(ctx[(b - 1) & 1]);
+        t_format += now() - t0;
     }
+    if (verbose)
+        fprintf(stderr, "\n[pa ingest] %llu reads, %d threads: scan %.3f s, pack %.3f s (records %.3f, alloc %.3f, tiles %.3f), wait GPU %.3f s, launch %.3f s, format %.3f s (writer wait %.3f), total %.3f s\n",
+                (unsigned long long)nrec, T, t_scan, t_pack, t_pack_rec, t_pack_alloc, t_pack_tiles, t_finish, t_launch, t_format, t_push, now() - t_begin);
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     const bool wrote = writer.finish();
     if (rc == PA_OK && !wrote) rc = fail(PA_ERR_IO, "short write to %s", out_path);

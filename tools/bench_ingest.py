@@ -52,8 +52,14 @@ def main():
     size = fq.stat().st_size
     print("[ingest] %d reads, %.2f GB FASTQ written in %.1f s" % (n, size / 1e9, time.time() - t0), file=sys.stderr)
     ncpu = os.cpu_count() or 1
+    try:
+        print("[ingest] cpu_count %d, affinity %d, cgroup cpu.max %s" % (ncpu, len(os.sched_getaffinity(0)),
+              open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "?"), file=sys.stderr)
+    except OSError:
+        pass
     threads = [int(x) for x in args.threads.split(",") if x] or sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(16, ncpu)}, reverse=True)
     pa.process_reads(str(fq), al, "/dev/null", ncpu)   # warm-up (page cache, pinned buffers, kernels)
+    os.environ["PA_VERBOSE"] = "1"
     for t in threads:
         t0 = time.time()
         got, flagged = pa.process_reads(str(fq), al, "/dev/null", t)
