@@ -220,7 +220,7 @@ def main() -> None:
         t0 = time.time()
         oracle = helpers.Oracle(host)
         log("oracle index built (%.1f s)" % (time.time() - t0))
-        ncpu = os.cpu_count() or 1
+        ncpu = usable_cpus()
         sample_n = 200_000
         first = (rank * (K + W) + (W % n_batches)) * B   # the first timed batch
         s_tiles, s_lens = txome.simulate_host(read_len, wl["read_seed"], sample_n, ppm, first, wpr)
@@ -254,11 +254,35 @@ def main() -> None:
             b_tiles, b_lens = txome.simulate_host(read_len, wl["read_seed"], big_n, ppm, first, wpr)
             secs = _time_oracle(oracle, b_tiles, b_lens, wpr, ncpu)
             out["cpu_baseline"] = {"value": big_n / secs, "unit": "reads/s", "cores": ncpu, "kind": "port",
-                                   "sample": "first %d reads of the first timed batch, oracle/pa_oracle.c on %d pthreads, %.1f s" % (big_n, ncpu, secs)}
+                                   "sample": "first %d reads of the first timed batch, oracle/pa_oracle.c on %d pthreads (%d CPUs visible, quota/affinity %d), %.1f s"
+                                             % (big_n, ncpu, os.cpu_count() or 1, ncpu, secs)}
         print(json.dumps(out), flush=True)
     barrier()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: visible CPUs, affinity mask and the cgroup CPU quota (a container that sees 256
+    CPUs may be limited to 16 CPUs' worth of time; timing 256 threads there would mislabel the baseline)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())         # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def _time_oracle(oracle, tiles, lens, wpr, threads) -> float:
