@@ -47,7 +47,7 @@ extern "C" {
 
 #define PA_NO_EDGE 0xFFFFFFFFu
 #define PA_MIN_K 8u
-#define PA_MAX_K 32u                     /* one 64-bit word per k-mer (Kmer20/24/30/32 of the debruijn crate) */
+#define PA_MAX_K 64u                     /* one or two 64-bit words per k-mer (Kmer20..Kmer32, Kmer48, Kmer64 of the debruijn crate) */
 #define PA_MAX_READ_LEN 2048u
 
 typedef enum pa_status {

@@ -44,13 +44,16 @@ const char* oracle_last_error(void) { return g_err; }
 /* ---- DnaString::get / get_kmer restated on LSB-first packed words ---- */
 static inline uint8_t seq_get(const uint64_t* w, uint64_t pos) { return (uint8_t)((w[pos >> 5] >> ((pos & 31) * 2)) & 3u); }
 
-static inline uint64_t seq_get_kmer(const uint64_t* w, uint64_t pos, uint32_t k) {
-    uint64_t v = 0;
-    for (uint32_t i = 0; i < k; ++i) v |= (uint64_t)seq_get(w, pos + i) << (2 * i);
+/* K: Kmer — up to 64 bases (Kmer64, the other size the reference's CLI accepts: src/bin/pseudoaligner.rs:88) */
+typedef unsigned __int128 kmer_t;
+
+static inline kmer_t seq_get_kmer(const uint64_t* w, uint64_t pos, uint32_t k) {
+    kmer_t v = 0;
+    for (uint32_t i = 0; i < k; ++i) v |= (kmer_t)seq_get(w, pos + i) << (2 * i);
     return v;
 }
 
-static inline uint64_t dict_hash(uint64_t x) { /* splitmix64 finaliser; any hash works, hits are verified */
+static inline uint64_t mix_word(uint64_t x) { /* splitmix64 finaliser; any hash works, hits are verified */
     x ^= x >> 30;
     x *= 0xbf58476d1ce4e5b9ull;
     x ^= x >> 27;
@@ -58,9 +61,17 @@ static inline uint64_t dict_hash(uint64_t x) { /* splitmix64 finaliser; any hash
     x ^= x >> 31;
     return x;
 }
+static inline uint64_t dict_hash(kmer_t x) { return mix_word((uint64_t)x ^ (mix_word((uint64_t)(x >> 64)) + 0x9e3779b97f4a7c15ull)); }
+
+static int lookup_kmer(const oracle_index* idx, kmer_t kmer, uint32_t* node, uint32_t* offset);
+
+/* test surface: the k-mer as two 64-bit halves (bases 0..31 in `lo`) */
+int oracle_lookup_kmer(const oracle_index* idx, uint64_t lo, uint64_t hi, uint32_t* node, uint32_t* offset) {
+    return lookup_kmer(idx, ((kmer_t)hi << 64) | lo, node, offset);
+}
 
 /* dbg_index.get(&read_kmer) followed by the verification of :99-107 */
-int oracle_lookup_kmer(const oracle_index* idx, uint64_t kmer, uint32_t* node, uint32_t* offset) {
+static int lookup_kmer(const oracle_index* idx, kmer_t kmer, uint32_t* node, uint32_t* offset) {
     uint64_t i = dict_hash(kmer) % idx->dict_cap;
     for (;;) {
         const uint32_t nid = idx->dict_node[i];
@@ -100,7 +111,7 @@ void oracle_index_free(oracle_index* idx) {
 
 typedef struct { oracle_index* idx; int phase; uint32_t begin, end, bad; } build_job;
 
-static void dict_insert_mt(oracle_index* idx, uint64_t kmer, uint32_t nid, uint32_t off) {
+static void dict_insert_mt(oracle_index* idx, kmer_t kmer, uint32_t nid, uint32_t off) {
     uint64_t i = dict_hash(kmer) % idx->dict_cap;
     for (;;) {
         uint32_t expect = NO_SLOT;
@@ -126,23 +137,23 @@ static void* build_worker(void* arg) {
     build_job* j = (build_job*)arg;
     oracle_index* idx = j->idx;
     const uint32_t k = idx->k;
-    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const kmer_t mask = k == 64 ? ~(kmer_t)0 : (((kmer_t)1 << (2 * k)) - 1);
     for (uint32_t n = j->begin; n < j->end; ++n) {
         const uint64_t s = idx->node_start[n];
         const uint32_t len = idx->node_len[n];
         if (j->phase < 2) {
-            uint64_t km = seq_get_kmer(idx->seq, s, k);
+            kmer_t km = seq_get_kmer(idx->seq, s, k);
             const uint32_t nk = len - k + 1;
             for (uint32_t o = 0; o < nk; ++o) {
-                if (o) km = ((km >> 2) | ((uint64_t)seq_get(idx->seq, s + o + k - 1) << (2 * (k - 1)))) & mask;
+                if (o) km = ((km >> 2) | ((kmer_t)seq_get(idx->seq, s + o + k - 1) << (2 * (k - 1)))) & mask;
                 if (j->phase == 0) dict_insert_mt(idx, km, n, o);
                 else {
                     uint32_t a, b;
-                    if (!oracle_lookup_kmer(idx, km, &a, &b) || a != n || b != o) j->bad = n;
+                    if (!lookup_kmer(idx, km, &a, &b) || a != n || b != o) j->bad = n;
                 }
             }
         } else {
-            const uint64_t first = seq_get_kmer(idx->seq, s, k), last = seq_get_kmer(idx->seq, s + len - k, k);
+            const kmer_t first = seq_get_kmer(idx->seq, s, k), last = seq_get_kmer(idx->seq, s + len - k, k);
             uint32_t rr = 0, lr = 0;
             for (uint32_t b = 0; b < 4; ++b) {
                 idx->r_edges[4 * n + b] = NO_SLOT;
@@ -151,13 +162,13 @@ static void* build_worker(void* arg) {
             for (uint32_t b = 0; b < 4; ++b) {
                 uint32_t tn, to;
                 if (idx->node_exts[n] & (1u << b)) {
-                    const uint64_t nx = ((last >> 2) | ((uint64_t)b << (2 * (k - 1)))) & mask;
-                    if (!oracle_lookup_kmer(idx, nx, &tn, &to) || to != 0) j->bad = n;
+                    const kmer_t nx = ((last >> 2) | ((kmer_t)b << (2 * (k - 1)))) & mask;
+                    if (!lookup_kmer(idx, nx, &tn, &to) || to != 0) j->bad = n;
                     else idx->r_edges[4 * n + rr++] = tn;
                 }
                 if (idx->node_exts[n] & (1u << (4 + b))) {
-                    const uint64_t pv = ((first << 2) | b) & mask;
-                    if (!oracle_lookup_kmer(idx, pv, &tn, &to) || to != idx->node_len[tn] - k) j->bad = n;
+                    const kmer_t pv = ((first << 2) | b) & mask;
+                    if (!lookup_kmer(idx, pv, &tn, &to) || to != idx->node_len[tn] - k) j->bad = n;
                     else idx->l_edges[4 * n + lr++] = tn;
                 }
             }
@@ -170,7 +181,7 @@ oracle_index* oracle_index_new(uint32_t k, uint32_t num_nodes, const uint64_t* n
                                const uint32_t* node_len, const uint8_t* node_exts, const uint32_t* node_colour,
                                uint32_t num_classes, const uint64_t* ec_offset, const uint32_t* ec_ids) {
     g_err[0] = 0;
-    if (k < 2 || k > 32) {
+    if (k < 2 || k > 64) {
         snprintf(g_err, sizeof g_err, "k=%u unsupported", k);
         return NULL;
     }
@@ -296,9 +307,9 @@ static int nv_push(nodevec* v, uint32_t x) {
 static int find_kmer_match(const oracle_index* idx, const uint64_t* read, size_t last_kmer_pos, size_t* kmer_pos,
                            uint32_t* nid, uint32_t* offset, oracle_counters* ctr) {
     while (*kmer_pos <= last_kmer_pos) {                                   /* :92 */
-        const uint64_t read_kmer = seq_get_kmer(read, *kmer_pos, idx->k);  /* :93 */
+        const kmer_t read_kmer = seq_get_kmer(read, *kmer_pos, idx->k);    /* :93 */
         if (ctr) ctr->probes += 1;                                         /* :95 */
-        if (oracle_lookup_kmer(idx, read_kmer, nid, offset)) return 1;     /* :96-108 */
+        if (lookup_kmer(idx, read_kmer, nid, offset)) return 1;     /* :96-108 */
         *kmer_pos += SEEK_STRIDE;                                          /* :110 */
     }
     return 0;                                                              /* :113 */

@@ -83,7 +83,7 @@ void oracle_free(void* p);
 double oracle_last_batch_seconds(void);
 
 /* dbg_index.get(kmer) + verification (:96-108): 1 = found. */
-int oracle_lookup_kmer(const oracle_index* idx, uint64_t kmer, uint32_t* node, uint32_t* offset);
+int oracle_lookup_kmer(const oracle_index* idx, uint64_t kmer_lo, uint64_t kmer_hi, uint32_t* node, uint32_t* offset);
 
 #ifdef __cplusplus
 }

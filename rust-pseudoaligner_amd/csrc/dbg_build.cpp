@@ -28,24 +28,28 @@
 namespace pa {
 namespace {
 
+template <class KT>
 struct Rec {   // trivially default-constructible: arrays of it are left uninitialised
-    uint64_t kmer;
+    KT kmer;
     uint32_t tx;
     uint32_t exts;
 };
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 
+template <class KT>
 struct KEntry {
-    uint64_t kmer;
+    KT kmer;
     uint32_t colour;   // EMPTY = free slot
     uint8_t exts;
     uint8_t visited;
     uint16_t pad;
 };
-static_assert(sizeof(KEntry) == 16, "KEntry");
+static_assert(sizeof(KEntry<uint64_t>) == 16, "KEntry");
 
+template <class KT>
 struct KTable {
+    typedef struct KEntry<KT> KEntry;
     uint64_t cap = 0;
     std::unique_ptr<KEntry[]> e;
     void init(uint64_t n, int threads) {   // first touch in parallel: page faults dominate a serial fill
@@ -58,8 +62,8 @@ struct KTable {
             });
         for (auto& x : th) x.join();
     }
-    uint64_t home(uint64_t kmer) const { return (uint64_t)(((unsigned __int128)mix64(kmer) * cap) >> 64); }
-    void insert_mt(uint64_t kmer, uint32_t colour, uint8_t exts) {
+    uint64_t home(KT kmer) const { return (uint64_t)(((unsigned __int128)KmerOps<KT>::hash(kmer) * cap) >> 64); }
+    void insert_mt(KT kmer, uint32_t colour, uint8_t exts) {
         uint64_t i = home(kmer);
         for (;;) {
             uint32_t expect = EMPTY;
@@ -71,7 +75,7 @@ struct KTable {
             if (++i == cap) i = 0;
         }
     }
-    KEntry* find(uint64_t kmer) {
+    KEntry* find(KT kmer) {
         uint64_t i = home(kmer);
         for (;;) {
             KEntry& s = e[i];
@@ -118,8 +122,9 @@ struct Interner {
     }
 };
 
+template <class KT>
 struct DK {   // distinct k-mer
-    uint64_t kmer;
+    KT kmer;
     uint32_t colour;
     uint32_t exts;
 };
@@ -154,11 +159,19 @@ struct NodeOut {   // nodes produced by one partition's start k-mers
 
 }  // namespace
 
-int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx, uint32_t k, int threads, HostIndex& out) {
-    if (k < PA_MIN_K || k > PA_MAX_K) return fail(PA_ERR_UNSUPPORTED, "k=%u outside [%u,%u]", k, PA_MIN_K, PA_MAX_K);
+template <class KT>
+static int build_graph_t(const uint64_t* packed_in, const uint64_t* tx_start, uint32_t num_tx, uint32_t k, int threads, HostIndex& out) {
+    typedef struct Rec<KT> Rec;
+    typedef struct KEntry<KT> KEntry;
+    typedef struct DK<KT> DK;
     if (threads < 1) threads = 1;
-    const uint64_t mask = kmer_mask(k);
+    const KT mask = KmerOps<KT>::mask(k);
     const uint32_t topshift = 2 * (k - 1);
+    // k-mer extraction reads up to two words past the last base: work on a padded copy
+    const uint64_t nwords = (tx_start[num_tx] + 31) / 32;
+    std::vector<uint64_t> padded(packed_in, packed_in + nwords);
+    padded.resize(nwords + 3, 0);
+    const uint64_t* packed = padded.data();
 
     const bool verbose = std::getenv("PA_VERBOSE") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -201,7 +214,7 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
             if (len < k) continue;
             const uint64_t nk = len - k + 1;
             for (uint64_t p = 0; p < nk; ++p) {
-                const uint64_t km = get_kmer(packed, s + p, k);
+                const KT km = KmerOps<KT>::get(packed, s + p, k);
                 uint32_t ex = 0;
                 if (p > 0) ex |= 1u << (4 + get_base(packed, s + p - 1));          // left ext
                 if (p + k < len) ex |= 1u << get_base(packed, s + p + k);          // right ext
@@ -214,7 +227,7 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
     std::vector<std::vector<uint64_t>> cnt(T, std::vector<uint64_t>(P, 0));
     parallel_for(T, T, [&](uint64_t ti, int) {
         auto& c = cnt[ti];
-        for_each_kmer(tx_split[ti], tx_split[ti + 1], [&](uint64_t km, uint32_t, uint32_t) { ++c[mix64(km) >> (64 - logp)]; });
+        for_each_kmer(tx_split[ti], tx_split[ti + 1], [&](KT km, uint32_t, uint32_t) { ++c[KmerOps<KT>::hash(km) >> (64 - logp)]; });
     });
     stage("  count pass");
     std::vector<uint64_t> pstart(P + 1, 0);
@@ -231,8 +244,8 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
     if (!recs) return fail(PA_ERR_OOM, "out of memory for %llu k-mer records", (unsigned long long)total);
     parallel_for(T, T, [&](uint64_t ti, int) {
         auto& c = cnt[ti];
-        for_each_kmer(tx_split[ti], tx_split[ti + 1], [&](uint64_t km, uint32_t t, uint32_t ex) {
-            recs[c[mix64(km) >> (64 - logp)]++] = Rec{km, t, ex};
+        for_each_kmer(tx_split[ti], tx_split[ti + 1], [&](KT km, uint32_t t, uint32_t ex) {
+            recs[c[KmerOps<KT>::hash(km) >> (64 - logp)]++] = Rec{km, t, ex};
         });
     });
     cnt.clear();
@@ -286,7 +299,7 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
     // ---- 5. k-mer table ----
     uint64_t ndistinct = 0;
     for (auto& d : dks) ndistinct += d.size();
-    KTable tab;
+    KTable<KT> tab;
     tab.init(ndistinct, T);
     parallel_for(T, P, [&](uint64_t p, int) {
         for (auto& d : dks[p]) {
@@ -302,8 +315,8 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
     auto right_join = [&](const KEntry& x) -> KEntry* {
         const uint32_t r = x.exts & 15u;
         if (popc4(r) != 1) return nullptr;
-        const uint64_t b = (uint64_t)__builtin_ctz(r);
-        const uint64_t y = (x.kmer >> 2) | (b << topshift);
+        const KT b = (KT)__builtin_ctz(r);
+        const KT y = (x.kmer >> 2) | (b << topshift);
         if (y == x.kmer) return nullptr;
         KEntry* ey = tab.find(y);
         if (!ey) return nullptr;   // cannot happen for a consistent transcript set
@@ -313,8 +326,8 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
     auto left_joinable = [&](const KEntry& x) -> bool {
         const uint32_t l = (x.exts >> 4) & 15u;
         if (popc4(l) != 1) return false;
-        const uint64_t b = (uint64_t)__builtin_ctz(l);
-        const uint64_t z = ((x.kmer << 2) | b) & mask;
+        const KT b = (KT)__builtin_ctz(l);
+        const KT z = ((x.kmer << 2) | b) & mask;
         if (z == x.kmer) return false;
         KEntry* ez = tab.find(z);
         if (!ez) return false;
@@ -378,6 +391,12 @@ int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_t
     }
     stage("concatenate");
     return PA_OK;
+}
+
+int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx, uint32_t k, int threads, HostIndex& out) {
+    if (k < PA_MIN_K || k > PA_MAX_K) return fail(PA_ERR_UNSUPPORTED, "k=%u outside [%u,%u]", k, PA_MIN_K, PA_MAX_K);
+    return k <= 32 ? build_graph_t<uint64_t>(packed, tx_start, num_tx, k, threads, out)
+                   : build_graph_t<u128>(packed, tx_start, num_tx, k, threads, out);
 }
 
 }  // namespace pa

@@ -27,6 +27,7 @@ DevIndexView FlatDevice::host_view() const {
     v.wtable = wtable.data();
     v.wbuckets = wbuckets;
     v.kmask = kmer_mask(k);
+    v.kmask_hi = k > 32 ? kmer_mask(k - 32) : 0;
     v.k = k;
     v.num_nodes = num_nodes;
     v.num_classes = num_classes;
@@ -43,7 +44,57 @@ void par_ranges(int threads, uint64_t n, F f) {   // static contiguous ranges
     for (auto& x : th) x.join();
 }
 
-struct Dict {   // host-side builder/reader of the bucket lines described in device_layout.hpp
+template <class KT> struct Dict;
+
+template <>
+struct Dict<u128> {   // k > 32: two whole entries {key word 0..3, handle, off, -, -} per line
+    static constexpr double LOAD = 1.0 / 3.0;
+    static constexpr uint32_t SLOTS = 2;
+    uint32_t* words;
+    uint64_t nbuckets;
+    uint64_t bucket_of(u128 kmer) const { return ((pa_mix128((uint64_t)kmer, (uint64_t)(kmer >> 64)) >> 32) * (uint64_t)(uint32_t)nbuckets) >> 32; }
+    void insert_mt(u128 kmer, uint32_t handle, uint32_t off) {
+        uint64_t b = bucket_of(kmer);
+        for (;;) {
+            uint32_t* line = words + b * BUCKET_WORDS;
+            for (uint32_t i = 0; i < SLOTS; ++i) {
+                uint32_t expect = NO_HANDLE;
+                if (__atomic_compare_exchange_n(&line[8 * i + 4], &expect, handle, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+                    line[8 * i] = (uint32_t)kmer; line[8 * i + 1] = (uint32_t)(kmer >> 32);
+                    line[8 * i + 2] = (uint32_t)(kmer >> 64); line[8 * i + 3] = (uint32_t)(kmer >> 96);
+                    line[8 * i + 5] = off;
+                    return;
+                }
+            }
+            if (++b == nbuckets) b = 0;
+        }
+    }
+    bool find(u128 kmer, uint32_t& handle, uint32_t& off, uint32_t* probes_out = nullptr) const {
+        uint64_t b = bucket_of(kmer);
+        for (uint64_t probes = 0; probes < nbuckets; ++probes) {
+            const uint32_t* line = words + b * BUCKET_WORDS;
+            bool full = true;
+            for (uint32_t i = 0; i < SLOTS; ++i) {
+                if (line[8 * i + 4] == NO_HANDLE) { full = false; continue; }
+                if (line[8 * i] == (uint32_t)kmer && line[8 * i + 1] == (uint32_t)(kmer >> 32) && line[8 * i + 2] == (uint32_t)(kmer >> 64) &&
+                    line[8 * i + 3] == (uint32_t)(kmer >> 96)) {
+                    handle = line[8 * i + 4];
+                    off = line[8 * i + 5];
+                    if (probes_out) *probes_out = (uint32_t)probes;
+                    return true;
+                }
+            }
+            if (!full) return false;
+            if (++b == nbuckets) b = 0;
+        }
+        return false;
+    }
+};
+
+template <>
+struct Dict<uint64_t> {   // host-side builder/reader of the bucket lines described in device_layout.hpp
+    static constexpr double LOAD = 0.5;
+    static constexpr uint32_t SLOTS = SLOTS_PER_BUCKET;
     uint32_t* words;
     uint64_t nbuckets;
     uint64_t bucket_of(uint64_t kmer) const { return pa_bucket(kmer, (uint32_t)nbuckets); }   // same function as the kernel
@@ -64,7 +115,7 @@ struct Dict {   // host-side builder/reader of the bucket lines described in dev
             if (++b == nbuckets) b = 0;
         }
     }
-    bool find(uint64_t kmer, uint32_t& handle, uint32_t& off) const {
+    bool find(uint64_t kmer, uint32_t& handle, uint32_t& off, uint32_t* probes_out = nullptr) const {
         const uint32_t klo = (uint32_t)kmer, want = klo & 0x7FFFFFFFu, khi = (uint32_t)(kmer >> 32);
         uint64_t b = bucket_of(kmer);
         for (uint64_t probes = 0; probes < nbuckets; ++probes) {
@@ -75,6 +126,7 @@ struct Dict {   // host-side builder/reader of the bucket lines described in dev
                 if (line[i] == want && line[4 + 3 * i] == khi && (line[6 + 3 * i] >> 31) == (klo >> 31)) {
                     handle = line[5 + 3 * i];
                     off = line[6 + 3 * i] & 0x7FFFFFFFu;
+                    if (probes_out) *probes_out = (uint32_t)probes;
                     return true;
                 }
             }
@@ -87,15 +139,15 @@ struct Dict {   // host-side builder/reader of the bucket lines described in dev
 
 }  // namespace
 
-int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
+template <class KT>
+static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out) {
     if (threads < 1) threads = 1;
     const uint32_t k = f.k, N = f.num_nodes;
-    if (k < PA_MIN_K || k > PA_MAX_K) return fail(PA_ERR_UNSUPPORTED, "k=%u outside [%u,%u]", k, PA_MIN_K, PA_MAX_K);
     out = FlatDevice();
     out.k = k;
     out.num_nodes = N;
     out.num_classes = f.num_classes;
-    const uint64_t mask = kmer_mask(k);
+    const KT mask = KmerOps<KT>::mask(k);
     const uint32_t topshift = 2 * (k - 1);
 
     // ---- classes: 16-byte aligned records {class id, id0, id1, ...} ----
@@ -166,32 +218,42 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
     out.num_kmers = nk;
     out.blobs.assign(cursor + 64, 0);   // tail pad: fwd_step reads up to 5 words past a node's last word
 
-    // ---- dictionary: every k-mer of every node -> (handle, offset) ----
-    out.nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (SLOTS_PER_BUCKET * 0.5)) + 1);
-    if (out.nbuckets >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "dictionary exceeds 2^32 buckets");
-    out.table.assign(out.nbuckets * BUCKET_WORDS, FP_EMPTY);
-    Dict dict{out.table.data(), out.nbuckets};
+    // ---- dictionary: every k-mer of every node -> (handle, offset); the kernel follows at most 15 overflow buckets, so
+    // the table is rebuilt larger in the (practically impossible) case that some key sits further from its home ----
+    // the node sequence is read up to two words past its end: work on a padded copy
+    std::vector<uint64_t> seq_pad(f.node_seq, f.node_seq + (f.seq_bases + 31) / 32);
+    seq_pad.resize(seq_pad.size() + 3, 0);
+    const uint64_t* node_seq = seq_pad.data();
     auto node_kmers = [&](uint32_t i, auto&& fn) {
         const uint64_t s = f.node_start[i];
         const uint32_t n = f.node_len[i] - k + 1;
-        uint64_t km = get_kmer(f.node_seq, s, k);
+        KT km = KmerOps<KT>::get(node_seq, s, k);
         for (uint32_t o = 0; o < n; ++o) {
-            if (o) km = (km >> 2) | ((uint64_t)get_base(f.node_seq, s + o + k - 1) << topshift);
+            if (o) km = (km >> 2) | ((KT)get_base(node_seq, s + o + k - 1) << topshift);
             fn(km, o);
         }
     };
-    par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
-        for (uint64_t i = a; i < b; ++i) node_kmers((uint32_t)i, [&](uint64_t km, uint32_t o) { dict.insert_mt(km, out.handle[i], o); });
-    });
-    std::atomic<uint32_t> bad{NO_HANDLE};
-    par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
-        for (uint64_t i = a; i < b; ++i)
-            node_kmers((uint32_t)i, [&](uint64_t km, uint32_t o) {
-                uint32_t h, off;
-                if (!dict.find(km, h, off) || h != out.handle[i] || off != o) bad.store((uint32_t)i);
-            });
-    });
-    if (bad.load() != NO_HANDLE) return fail(PA_ERR_FORMAT, "a k-mer of node %u occurs twice in the graph", bad.load());
+    Dict<KT> dict{nullptr, 0};
+    for (double load = Dict<KT>::LOAD;; load *= 0.75) {
+        out.nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (Dict<KT>::SLOTS * load)) + 1);
+        if (out.nbuckets >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "dictionary exceeds 2^32 buckets");
+        out.table.assign(out.nbuckets * BUCKET_WORDS, FP_EMPTY);
+        dict = Dict<KT>{out.table.data(), out.nbuckets};
+        par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
+            for (uint64_t i = a; i < b; ++i) node_kmers((uint32_t)i, [&](KT km, uint32_t o) { dict.insert_mt(km, out.handle[i], o); });
+        });
+        std::atomic<uint32_t> bad{NO_HANDLE}, far{0};
+        par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
+            for (uint64_t i = a; i < b; ++i)
+                node_kmers((uint32_t)i, [&](KT km, uint32_t o) {
+                    uint32_t h, off, probes = 0;
+                    if (!dict.find(km, h, off, &probes) || h != out.handle[i] || off != o) bad.store((uint32_t)i);
+                    if (probes > 15) far.store(1);
+                });
+        });
+        if (bad.load() != NO_HANDLE) return fail(PA_ERR_FORMAT, "a k-mer of node %u occurs twice in the graph", bad.load());
+        if (!far.load()) break;
+    }
 
     // ---- blobs + edges ----
     const uint64_t granules = out.blobs.size() / BLOB_GRANULE;
@@ -213,12 +275,12 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
             const U4 cw = cwin[f.node_colour[i]];
             hd[8] = cw.x; hd[9] = cw.y; hd[10] = cw.z; hd[11] = cw.w;
             for (uint32_t w = 0; w < (len + 31) / 32; ++w) {
-                uint64_t v = window32(f.node_seq, s + 32ull * w);
+                uint64_t v = window32(node_seq, s + 32ull * w);
                 const uint32_t rem = len - 32 * w;
                 if (rem < 32) v &= (1ull << (2 * rem)) - 1;
                 sq[w] = v;
             }
-            const uint64_t first = get_kmer(f.node_seq, s, k), last = get_kmer(f.node_seq, s + len - k, k);
+            const KT first = KmerOps<KT>::get(node_seq, s, k), last = KmerOps<KT>::get(node_seq, s + len - k, k);
             for (uint32_t base = 0; base < 4; ++base) {
                 uint32_t re = NO_HANDLE, le = NO_HANDLE;
                 if (f.node_exts[i] & (1u << base)) {
@@ -228,7 +290,7 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
                     } else {
                         // find_link(last.extend_right(b), Dir::Right): node whose FIRST k-mer it is (offset 0)
                         uint32_t h, off;
-                        if (dict.find((last >> 2) | ((uint64_t)base << topshift), h, off) && off == 0) re = h;
+                        if (dict.find((last >> 2) | ((KT)base << topshift), h, off) && off == 0) re = h;
                     }
                     if (re == NO_HANDLE) dangling.store((uint32_t)i);
                 }
@@ -255,7 +317,7 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
     if (!f.node_ledge) {
         par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
             for (uint64_t i = a; i < b; ++i) {
-                const uint64_t first = get_kmer(f.node_seq, f.node_start[i], k);
+                const KT first = KmerOps<KT>::get(node_seq, f.node_start[i], k);
                 for (uint32_t base = 0; base < 4; ++base) {
                     if (!(f.node_exts[i] & (1u << (4 + base)))) continue;
                     uint32_t h = 0, off = 0;
@@ -269,6 +331,11 @@ int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
             return fail(PA_ERR_FORMAT, "node %u: left neighbour k-mer is not the last k-mer of its node", dangling.load());
     }
     return PA_OK;
+}
+
+int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
+    if (f.k < PA_MIN_K || f.k > PA_MAX_K) return fail(PA_ERR_UNSUPPORTED, "k=%u outside [%u,%u]", f.k, PA_MIN_K, PA_MAX_K);
+    return f.k <= 32 ? flatten_t<uint64_t>(f, threads, out) : flatten_t<u128>(f, threads, out);
 }
 
 }  // namespace pa

@@ -11,6 +11,8 @@
 //               dependent 12-byte load from the same line that both returns (handle, off) and VERIFIES the remaining
 //               33 key bits — the dictionary stores whole keys, so unlike the reference's MPHF (src/pseudoaligner.rs:
 //               96-107) no node sequence has to be fetched to confirm a hit.
+//               k > 32 (two-word k-mers): a line holds two whole entries {key word 0..3, handle, off, -, -}, handle
+//               0xFFFFFFFF = empty, load <= 1/3.
 //   node blobs  one blob per unitig, 64-byte aligned (one HBM line), addressed by handle = byte offset / 64:
 //                 +0  u32 len (bits 0..23) | debruijn::Exts byte (bits 24..31)
 //                 +4  u32 class id         +8  u32 class record ref      +12 u32 class length (ids)
@@ -78,7 +80,8 @@ struct DevIndexView {
     const uint32_t* class_len;   // [num_classes]
     const uint32_t* wtable;      // wbuckets * 16 words
     uint32_t wbuckets;
-    uint64_t kmask;
+    uint64_t kmask;           // k <= 32: mask of the k-mer word
+    uint64_t kmask_hi;        // k > 32: mask of the second k-mer word (bases 32..k-1)
     uint32_t k;
     uint32_t num_nodes, num_classes;
 };

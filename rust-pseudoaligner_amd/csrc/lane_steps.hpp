@@ -316,24 +316,9 @@ PA_HD void restart_lists(Lane& s, uint32_t k) {
 }
 
 // ---------------------------------------------------------------------------------------------- SEEK
-// One dictionary probe of find_kmer_match (:91-114): dbg_index.get + verification collapse into one bucket line.
-PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
-    const uint32_t K = ix.k, L = l_L(s), kp = l_kp(s);
-    const uint64_t kmer = read_window(rd, kp) & ix.kmask;           // read_seq.get_kmer(kmer_pos) (:93)
-    const uint32_t probe = l_probe(s);
-    uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + probe;
-    if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
-    const uint32_t* linew = ix.table + (uint64_t)b * BUCKET_WORDS;
-    const U4 fp = *reinterpret_cast<const U4*>(linew);
-    const uint32_t klo = (uint32_t)kmer, khi = (uint32_t)(kmer >> 32);
-    const uint32_t want = klo & 0x7FFFFFFFu, top = klo >> 31;
-    // entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j: fetch the one whose fingerprint matches (same line)
-    const uint32_t j = fp.x == want ? 0u : fp.y == want ? 1u : fp.z == want ? 2u : 3u;
-    const U3 e = *reinterpret_cast<const U3*>(linew + 4 + 3 * j);
-    const bool anyfp = (fp.x == want) | (fp.y == want) | (fp.z == want) | (fp.w == want);
-    const bool hit = anyfp && e.x == khi && (e.z >> 31) == top;
-    const uint32_t h = hit ? e.y : NO_HANDLE;
-    const uint32_t off = e.z & 0x7FFFFFFFu;
+// what a probe found -> the lane's next state (the tail of find_kmer_match and of :118-129)
+PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe) {
+    const uint32_t L = l_L(s), kp = l_kp(s);
     s.nc &= ~(15u << 12);                                           // probe index back to 0
     if (h != NO_HANDLE) {                                           // Some((nid, offset)) (:106)
         s.h = h;
@@ -351,14 +336,50 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
         }
         return;
     }
-    const bool full = ((fp.x | fp.y | fp.z | fp.w) >> 31) == 0;     // no free slot: the key may live in the next bucket
-    if (full && probe < 15) {
+    if (full && probe < 15) {                                       // no free slot: the key may live in the next bucket
         s.nc |= (probe + 1) << 12;
         return;
     }
     const uint32_t nkp = kp + PA_SEEK_STRIDE;                       // :110
     l_set_kp(s, nkp);
     if (nkp > L - K) l_set_st(s, l_ncol(s) ? ST_ISECT : ST_NONE);   // None (:113) -> :294 break / :305-314
+}
+
+// hash of a k-mer of more than 32 bases (two words)
+PA_HD uint64_t pa_mix128(uint64_t lo, uint64_t hi) { return pa_mix64(lo ^ (pa_mix64(hi) * 0x9e3779b97f4a7c15ull)); }
+
+// One dictionary probe of find_kmer_match (:91-114): dbg_index.get + verification collapse into one bucket line.
+PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
+    const uint32_t K = ix.k, kp = l_kp(s), probe = l_probe(s);
+    if (K > 32) {   // two-word k-mers: a line holds two whole entries {key word 0..3, handle, off, -, -}
+        const uint64_t klo = read_window(rd, kp), khi = read_window(rd, kp + 32) & ix.kmask_hi;   // read_seq.get_kmer(kmer_pos) (:93)
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t b = __umulhi((uint32_t)(pa_mix128(klo, khi) >> 32), (uint32_t)ix.nbuckets) + probe;
+#else
+        uint32_t b = (uint32_t)(((pa_mix128(klo, khi) >> 32) * (uint32_t)ix.nbuckets) >> 32) + probe;
+#endif
+        if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
+        const U4* line = reinterpret_cast<const U4*>(ix.table + (uint64_t)b * BUCKET_WORDS);
+        const U4 k0 = line[0], v0 = line[1], k1 = line[2], v1 = line[3];
+        const uint32_t w0 = (uint32_t)klo, w1 = (uint32_t)(klo >> 32), w2 = (uint32_t)khi, w3 = (uint32_t)(khi >> 32);
+        const bool h0 = k0.x == w0 && k0.y == w1 && k0.z == w2 && k0.w == w3 && v0.x != NO_HANDLE,
+                   h1 = k1.x == w0 && k1.y == w1 && k1.z == w2 && k1.w == w3 && v1.x != NO_HANDLE;
+        seek_finish(s, K, h0 ? v0.x : h1 ? v1.x : NO_HANDLE, h0 ? v0.y : v1.y, v0.x != NO_HANDLE && v1.x != NO_HANDLE, probe);
+        return;
+    }
+    const uint64_t kmer = read_window(rd, kp) & ix.kmask;           // read_seq.get_kmer(kmer_pos) (:93)
+    uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + probe;
+    if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
+    const uint32_t* linew = ix.table + (uint64_t)b * BUCKET_WORDS;
+    const U4 fp = *reinterpret_cast<const U4*>(linew);
+    const uint32_t klo = (uint32_t)kmer, khi = (uint32_t)(kmer >> 32);
+    const uint32_t want = klo & 0x7FFFFFFFu, top = klo >> 31;
+    // entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j: fetch the one whose fingerprint matches (same line)
+    const uint32_t j = fp.x == want ? 0u : fp.y == want ? 1u : fp.z == want ? 2u : 3u;
+    const U3 e = *reinterpret_cast<const U3*>(linew + 4 + 3 * j);
+    const bool anyfp = (fp.x == want) | (fp.y == want) | (fp.z == want) | (fp.w == want);
+    const bool hit = anyfp && e.x == khi && (e.z >> 31) == top;
+    seek_finish(s, K, hit ? e.y : NO_HANDLE, e.z & 0x7FFFFFFFu, ((fp.x | fp.y | fp.z | fp.w) >> 31) == 0, probe);
 }
 
 // ---------------------------------------------------------------------------------------------- FWD

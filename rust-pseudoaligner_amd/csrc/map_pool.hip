@@ -42,7 +42,7 @@ __device__ __forceinline__ DevIndexView view_of(karg_ptr p) {   // member-wise: 
     DevIndexView v;
     v.table = p->ix.table; v.nbuckets = p->ix.nbuckets; v.blobs = p->ix.blobs; v.ledge = p->ix.ledge;
     v.nid_of_handle = p->ix.nid_of_handle; v.ec = p->ix.ec; v.class_ref = p->ix.class_ref; v.class_len = p->ix.class_len;
-    v.wtable = p->ix.wtable; v.wbuckets = p->ix.wbuckets; v.kmask = p->ix.kmask; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes;
+    v.wtable = p->ix.wtable; v.wbuckets = p->ix.wbuckets; v.kmask = p->ix.kmask; v.kmask_hi = p->ix.kmask_hi; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes;
     return v;
 }
 

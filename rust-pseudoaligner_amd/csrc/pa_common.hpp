@@ -59,6 +59,24 @@ static inline uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// ---- k-mers of up to 32 bases (one word) or up to 64 bases (two words: Kmer64 of the debruijn crate, the other k the
+// reference's CLI accepts, src/bin/pseudoaligner.rs:88) ----
+typedef unsigned __int128 u128;
+
+template <class KT> struct KmerOps;
+template <> struct KmerOps<uint64_t> {
+    static uint64_t mask(uint32_t k) { return kmer_mask(k); }
+    static uint64_t get(const uint64_t* w, uint64_t pos, uint32_t k) { return get_kmer(w, pos, k); }   // words (pos>>5)+1 readable
+    static uint64_t hash(uint64_t km) { return mix64(km); }
+};
+template <> struct KmerOps<u128> {   // 32 < k <= 64
+    static u128 mask(uint32_t k) { return k >= 64 ? ~(u128)0 : (((u128)1 << (2 * k)) - 1); }
+    static u128 get(const uint64_t* w, uint64_t pos, uint32_t k) {   // words (pos>>5)+2 readable
+        return ((u128)(window32(w, pos + 32) & kmer_mask(k - 32)) << 64) | window32(w, pos);
+    }
+    static uint64_t hash(u128 km) { return mix64((uint64_t)km ^ (mix64((uint64_t)(km >> 64)) * 0x9e3779b97f4a7c15ull)); }
+};
+
 static inline uint64_t splitmix64(uint64_t& s) {
     uint64_t z = (s += 0x9e3779b97f4a7c15ull);
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;

@@ -73,7 +73,7 @@ def oracle_lib():
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p]
         L.oracle_free.argtypes = [C.c_void_p]
         L.oracle_last_batch_seconds.restype = C.c_double
-        L.oracle_lookup_kmer.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.oracle_lookup_kmer.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         _oracle_lib = L
     return _oracle_lib
 
@@ -156,7 +156,7 @@ class Oracle:
 
     def lookup(self, kmer: int):
         n, o = C.c_uint32(), C.c_uint32()
-        ok = oracle_lib().oracle_lookup_kmer(self._h, kmer, C.byref(n), C.byref(o))
+        ok = oracle_lib().oracle_lookup_kmer(self._h, kmer & 0xFFFFFFFFFFFFFFFF, kmer >> 64, C.byref(n), C.byref(o))
         return (n.value, o.value) if ok else None
 
     def __del__(self):

@@ -24,7 +24,8 @@ def test_small_fq(small_index, k):
 
 @pytest.mark.parametrize("k,read_len,ppm,allowed", [(24, 100, 0, 2), (24, 150, 10000, 2), (31, 150, 10000, 2), (20, 75, 50000, 2),
                                                     (31, 150, 30000, 0), (24, 150, 30000, 1), (24, 150, 60000, 3), (32, 150, 10000, 2),
-                                                    (8, 40, 20000, 2)])
+                                                    (8, 40, 20000, 2), (33, 150, 10000, 2), (48, 150, 5000, 2), (64, 150, 5000, 2),
+                                                    (64, 100, 0, 2)])
 def test_simulated_reads(small_index, built, k, read_len, ppm, allowed):
     host = small_index(k) if k in (20, 24, 31) else pa.build_index(str(helpers.FASTA), k, 8)
     tx = pa.Txome.from_host_index(host)

@@ -56,7 +56,7 @@ def test_reference_literals_through_map_read(aligners):
 
 @pytest.mark.parametrize("k,read_len,ppm,allowed,n", [(24, 100, 0, 2, 300000), (24, 150, 10000, 2, 300000), (31, 150, 10000, 2, 300000),
                                                       (20, 75, 50000, 2, 100000), (31, 150, 30000, 0, 100000), (24, 150, 30000, 1, 100000),
-                                                      (24, 150, 60000, 3, 100000)])
+                                                      (24, 150, 60000, 3, 100000), (64, 150, 5000, 2, 100000), (40, 100, 10000, 2, 100000)])
 def test_simulated_reads_device_batches(aligners, k, read_len, ppm, allowed, n):
     """device-resident API: reads simulated on the GPU, mapped, compared with the oracle on the host-simulated twins"""
     import torch

@@ -97,7 +97,7 @@ def random_txome(rng, n_tx, alphabet="ACGT"):
 @pytest.mark.parametrize("seed", range(12))
 def test_builder_matches_naive_graph(built, seed):
     rng = np.random.RandomState(seed)
-    k = int(rng.choice([8, 9, 12, 16]))
+    k = int(rng.choice([8, 9, 12, 16, 33, 48, 64]))   # one- and two-word k-mers
     seqs = random_txome(rng, rng.randint(2, 25), "ACGT" if seed % 3 else "AC")
     words, tx_start = pack(seqs)
     host = pa.HostIndex.build_packed(words, tx_start, k, 1 + seed % 4)
@@ -173,7 +173,7 @@ def test_container_and_flat_round_trip(built, small_index, tmp_path):
 
 def test_invalid_arguments_fail_loudly(built):
     words, tx_start = pack(["ACGTACGTACGTACGT"])
-    for k in (0, 7, 33):
+    for k in (0, 7, 65):
         with pytest.raises(pa.PaError):
             pa.HostIndex.build_packed(words, tx_start, k, 1)
     with pytest.raises(pa.PaError):

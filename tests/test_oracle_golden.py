@@ -49,10 +49,13 @@ def test_small_fq_matches_committed_fixture(small_index, k):
     assert "".join(lines) == (helpers.GOLDEN / ("small_fq_k%d.tsv" % k)).read_text()
 
 
+KMER = np.dtype([("hi", "<u8"), ("lo", "<u8")])   # k-mers of up to 64 bases, sortable (hi first)
+
+
 def _kmers_of(codes: np.ndarray, k: int) -> np.ndarray:
-    out = np.zeros(len(codes) - k + 1, np.uint64)
+    out = np.zeros(len(codes) - k + 1, KMER)
     for j in range(k):
-        out |= codes[j:len(codes) - k + 1 + j].astype(np.uint64) << np.uint64(2 * j)
+        out["lo" if j < 32 else "hi"] |= codes[j:len(codes) - k + 1 + j].astype(np.uint64) << np.uint64(2 * (j % 32))
     return out
 
 
@@ -67,7 +70,7 @@ def _unpack(words: np.ndarray, start: int, length: int) -> np.ndarray:
     return ((words[pos >> 5] >> ((pos & 31) * 2).astype(np.uint64)) & np.uint64(3)).astype(np.uint8)
 
 
-@pytest.mark.parametrize("k", [20, 31])
+@pytest.mark.parametrize("k", [20, 31, 64])   # the reference runs validate_dbg at K = 20 and K = 64 (src/build_index.rs:394-409)
 def test_validate_dbg_kmer_colours(small_index, k):
     """validate_dbg part 1 (src/build_index.rs:263-298): for EVERY k-mer of every transcript the graph's colour list
     equals the naive list of transcripts containing it, and the graph holds no other k-mers (vectorised)."""
@@ -79,7 +82,7 @@ def test_validate_dbg_kmer_colours(small_index, k):
             km.append(v)
             tx.append(np.full(len(v), i, np.uint32))
     km, tx = np.concatenate(km), np.concatenate(tx)
-    order = np.lexsort((tx, km))
+    order = np.lexsort((tx, km["lo"], km["hi"]))
     km, tx = km[order], tx[order]
     keep = np.ones(len(km), bool)
     keep[1:] = (km[1:] != km[:-1]) | (tx[1:] != tx[:-1])        # test_eqclass.dedup() (:275)
@@ -107,13 +110,13 @@ def test_validate_dbg_kmer_colours(small_index, k):
         gs.append(np.full(len(v), class_sig[a["node_colour"][n]], np.uint64))
         gl.append(np.full(len(v), class_len[a["node_colour"][n]], np.int64))
     gk, gs, gl = np.concatenate(gk), np.concatenate(gs), np.concatenate(gl)
-    order = np.argsort(gk, kind="stable")
+    order = np.lexsort((gk["lo"], gk["hi"]))
     gk, gs, gl = gk[order], gs[order], gl[order]
     assert len(gk) == len(naive_kmers) and np.array_equal(gk, naive_kmers)     # same k-mer set, each exactly once
     assert np.array_equal(gl, naive_len) and np.array_equal(gs, naive_sig)     # same transcript list per k-mer
 
 
-@pytest.mark.parametrize("k", [20, 31])
+@pytest.mark.parametrize("k", [20, 31, 64])
 def test_validate_dbg_self_mapping(small_index, k):
     """validate_dbg part 2 (src/build_index.rs:300-367): every transcript with len >= k maps with bases_aligned == len;
     the class is [i] or contains i; identical sequences share a class."""
