@@ -7,6 +7,7 @@ run in this image, so these are restatement outputs, not reference outputs — s
                             (the line format whose SHA-256 SURVEY.md appendix B lists for an independent Python model)
   synth_err_k31.tsv          400 simulated 150 bp reads with 1 % substitutions on gencode_small at K=31 (read seed 4):
                             "<read ascii>\t<ids>\t<coverage>\t<mismatches>" or "<read ascii>\tNone"
+  synth_err_k64.tsv          the same at K=64 (two-word k-mers; the other k the reference's CLI accepts), 0.5 % substitutions
 Inputs gencode_small.fa / small.fq are the reference's own test data files (test/gencode_small.fa, test/small.fq).
 """
 import sys
@@ -35,6 +36,14 @@ def main():
             res, coff, cids, _ = oracle.map_tiles(tiles, lens, 5, 2, 4)
             lines = helpers.result_lines(reads, res["mapped"], res["coverage"], res["mismatches"], coff, cids)
             (HERE / "synth_err_k31.tsv").write_text("".join(lines))
+    host = pa.build_index(str(helpers.FASTA), 64, 8)
+    tx = pa.Txome.from_host_index(host)
+    tiles, lens = tx.simulate_host(150, 4, 400, 5000)
+    reads = pa.unpack_tiles(tiles, lens, 5)
+    res, coff, cids, _ = helpers.Oracle(host).map_tiles(tiles, lens, 5, 2, 4)
+    lines = helpers.result_lines(reads, res["mapped"], res["coverage"], res["mismatches"], coff, cids)
+    (HERE / "synth_err_k64.tsv").write_text("".join(lines))
+    print("k=64 sha256=%s" % helpers.sha256_lines(lines))
 
 
 if __name__ == "__main__":

@@ -73,11 +73,14 @@ def test_long_reads_cross_many_nodes(small_index):
     check(host, tiles, lens, wpr, 2, col_cap=4)
 
 
-def test_golden_synthetic_error_reads(small_index):
-    lines = (helpers.GOLDEN / "synth_err_k31.tsv").read_text().splitlines()
+@pytest.mark.parametrize("k", [31, 64])
+def test_golden_synthetic_error_reads(small_index, k):
+    lines = (helpers.GOLDEN / ("synth_err_k%d.tsv" % k)).read_text().splitlines()
     reads = [l.split("\t")[0] for l in lines]
     tiles, lens, wpr = pa.encode_reads_host(reads)
-    r = helpers.Emu(small_index(31)).map_tiles(tiles, lens, wpr)
+    o_res, o_coff, o_ids, _ = helpers.Oracle(small_index(k)).map_tiles(tiles, lens, wpr, 2, 2)
+    assert [g.rstrip("\n") for g in helpers.result_lines(reads, o_res["mapped"], o_res["coverage"], o_res["mismatches"], o_coff, o_ids)] == lines
+    r = helpers.Emu(small_index(k)).map_tiles(tiles, lens, wpr)
     res = r["results"]
     got = helpers.result_lines(reads, res["mismatches"] >> 31, res["coverage"], res["mismatches"] & 0x7FFFFFFF, r["coff"], r["ids"])
     assert [g.rstrip("\n") for g in got] == lines
