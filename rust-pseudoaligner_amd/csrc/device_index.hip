@@ -208,20 +208,20 @@ static uint32_t spill_cap_of(uint32_t wpr) { return 256 * wpr + 24; }
 
 // pooled kernel: slots per wave such that `per_cu` workgroups share the 160 KiB of LDS of a CU
 static int pool_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t* grid, size_t* lds, uint32_t* slots) {
-    const size_t cu_lds = 160 * 1024;
+    const size_t cu_lds = 160 * 1024 - 4096;   // LDS is allocated in granules: a pool sized to the last byte loses a whole workgroup per CU
     int per_cu = env_int("PA_MAP_BLOCKS_PER_CU", 3);
     uint32_t S = 0;
     for (; per_cu >= 1; --per_cu) {
         const size_t per_wave = cu_lds / (size_t)per_cu / (PA_MAP_BLOCK / 64);
         const size_t per_slot = pool_slot_bytes(wpr);
-        if (per_wave < 256 + 64 * per_slot + 16) continue;
-        S = (uint32_t)((per_wave - 256 - 16) / per_slot) & ~7u;
+        if (per_wave < 768 + 64 * per_slot + 16) continue;
+        S = (uint32_t)((per_wave - 768 - 16) / per_slot) & ~1u;
         break;
     }
     if (S < 64) return fail(PA_ERR_UNSUPPORTED, "reads of %u words do not fit the LDS of a compute unit", wpr);
     if (S > 256) S = 256;
     const int want = env_int("PA_POOL_SLOTS", 0);
-    if (want >= 64 && (uint32_t)want <= S) S = (uint32_t)want & ~7u;
+    if (want >= 64 && (uint32_t)want <= S) S = (uint32_t)want & ~1u;
     *slots = S;
     *lds = pool_lds_bytes(wpr, S);
     int occ = 0;
