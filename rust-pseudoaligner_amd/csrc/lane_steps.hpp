@@ -387,7 +387,7 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
 // words, issued together). Fast mode compares up to 128 bases by counting mismatches only; when a node visit would
 // exceed its mismatch budget nothing is consumed and the lane switches to careful mode, which walks the same node 32
 // bases per call and locates the breaking base exactly as the reference's loop does (:236-255).
-template <bool TRACE = false, int EXP = 0>   // EXP != 0: timing experiments only (wrong results)
+template <bool TRACE = false>
 PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
     const uint32_t K = ix.k, L = l_L(s);
     const uint32_t fl = l_flags(s);
@@ -396,10 +396,13 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
     const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
     const Hdr hd = load_hdr(ix, s.h);                                 // dbg.get_node (:210)
     const Q2* sq2 = reinterpret_cast<const Q2*>(node_seq(ix, s.h) + (ro0 >> 5));
-    const Q2 zero2{0, 0};
-    const Q2 s01 = EXP == 2 ? zero2 : sq2[0], s23 = (EXP == 1 || EXP == 2) ? zero2 : sq2[1], s45 = (EXP == 1 || EXP == 2) ? zero2 : sq2[2];
-    const uint64_t a[5] = {s01.a, s01.b, s23.a, s23.b, s45.a};
     uint32_t rem = s.rm & 0xFFFFu, snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
+    // sequence words this step can need, known before the header arrives: the node visit compares at most the rest of the
+    // read (fresh) / of the visit (continued), 128 bases per step; words beyond are not fetched (each may be another line)
+    const uint32_t most = pa_min(fresh ? L - kp0 : rem, 128u), nwords = ((ro0 & 31) + most + 31) >> 5;
+    const Q2 zero2{0, 0};
+    const Q2 s01 = sq2[0], s23 = nwords > 2 ? sq2[1] : zero2, s45 = nwords > 4 ? sq2[2] : zero2;
+    const uint64_t a[5] = {s01.a, s01.b, s23.a, s23.b, s45.a};
     if (fresh) {
         cov += K;                                                     // :216
         if (push_node<TRACE>(s, cols, ix, hd, s.h)) {                 // nodes.push (:219)
@@ -421,8 +424,7 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const uint32_t done = 32u * c;
-            if (EXP != 3 && EXP != 2 && EXP != 1 && n > done) cnt += pa_popc64(diff_mask(funnel(r[c], r[c + 1], sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u)));
-            if (EXP == 1 && c == 0 && n > done) cnt += pa_popc64(diff_mask(funnel(r[c], r[c + 1], sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u))) & 0u;
+            if (n > done) cnt += pa_popc64(diff_mask(funnel(r[c], r[c + 1], sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u)));
         }
         if (snp + cnt <= allowed) {
             matched = n;
