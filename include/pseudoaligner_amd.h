@@ -109,6 +109,17 @@ int pa_host_index_load(const char* path, pa_host_index** out);
 uint32_t pa_host_index_num_transcripts(const pa_host_index* h);
 const char* pa_host_index_tx_name(const pa_host_index* h, uint32_t tx);
 const char* pa_host_index_tx_gene(const pa_host_index* h, uint32_t tx);
+/* Gene-level collapse of the class-count table through tx_gene_mapping (src/pseudoaligner.rs:32; the reference stores the
+ * mapping and leaves the collapse to its callers). Genes are numbered by first appearance in transcript order.
+ *   pa_host_index_genes            tx_gene[num_transcripts] (may be NULL) and the number of genes
+ *   pa_host_index_gene_name        name of gene g
+ *   pa_counts_collapse_genes       gene_counts[g] += class_counts[c] for every class c whose transcripts all belong to gene
+ *                                  g; classes that span several genes go to gene_counts[num_genes]; the three tail slots
+ *                                  of the class table (novel / empty / unmapped, pa_counts_len) are not gene-resolvable
+ *                                  and are skipped. gene_counts has num_genes + 1 entries and is NOT cleared. */
+int pa_host_index_genes(const pa_host_index* h, uint32_t* tx_gene, uint32_t* num_genes);
+const char* pa_host_index_gene_name(const pa_host_index* h, uint32_t gene);
+int pa_counts_collapse_genes(const pa_host_index* h, const uint64_t* class_counts, uint64_t counts_len, uint64_t* gene_counts);
 /* packed transcripts the index was built from (kept for read simulation / validation) */
 int pa_host_index_transcripts(const pa_host_index* h, const uint64_t** packed, const uint64_t** tx_start,
                               uint32_t* num_tx);

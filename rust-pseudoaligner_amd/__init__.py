@@ -115,6 +115,22 @@ class HostIndex:
     def tx_genes(self) -> List[str]:
         return [lib().pa_host_index_tx_gene(self._h, i).decode() for i in range(self.num_transcripts)]
 
+    def genes(self) -> Tuple[np.ndarray, List[str]]:
+        """(gene id of each transcript, gene names): tx_gene_mapping (src/pseudoaligner.rs:32), genes numbered by first appearance"""
+        n = C.c_uint32()
+        tx_gene = np.zeros(max(self.num_transcripts, 1), np.uint32)
+        check(lib().pa_host_index_genes(self._h, tx_gene.ctypes.data, C.byref(n)))
+        return tx_gene[: self.num_transcripts], [lib().pa_host_index_gene_name(self._h, g).decode() for g in range(n.value)]
+
+    def collapse_to_genes(self, class_counts: np.ndarray) -> np.ndarray:
+        """gene-level counts (last entry: classes spanning several genes) from a class-count table of counts_len entries"""
+        n = C.c_uint32()
+        check(lib().pa_host_index_genes(self._h, None, C.byref(n)))
+        cc = np.ascontiguousarray(class_counts, np.uint64)
+        out = np.zeros(n.value + 1, np.uint64)
+        check(lib().pa_counts_collapse_genes(self._h, cc.ctypes.data, len(cc), out.ctypes.data))
+        return out
+
     def transcripts(self) -> Tuple[np.ndarray, np.ndarray]:
         p, s, n = vp(), vp(), C.c_uint32()
         check(lib().pa_host_index_transcripts(self._h, C.byref(p), C.byref(s), C.byref(n)))

@@ -54,6 +54,9 @@ SIGNATURES = {
     "pa_host_index_num_transcripts": (C.c_uint32, [vp]),
     "pa_host_index_tx_name": (C.c_char_p, [vp, C.c_uint32]),
     "pa_host_index_tx_gene": (C.c_char_p, [vp, C.c_uint32]),
+    "pa_host_index_genes": (C.c_int, [vp, vp, u32p]),
+    "pa_host_index_gene_name": (C.c_char_p, [vp, C.c_uint32]),
+    "pa_counts_collapse_genes": (C.c_int, [vp, vp, C.c_uint64, vp]),
     "pa_host_index_transcripts": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), u32p]),
     "pa_host_index_destroy": (None, [vp]),
     "pa_index_create": (C.c_int, [C.POINTER(FlatIndex), C.c_int, C.POINTER(vp)]),

@@ -3,6 +3,8 @@
 #include <fstream>
 #include <thread>
 
+#include <unordered_map>
+
 #include "pa_common.hpp"
 
 namespace pa {
@@ -222,6 +224,58 @@ const char* pa_host_index_tx_name(const pa_host_index* h, uint32_t tx) {
 const char* pa_host_index_tx_gene(const pa_host_index* h, uint32_t tx) {
     return (h && tx < h->h.tx_genes.size()) ? h->h.tx_genes[tx].c_str() : "";
 }
+// ---- gene-level collapse (tx_gene_mapping, src/pseudoaligner.rs:32) ----
+static void gene_table(const pa_host_index* h, std::vector<uint32_t>& tx_gene, std::vector<const std::string*>& names) {
+    std::unordered_map<std::string, uint32_t> id;
+    tx_gene.resize(h->h.tx_genes.size());
+    for (size_t t = 0; t < h->h.tx_genes.size(); ++t) {
+        auto it = id.find(h->h.tx_genes[t]);
+        if (it == id.end()) { it = id.emplace(h->h.tx_genes[t], (uint32_t)names.size()).first; names.push_back(&h->h.tx_genes[t]); }
+        tx_gene[t] = it->second;
+    }
+}
+
+int pa_host_index_genes(const pa_host_index* h, uint32_t* tx_gene, uint32_t* num_genes) {
+    if (!h) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::vector<uint32_t> tg;
+    std::vector<const std::string*> names;
+    gene_table(h, tg, names);
+    if (tx_gene && !tg.empty()) memcpy(tx_gene, tg.data(), tg.size() * 4);
+    if (num_genes) *num_genes = (uint32_t)names.size();
+    return PA_OK;
+}
+
+const char* pa_host_index_gene_name(const pa_host_index* h, uint32_t gene) {
+    if (!h) return "";
+    std::vector<uint32_t> tg;
+    std::vector<const std::string*> names;
+    gene_table(h, tg, names);
+    return gene < names.size() ? names[gene]->c_str() : "";
+}
+
+int pa_counts_collapse_genes(const pa_host_index* h, const uint64_t* class_counts, uint64_t counts_len, uint64_t* gene_counts) {
+    if (!h || !class_counts || !gene_counts) return fail(PA_ERR_INVALID_ARG, "null argument");
+    const uint64_t nc = h->h.ec_offset.size() - 1;
+    if (counts_len != nc + 3) return fail(PA_ERR_INVALID_ARG, "class table has %llu entries, index has %llu classes (+3)",
+                                          (unsigned long long)counts_len, (unsigned long long)nc);
+    if (h->h.tx_genes.size() != h->h.num_transcripts) return fail(PA_ERR_FORMAT, "index carries no gene of each transcript");
+    std::vector<uint32_t> tg;
+    std::vector<const std::string*> names;
+    gene_table(h, tg, names);
+    const uint32_t multi = (uint32_t)names.size();
+    for (uint64_t c = 0; c < nc; ++c) {
+        if (!class_counts[c]) continue;
+        uint32_t g = multi;
+        for (uint64_t j = h->h.ec_offset[c]; j < h->h.ec_offset[c + 1]; ++j) {
+            const uint32_t gj = tg[h->h.ec_ids[j]];
+            if (j == h->h.ec_offset[c]) g = gj;
+            else if (gj != g) { g = multi; break; }
+        }
+        gene_counts[g] += class_counts[c];
+    }
+    return PA_OK;
+}
+
 int pa_host_index_transcripts(const pa_host_index* h, const uint64_t** packed, const uint64_t** tx_start, uint32_t* num_tx) {
     if (!h) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (packed) *packed = h->h.tx_packed.data();

@@ -184,3 +184,24 @@ def test_invalid_arguments_fail_loudly(built):
     flat.node_colour = bad.ctypes.data
     with pytest.raises(pa.PaError):
         pa.HostIndex.from_flat(flat)
+
+
+def test_gene_level_collapse(small_index):
+    """tx_gene_mapping (src/pseudoaligner.rs:32): class counts fold into per-gene counts; multi-gene classes are kept apart"""
+    host = small_index(24)
+    a = host.arrays()
+    genes = host.tx_genes()
+    tx_gene, names = host.genes()
+    assert len(tx_gene) == a["num_transcripts"] and [names[g] for g in tx_gene] == genes
+    assert names == list(dict.fromkeys(genes))                                   # numbered by first appearance
+    rng = np.random.RandomState(11)
+    counts = rng.randint(0, 50, a["num_classes"] + 3).astype(np.uint64)
+    got = host.collapse_to_genes(counts)
+    want = np.zeros(len(names) + 1, np.uint64)
+    eo, ei = a["ec_offset"].astype(np.int64), a["ec_ids"]
+    for c in range(a["num_classes"]):
+        gs = set(tx_gene[ei[eo[c]:eo[c + 1]]].tolist())
+        want[gs.pop() if len(gs) == 1 else len(names)] += counts[c]
+    assert np.array_equal(got, want) and got.sum() == counts[:-3].sum()
+    with pytest.raises(pa.PaError):
+        host.collapse_to_genes(counts[:-1])
