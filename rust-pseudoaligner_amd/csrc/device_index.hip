@@ -41,7 +41,7 @@ struct DevBuf {   // grow-only device scratch
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-uint64_t list_hash_host(const uint32_t* v, uint32_t n) {   // must equal list_hash_dev (kernels.hip)
+uint64_t list_hash_host(const uint32_t* v, uint32_t n) {   // must equal list_hash_dev (kernel_utils.hpp)
     uint64_t h = 0x243f6a8885a308d3ull ^ n;
     for (uint32_t i = 0; i < n; ++i) h = mix64(h ^ v[i]) + 0x9e3779b97f4a7c15ull;
     return h;

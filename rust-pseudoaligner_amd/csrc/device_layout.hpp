@@ -1,5 +1,5 @@
 // GPU-resident form of the index and the per-lane state of the mapping kernel. Shared by the host flattener
-// (device_index.cpp), the HIP kernels (kernels.hip) and the host lane emulator used by the CPU tests (tests/emu).
+// (device_flatten.cpp), the HIP kernels (map_pool.hip) and the host lane emulator used by the CPU tests (tests/emu).
 //
 // HBM layout (all little-endian, all read-only after pa_index_create):
 //

@@ -1,4 +1,4 @@
-// Kernel parameter blocks and launch entry points shared by kernels.hip and device_index.hip.
+// Kernel parameter blocks and launch entry points shared by map_pool.hip, kernels.hip and device_index.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 

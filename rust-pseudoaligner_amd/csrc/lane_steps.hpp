@@ -1,18 +1,19 @@
-// Per-lane state machine of the mapping kernel: one lane = one read, one call = one memory-dependent step.
+// Per-read state machine of the mapping kernel: one lane works on one read at a time, one call = one memory-dependent step.
 //
 // This is the reference's map_read_to_nodes_with_mismatch (src/pseudoaligner.rs:64-319) re-expressed for a
 // 64-wide wavefront: the three data-dependent loops of the reference (dictionary scan :91-114, left extension
 // :131-203, forward extension :209-301) become the states SEEK / LEFT / FWD, each advancing by one dependent HBM
-// fetch per call, so that a wave can run the same state for many reads at once (kernels.hip schedules the states).
+// fetch per call, so that a wave can run the same state for many reads at once (map_pool.hip schedules the states).
 // The per-base comparison loops (:151-170, :236-255) are replaced by XOR + popcount on 32-base windows with a slow
 // path (position of the (allowed+1)-th mismatch) that only runs when a node visit exceeds its mismatch budget; the
-// nodes Vec (:219) is replaced by the set of DISTINCT classes seen, because nodes_to_eq_class (:323-356) only uses
-// the id lists and intersection is idempotent/commutative.
+// nodes Vec (:219) is replaced by the running intersection of the classes seen as two 32-id windows (or, for classes
+// that do not fit, by the set of DISTINCT classes), because nodes_to_eq_class (:323-356) only uses the id lists and
+// intersection is idempotent/commutative.
 //
-// Written for instruction economy on gfx950: the lane state is packed into 9 VGPRs, 64-bit funnel shifts are two
-// v_alignbit_b32, the bucket index is one v_mul_hi_u32, the lane's class list is one ds_read_b128.
+// Written for instruction economy on gfx950: the read's state is 8 packed words + its id (two 16-byte LDS vectors in the
+// pooled kernel), 64-bit funnel shifts are two v_alignbit_b32, the bucket index is one v_mul_hi_u32.
 //
-// Compiled for gfx950 by kernels.hip and for the host by tests/emu (CPU parity tests of exactly this text).
+// Compiled for gfx950 by map_pool.hip and for the host by tests/emu (CPU parity tests of exactly this text).
 #pragma once
 #include "device_layout.hpp"
 
@@ -23,9 +24,9 @@ enum : uint32_t { ST_EMPTY = 0, ST_SEEK = 1, ST_FWD = 2, ST_LEFT = 3, ST_ISECT =
                   ST_F_LIGHT = 6, ST_F_SCAN = 7, ST_F_COOP = 8, ST_F_BITS = 9, ST_F_NOVEL = 10, ST_COUNT = 11 };
 enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_CAREFUL = 16u, F_LISTS = 32u };
 constexpr uint32_t NO_CLASS = 0xFFFFFFFFu;
-constexpr uint32_t LDS_CLASSES = 4;   // distinct classes per lane kept in LDS (one 16-byte vector of refs + one of lengths)
+constexpr uint32_t LDS_CLASSES = 4;   // list mode: distinct classes kept inline (one 16-byte vector each of refs, lengths, class ids)
 
-// Packed lane state (9 VGPRs). Limits: read length <= 2048 (PA_MAX_READ_LEN; 12 bits hold 0..4095), node length < 2^24.
+// Packed state of a read (9 words). Limits: read length <= 2048 (PA_MAX_READ_LEN; 12 bits hold 0..4095), node length < 2^24.
 struct Lane {
     uint32_t rid;
     uint32_t lk;    // L (bits 0..11) | kmer_pos (12..23) | state (24..27)                  (:70, :79)

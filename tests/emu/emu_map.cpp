@@ -4,7 +4,7 @@
 // flattener (device_flatten.cpp) for the host, and runs every read to completion by calling the same step
 // functions the HIP kernel calls. It lets the CPU-only test tier (`-m "not gpu"`) check the device data layout and
 // the step logic against the oracle bit for bit; wave scheduling, LDS staging and arena allocation exist only in
-// kernels.hip and are covered by the `-m gpu` tier. Nothing in the product links or loads this file.
+// map_pool.hip and are covered by the `-m gpu` tier. Nothing in the product links or loads this file.
 #include <cstdlib>
 #include <cstring>
 #include <map>
