@@ -3,8 +3,8 @@
 // The per-read state machine of lane_steps.hpp has data-dependent length (node visits per read are heavy-tailed) and
 // several kinds of step (dictionary probe, node visit, left extension, class intersection, output). Running it with one
 // fixed read per lane leaves most lanes idle in every step: the lanes of a wave are never all in the same state.
-// Here a wave owns a POOL of S read slots (S > 64, typically 128) that lives in LDS — packed read, 32-byte lane state,
-// class window — and one byte queue per state. Each iteration the wave
+// Here a wave owns a POOL of S read slots (S > 64, 116 at 150 bp) that lives in LDS — packed read, 32-byte lane state,
+// class windows — and one byte queue per state. Each iteration the wave
 //     1. picks a queue (one that holds a full wave of 64 slots, preferring the states nearest to completion; otherwise
 //        the longest one), pops up to 64 slot ids from it and loads their lane state from LDS,
 //     2. runs that state's step for all of them (one dependent HBM round trip; every lane does the same thing),
@@ -12,7 +12,8 @@
 // Rare states simply wait in their queue until enough of them have gathered, so they are executed at full width too.
 // Nothing is shared between waves: no locks, no barriers, no atomics besides the arena chunk grab and the count table.
 //
-// LDS per wave (S slots, wpr words per read):   [256 B fixed | rd u64[wpr][S] | st {u32 x 8}[S] | win {u32 x 4}[S] | q u8[ST_COUNT][S]]
+// LDS per wave (S slots, wpr words per read):   [768 B fixed: arena chunk, statistics, count cache | rd u64[wpr][S] |
+//                                                 st {u32 x 8}[S] | win {u32 x 4}[S] | {class id, read id}[S] | q u8[ST_COUNT][S]]
 // HBM per slot: a row of spill_cap u32 that holds the class lists of a read in list mode (lane_steps.hpp, ColRef) and,
 // in TRACE builds, a second row with the visited node ids.
 #include <hip/hip_runtime.h>
