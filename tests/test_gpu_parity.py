@@ -260,6 +260,33 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
         pa.process_reads(str(trunc), a, str(out), 2)
 
 
+def test_hot_classes_count_table(tmp_path):
+    """a handful of classes take every read (a highly expressed gene): the per-wave count cache and the per-XCD replicas
+    must still add up to exactly the histogram of the per-read results, also across repeated launches into one table"""
+    import torch
+    _, seqs = helpers.read_fasta()
+    fa = tmp_path / "hot.fa"
+    fa.write_text("".join(">t%d\n%s\n" % (i, s) for i, s in enumerate([s for s in seqs if len(s) >= 300][:6])))
+    host = pa.HostIndex.build_fasta(str(fa), 24, 4)
+    a = pa.Pseudoaligner(host)
+    tx = pa.Txome.from_host_index(host)
+    n, L, wpr = 400_000, 100, 4
+    dev = torch.device("cuda", 0)
+    h_tiles, h_lens = tx.simulate_host(L, 9, n, 20000, 0, wpr)                   # 2 % substitutions: some novel / empty / unmapped too
+    d_tiles = torch.from_numpy(h_tiles.view(np.int64)).to(dev)
+    d_lens = torch.from_numpy(h_lens.view(np.int32)).to(dev)
+    cap = a.arena_hint(n)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    for _ in range(3):
+        a.map_count_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, d_counts.data_ptr(), 2)
+        a.map_finish()
+    o_res, o_coff, o_ids, _ = helpers.Oracle(host).map_tiles(h_tiles, h_lens, wpr, 2, 8)
+    want = helpers.counts_reference(o_res, o_coff, o_ids, host)
+    assert np.array_equal(d_counts.cpu().numpy(), 3 * want) and int(want.sum()) == n
+
+
 def test_full_size_batch_properties(aligners):
     """BASELINE.json configs[1] size (10 M x 100 bp on gencode_small, K=24) through size-independent properties:
     every error-free read maps over its full length with 0 mismatches and a non-empty class; the count table adds up;
