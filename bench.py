@@ -28,11 +28,11 @@ for p in (str(ROOT), str(ROOT / "tests")):
 
 WORKLOADS = {
     # name: (genes, transcripts, txome seed, k, read_len, read seed, substitution ppm)
-    "config3": dict(genes=58000, transcripts=203000, txome_seed=7, k=24, read_len=150, read_seed=2, ppm=0,
+    "config3": dict(genes=58000, transcripts=203000, txome_seed=7, k=24, read_len=150, read_seed=2, ppm=0, batch=100_000_000,
                     desc="~202k-transcript synthetic GENCODE-scale index (K=24), error-free 150bp reads"),
-    "config5": dict(genes=58000, transcripts=203000, txome_seed=7, k=31, read_len=150, read_seed=4, ppm=10000,
+    "config5": dict(genes=58000, transcripts=203000, txome_seed=7, k=31, read_len=150, read_seed=4, ppm=10000, batch=100_000_000,
                     desc="same transcriptome at K=31, 150bp reads with 1% substitutions"),
-    "config2": dict(fasta=str(ROOT / "tests" / "golden" / "gencode_small.fa"), k=24, read_len=100, read_seed=1, ppm=0,
+    "config2": dict(fasta=str(ROOT / "tests" / "golden" / "gencode_small.fa"), k=24, read_len=100, read_seed=1, ppm=0, batch=10_000_000,
                     desc="gencode_small (1832 transcripts) index (K=24), error-free 100bp reads"),
 }
 
@@ -59,7 +59,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=10_000_000, help="reads per step per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="reads per step per GPU (default: the batch BASELINE.json quotes for the workload: "
+                    "100 M reads for configs 3/5, 10 M for config 2)")
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,9 +131,9 @@ def main() -> None:
             pass
 
     # ---- resident inputs: distinct batches of packed reads in HBM, generated on the device ----
-    B, K, W = args.batch, args.steps, args.warmup
+    B, K, W = args.batch or wl["batch"], args.steps, args.warmup
     wpr = pa.lib().pa_words_per_read(read_len)
-    n_batches = min(K + W, 12)
+    n_batches = max(2, min(K + W, 12, int(64e9 // (B * (wpr * 8 + 4)))))   # distinct resident batches, at most ~64 GB of HBM
     tile_words = pa.lib().pa_tiles_words(B, wpr)
     stream = torch.cuda.current_stream().cuda_stream
     tiles = [torch.empty(tile_words, dtype=torch.int64, device=dev) for _ in range(n_batches)]
