@@ -59,7 +59,7 @@ struct pa_index {
     pa_index_stats stats{};
     // per-launch scratch (one batch in flight per index handle; calls are serialised by `mu`)
     std::mutex mu;
-    DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status
+    DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status, [12..15] tile counter, [16..] statistics
     DevBuf spill, trace, xcd_counts;
     uint32_t last_grid = 0;
     // host-buffer convenience path
@@ -265,6 +265,7 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.colour_out = d_colour;
     p.arena_top = idx->ctl.as<unsigned long long>();
     p.status = idx->ctl.as<uint32_t>() + 2;
+    p.tile_ctr = idx->ctl.as<uint32_t>() + 3;
     p.spill = idx->spill.as<uint32_t>();
     p.spill_cap = spill_cap;
     p.counts = reinterpret_cast<unsigned long long*>(d_counts);

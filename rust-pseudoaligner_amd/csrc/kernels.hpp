@@ -25,6 +25,7 @@ struct MapParams {
     uint32_t* colour_out;
     unsigned long long* arena_top;
     uint32_t* status;
+    uint32_t* tile_ctr;        // tiles handed out beyond every wave's first chunk (zero at launch)
     uint32_t* spill;
     uint32_t spill_cap;
     uint32_t pool_slots;       // read slots per wave (<= 256)
