@@ -32,6 +32,8 @@ WORKLOADS = {
                     desc="~202k-transcript synthetic GENCODE-scale index (K=24), error-free 150bp reads"),
     "config5": dict(genes=58000, transcripts=203000, txome_seed=7, k=31, read_len=150, read_seed=4, ppm=10000, batch=100_000_000,
                     desc="same transcriptome at K=31, 150bp reads with 1% substitutions"),
+    "config3k64": dict(genes=58000, transcripts=203000, txome_seed=7, k=64, read_len=150, read_seed=2, ppm=0, batch=100_000_000,
+                       desc="config 3 rebuilt at K=64 (two-word k-mers, the other k of the reference's CLI), error-free 150bp reads"),
     "config2": dict(fasta=str(ROOT / "tests" / "golden" / "gencode_small.fa"), k=24, read_len=100, read_seed=1, ppm=0, batch=10_000_000,
                     desc="gencode_small (1832 transcripts) index (K=24), error-free 100bp reads"),
 }
