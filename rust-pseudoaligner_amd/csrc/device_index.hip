@@ -120,7 +120,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     int rc = use_device(device);
     if (rc != PA_OK) return rc;
     FlatDevice fd;
-    int threads = (int)std::thread::hardware_concurrency();
+    int threads = usable_threads();
     if (threads < 1) threads = 1;
     rc = flatten_for_device(*flat, threads, fd);
     if (rc != PA_OK) return rc;

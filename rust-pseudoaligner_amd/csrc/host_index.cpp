@@ -9,6 +9,30 @@
 
 namespace pa {
 
+int usable_threads() {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                 // cgroup v2: "<quota|max> <period>"
+        char q[32];
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long long c = atoll(q) / period;
+            if (c >= 1 && c < n) n = (int)c;
+        }
+        fclose(f);
+    } else {
+        long long quota = -1, period = 0;                                // cgroup v1
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+        if (quota > 0 && period > 0 && quota / period >= 1 && quota / period < n) n = (int)(quota / period);
+    }
+    return n;
+}
+
+}  // namespace pa
+
+namespace pa {
+
 std::string& last_error_ref() {
     static thread_local std::string s;
     return s;
@@ -140,7 +164,7 @@ const char* pa_last_error(void) { return last_error_ref().c_str(); }
 int pa_host_index_build_packed(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx, uint32_t k,
                                int num_threads, pa_host_index** out) {
     if (!packed || !tx_start || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
-    if (num_threads <= 0) num_threads = (int)std::thread::hardware_concurrency();
+    if (num_threads <= 0) num_threads = usable_threads();
     pa_host_index* h = new (std::nothrow) pa_host_index();
     if (!h) return fail(PA_ERR_OOM, "out of memory");
     try {

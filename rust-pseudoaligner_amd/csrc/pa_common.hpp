@@ -19,6 +19,10 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // resolve results returned by reference (PA_CLASS_REF) without a device round trip
 void index_host_classes(const pa_index* idx, const uint32_t** ec, const uint32_t** class_ref, int* device);
 
+// CPUs this process may use: hardware threads, capped by the cgroup CPU quota (a container that sees 256 CPUs may be
+// limited to 16 CPUs' worth of time; 256 threads there only add scheduling noise). host_index.cpp
+int usable_threads();
+
 // ---- 2-bit packed sequences, LSB-first (base j -> bits 2*(j%32) of word j/32) ----
 static inline uint64_t kmer_mask(uint32_t k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1); }
 
