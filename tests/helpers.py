@@ -293,3 +293,41 @@ def counts_reference(results, coff, cids, host_index):
             c = table.get(tuple(cids[int(coff[i]):int(coff[i + 1])].tolist()))
             counts[nc if c is None else c] += 1
     return counts
+
+
+def random_txome_case(seed, tmp_path):
+    """differential-fuzz input: a small random transcriptome built from shared segments (repeats, cycles on a two-letter
+    alphabet, transcripts shorter than k), a k from 8 to 64, 0..3 allowed mismatches and 3000 reads: substrings with
+    substitutions, chimeras of two transcripts, random sequence, N and lower case. Returns (host index or None, k, reads,
+    reads as the reference encodes them, allowed)."""
+    rng = np.random.RandomState(100 + seed)
+    k = int(rng.choice([8, 11, 16, 21, 32, 33, 47, 64]))
+    alphabet = "ACGT" if seed % 3 else "AC"
+    segs = ["".join(rng.choice(list(alphabet), rng.randint(5, 90))) for _ in range(16)]
+    txs = ["".join(segs[j] for j in rng.choice(len(segs), rng.randint(1, 9))) for _ in range(int(rng.randint(3, 60)))]
+    fa = tmp_path / "r.fa"
+    fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i // 3, s) for i, s in enumerate(txs)))
+    host = pa.HostIndex.build_fasta(str(fa), k, 3)
+    if host.arrays()["num_nodes"] == 0:
+        return None, k, [], [], 0
+    reads = []
+    for _ in range(3000):
+        kind = rng.randint(0, 10)
+        t = txs[rng.randint(len(txs))]
+        if kind < 6:                                   # substring with substitutions
+            lo = rng.randint(0, max(1, len(t) - 10))
+            r = list(t[lo:lo + rng.randint(1, 200)])
+            for j in range(len(r)):
+                if rng.rand() < 0.02:
+                    r[j] = "ACGT"[rng.randint(4)]
+            reads.append("".join(r))
+        elif kind < 8:                                 # chimera
+            u = txs[rng.randint(len(txs))]
+            reads.append((t[: rng.randint(1, len(t) + 1)] + u[rng.randint(0, len(u)):])[:250])
+        elif kind == 8:
+            reads.append("".join(rng.choice(list(alphabet), rng.randint(0, 150))))
+        else:
+            r = t[: rng.randint(1, len(t) + 1)]
+            reads.append((r[: len(r) // 2] + "N" + r[len(r) // 2 + 1:]).lower() if rng.rand() < 0.5 else r.lower())
+    allowed = int(rng.randint(0, 4))
+    return host, k, reads, [r.upper().replace("N", "A") for r in reads], allowed

@@ -37,6 +37,18 @@ def test_simulated_reads(small_index, built, k, read_len, ppm, allowed):
         assert np.all(o_res["coverage"] == read_len)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_transcriptomes(tmp_path, seed):
+    """differential fuzz (helpers.random_txome_case): the kernel's steps and GPU index layout on the host vs the oracle"""
+    host, k, reads, clean, allowed = helpers.random_txome_case(seed, tmp_path)
+    if host is None:
+        pytest.skip("every transcript is shorter than k")
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    ctiles, clens, cwpr = pa.encode_reads_host(clean)
+    assert np.array_equal(tiles, ctiles) and np.array_equal(lens, clens)      # N and lower case encode like the reference says
+    check(host, tiles, lens, wpr, allowed)
+
+
 def test_ragged_short_and_unmappable_reads(small_index):
     host = small_index(24)
     _, seqs = helpers.read_fastq()

@@ -260,6 +260,31 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
         pa.process_reads(str(trunc), a, str(out), 2)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_transcriptomes(tmp_path, seed):
+    """differential fuzz (helpers.random_txome_case): GPU vs oracle, bit exact, incl. the fused count table"""
+    import torch
+    host, k, reads, clean, allowed = helpers.random_txome_case(seed, tmp_path)
+    if host is None:
+        pytest.skip("every transcript is shorter than k")
+    a = pa.Pseudoaligner(host)
+    res, coff, cids = a.map_batch(reads, allowed)
+    o_res, o_coff, o_ids, _ = helpers.Oracle(host).map_reads(clean, allowed, 4)
+    helpers.assert_same_as_oracle(res, coff, cids, o_res, o_coff, o_ids, "random txome seed %d k=%d" % (seed, k))
+    # fused count table through the device API
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    dev = torch.device("cuda", 0)
+    d_tiles, d_lens = torch.from_numpy(tiles.view(np.int64)).to(dev), torch.from_numpy(np.asarray(lens, np.uint32).view(np.int32)).to(dev)
+    n = len(reads)
+    cap = a.arena_hint(n)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    a.map_count_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, d_counts.data_ptr(), allowed)
+    a.map_finish()
+    assert np.array_equal(d_counts.cpu().numpy(), helpers.counts_reference(o_res, o_coff, o_ids, host))
+
+
 def test_hot_classes_count_table(tmp_path):
     """a handful of classes take every read (a highly expressed gene): the per-wave count cache and the per-XCD replicas
     must still add up to exactly the histogram of the per-read results, also across repeated launches into one table"""
