@@ -172,13 +172,16 @@ int pa_encode_reads_host(const uint8_t* ascii, const uint64_t* offsets, uint64_t
  *   d_arena    [arena_cap] u32: ids of the classes that are not index classes, referenced by (class_off, class_len)
  *   d_colour   optional [n_reads] u32: equivalence-class id of the result when it equals an index class
  *              reached by the read, 0xFFFFFFFF otherwise (input of pa_counts_accumulate_device); may be NULL
- * Asynchronous on `stream`; completion status is fetched with pa_map_finish (which synchronises the stream). */
+ * Asynchronous on `stream`; completion status is fetched with pa_map_finish (which synchronises the stream). Launches on
+ * ONE index handle share its control block and scratch: issue them on one stream, or call pa_map_finish in between
+ * (several handles are independent). */
 int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads,
                         uint32_t words_per_read, uint32_t allowed_mismatches, pa_read_result* d_results,
                         uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour, void* stream);
 /* Same launch with the class-count table fused in: d_counts[pa_counts_len(idx)] (u64, caller-owned so that it can be
- * all-reduced with RCCL) is incremented once per read as pa_counts_accumulate_device would. On PA_ERR_ARENA_FULL the
- * counts of that launch are still complete (they do not depend on the arena), the class ids are not. */
+ * all-reduced with RCCL) is incremented once per read as pa_counts_accumulate_device would. On PA_ERR_ARENA_FULL every
+ * read of that launch is still counted once, but a list-mode result whose ids did not fit cannot be looked up by content
+ * and lands in the "novel" slot; the class ids are incomplete. Re-run the batch with the arena pa_map_finish asks for. */
 int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads,
                               uint32_t words_per_read, uint32_t allowed_mismatches, pa_read_result* d_results,
                               uint32_t* d_arena, uint64_t arena_cap, uint64_t* d_counts, void* stream);
