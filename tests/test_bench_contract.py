@@ -1,0 +1,37 @@
+"""bench.py's helpers and the shape of the bench line it emits (checked on the committed line of the last GPU run)."""
+import importlib.util
+import json
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+spec = importlib.util.spec_from_file_location("bench", ROOT / "bench.py")
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_algorithmic_bytes_formula():
+    # SURVEY.md §8(d) with p=1, n=2, c=126, E=10, r=3 at L=150, K=24
+    ctr = dict(reads=1, probes=1, node_visits=2, bases_compared=126, class_sizes=10, result_sizes=3)
+    want = 38 + 4 + 1 * (8 + 6 + 12) + 2 * 21 + 2 * 126 / 8 + 8 * 2 + 4 * 10 + 12 + 4 * 3
+    assert abs(bench.algorithmic_bytes_per_read(ctr, 150, 24) - want) < 1e-9
+
+
+def test_usable_cpus_is_sane():
+    import os
+    n = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    line = json.loads((ROOT / "profiles" / "r01_pool_bench.json").read_text())
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["vs_baseline"] is None and line["scaling"] == "weak" and line["higher_is_better"] is True and "workload" in line["config"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["peak"] == 8000.0
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_read"] * r["reads_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_read"] * r["reads_per_launch"]
+    c = line["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == line["unit"] and "sample" in c
+    assert abs(line["value"] - line["config"]["reads_per_step_per_gpu"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
