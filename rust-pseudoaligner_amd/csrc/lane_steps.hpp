@@ -687,32 +687,31 @@ PA_HD uint32_t scan_tail(const DevIndexView& ix, uint32_t ref, uint32_t len, uin
     return m;
 }
 
-// membership mask of the base ids in the (<= 64 ids) lists of two LDS slots, first three chunks of each fetched together
-PA_HD void scan_pair(const DevIndexView& ix, uint32_t refA, uint32_t lenA, bool useA, uint32_t refB, uint32_t lenB, bool useB,
-                     uint32_t base_ref, const uint32_t (&b)[8], uint32_t& alive) {
+// membership of the base ids in up to four other lists: the first three chunks (11 ids) of each are fetched together —
+// twelve loads, one round trip — longer lists continue in scan_tail
+PA_HD void scan_quad(const DevIndexView& ix, const uint32_t (&ref)[4], const uint32_t (&len)[4], const bool (&use)[4], uint32_t base_ref,
+                     const uint32_t (&b)[8], uint32_t& alive) {
     const U4* brec = reinterpret_cast<const U4*>(ix.ec + 4ull * base_ref);
-    const U4* ra = useA ? reinterpret_cast<const U4*>(ix.ec + 4ull * refA) : brec;   // an unused slot re-reads the base record
-    const U4* rb = useB ? reinterpret_cast<const U4*>(ix.ec + 4ull * refB) : brec;
-    const uint32_t na = useA && lenA <= 64 ? (lenA + 4) >> 2 : 0, nb = useB && lenB <= 64 ? (lenB + 4) >> 2 : 0;
-    U4 wa[3], wb[3];
+    const U4* rec[4];
+    uint32_t n[4];
+    U4 w[4][3];
 #pragma unroll
-    for (uint32_t q = 0; q < 3; ++q) {
-        wa[q] = ra[q < na ? q : 0];
-        wb[q] = rb[q < nb ? q : 0];
-    }
-    uint32_t ma = 0, mb = 0;
+    for (uint32_t t = 0; t < 4; ++t) {
+        rec[t] = use[t] ? reinterpret_cast<const U4*>(ix.ec + 4ull * ref[t]) : brec;   // an unused slot re-reads the base record
+        n[t] = use[t] && len[t] <= 64 ? (len[t] + 4) >> 2 : 0;
 #pragma unroll
-    for (uint32_t q = 0; q < 3; ++q) {
-        if (q < na) ma |= scan_words(wa[q], q == 0, b);
-        if (q < nb) mb |= scan_words(wb[q], q == 0, b);
+        for (uint32_t q = 0; q < 3; ++q) w[t][q] = rec[t][q < n[t] ? q : 0];
     }
-    if (useA) {
-        if (na == 0 || na > 3) ma |= scan_tail(ix, refA, lenA, na == 0 ? 0 : 3, alive, b);
-        alive &= ma;
-    }
-    if (useB) {
-        if (nb == 0 || nb > 3) mb |= scan_tail(ix, refB, lenB, nb == 0 ? 0 : 3, alive, b);
-        alive &= mb;
+#pragma unroll
+    for (uint32_t t = 0; t < 4; ++t) {
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 3; ++q)
+            if (q < n[t]) m |= scan_words(w[t][q], q == 0, b);
+        if (use[t]) {
+            if (n[t] == 0 || n[t] > 3) m |= scan_tail(ix, ref[t], len[t], n[t] == 0 ? 0 : 3, alive, b);
+            alive &= m;
+        }
     }
 }
 
@@ -723,13 +722,24 @@ PA_HD void isect_scan(const Lane& s, const DevIndexView& ix, ColRef cols, Isect&
     const U4 q0 = brec[0], q1 = brec[1], q2 = brec[2];
     const uint32_t b[8] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, r.base_len > 7 ? q2.x : 0xFFFFFFFFu};
     uint32_t alive = (1u << r.base_len) - 1;
-    scan_pair(ix, refs.x, lens.x, refs.x != r.base_ref, refs.y, lens.y, ncol > 1 && refs.y != r.base_ref, r.base_ref, b, alive);
-    if (ncol > 2) scan_pair(ix, refs.z, lens.z, refs.z != r.base_ref, refs.w, lens.w, ncol > 3 && refs.w != r.base_ref, r.base_ref, b, alive);
+    {
+        const uint32_t ref[4] = {refs.x, refs.y, refs.z, refs.w}, len[4] = {lens.x, lens.y, lens.z, lens.w};
+        const bool use[4] = {refs.x != r.base_ref, ncol > 1 && refs.y != r.base_ref, ncol > 2 && refs.z != r.base_ref,
+                             ncol > 3 && refs.w != r.base_ref};
+        scan_quad(ix, ref, len, use, r.base_ref, b, alive);
+    }
 #pragma unroll 1
-    for (uint32_t i = LDS_CLASSES; i < ncol && alive; ++i) {         // classes spilled to HBM (rare)
-        uint32_t ref, len;
-        get_class(cols, i, ref, len);
-        if (ref != r.base_ref) alive &= scan_tail(ix, ref, len, 0, alive, b);
+    for (uint32_t i = LDS_CLASSES; i < ncol && alive; i += 4) {      // classes spilled to HBM, four at a time
+        uint32_t ref[4], len[4];
+        bool use[4];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) {
+            const U4 qd = *reinterpret_cast<const U4*>(cols.spill + 4 * (i + t < ncol ? i + t - LDS_CLASSES : i - LDS_CLASSES));
+            ref[t] = qd.x;
+            len[t] = qd.y;
+            use[t] = i + t < ncol && qd.x != r.base_ref;
+        }
+        scan_quad(ix, ref, len, use, r.base_ref, b, alive);
     }
     r.alive = alive;
     r.count = pa_popc32(alive);
