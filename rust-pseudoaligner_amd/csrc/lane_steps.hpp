@@ -606,10 +606,13 @@ PA_HD uint32_t isect_pick(const Lane& s, ColRef cols, Isect& r) {
     uint32_t maxlen = lens.x > ln1 ? lens.x : ln1;
     maxlen = maxlen > ln2 ? maxlen : ln2;
     maxlen = maxlen > ln3 ? maxlen : ln3;
-    for (uint32_t i = LDS_CLASSES; i < ncol; ++i) {                 // spilled classes (rare)
-        uint32_t ref, len;
-        get_class(cols, i, ref, len);
-        if (len < r.base_len) { r.base_len = len; r.base_ref = ref; r.base_colour = get_class_id(cols, i); }
+    for (uint32_t i = LDS_CLASSES; i < ncol; i += 4) {              // spilled classes (rare): four (ref, len, class id) quads per round trip
+        U4 qd[4];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) qd[t] = *reinterpret_cast<const U4*>(cols.spill + 4 * (i + t < ncol ? i + t - LDS_CLASSES : i - LDS_CLASSES));
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t)
+            if (i + t < ncol && qd[t].y < r.base_len) { r.base_len = qd[t].y; r.base_ref = qd[t].x; r.base_colour = qd[t].z; }
     }
     if (ncol == 1) {                                                // eq_class = eq_classes[colour] (:346-350), no intersection
         r.count = r.base_len;
