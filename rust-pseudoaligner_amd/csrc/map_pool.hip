@@ -347,10 +347,10 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 s.lk = 0;   // ST_EMPTY
             }
         } else if (sel == ST_F_SCAN) {
-            // List mode, base list of <= 8 ids, other lists of any number and length: ONE LIST PER LANE. Reads of at most 16
-            // classes are taken four at a time, a row of 16 lanes each; lane j of the row loads the row's base ids, streams
-            // the chunks of class j's list (four 16-byte loads in flight) and notes which base ids it has seen; a base id
-            // survives when no lane of the row misses it (OR-reduce over the row). Reads of more classes get the whole wave.
+            // List mode, base list of <= 8 ids, other lists of any number and length: ONE LIST PER LANE. Reads of at most 8 (16)
+            // classes are taken eight (four) at a time, a group of 8 (16) lanes each; lane j of the group loads the group's
+            // base ids, streams the chunks of class j's list (four 16-byte loads in flight) and notes which base ids it has
+            // seen; a base id survives when no lane of the group misses it (OR-reduce). More classes: the whole wave.
             // Three or four round trips per group however many classes the reads met — the per-lane scan these reads used
             // to take (isect_scan) cost ~45 round trips for a 40-class read and stalled its whole step.
             Isect is;
@@ -358,59 +358,57 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             if (active) isect_pick(s, cols, is);
             const uint32_t ncol_mine = l_ncol(s);
             uint32_t my_alive = 0;
-            // reads of at most 16 classes: four at a time, a row of 16 lanes each (lane j of the row = class j)
-            const uint32_t rowi = lane >> 4, j16 = lane & 15u, row0 = lane & 48u;
-            for (uint64_t todo = __ballot(active && ncol_mine <= 16); todo;) {
-                uint32_t own[4];
+            // reads of at most 8 classes: eight at a time, 8 lanes each; of at most 16 classes: four at a time, 16 lanes each
+            // (lane j of a group = class j of its read)
+            for (uint32_t gw = 8; gw <= 16; gw <<= 1) {
+                const uint32_t grp = lane / gw, jg = lane & (gw - 1), ngrp = 64 / gw;
+                for (uint64_t todo = __ballot(active && ncol_mine <= gw && ncol_mine > (gw == 8 ? 0u : 8u)); todo;) {
+                    uint32_t Lr = 64, ogrp = 64;   // the read this lane's group works on; the group that works on this lane's read
+                    for (uint32_t r = 0; r < ngrp; ++r) {   // uniform: hand the next reads out to the groups
+                        const uint32_t o = todo ? (uint32_t)(__ffsll((unsigned long long)todo) - 1) : 64u;
+                        todo &= todo - 1;
+                        if (grp == r) Lr = o;
+                        if (lane == o) ogrp = r;
+                    }
+                    const bool gact = Lr < 64;
+                    const int src = (int)(Lr & 63u);
+                    // (every shuffle with all lanes active: a source lane that is masked off returns garbage)
+                    const uint32_t bref = (uint32_t)__shfl((int)is.base_ref, src, 64), blen = (uint32_t)__shfl((int)is.base_len, src, 64),
+                                   ncol_s = (uint32_t)__shfl((int)ncol_mine, src, 64), slotL = (uint32_t)__shfl((int)slot, src, 64);
+                    const uint32_t ncolL = gact ? ncol_s : 0u;
+                    const glb_u32w rowL = (glb_u32w)p.spill + (uint64_t)(wave * S + slotL) * spill_cap;
+                    const glb_v4 brec = (glb_v4)(ec + 4ull * bref);
+                    const u32x4 q0 = brec[0], q1 = brec[1], q2 = brec[2];
+                    const uint32_t b[8] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, blen > 7 ? q2.x : 0xFFFFFFFFu};
+                    uint32_t xref = bref, xlen = 0;
+                    if (jg < ncolL) {
+                        if (jg < LDS_CLASSES) { xref = rowL[jg]; xlen = rowL[4 + jg]; }
+                        else { const u32x4 qd = *(glb_v4)(rowL + LIST_ROW_HDR + 4 * (jg - LDS_CLASSES)); xref = qd.x; xlen = qd.y; }
+                    }
+                    const bool mine = xref != bref;
+                    const uint32_t nch = mine ? (xlen + 4) >> 2 : 0u;
+                    uint32_t maxch = nch;
+                    for (uint32_t o = 32; o; o >>= 1) maxch = max(maxch, (uint32_t)__shfl_xor((int)maxch, (int)o, 64));
+                    maxch = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxch);
+                    const glb_v4 xrec = (glb_v4)(ec + 4ull * xref);
+                    uint32_t acc = 0;
+                    for (uint32_t c0 = 0; c0 < maxch; c0 += 4) {
+                        u32x4 w[4];
 #pragma unroll
-                for (uint32_t r = 0; r < 4; ++r) {
-                    own[r] = todo ? (uint32_t)(__ffsll((unsigned long long)todo) - 1) : 64u;
-                    todo &= todo - 1;
-                }
-                const uint32_t Lr = rowi == 0 ? own[0] : rowi == 1 ? own[1] : rowi == 2 ? own[2] : own[3];   // the read of this row
-                const bool rowact = Lr < 64;
-                const int src = (int)(Lr & 63u);
-                // (every shuffle with all lanes active: a source lane that is masked off returns garbage)
-                const uint32_t bref = (uint32_t)__shfl((int)is.base_ref, src, 64), blen = (uint32_t)__shfl((int)is.base_len, src, 64),
-                               ncol_s = (uint32_t)__shfl((int)ncol_mine, src, 64), slotL = (uint32_t)__shfl((int)slot, src, 64);
-                const uint32_t ncolL = rowact ? ncol_s : 0u;
-                const glb_u32w rowL = (glb_u32w)p.spill + (uint64_t)(wave * S + slotL) * spill_cap;
-                const glb_v4 brec = (glb_v4)(ec + 4ull * bref);
-                const u32x4 q0 = brec[0], q1 = brec[1], q2 = brec[2];
-                const uint32_t b[8] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, blen > 7 ? q2.x : 0xFFFFFFFFu};
-                uint32_t xref = bref, xlen = 0;
-                if (j16 < ncolL) {
-                    if (j16 < LDS_CLASSES) { xref = rowL[j16]; xlen = rowL[4 + j16]; }
-                    else { const u32x4 qd = *(glb_v4)(rowL + LIST_ROW_HDR + 4 * (j16 - LDS_CLASSES)); xref = qd.x; xlen = qd.y; }
-                }
-                const bool mine = xref != bref;
-                const uint32_t nch = mine ? (xlen + 4) >> 2 : 0u;
-                uint32_t maxch = nch;
-                for (uint32_t o = 32; o; o >>= 1) maxch = max(maxch, (uint32_t)__shfl_xor((int)maxch, (int)o, 64));
-                maxch = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxch);
-                const glb_v4 xrec = (glb_v4)(ec + 4ull * xref);
-                uint32_t acc = 0;
-                for (uint32_t c0 = 0; c0 < maxch; c0 += 4) {
-                    u32x4 w[4];
+                        for (uint32_t t = 0; t < 4; ++t) w[t] = xrec[c0 + t < nch ? c0 + t : 0];
 #pragma unroll
-                    for (uint32_t t = 0; t < 4; ++t) w[t] = xrec[c0 + t < nch ? c0 + t : 0];
-#pragma unroll
-                    for (uint32_t t = 0; t < 4; ++t)
-                        if (c0 + t < nch) {
-                            const U4 ww{w[t].x, w[t].y, w[t].z, w[t].w};
-                            acc |= scan_words(ww, c0 + t == 0, b);
-                        }
+                        for (uint32_t t = 0; t < 4; ++t)
+                            if (c0 + t < nch) {
+                                const U4 ww{w[t].x, w[t].y, w[t].z, w[t].w};
+                                acc |= scan_words(ww, c0 + t == 0, b);
+                            }
+                    }
+                    uint32_t miss = mine ? ~acc & 0xFFu : 0u;   // base ids this lane's list lacks; OR over the group
+                    for (uint32_t o = gw >> 1; o; o >>= 1) miss |= (uint32_t)__shfl_xor((int)miss, (int)o, 64);
+                    const uint32_t alive_grp = ((1u << blen) - 1) & ~miss;
+                    const uint32_t got = (uint32_t)__shfl((int)alive_grp, (int)((ogrp & (ngrp - 1)) * gw), 64);
+                    if (ogrp < 64) my_alive = got;
                 }
-                uint32_t miss = mine ? ~acc & 0xFFu : 0u;   // base ids this lane's list lacks; OR over the row
-                miss |= (uint32_t)__builtin_amdgcn_update_dpp((int)miss, (int)miss, 0x128, 0xf, 0xf, false);   // row_ror:8
-                miss |= (uint32_t)__builtin_amdgcn_update_dpp((int)miss, (int)miss, 0x124, 0xf, 0xf, false);   // row_ror:4
-                miss |= (uint32_t)__builtin_amdgcn_update_dpp((int)miss, (int)miss, 0x122, 0xf, 0xf, false);   // row_ror:2
-                miss |= (uint32_t)__builtin_amdgcn_update_dpp((int)miss, (int)miss, 0x121, 0xf, 0xf, false);   // row_ror:1
-                const uint32_t alive_row = ((1u << blen) - 1) & ~miss;
-                const uint32_t orow = lane == own[0] ? 0u : lane == own[1] ? 1u : lane == own[2] ? 2u : 3u;
-                const uint32_t got = (uint32_t)__shfl((int)alive_row, (int)(orow << 4), 64);
-                if (lane == own[0] || lane == own[1] || lane == own[2] || lane == own[3]) my_alive = got;
-                (void)row0;
             }
             for (uint64_t todo = __ballot(active && ncol_mine > 16); todo; todo &= todo - 1) {   // more classes: the whole wave per read
                 const uint32_t Lr = (uint32_t)(__ffsll((unsigned long long)todo) - 1);
