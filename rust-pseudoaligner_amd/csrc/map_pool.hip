@@ -123,6 +123,25 @@ __device__ __forceinline__ void emit_record(Lane& s, uint32_t cnt, uint32_t cnt_
     s.lk = 0;   // ST_EMPTY
 }
 
+// which of the eight base ids b[] occur in the list of record `xref` (nch 16-byte chunks; the loop runs to the wave-uniform
+// maxch so that every lane keeps four loads in flight per round trip)
+__device__ __forceinline__ uint32_t list_hits(glb_u32 ec, uint32_t xref, uint32_t nch, uint32_t maxch, const uint32_t (&b)[8]) {
+    const glb_v4 xrec = (glb_v4)(ec + 4ull * xref);
+    uint32_t acc = 0;
+    for (uint32_t c0 = 0; c0 < maxch; c0 += 4) {
+        u32x4 w[4];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) w[t] = xrec[c0 + t < nch ? c0 + t : 0];
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t)
+            if (c0 + t < nch) {
+                const U4 ww{w[t].x, w[t].y, w[t].z, w[t].w};
+                acc |= scan_words(ww, c0 + t == 0, b);
+            }
+    }
+    return acc;
+}
+
 // the queue a slot goes to after a step
 __device__ __forceinline__ uint32_t queue_of(Lane& s) {
     uint32_t st = l_st(s);
@@ -390,19 +409,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                     uint32_t maxch = nch;
                     for (uint32_t o = 32; o; o >>= 1) maxch = max(maxch, (uint32_t)__shfl_xor((int)maxch, (int)o, 64));
                     maxch = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxch);
-                    const glb_v4 xrec = (glb_v4)(ec + 4ull * xref);
-                    uint32_t acc = 0;
-                    for (uint32_t c0 = 0; c0 < maxch; c0 += 4) {
-                        u32x4 w[4];
-#pragma unroll
-                        for (uint32_t t = 0; t < 4; ++t) w[t] = xrec[c0 + t < nch ? c0 + t : 0];
-#pragma unroll
-                        for (uint32_t t = 0; t < 4; ++t)
-                            if (c0 + t < nch) {
-                                const U4 ww{w[t].x, w[t].y, w[t].z, w[t].w};
-                                acc |= scan_words(ww, c0 + t == 0, b);
-                            }
-                    }
+                    const uint32_t acc = list_hits(ec, xref, nch, maxch, b);
                     uint32_t miss = mine ? ~acc & 0xFFu : 0u;   // base ids this lane's list lacks; OR over the group
                     for (uint32_t o = gw >> 1; o; o >>= 1) miss |= (uint32_t)__shfl_xor((int)miss, (int)o, 64);
                     const uint32_t alive_grp = ((1u << blen) - 1) & ~miss;
@@ -433,19 +440,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                     uint32_t maxch = nch;
                     for (uint32_t o = 32; o; o >>= 1) maxch = max(maxch, (uint32_t)__shfl_xor((int)maxch, (int)o, 64));
                     maxch = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxch);
-                    const glb_v4 xrec = (glb_v4)(ec + 4ull * xref);
-                    uint32_t acc = 0;
-                    for (uint32_t c0 = 0; c0 < maxch; c0 += 4) {
-                        u32x4 w[4];
-#pragma unroll
-                        for (uint32_t t = 0; t < 4; ++t) w[t] = xrec[c0 + t < nch ? c0 + t : 0];
-#pragma unroll
-                        for (uint32_t t = 0; t < 4; ++t)
-                            if (c0 + t < nch) {
-                                const U4 ww{w[t].x, w[t].y, w[t].z, w[t].w};
-                                acc |= scan_words(ww, c0 + t == 0, b);
-                            }
-                    }
+                    const uint32_t acc = list_hits(ec, xref, nch, maxch, b);
 #pragma unroll
                     for (uint32_t kk = 0; kk < 8; ++kk)
                         if (__ballot(mine && !((acc >> kk) & 1u))) alive &= ~(1u << kk);
