@@ -3,8 +3,9 @@
 // Compiles the product's per-lane state machine (rust-pseudoaligner_amd/csrc/lane_steps.hpp) and its GPU index
 // flattener (device_flatten.cpp) for the host, and runs every read to completion by calling the same step
 // functions the HIP kernel calls. It lets the CPU-only test tier (`-m "not gpu"`) check the device data layout and
-// the step logic against the oracle bit for bit; wave scheduling, LDS staging and arena allocation exist only in
-// map_pool.hip and are covered by the `-m gpu` tier. Nothing in the product links or loads this file.
+// the step logic against the oracle bit for bit; the pooled scheduling, LDS staging, arena allocation, the count cache and
+// the group (one-list-per-lane / whole-wave) forms of the list intersection exist only in map_pool.hip and are covered
+// by the `-m gpu` tier — here list mode runs the per-lane forms (isect_light / isect_scan / binary search). Nothing in the product links or loads this file.
 #include <cstdlib>
 #include <cstring>
 #include <map>
