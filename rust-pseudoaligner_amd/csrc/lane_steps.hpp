@@ -375,12 +375,17 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
     const U4 fp = *reinterpret_cast<const U4*>(linew);
     const uint32_t klo = (uint32_t)kmer, khi = (uint32_t)(kmer >> 32);
     const uint32_t want = klo & 0x7FFFFFFFu, top = klo >> 31;
-    // entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j: fetch the one whose fingerprint matches (same line)
-    const uint32_t j = fp.x == want ? 0u : fp.y == want ? 1u : fp.z == want ? 2u : 3u;
-    const U3 e = *reinterpret_cast<const U3*>(linew + 4 + 3 * j);
-    const bool anyfp = (fp.x == want) | (fp.y == want) | (fp.z == want) | (fp.w == want);
-    const bool hit = anyfp && e.x == khi && (e.z >> 31) == top;
-    seek_finish(s, K, hit ? e.y : NO_HANDLE, e.z & 0x7FFFFFFFu, ((fp.x | fp.y | fp.z | fp.w) >> 31) == 0, probe);
+    // entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j: fetch the one whose fingerprint matches (same line).
+    // Two keys of one bucket can share their low 31 bits (low-complexity sequence): every matching slot is tried.
+    uint32_t cand = (fp.x == want ? 1u : 0u) | (fp.y == want ? 2u : 0u) | (fp.z == want ? 4u : 0u) | (fp.w == want ? 8u : 0u);
+    uint32_t h = NO_HANDLE, off = 0;
+    while (cand) {                                                  // almost always exactly one candidate on a hit
+        const uint32_t j = pa_ctz32(cand);
+        cand &= cand - 1;
+        const U3 e = *reinterpret_cast<const U3*>(linew + 4 + 3 * j);
+        if (e.x == khi && (e.z >> 31) == top) { h = e.y; off = e.z & 0x7FFFFFFFu; cand = 0; }
+    }
+    seek_finish(s, K, h, off, ((fp.x | fp.y | fp.z | fp.w) >> 31) == 0, probe);
 }
 
 // ---------------------------------------------------------------------------------------------- FWD

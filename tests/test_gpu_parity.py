@@ -260,7 +260,9 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
         pa.process_reads(str(trunc), a, str(out), 2)
 
 
-@pytest.mark.parametrize("seed", range(10))
+# 12..308: seeds on which a lookup that only tried the first fingerprint match of a bucket missed k-mers (two keys of one
+# bucket sharing their low 31 bits — low-complexity sequence); found by tools/gpu_soak.py
+@pytest.mark.parametrize("seed", list(range(10)) + [12, 19, 31, 39, 48, 55, 96, 242, 278, 308])
 def test_random_transcriptomes(tmp_path, seed):
     """differential fuzz (helpers.random_txome_case): GPU vs oracle, bit exact, incl. the fused count table"""
     import torch
