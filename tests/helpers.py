@@ -295,7 +295,7 @@ def counts_reference(results, coff, cids, host_index):
     return counts
 
 
-def random_txome_case(seed, tmp_path):
+def random_txome_case(seed, tmp_path, big=False):
     """differential-fuzz input: a small random transcriptome built from shared segments (repeats, cycles on a two-letter
     alphabet, transcripts shorter than k), a k from 8 to 64, 0..3 allowed mismatches and 3000 reads: substrings with
     substitutions, chimeras of two transcripts, random sequence, N and lower case. Returns (host index or None, k, reads,
@@ -303,8 +303,11 @@ def random_txome_case(seed, tmp_path):
     rng = np.random.RandomState(100 + seed)
     k = int(rng.choice([8, 11, 16, 21, 32, 33, 47, 64]))
     alphabet = "ACGT" if seed % 3 else "AC"
-    segs = ["".join(rng.choice(list(alphabet), rng.randint(5, 90))) for _ in range(16)]
-    txs = ["".join(segs[j] for j in rng.choice(len(segs), rng.randint(1, 9))) for _ in range(int(rng.randint(3, 60)))]
+    # big: hundreds of transcripts over few segments: classes of many ids spread over more than two 32-id windows, i.e.
+    # list mode with long lists, many classes per read, bases of more than 8 ids
+    nseg, ntx = (int(rng.randint(12, 40)), int(rng.randint(150, 500))) if big else (16, int(rng.randint(3, 60)))
+    segs = ["".join(rng.choice(list(alphabet), rng.randint(5, 90))) for _ in range(nseg)]
+    txs = ["".join(segs[j] for j in rng.choice(len(segs), rng.randint(1, 9))) for _ in range(ntx)]
     fa = tmp_path / "r.fa"
     fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i // 3, s) for i, s in enumerate(txs)))
     host = pa.HostIndex.build_fasta(str(fa), k, 3)

@@ -51,6 +51,17 @@ def test_random_transcriptomes(tmp_path, seed):
     check(host, tiles, lens, wpr, allowed)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_transcriptomes_list_mode(tmp_path, seed):
+    """the same fuzz on hundreds of transcripts over few shared segments: classes of many ids spread over more than two
+    windows (list mode, many classes per read, bases of more than 8 ids)"""
+    host, k, reads, clean, allowed = helpers.random_txome_case(seed, tmp_path, big=True)
+    if host is None:
+        pytest.skip("every transcript is shorter than k")
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    check(host, tiles, lens, wpr, allowed)
+
+
 def test_ragged_short_and_unmappable_reads(small_index):
     host = small_index(24)
     _, seqs = helpers.read_fastq()

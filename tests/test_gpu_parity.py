@@ -106,6 +106,18 @@ def test_simulated_reads_device_batches(aligners, k, read_len, ppm, allowed, n):
     assert np.array_equal(d_counts3.cpu().numpy(), want_sub)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_transcriptomes_list_mode(tmp_path, seed):
+    """the same fuzz on hundreds of transcripts over few shared segments: classes of many ids spread over more than two
+    windows (list mode, many classes per read, bases of more than 8 ids)"""
+    host, k, reads, clean, allowed = helpers.random_txome_case(seed, tmp_path, big=True)
+    if host is None:
+        pytest.skip("every transcript is shorter than k")
+    res, coff, cids = pa.Pseudoaligner(host).map_batch(reads, allowed)
+    o_res, o_coff, o_ids, _ = helpers.Oracle(host).map_reads(clean, allowed, 4)
+    helpers.assert_same_as_oracle(res, coff, cids, o_res, o_coff, o_ids, "big random txome seed %d k=%d" % (seed, k))
+
+
 def test_ragged_empty_short_and_odd_reads(aligners):
     a = aligners(24)
     _, seqs = helpers.read_fastq()
