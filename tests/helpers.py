@@ -295,7 +295,7 @@ def counts_reference(results, coff, cids, host_index):
     return counts
 
 
-def random_txome_case(seed, tmp_path, big=False):
+def random_txome_case(seed, tmp_path, big=False, max_read=250):
     """differential-fuzz input: a small random transcriptome built from shared segments (repeats, cycles on a two-letter
     alphabet, transcripts shorter than k), a k from 8 to 64, 0..3 allowed mismatches and 3000 reads: substrings with
     substitutions, chimeras of two transcripts, random sequence, N and lower case. Returns (host index or None, k, reads,
@@ -319,14 +319,14 @@ def random_txome_case(seed, tmp_path, big=False):
         t = txs[rng.randint(len(txs))]
         if kind < 6:                                   # substring with substitutions
             lo = rng.randint(0, max(1, len(t) - 10))
-            r = list(t[lo:lo + rng.randint(1, 200)])
+            r = list(t[lo:lo + rng.randint(1, max(2, max_read * 4 // 5))])
             for j in range(len(r)):
                 if rng.rand() < 0.02:
                     r[j] = "ACGT"[rng.randint(4)]
             reads.append("".join(r))
         elif kind < 8:                                 # chimera
             u = txs[rng.randint(len(txs))]
-            reads.append((t[: rng.randint(1, len(t) + 1)] + u[rng.randint(0, len(u)):])[:250])
+            reads.append((t[: rng.randint(1, len(t) + 1)] + u[rng.randint(0, len(u)):] + (t + u) * (max_read // 250 - 1))[:max_read])
         elif kind == 8:
             reads.append("".join(rng.choice(list(alphabet), rng.randint(0, 150))))
         else:

@@ -246,7 +246,10 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
         kind = i % 4
         seqs[i] = s[: int(rng.integers(1, len(s)))] if kind == 0 else (s + seqs[(i + 1) % 3000] + s)[: int(rng.integers(61, 181))] if kind == 1 else \
             s.lower() if kind == 2 else s[:20] + "N" + s[21:]
+    ids[5], ids[6] = 'qu"ote', "back\\slash\x01ctl"          # Debug formatting of the id (:490): \" \\\\ \\u{1}
     want = _expected_lines(a, ids, [s.upper().replace("N", "A") for s in seqs])
+    want[5] = want[5].replace('qu"ote', 'qu\\"ote')
+    want[6] = want[6].replace("back\\slash\x01ctl", "back\\\\slash\\u{1}ctl")
     out = tmp_path / "o.txt"
     variants = {
         "plain": "".join("@%s extra words\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in zip(ids, seqs)),

@@ -10,7 +10,7 @@ nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 bad = 0
 for seed in range(10, 10 + nseeds):
     with tempfile.TemporaryDirectory() as d:
-        host, k, reads, clean, allowed = helpers.random_txome_case(seed, Path(d), big=seed % 3 == 0)   # every third: list-mode heavy
+        host, k, reads, clean, allowed = helpers.random_txome_case(seed, Path(d), big=seed % 3 == 0, max_read=2000 if seed % 5 == 0 else 250)   # every third: list-mode heavy; every fifth: long reads
         if host is None:
             continue
         a = pa.Pseudoaligner(host)
