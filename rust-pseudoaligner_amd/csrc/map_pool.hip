@@ -495,10 +495,13 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                         if (len <= 64) {             // short list: scan it, no dependent loads
                             const glb_v4 rec = (glb_v4)(ec + 4ull * ref);
                             const uint32_t nchunks = (len + 4) >> 2;
-#pragma unroll 2
-                            for (uint32_t qq = 0; qq < nchunks; ++qq) {
-                                const u32x4 x = rec[qq];
-                                hit |= (qq != 0 && x.x == v) | (x.y == v) | (x.z == v) | (x.w == v);
+                            for (uint32_t q0 = 0; q0 < nchunks; q0 += 4) {   // four loads in flight per round trip
+                                u32x4 x[4];
+#pragma unroll
+                                for (uint32_t t = 0; t < 4; ++t) x[t] = rec[q0 + t < nchunks ? q0 + t : q0];
+#pragma unroll
+                                for (uint32_t t = 0; t < 4; ++t)
+                                    if (q0 + t < nchunks) hit |= (q0 + t != 0 && x[t].x == v) | (x[t].y == v) | (x[t].z == v) | (x[t].w == v);
                             }
                         } else {                     // long list: binary_search (:404)
                             const glb_u32 ids = ec + 4ull * ref + 1;
