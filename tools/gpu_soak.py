@@ -18,6 +18,19 @@ for seed in range(10, 10 + nseeds):
         o_res, o_coff, o_ids, _ = helpers.Oracle(host).map_reads(clean, allowed, 4)
         try:
             helpers.assert_same_as_oracle(res, coff, cids, o_res, o_coff, o_ids, "seed %d k=%d" % (seed, k))
+            # fused count table (window table / class-list table lookups of strict-subset results) through the device API
+            tiles, lens, wpr = pa.encode_reads_host(reads)
+            dev = torch.device("cuda", 0)
+            d_tiles = torch.from_numpy(tiles.view(np.int64)).to(dev)
+            d_lens = torch.from_numpy(np.asarray(lens, np.uint32).view(np.int32)).to(dev)
+            n = len(reads)
+            cap = a.arena_hint(n)
+            d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+            d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+            d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+            a.map_count_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, d_counts.data_ptr(), allowed)
+            a.map_finish()
+            assert np.array_equal(d_counts.cpu().numpy(), helpers.counts_reference(o_res, o_coff, o_ids, host)), "seed %d: count table differs" % seed
         except AssertionError as e:
             bad += 1
             print("MISMATCH", str(e)[:300])
