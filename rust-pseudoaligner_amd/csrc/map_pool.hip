@@ -366,58 +366,63 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 s.lk = 0;   // ST_EMPTY
             }
         } else if (sel == ST_F_SCAN) {
-            // List mode, base list of <= 8 ids, other lists of any number and length: ONE LIST PER LANE. Reads of at most 8 (16)
-            // classes are taken eight (four) at a time, a group of 8 (16) lanes each; lane j of the group loads the group's
-            // base ids, streams the chunks of class j's list (four 16-byte loads in flight) and notes which base ids it has
-            // seen; a base id survives when no lane of the group misses it (OR-reduce). More classes: the whole wave.
-            // Three or four round trips per group however many classes the reads met — the per-lane scan these reads used
-            // to take (isect_scan) cost ~45 round trips for a 40-class read and stalled its whole step.
+            // List mode, base list of <= 8 ids, other lists of any number and length: ONE LIST PER LANE. The waiting reads
+            // are packed into the wave, ncol lanes each; lane j of a read's segment loads the read's base ids, streams the
+            // chunks of class j's list (four 16-byte loads in flight) and notes which base ids it has seen; a base id
+            // survives when no lane of the segment misses it (one ballot per base id, masked by the segment). Reads of more
+            // than 64 classes take the whole wave, 64 lists at a time. Three or four round trips per pass however many
+            // classes the reads met — the per-lane scan these reads used to take (isect_scan) cost ~45 round trips for a
+            // 40-class read and stalled its whole step.
             Isect is;
             is.base_len = is.base_ref = is.base_colour = 0;
             if (active) isect_pick(s, cols, is);
             const uint32_t ncol_mine = l_ncol(s);
             uint32_t my_alive = 0;
-            // reads of at most 8 classes: eight at a time, 8 lanes each; of at most 16 classes: four at a time, 16 lanes each
-            // (lane j of a group = class j of its read)
-            for (uint32_t gw = 8; gw <= 16; gw <<= 1) {
-                const uint32_t grp = lane / gw, jg = lane & (gw - 1), ngrp = 64 / gw;
-                for (uint64_t todo = __ballot(active && ncol_mine <= gw && ncol_mine > (gw == 8 ? 0u : 8u)); todo;) {
-                    uint32_t Lr = 64, ogrp = 64;   // the read this lane's group works on; the group that works on this lane's read
-                    for (uint32_t r = 0; r < ngrp; ++r) {   // uniform: hand the next reads out to the groups
-                        const uint32_t o = todo ? (uint32_t)(__ffsll((unsigned long long)todo) - 1) : 64u;
-                        todo &= todo - 1;
-                        if (grp == r) Lr = o;
-                        if (lane == o) ogrp = r;
-                    }
-                    const bool gact = Lr < 64;
-                    const int src = (int)(Lr & 63u);
-                    // (every shuffle with all lanes active: a source lane that is masked off returns garbage)
-                    const uint32_t bref = (uint32_t)__shfl((int)is.base_ref, src, 64), blen = (uint32_t)__shfl((int)is.base_len, src, 64),
-                                   ncol_s = (uint32_t)__shfl((int)ncol_mine, src, 64), slotL = (uint32_t)__shfl((int)slot, src, 64);
-                    const uint32_t ncolL = gact ? ncol_s : 0u;
-                    const glb_u32w rowL = (glb_u32w)p.spill + (uint64_t)(wave * S + slotL) * spill_cap;
-                    const glb_v4 brec = (glb_v4)(ec + 4ull * bref);
-                    const u32x4 q0 = brec[0], q1 = brec[1], q2 = brec[2];
-                    const uint32_t b[8] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, blen > 7 ? q2.x : 0xFFFFFFFFu};
-                    uint32_t xref = bref, xlen = 0;
-                    if (jg < ncolL) {
-                        if (jg < LDS_CLASSES) { xref = rowL[jg]; xlen = rowL[4 + jg]; }
-                        else { const u32x4 qd = *(glb_v4)(rowL + LIST_ROW_HDR + 4 * (jg - LDS_CLASSES)); xref = qd.x; xlen = qd.y; }
-                    }
-                    const bool mine = xref != bref;
-                    const uint32_t nch = mine ? (xlen + 4) >> 2 : 0u;
-                    uint32_t maxch = nch;
-                    for (uint32_t o = 32; o; o >>= 1) maxch = max(maxch, (uint32_t)__shfl_xor((int)maxch, (int)o, 64));
-                    maxch = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxch);
-                    const uint32_t acc = list_hits(ec, xref, nch, maxch, b);
-                    uint32_t miss = mine ? ~acc & 0xFFu : 0u;   // base ids this lane's list lacks; OR over the group
-                    for (uint32_t o = gw >> 1; o; o >>= 1) miss |= (uint32_t)__shfl_xor((int)miss, (int)o, 64);
-                    const uint32_t alive_grp = ((1u << blen) - 1) & ~miss;
-                    const uint32_t got = (uint32_t)__shfl((int)alive_grp, (int)((ogrp & (ngrp - 1)) * gw), 64);
-                    if (ogrp < 64) my_alive = got;
+            // reads of at most 64 classes are packed into the wave: read r takes ncol_r consecutive lanes (lane start_r + j =
+            // class j of read r); a pass takes the longest prefix of the waiting reads that fits in 64 lanes
+            for (uint64_t todo = __ballot(active && ncol_mine > 0 && ncol_mine <= 64); todo;) {
+                const uint32_t want = ((todo >> lane) & 1ull) ? ncol_mine : 0u;
+                const uint32_t incl = wave_incl_scan(want);
+                const uint32_t start = incl - want;
+                const bool inpass = want != 0 && incl <= 64;   // the first waiting read always is
+                const uint64_t pass = __ballot(inpass);
+                todo &= ~pass;
+                uint32_t Lr = 64, jg = 0;   // the read this lane works for, and which of its classes
+                for (uint64_t m = pass; m; m &= m - 1) {   // uniform: hand the lanes out
+                    const uint32_t o = (uint32_t)(__ffsll((unsigned long long)m) - 1);
+                    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)start, (int)o);
+                    const uint32_t nc = (uint32_t)__builtin_amdgcn_readlane((int)ncol_mine, (int)o);
+                    if (lane - st < nc) { Lr = o; jg = lane - st; }
                 }
+                const bool gact = Lr < 64;
+                const int src = (int)(Lr & 63u);
+                // (every shuffle with all lanes active: a source lane that is masked off returns garbage)
+                const uint32_t bref = (uint32_t)__shfl((int)is.base_ref, src, 64), blen = (uint32_t)__shfl((int)is.base_len, src, 64),
+                               slotL = (uint32_t)__shfl((int)slot, src, 64);
+                const glb_u32w rowL = (glb_u32w)p.spill + (uint64_t)(wave * S + slotL) * spill_cap;
+                const glb_v4 brec = (glb_v4)(ec + 4ull * bref);
+                const u32x4 q0 = brec[0], q1 = brec[1], q2 = brec[2];
+                const uint32_t b[8] = {q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, blen > 7 ? q2.x : 0xFFFFFFFFu};
+                uint32_t xref = bref, xlen = 0;
+                if (gact) {
+                    if (jg < LDS_CLASSES) { xref = rowL[jg]; xlen = rowL[4 + jg]; }
+                    else { const u32x4 qd = *(glb_v4)(rowL + LIST_ROW_HDR + 4 * (jg - LDS_CLASSES)); xref = qd.x; xlen = qd.y; }
+                }
+                const bool mine = xref != bref;   // a list other than the base
+                const uint32_t nch = mine ? (xlen + 4) >> 2 : 0u;
+                uint32_t maxch = nch;
+                for (uint32_t o = 32; o; o >>= 1) maxch = max(maxch, (uint32_t)__shfl_xor((int)maxch, (int)o, 64));
+                maxch = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxch);
+                const uint32_t acc = list_hits(ec, xref, nch, maxch, b);
+                const uint32_t miss = mine ? ~acc & 0xFFu : 0u;   // base ids this lane's list lacks
+                const uint64_t seg = inpass ? (want == 64 ? ~0ull : ((1ull << want) - 1) << start) : 0ull;   // the lanes of this read
+                uint32_t alive = (1u << is.base_len) - 1;
+#pragma unroll
+                for (uint32_t kk = 0; kk < 8; ++kk)
+                    if (__ballot((miss >> kk) & 1u) & seg) alive &= ~(1u << kk);
+                if (inpass) my_alive = alive;
             }
-            for (uint64_t todo = __ballot(active && ncol_mine > 16); todo; todo &= todo - 1) {   // more classes: the whole wave per read
+            for (uint64_t todo = __ballot(active && ncol_mine > 64); todo; todo &= todo - 1) {   // more classes: the whole wave per read
                 const uint32_t Lr = (uint32_t)(__ffsll((unsigned long long)todo) - 1);
                 const uint32_t bref = (uint32_t)__shfl((int)is.base_ref, (int)Lr, 64);
                 const uint32_t blen = (uint32_t)__shfl((int)is.base_len, (int)Lr, 64);
@@ -482,14 +487,28 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 const bool fits = off + blen <= arena_cap;
                 const glb_u32w rowL = (glb_u32w)p.spill + (uint64_t)(wave * S + slotL) * spill_cap;
                 uint32_t total = 0;
+                // lane i keeps (ref, len) of the read's i-th list: one row read per read, not per base block
+                uint32_t cref = 0, clen = 0;
+                if (lane < ncolL) {
+                    const glb_u32w e = lane < LDS_CLASSES ? rowL + lane : rowL + LIST_ROW_HDR + 4 * (lane - LDS_CLASSES);
+                    cref = e[0];
+                    clen = lane < LDS_CLASSES ? e[4] : e[1];
+                }
                 for (uint32_t c = 0; c < blen; c += 64) {
                     const uint32_t j = c + lane;
                     const bool valid = j < blen;
                     const uint32_t v = valid ? ec[4ull * bref + 1 + j] : 0u;
                     bool ok = valid;
                     for (uint32_t i = 0; i < ncolL; ++i) {
-                        const glb_u32w e = i < LDS_CLASSES ? rowL + i : rowL + LIST_ROW_HDR + 4 * (i - LDS_CLASSES);
-                        const uint32_t ref = e[0], len = i < LDS_CLASSES ? e[4] : e[1];
+                        uint32_t ref, len;
+                        if (i < 64) {
+                            ref = (uint32_t)__shfl((int)cref, (int)i, 64);
+                            len = (uint32_t)__shfl((int)clen, (int)i, 64);
+                        } else {
+                            const glb_u32w e = rowL + LIST_ROW_HDR + 4 * (i - LDS_CLASSES);
+                            ref = e[0];
+                            len = e[1];
+                        }
                         if (ref == bref) continue;   // uniform
                         bool hit = false;
                         if (len <= 64) {             // short list: scan it, no dependent loads
