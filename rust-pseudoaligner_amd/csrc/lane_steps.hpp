@@ -22,7 +22,8 @@ namespace pa {
 // walk states, then the finishing states the kernel schedules separately (ST_ISECT = walk ended, tier not yet chosen)
 enum : uint32_t { ST_EMPTY = 0, ST_SEEK = 1, ST_FWD = 2, ST_LEFT = 3, ST_ISECT = 4, ST_NONE = 5,
                   ST_F_LIGHT = 6, ST_F_SCAN = 7, ST_F_COOP = 8, ST_F_BITS = 9, ST_F_NOVEL = 10, ST_COUNT = 11 };
-enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_CAREFUL = 16u, F_LISTS = 32u };
+enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_CAREFUL = 16u, F_LISTS = 32u,
+                  F_SMALL_BASE = 64u };   // list mode: the shortest class met has <= 8 ids
 constexpr uint32_t NO_CLASS = 0xFFFFFFFFu;
 constexpr uint32_t LDS_CLASSES = 4;   // list mode: distinct classes kept inline (one 16-byte vector each of refs, lengths, class ids)
 
@@ -66,8 +67,11 @@ struct ReadRef {   // the lane's packed read: word w < wmax at p[w * stride]; wo
 //                          node pushed so far as two 32-id windows (bit i of mask w = transcript base w + i; base2 >=
 //                          base1 + 32) and wcand[0] = the class id when that intersection IS one of the classes seen,
 //                          else NO_CLASS. Nothing else is kept.
-//   list mode (F_LISTS)    the distinct classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] / cids[0..3]
-//                          (LDS, each one 16-byte vector), the rest as (ref, len, class id, -) quads in `spill` (HBM).
+//   list mode (F_LISTS)    the classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] / cids[0..3] (each one
+//                          16-byte vector), the rest as (ref, len, class id, -) quads in `spill` — all of it in HBM and
+//                          only written during the walk. What the walk reads back is in LDS: win[0..2] = refs of the
+//                          first three classes (exact dedupe while there are <= 3, which the register tier needs),
+//                          win[3] / wcand[0] = ref / length of the shortest class so far (the base of the intersection).
 // A read starts in window mode; the first node whose class does not fit two windows (cmask == 0) restarts the read in
 // list mode.
 struct ColRef {
@@ -285,9 +289,20 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
         s.nc = (s.nc & ~0xFFFu) | 1u;
         return false;
     }
-    const U4 r = *reinterpret_cast<const U4*>(c.refs);
-    const bool dup = (n > 0 && r.x == hd.ec_ref) | (n > 1 && r.y == hd.ec_ref) | (n > 2 && r.z == hd.ec_ref) | (n > 3 && r.w == hd.ec_ref);
+    // list mode: win = {ref of class 0, 1, 2, ref of the shortest class so far}, wcand = the shortest length (both in LDS:
+    // the row in HBM is only written during the walk, never read)
+    U4 r = *reinterpret_cast<const U4*>(c.win);
+    const bool dup = (n > 0 && r.x == hd.ec_ref) | (n > 1 && r.y == hd.ec_ref) | (n > 2 && r.z == hd.ec_ref) | (n > 0 && r.w == hd.ec_ref);
     if (dup) return false;
+    if (n == 0) r.x = hd.ec_ref;
+    if (n == 1) r.y = hd.ec_ref;
+    if (n == 2) r.z = hd.ec_ref;
+    if (n == 0 || hd.ec_len < c.wcand[0]) {   // strict: the first of the shortest classes is the base
+        r.w = hd.ec_ref;
+        c.wcand[0] = hd.ec_len;
+        if (hd.ec_len <= 8) l_or_flags(s, F_SMALL_BASE);
+    }
+    *reinterpret_cast<U4*>(c.win) = r;
     if (n < LDS_CLASSES) {
         c.refs[n] = hd.ec_ref;
         c.lens[n] = hd.ec_len;
@@ -423,7 +438,7 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
 #pragma unroll
     for (int i = 0; i < 5; ++i) r[i] = read_word(rd, rw + i);         // all LDS reads in flight together
     bool premature = false;
-    uint32_t matched, nfl = fl & ~F_FRESH;
+    uint32_t matched, nfl = (fl & ~F_FRESH) | (l_flags(s) & F_SMALL_BASE);   // (push_node may just have set F_SMALL_BASE)
     if (!careful) {
         const uint32_t n = pa_min(rem, 128u);
         uint32_t cnt = 0;
@@ -598,34 +613,33 @@ PA_HD uint32_t isect_pick(const Lane& s, ColRef cols, Isect& r) {
     r.count = 0;
     r.in_regs = false;
     const uint32_t ncol = l_ncol(s);
+    if (ncol > 3) {   // the walk kept the shortest class: nothing to load. base_colour = word 0 of the record (class_colour)
+        r.base_ref = cols.win[3];
+        r.base_len = cols.wcand[0];
+        r.base_colour = NO_CLASS;
+        r.base_slot = 0;
+        return r.base_len <= 8 ? 1u : 2u;
+    }
     const U4 refs = *reinterpret_cast<const U4*>(cols.refs), lens = *reinterpret_cast<const U4*>(cols.lens),
              cids = *reinterpret_cast<const U4*>(cols.cids);
-    const uint32_t ln1 = ncol > 1 ? lens.y : lens.x, ln2 = ncol > 2 ? lens.z : lens.x, ln3 = ncol > 3 ? lens.w : lens.x;
+    const uint32_t ln1 = ncol > 1 ? lens.y : lens.x, ln2 = ncol > 2 ? lens.z : lens.x;
     r.base_len = lens.x;
     r.base_ref = refs.x;
     r.base_colour = cids.x;
     r.base_slot = 0;
     if (ln1 < r.base_len) { r.base_len = ln1; r.base_ref = refs.y; r.base_colour = cids.y; r.base_slot = 1; }
     if (ln2 < r.base_len) { r.base_len = ln2; r.base_ref = refs.z; r.base_colour = cids.z; r.base_slot = 2; }
-    if (ln3 < r.base_len) { r.base_len = ln3; r.base_ref = refs.w; r.base_colour = cids.w; r.base_slot = 3; }
     uint32_t maxlen = lens.x > ln1 ? lens.x : ln1;
     maxlen = maxlen > ln2 ? maxlen : ln2;
-    maxlen = maxlen > ln3 ? maxlen : ln3;
-    for (uint32_t i = LDS_CLASSES; i < ncol; i += 4) {              // spilled classes (rare): four (ref, len, class id) quads per round trip
-        U4 qd[4];
-#pragma unroll
-        for (uint32_t t = 0; t < 4; ++t) qd[t] = *reinterpret_cast<const U4*>(cols.spill + 4 * (i + t < ncol ? i + t - LDS_CLASSES : i - LDS_CLASSES));
-#pragma unroll
-        for (uint32_t t = 0; t < 4; ++t)
-            if (i + t < ncol && qd[t].y < r.base_len) { r.base_len = qd[t].y; r.base_ref = qd[t].x; r.base_colour = qd[t].z; }
-    }
     if (ncol == 1) {                                                // eq_class = eq_classes[colour] (:346-350), no intersection
         r.count = r.base_len;
         return 0;
     }
-    if (ncol <= 3 && maxlen <= 7) return 0;
+    if (maxlen <= 7) return 0;
     return r.base_len <= 8 ? 1u : 2u;
 }
+// the class id of a class record (its first word)
+PA_HD uint32_t class_colour(const DevIndexView& ix, uint32_t ec_ref) { return ix.ec[4ull * ec_ref]; }
 
 PA_HD uint32_t match7(const U4& o0, const U4& o1, const uint32_t (&b)[7]) {
     const uint32_t o[7] = {o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
@@ -762,6 +776,7 @@ PA_HD Isect isect_count(const Lane& s, const DevIndexView& ix, ColRef cols) {
         return r;
     }
     const uint32_t ncol = l_ncol(s);
+    if (ncol > 3) r.base_colour = class_colour(ix, r.base_ref);
     if (tier == 1) {
         isect_scan(s, ix, cols, r);
         return r;

@@ -145,8 +145,9 @@ __device__ __forceinline__ uint32_t list_hits(glb_u32 ec, uint32_t xref, uint32_
 // the queue a slot goes to after a step
 __device__ __forceinline__ uint32_t queue_of(Lane& s) {
     uint32_t st = l_st(s);
-    if (st == ST_ISECT) {   // the walk just ended: window mode has nothing left to intersect; list mode picks a tier later
-        st = (l_flags(s) & F_LISTS) ? ST_F_LIGHT : ST_F_BITS;
+    if (st == ST_ISECT) {   // the walk just ended: window mode has nothing left to intersect; list mode goes to its tier
+        const uint32_t fl = l_flags(s);
+        st = !(fl & F_LISTS) ? ST_F_BITS : l_ncol(s) <= 3 ? ST_F_LIGHT : (fl & F_SMALL_BASE) ? ST_F_SCAN : ST_F_COOP;
         l_set_st(s, st);
     }
     return st == ST_NONE ? (uint32_t)ST_F_BITS : st;   // unmapped reads share the output queue
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             is.base_len = is.base_ref = is.base_colour = 0;
             if (active) isect_pick(s, cols, is);
             const uint32_t ncol_mine = l_ncol(s);
+            if (active && ncol_mine > 3) is.base_colour = ec[4ull * is.base_ref];   // only needed at the end: not waited for here
             uint32_t my_alive = 0;
             // reads of at most 64 classes are packed into the wave: read r takes ncol_r consecutive lanes (lane start_r + j =
             // class j of read r); a pass takes the longest prefix of the waiting reads that fits in 64 lanes
@@ -472,6 +474,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             is.count = 0;
             is.base_len = is.base_ref = is.base_colour = 0;
             if (active) isect_pick(s, cols, is);
+            if (active && l_ncol(s) > 3) is.base_colour = ec[4ull * is.base_ref];   // only needed at the end: not waited for here
             const uint32_t cnt_alloc = active ? is.base_len : 0u;   // upper bound: the survivors are a subset of the base list
             const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
             const uint64_t arena_cap = p.arena_cap;
