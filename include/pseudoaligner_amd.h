@@ -120,6 +120,17 @@ const char* pa_host_index_tx_gene(const pa_host_index* h, uint32_t tx);
 int pa_host_index_genes(const pa_host_index* h, uint32_t* tx_gene, uint32_t* num_genes);
 const char* pa_host_index_gene_name(const pa_host_index* h, uint32_t gene);
 int pa_counts_collapse_genes(const pa_host_index* h, const uint64_t* class_counts, uint64_t counts_len, uint64_t* gene_counts);
+/* Mappability of every transcript (analyze_graph, src/mappability.rs:120-156; `pseudoaligner mappability`,
+ * src/bin/pseudoaligner.rs:152-172): a node of L bases holds L - K + 1 k-mers shared by the transcripts of its class.
+ *   tx_mult[t * PA_MAPPABILITY_COUNTS_LEN + min(j, LEN) - 1]   k-mers of transcript t whose class has j transcripts
+ *   gene_mult[t * PA_MAPPABILITY_COUNTS_LEN + min(g, LEN) - 1] k-mers of transcript t whose class spans g distinct genes
+ * Both arrays have num_transcripts * PA_MAPPABILITY_COUNTS_LEN entries and are overwritten; either may be NULL.
+ * pa_write_mappability_tsv writes the reference's tx_mappability.tsv (write_mappability_tsv, src/mappability.rs:91-104:
+ * header + "tx_name gene_name tx_kmer_count frac_kmer_unique_tx frac_kmer_unique_gene", tab separated, fractions printed
+ * like Rust's `{}` of an f64: shortest round-trip digits, fixed notation, "NaN" for a transcript without k-mers). */
+#define PA_MAPPABILITY_COUNTS_LEN 11   /* src/config.rs:23 */
+int pa_host_index_mappability(const pa_host_index* h, uint64_t* tx_mult, uint64_t* gene_mult);
+int pa_write_mappability_tsv(const pa_host_index* h, const char* path);
 /* packed transcripts the index was built from (kept for read simulation / validation) */
 int pa_host_index_transcripts(const pa_host_index* h, const uint64_t** packed, const uint64_t** tx_start,
                               uint32_t* num_tx);

@@ -131,6 +131,18 @@ class HostIndex:
         check(lib().pa_counts_collapse_genes(self._h, cc.ctypes.data, len(cc), out.ctypes.data))
         return out
 
+    def mappability(self) -> Tuple[np.ndarray, np.ndarray]:
+        """analyze_graph (src/mappability.rs:120-156): (tx_multiplicity, gene_multiplicity), each [num_transcripts, 11]"""
+        W = 11   # PA_MAPPABILITY_COUNTS_LEN
+        tm = np.zeros((max(self.num_transcripts, 1), W), np.uint64)
+        gm = np.zeros_like(tm)
+        check(lib().pa_host_index_mappability(self._h, tm.ctypes.data, gm.ctypes.data))
+        return tm[: self.num_transcripts], gm[: self.num_transcripts]
+
+    def write_mappability_tsv(self, path: str) -> None:
+        """write_mappability_tsv (src/mappability.rs:91-104)"""
+        check(lib().pa_write_mappability_tsv(self._h, str(path).encode()))
+
     def transcripts(self) -> Tuple[np.ndarray, np.ndarray]:
         p, s, n = vp(), vp(), C.c_uint32()
         check(lib().pa_host_index_transcripts(self._h, C.byref(p), C.byref(s), C.byref(n)))

@@ -57,6 +57,8 @@ SIGNATURES = {
     "pa_host_index_genes": (C.c_int, [vp, vp, u32p]),
     "pa_host_index_gene_name": (C.c_char_p, [vp, C.c_uint32]),
     "pa_counts_collapse_genes": (C.c_int, [vp, vp, C.c_uint64, vp]),
+    "pa_host_index_mappability": (C.c_int, [vp, vp, vp]),
+    "pa_write_mappability_tsv": (C.c_int, [vp, C.c_char_p]),
     "pa_host_index_transcripts": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), u32p]),
     "pa_host_index_destroy": (None, [vp]),
     "pa_index_create": (C.c_int, [C.POINTER(FlatIndex), C.c_int, C.POINTER(vp)]),

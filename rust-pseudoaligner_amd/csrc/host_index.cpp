@@ -1,4 +1,8 @@
 // Host-side index object: FASTA ingest, flat view, own on-disk container, C ABI.
+#include <algorithm>
+#include <charconv>
+#include <cstdio>
+#include <cstring>
 #include <cerrno>
 #include <fstream>
 #include <thread>
@@ -297,6 +301,70 @@ int pa_counts_collapse_genes(const pa_host_index* h, const uint64_t* class_count
         }
         gene_counts[g] += class_counts[c];
     }
+    return PA_OK;
+}
+
+// ---- mappability (src/mappability.rs) ----
+int pa_host_index_mappability(const pa_host_index* h, uint64_t* tx_mult, uint64_t* gene_mult) {
+    if (!h) return fail(PA_ERR_INVALID_ARG, "null argument");
+    const pa::HostIndex& x = h->h;
+    const size_t ntx = x.num_transcripts, W = PA_MAPPABILITY_COUNTS_LEN;
+    if (gene_mult && x.tx_genes.size() != ntx) return fail(PA_ERR_FORMAT, "index carries no gene of each transcript");
+    if (tx_mult) memset(tx_mult, 0, ntx * W * sizeof(uint64_t));
+    if (gene_mult) memset(gene_mult, 0, ntx * W * sizeof(uint64_t));
+    std::vector<uint32_t> tg;
+    std::vector<const std::string*> names;
+    if (gene_mult) gene_table(h, tg, names);
+    // genes per class, once per class (the reference recounts them at every node, :137-144)
+    const size_t nc = x.ec_offset.size() - 1;
+    std::vector<uint32_t> class_genes(gene_mult ? nc : 0);
+    std::vector<uint32_t> scratch;
+    for (size_t c = 0; c < class_genes.size(); ++c) {
+        scratch.clear();
+        for (uint64_t j = x.ec_offset[c]; j < x.ec_offset[c + 1]; ++j) scratch.push_back(tg[x.ec_ids[j]]);
+        std::sort(scratch.begin(), scratch.end());
+        class_genes[c] = (uint32_t)(std::unique(scratch.begin(), scratch.end()) - scratch.begin());
+    }
+    for (size_t n = 0; n < x.node_len.size(); ++n) {
+        const uint64_t num_kmer = x.node_len[n] - x.k + 1;                        // :131
+        const uint32_t c = x.node_colour[n];                                      // :133-134
+        const uint64_t num_tx = x.ec_offset[c + 1] - x.ec_offset[c];              // :136
+        const size_t tslot = (num_tx > W ? W : num_tx) - 1;                       // add_tx_count (:58-64)
+        const size_t gslot = gene_mult ? (class_genes[c] > W ? W : class_genes[c]) - 1 : 0;   // add_gene_count (:66-72)
+        for (uint64_t j = x.ec_offset[c]; j < x.ec_offset[c + 1]; ++j) {          // :146-150
+            const size_t t = x.ec_ids[j];
+            if (tx_mult) tx_mult[t * W + tslot] += num_kmer;
+            if (gene_mult) gene_mult[t * W + gslot] += num_kmer;
+        }
+    }
+    return PA_OK;
+}
+
+// Rust's `{}` of an f64: shortest digits that round-trip, never scientific
+static std::string rust_f64(double v) {
+    if (v != v) return "NaN";
+    char buf[400];
+    const auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed);
+    return std::string(buf, r.ptr);
+}
+
+int pa_write_mappability_tsv(const pa_host_index* h, const char* path) {
+    if (!h || !path) return fail(PA_ERR_INVALID_ARG, "null argument");
+    const size_t ntx = h->h.num_transcripts, W = PA_MAPPABILITY_COUNTS_LEN;
+    std::vector<uint64_t> tm(ntx * W), gm(ntx * W);
+    const int rc = pa_host_index_mappability(h, tm.data(), gm.data());
+    if (rc != PA_OK) return rc;
+    FILE* f = fopen(path, "w");
+    if (!f) return fail(PA_ERR_IO, "cannot write %s", path);
+    fputs("tx_name\tgene_name\ttx_kmer_count\tfrac_kmer_unique_tx\tfrac_kmer_unique_gene\n", f);   // :32-33
+    for (size_t t = 0; t < ntx; ++t) {
+        uint64_t total = 0;                                                       // total_kmer_count (:54-56)
+        for (size_t j = 0; j < W; ++j) total += tm[t * W + j];
+        const double ft = (double)tm[t * W] / (double)total, fg = (double)gm[t * W] / (double)total;   // :74-80
+        fprintf(f, "%s\t%s\t%llu\t%s\t%s\n", h->h.tx_names[t].c_str(), h->h.tx_genes[t].c_str(), (unsigned long long)total,
+                rust_f64(ft).c_str(), rust_f64(fg).c_str());
+    }
+    if (fclose(f) != 0) return fail(PA_ERR_IO, "cannot write %s", path);
     return PA_OK;
 }
 

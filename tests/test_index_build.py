@@ -205,3 +205,48 @@ def test_gene_level_collapse(small_index):
     assert np.array_equal(got, want) and got.sum() == counts[:-3].sum()
     with pytest.raises(pa.PaError):
         host.collapse_to_genes(counts[:-1])
+
+
+def test_mappability(tmp_path):
+    """analyze_graph / write_mappability_tsv (src/mappability.rs:91-156) against a brute-force count over the transcripts'
+    own k-mers: a k-mer shared by j transcripts (g genes) adds one to slot min(j, 11) - 1 (min(g, 11) - 1) of each."""
+    k, W = 24, 11
+    names, seqs = helpers.read_fasta()
+    names, seqs = names[:80], [s.upper() for s in seqs[:80]]
+    names.append("ENSTSHORT.1|ENSGSHORT.1|-|-|SHORT-201|SHORT|10|x|")          # shorter than K: no k-mers, fractions 0/0
+    seqs.append("ACGTACGTAC")
+    fa = tmp_path / "m.fa"
+    fa.write_text("".join(">%s\n%s\n" % (n, s) for n, s in zip(names, seqs)))
+    host = pa.build_index(str(fa), k, 4)
+    genes = host.tx_genes()
+    owners = {}
+    for t, s in enumerate(seqs):
+        for i in range(len(s) - k + 1):
+            owners.setdefault(s[i:i + k], set()).add(t)
+    want_t = np.zeros((len(seqs), W), np.uint64)
+    want_g = np.zeros((len(seqs), W), np.uint64)
+    for txs in owners.values():
+        j = min(len(txs), W) - 1
+        g = min(len({genes[t] for t in txs}), W) - 1
+        for t in txs:
+            want_t[t, j] += 1
+            want_g[t, g] += 1
+    tm, gm = host.mappability()
+    assert np.array_equal(tm, want_t) and np.array_equal(gm, want_g)
+    assert (tm.sum(1) == gm.sum(1)).all() and tm[-1].sum() == 0
+    out = tmp_path / "tx_mappability.tsv"
+    host.write_mappability_tsv(out)
+    lines = out.read_text().split("\n")
+    assert lines[0] == "tx_name\tgene_name\ttx_kmer_count\tfrac_kmer_unique_tx\tfrac_kmer_unique_gene" and lines[-1] == ""
+    tx_names = host.tx_names()
+    for t, line in enumerate(lines[1:-1]):
+        name, gene, total, ft, fg = line.split("\t")
+        assert (name, gene, int(total)) == (tx_names[t], genes[t], int(tm[t].sum()))
+        if int(total) == 0:
+            assert (ft, fg) == ("NaN", "NaN")
+            continue
+        for txt, num in ((ft, tm[t, 0]), (fg, gm[t, 0])):
+            x = float(num) / float(total)
+            assert float(txt) == x and "e" not in txt.lower()
+            # Rust's `{}`: the shortest digits that round-trip ("1", "0.5", "0.3333333333333333")
+            assert txt == (repr(x)[:-2] if repr(x).endswith(".0") else repr(x)) or "e" in repr(x)
