@@ -195,7 +195,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
 
     // Work distribution: chunks of up to 16 tiles (1024 reads). Chunk w is wave w's first one; further chunks come from a
     // global counter, so that the waves finish together whatever their reads cost (a static split left the chip 9 % idle
-    // at the end of a 100 M-read launch). One grab per ~100 iterations: far from the ~88 M ops/s of one hot atomic word.
+    // at the end of a 100 M-read launch), and shrink towards the end of the launch (a wave needs ~0.4 ms for 1024 reads:
+    // fixed chunks left the chip half idle for that long). One grab per ~100 iterations: far from the ~88 M ops/s of one
+    // hot atomic word.
     const uint32_t ntiles = (uint32_t)((p.n_reads + 63) >> 6);
     const uint32_t chunk_tiles = ntiles / (nwaves * 4) >= 16 ? 16u : ntiles / (nwaves * 4) >= 1 ? ntiles / (nwaves * 4) : 1u;
     uint64_t next = (uint64_t)wave * chunk_tiles << 6;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     if (end > p.n_reads) end = p.n_reads;
     if (next > end) next = end;
     bool more = true;   // chunks may be left
+    uint32_t seen = nwaves * chunk_tiles;   // tiles known to be handed out
 
     // this XCD's replica of the count table (HW_REG_XCC_ID, bits 3:0)
     const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (PA_COUNT_REPLICAS - 1);
@@ -217,13 +220,18 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         const glb_u32 ec = (glb_u32)ix.ec;
         const uint32_t K = ix.k, allowed = p.allowed, spill_cap = p.spill_cap;
         if (next == end && more) {   // this wave's chunk is used up: take the next one
+            // guided: half of an even share of what was left at this wave's previous grab, 2..16 tiles (the estimate is one
+            // chunk old, so the sizes decay geometrically towards the end and the last chunks are ~128 reads)
+            const uint32_t share = (ntiles > seen ? ntiles - seen : 0u) / (2 * nwaves);
+            const uint32_t take = share >= 16 ? 16u : share >= 2 ? share : 2u;
             uint32_t t0 = 0;
-            if (lane == 0) t0 = atomicAdd(p.tile_ctr, chunk_tiles);
+            if (lane == 0) t0 = atomicAdd(p.tile_ctr, take);
             t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0) + nwaves * chunk_tiles;
+            seen = t0 + take;
             if (t0 >= ntiles) more = false;
             else {
                 next = (uint64_t)t0 << 6;
-                end = (uint64_t)(t0 + chunk_tiles) << 6;
+                end = (uint64_t)(t0 + take) << 6;
                 if (end > p.n_reads) end = p.n_reads;
             }
         }
