@@ -202,14 +202,14 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out) {
         }
     }
 
-    // ---- blob placement: every blob starts on a 64-byte line ----
+    // ---- blob placement: every blob starts on a 128-byte block (handles stay in 64-byte units) ----
     out.handle.resize(N);
     uint64_t cursor = 0, nk = 0;
     for (uint32_t i = 0; i < N; ++i) {
         if (f.node_len[i] < k) return fail(PA_ERR_FORMAT, "node %u shorter than k", i);
         if (f.node_len[i] >= (1u << 24)) return fail(PA_ERR_UNSUPPORTED, "node %u longer than 2^24 bases", i);
         if (f.node_colour[i] >= f.num_classes) return fail(PA_ERR_FORMAT, "node %u: colour out of range", i);
-        const uint64_t size = (BLOB_HDR_BYTES + 8ull * ((f.node_len[i] + 31) / 32) + BLOB_GRANULE - 1) / BLOB_GRANULE * BLOB_GRANULE;
+        const uint64_t size = (BLOB_HDR_BYTES + 8ull * ((f.node_len[i] + 31) / 32) + BLOB_ALIGN - 1) / BLOB_ALIGN * BLOB_ALIGN;
         if (cursor / BLOB_GRANULE >= NO_HANDLE) return fail(PA_ERR_UNSUPPORTED, "graph exceeds the 256 GiB blob address space");
         out.handle[i] = (uint32_t)(cursor / BLOB_GRANULE);
         cursor += size;

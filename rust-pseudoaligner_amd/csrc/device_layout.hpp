@@ -51,6 +51,7 @@ namespace pa {
 
 constexpr uint32_t NO_HANDLE = 0xFFFFFFFFu;
 constexpr uint32_t BLOB_GRANULE = 64;
+constexpr uint32_t BLOB_ALIGN = 128;   // the memory system moves 128-byte blocks: two adjacent 64-byte lines of ONE block cost what one line costs, lines of two blocks cost double (tools/microbench/gather_pair.hip); header + first 320 bases = one block
 constexpr uint32_t BLOB_HDR_BYTES = 48;
 constexpr uint32_t CLASS_WINDOW = 32;   // ids per class window (one mask word)
 constexpr uint32_t SLOTS_PER_BUCKET = 4;
