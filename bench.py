@@ -84,13 +84,21 @@ def main() -> None:
 
     if not torch.cuda.is_available() or pa.lib().pa_device_count() < 1:
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    # rehearsal of the multi-rank path on a box with fewer GPUs than ranks: PA_BENCH_BACKEND=gloo lets several ranks share a
+    # device (RCCL refuses that); the driver's runs use neither variable
+    backend = os.environ.get("PA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     def barrier():
         if dist is not None:
