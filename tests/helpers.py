@@ -334,3 +334,26 @@ def random_txome_case(seed, tmp_path, big=False, max_read=250):
             reads.append((r[: len(r) // 2] + "N" + r[len(r) // 2 + 1:]).lower() if rng.rand() < 0.5 else r.lower())
     allowed = int(rng.randint(0, 4))
     return host, k, reads, [r.upper().replace("N", "A") for r in reads], allowed
+
+
+def many_classes_case(seed, tmp_path, k=11, ntx=300, read_len=1500, nreads=400):
+    """list-mode stress: transcripts that are long chains of short shared segments, so that every node is in ~half of the
+    transcripts (classes far beyond two windows) and a long read crosses more than 64 nodes of DIFFERENT classes.
+    Returns (host index, reads)."""
+    rng = np.random.RandomState(7000 + seed)
+    segs = ["".join(rng.choice(list("ACGT"), rng.randint(12, 22))) for _ in range(90)]
+    txs = ["".join(segs[j] for j in rng.choice(len(segs), 120)) for _ in range(ntx)]
+    fa = tmp_path / "mc.fa"
+    fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i // 4, s) for i, s in enumerate(txs)))
+    host = pa.HostIndex.build_fasta(str(fa), k, 4)
+    reads = []
+    for _ in range(nreads):
+        t = txs[rng.randint(len(txs))]
+        n = int(rng.randint(40, read_len + 1))               # tens of classes for the short reads, hundreds for the long
+        lo = rng.randint(0, len(t) - n)
+        r = list(t[lo:lo + n])
+        for j in range(len(r)):
+            if rng.rand() < 0.002:
+                r[j] = "ACGT"[rng.randint(4)]
+        reads.append("".join(r))
+    return host, reads

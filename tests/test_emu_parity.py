@@ -62,6 +62,14 @@ def test_random_transcriptomes_list_mode(tmp_path, seed):
     check(host, tiles, lens, wpr, allowed)
 
 
+def test_many_classes_per_read(tmp_path):
+    """list mode with tens to hundreds of DIFFERENT classes per read (chains of short shared segments, K = 11, reads of up to
+    1500 bases): class rows far into the spill area, bases of one or two ids"""
+    host, reads = helpers.many_classes_case(0, tmp_path, nreads=150)
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    check(host, tiles, lens, wpr, 2)
+
+
 def test_ragged_short_and_unmappable_reads(small_index):
     host = small_index(24)
     _, seqs = helpers.read_fastq()
