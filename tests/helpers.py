@@ -336,13 +336,21 @@ def random_txome_case(seed, tmp_path, big=False, max_read=250):
     return host, k, reads, [r.upper().replace("N", "A") for r in reads], allowed
 
 
-def many_classes_case(seed, tmp_path, k=11, ntx=300, read_len=1500, nreads=400):
+def many_classes_case(seed, tmp_path, k=11, ntx=300, read_len=1500, nreads=400, ordered=False):
     """list-mode stress: transcripts that are long chains of short shared segments, so that every node is in ~half of the
     transcripts (classes far beyond two windows) and a long read crosses more than 64 nodes of DIFFERENT classes.
     Returns (host index, reads)."""
     rng = np.random.RandomState(7000 + seed)
-    segs = ["".join(rng.choice(list("ACGT"), rng.randint(12, 22))) for _ in range(90)]
-    txs = ["".join(segs[j] for j in rng.choice(len(segs), 120)) for _ in range(ntx)]
+    if ordered:   # transcripts = windows of ONE long cycle of segments: every node is in ~90 transcripts, a sliding set, so
+                  # that even the shortest class of a read has far more than 8 ids (the cooperative step, > 64 lists)
+        segs = ["".join(rng.choice(list("ACGT"), rng.randint(12, 22))) for _ in range(400)]
+        txs = []
+        for _ in range(ntx):
+            st = rng.randint(len(segs))
+            txs.append("".join(segs[(st + j) % len(segs)] for j in range(120)))
+    else:
+        segs = ["".join(rng.choice(list("ACGT"), rng.randint(12, 22))) for _ in range(90)]
+        txs = ["".join(segs[j] for j in rng.choice(len(segs), 120)) for _ in range(ntx)]
     fa = tmp_path / "mc.fa"
     fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i // 4, s) for i, s in enumerate(txs)))
     host = pa.HostIndex.build_fasta(str(fa), k, 4)

@@ -62,10 +62,11 @@ def test_random_transcriptomes_list_mode(tmp_path, seed):
     check(host, tiles, lens, wpr, allowed)
 
 
-def test_many_classes_per_read(tmp_path):
+@pytest.mark.parametrize("ordered", [False, True])
+def test_many_classes_per_read(tmp_path, ordered):
     """list mode with tens to hundreds of DIFFERENT classes per read (chains of short shared segments, K = 11, reads of up to
     1500 bases): class rows far into the spill area, bases of one or two ids"""
-    host, reads = helpers.many_classes_case(0, tmp_path, nreads=150)
+    host, reads = helpers.many_classes_case(0, tmp_path, nreads=150, ordered=ordered)
     tiles, lens, wpr = pa.encode_reads_host(reads)
     check(host, tiles, lens, wpr, 2)
 
