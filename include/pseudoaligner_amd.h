@@ -166,6 +166,9 @@ typedef struct pa_read_result {   /* one per read, same order as the input */
 } pa_read_result;
 #define PA_MAPPED_BIT 0x80000000u
 #define PA_CLASS_REF 0x80000000u
+/* Arena offsets must leave bit 31 of class_off free: a launch uses at most this many arena entries, however large the
+ * caller's buffer is (a batch that needs more fails with PA_ERR_ARENA_FULL: split it). */
+#define PA_MAX_ARENA_ENTRIES 0x7FFFFFFFull
 
 size_t pa_tiles_words(uint64_t n_reads, uint32_t words_per_read);   /* u64 words in the tile buffer */
 uint32_t pa_words_per_read(uint32_t max_read_len);
@@ -192,11 +195,14 @@ int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* 
 /* Same launch with the class-count table fused in: d_counts[pa_counts_len(idx)] (u64, caller-owned so that it can be
  * all-reduced with RCCL) is incremented once per read as pa_counts_accumulate_device would. On PA_ERR_ARENA_FULL every
  * read of that launch is still counted once, but a list-mode result whose ids did not fit cannot be looked up by content
- * and lands in the "novel" slot; the class ids are incomplete. Re-run the batch with the arena pa_map_finish asks for. */
+ * and lands in the "novel" slot; the class ids are incomplete. Re-run the batch with the arena pa_map_finish asks for —
+ * into a table restored to its value before the failed launch (snapshot it, or count into a scratch table and add it on
+ * success): the failed launch has already added its reads. */
 int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads,
                               uint32_t words_per_read, uint32_t allowed_mismatches, pa_read_result* d_results,
                               uint32_t* d_arena, uint64_t arena_cap, uint64_t* d_counts, void* stream);
-/* Synchronise and report: PA_OK, or PA_ERR_ARENA_FULL with *arena_needed set (re-run with a larger arena). */
+/* Synchronise and report: PA_OK, or PA_ERR_ARENA_FULL with *arena_needed set (re-run with a larger arena).
+ * *arena_used = entries of d_arena that may hold ids (never more than the arena_cap of the launch). */
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed);
 /* arena capacity (u32 entries) that suffices for typical batches of n_reads; the exact need is data dependent */
 uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads);

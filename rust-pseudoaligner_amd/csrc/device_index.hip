@@ -62,6 +62,7 @@ struct pa_index {
     DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status, [12..15] tile counter, [16..] statistics
     DevBuf spill, trace, xcd_counts;
     uint32_t last_grid = 0;
+    uint64_t last_arena_cap = 0;
     // host-buffer convenience path
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
     std::vector<uint32_t> h_class_ids;
@@ -261,7 +262,8 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.allowed = allowed;
     p.results = d_results;
     p.arena = d_arena;
-    p.arena_cap = arena_cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : arena_cap;
+    // bit 31 of class_off means "class by reference" (PA_CLASS_REF): offsets handed out by the arena must stay below 2^31
+    p.arena_cap = arena_cap > PA_MAX_ARENA_ENTRIES ? PA_MAX_ARENA_ENTRIES : arena_cap;
     p.colour_out = d_colour;
     p.arena_top = idx->ctl.as<unsigned long long>();
     p.status = idx->ctl.as<uint32_t>() + 2;
@@ -289,6 +291,7 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.nodes_out = d_nodes;
     p.nodes_len = d_nodes_len;
     idx->last_grid = grid;
+    idx->last_arena_cap = p.arena_cap;
     if (n_reads == 0) return PA_OK;
     const int e = launch_map_pool(p, grid, lds, stream);
     if (e) return fail(PA_ERR_HIP, "map launch (grid %u, lds %zu): %s", grid, lds, hipGetErrorString((hipError_t)e));
@@ -314,7 +317,9 @@ static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_
                         (double)d[2 * ST_COUNT + i] / (double)d[i]);
         fprintf(stderr, "\n");
     }
-    if (arena_used) *arena_used = ctl.top;
+    // the counter includes every wave's partly used chunk and may run past the caller's arena without any allocation having
+    // crossed its end: what may be copied back is min(top, capacity); `needed` is the capacity that would have sufficed
+    if (arena_used) *arena_used = ctl.top < idx->last_arena_cap ? ctl.top : idx->last_arena_cap;
     if (arena_needed) *arena_needed = ctl.top;
     if (ctl.status & PA_STATUS_SPILL_OVERFLOW) return fail(PA_ERR_INTERNAL, "colour spill buffer overflow (should be impossible)");
     if (ctl.status & PA_STATUS_ARENA_FULL) return fail(PA_ERR_ARENA_FULL, "class arena too small: %llu entries needed", ctl.top);

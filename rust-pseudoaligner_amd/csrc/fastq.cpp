@@ -257,8 +257,10 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     close(fd);
     FILE* out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
     if (!out) { if (data) munmap((void*)data, fsize); return fail(PA_ERR_IO, "cannot create %s: %s", out_path, strerror(errno)); }
-    std::vector<char> obuf(1 << 22);
-    setvbuf(out, obuf.data(), _IOFBF, obuf.size());
+    // a private 4 MiB stdio buffer only for a file this function opened (and closes before the buffer dies); the process-wide
+    // stdout keeps its own buffering: handing it a function-local buffer would leave it dangling after the return
+    std::vector<char> obuf(out != stdout ? (size_t)1 << 22 : 0);
+    if (out != stdout) setvbuf(out, obuf.data(), _IOFBF, obuf.size());
 
     uint64_t BATCH_READS = DEFAULT_BATCH_READS;
     if (const char* v = getenv("PA_INGEST_BATCH")) { const long long x = atoll(v); if (x >= 64) BATCH_READS = (uint64_t)x / 64 * 64; }
@@ -383,7 +385,11 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                     continue;
                 }
                 const char* ide = p + 1;
-                while (ide < l1e && *ide != ' ' && *ide != '\t' && *ide != '\r') ++ide;   // record.id() (:456): up to the first blank
+                // record.id() (:456) = header[1..].trim_end().splitn(2, ' ').next() in bio 1.5: cut at the first SPACE only (a tab
+                // stays part of the id), after trailing whitespace was trimmed
+                const char* hend = l1e;
+                while (hend > p + 1 && (hend[-1] == '\r' || hend[-1] == ' ' || hend[-1] == '\t' || hend[-1] == '\n')) --hend;
+                while (ide < hend && *ide != ' ') ++ide;
                 const char* se = l2e;
                 if (se > l2 && se[-1] == '\r') --se;
                 Record& rec = c.recs[i];

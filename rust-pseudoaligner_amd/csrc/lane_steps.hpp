@@ -438,7 +438,7 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
 #pragma unroll
     for (int i = 0; i < 5; ++i) r[i] = read_word(rd, rw + i);         // all LDS reads in flight together
     bool premature = false;
-    uint32_t matched, nfl = (fl & ~F_FRESH) | (l_flags(s) & F_SMALL_BASE);   // (push_node may just have set F_SMALL_BASE)
+    uint32_t matched, nfl = (fl & ~F_FRESH) | (l_flags(s) & (F_SMALL_BASE | F_SPILL_OVERFLOW));   // (what push_node may just have set)
     if (!careful) {
         const uint32_t n = pa_min(rem, 128u);
         uint32_t cnt = 0;

@@ -107,6 +107,36 @@ def pack_read(seq: str) -> np.ndarray:
     return words
 
 
+def pack_reads_tiles(reads, words_per_read=None):
+    """Independent (numpy) packer of the checker: ASCII reads -> (tiles, lens, words_per_read) in the tile layout the oracle's
+    batch entry reads (word-major tiles of 64 reads: tiles[(t*W + w)*64 + r], 2 bits per base LSB-first, A=0 C=1 G=2 T=3,
+    anything else -> A, as src/pseudoaligner.rs:450 / SURVEY appendix A). Shares no code with the product's encoders, so a
+    packing bug common to pa_encode_reads_host and pa_encode_kernel cannot hide in the batch parity tests."""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    n = len(bs)
+    lens = np.array([len(b) for b in bs], np.uint32)
+    wpr = int(words_per_read or max(1, (int(lens.max()) + 31) // 32 if n else 1))
+    tiles = np.zeros(((n + 63) // 64) * wpr * 64, np.uint64)
+    lut = np.zeros(256, np.uint64)
+    for ch, v in ((b"C", 1), (b"G", 2), (b"T", 3), (b"c", 1), (b"g", 2), (b"t", 3)):
+        lut[ch[0]] = v
+    shifts = (2 * np.arange(32, dtype=np.uint64))[None, None, :]
+    t3 = tiles.reshape(-1, wpr, 64)
+    for lo in range(0, n, 65536):
+        hi = min(n, lo + 65536)
+        m = np.zeros((hi - lo, wpr * 32), np.uint8)
+        flat = np.frombuffer(b"".join(bs[lo:hi]), np.uint8)
+        ll = lens[lo:hi].astype(np.int64)
+        row = np.repeat(np.arange(hi - lo), ll)
+        col = np.arange(len(flat)) - np.repeat(np.cumsum(ll) - ll, ll)
+        keep = col < wpr * 32
+        m[row[keep], col[keep]] = flat[keep]
+        words = (lut[m].reshape(hi - lo, wpr, 32) << shifts).sum(axis=2, dtype=np.uint64)      # disjoint bit fields: sum == or
+        rid = np.arange(lo, hi)
+        t3[rid >> 6, :, rid & 63] = words
+    return tiles, lens, wpr
+
+
 class Oracle:
     """oracle/pa_oracle.c over the flat arrays of a HostIndex (graph + classes only: the oracle builds its own
     dictionary and edges)."""
@@ -151,7 +181,7 @@ class Oracle:
         return res, coff, out, ctr.as_dict()
 
     def map_reads(self, reads, allowed=2, nthreads=1):
-        tiles, lens, wpr = pa.encode_reads_host(reads)
+        tiles, lens, wpr = pack_reads_tiles(reads)   # the checker's own packer, not the product's encoder
         return self.map_tiles(tiles, lens, wpr, allowed, nthreads)
 
     def lookup(self, kmer: int):
@@ -292,6 +322,63 @@ def counts_reference(results, coff, cids, host_index):
         else:
             c = table.get(tuple(cids[int(coff[i]):int(coff[i + 1])].tolist()))
             counts[nc if c is None else c] += 1
+    return counts
+
+
+def counts_reference_fast(results, coff, cids, host_index):
+    """counts_reference for millions of reads: reads are grouped by (class length, 64-bit content hash), every group is checked
+    id by id against its first member (so a hash collision cannot merge two classes), and only one dictionary lookup per
+    group is done in Python."""
+    a = host_index.arrays()
+    nc = a["num_classes"]
+    off = a["ec_offset"].astype(np.int64)
+    ec_ids = a["ec_ids"]
+    n = len(results)
+    coff = np.asarray(coff, np.int64)
+    cids = np.asarray(cids, np.uint32)
+    mapped = (results["mismatches"] >> 31).astype(bool) if "mapped" not in results.dtype.names else results["mapped"].astype(bool)
+    clen = (coff[1:] - coff[:-1])[:n]
+    counts = np.zeros(nc + 3, np.int64)
+    counts[nc + 2] = int((~mapped).sum())
+    counts[nc + 1] = int((mapped & (clen == 0)).sum())
+    sel = np.flatnonzero(mapped & (clen > 0))
+    if len(sel) == 0:
+        return counts
+
+    def content_hash(ids, starts, lens_):
+        x = ids.astype(np.uint64)
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) * np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(31)
+        x *= np.uint64(0x94D049BB133111EB)
+        within = np.arange(len(ids), dtype=np.uint64) - np.repeat(starts.astype(np.uint64), lens_)
+        x *= (within * np.uint64(2) + np.uint64(1))                  # position-dependent: order matters
+        csum = np.concatenate([[np.uint64(0)], np.cumsum(x, dtype=np.uint64)])
+        return csum[starts + lens_] - csum[starts]
+
+    with np.errstate(over="ignore"):
+        h_read = content_hash(cids, coff[sel], clen[sel])
+        h_cls = content_hash(ec_ids, off[:-1], off[1:] - off[:-1])
+    key = np.stack([h_read, clen[sel].astype(np.uint64)], axis=1)
+    uniq, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    # exactness: every read of a group has the ids of the group's first member
+    rep = sel[first][inv]
+    owner = np.repeat(np.arange(len(sel)), clen[sel])
+    within = np.arange(int(clen[sel].sum())) - np.repeat(np.cumsum(clen[sel]) - clen[sel], clen[sel])
+    assert np.array_equal(cids[coff[sel][owner] + within], cids[coff[rep][owner] + within]), "hash collision between result classes"
+    table = {}
+    cl_len = off[1:] - off[:-1]
+    for c in np.flatnonzero(np.isin(h_cls, uniq[:, 0])):
+        table.setdefault((int(h_cls[c]), int(cl_len[c])), []).append(int(c))
+    group_class = np.full(len(uniq), nc, np.int64)
+    for g in range(len(uniq)):
+        r = sel[first[g]]
+        ids = cids[coff[r]:coff[r + 1]]
+        for c in table.get((int(uniq[g, 0]), int(uniq[g, 1])), ()):
+            if np.array_equal(ec_ids[off[c]:off[c + 1]], ids):
+                group_class[g] = c
+                break
+    np.add.at(counts, group_class[inv], 1)
     return counts
 
 

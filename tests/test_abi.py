@@ -57,6 +57,20 @@ def test_encode_reads_host_layout(built):
     assert helpers.pack_read("ACGT")[0] == 0b11100100
 
 
+def test_checker_packer_is_independent_and_agrees(built):
+    """helpers.pack_reads_tiles (numpy, what the oracle is fed in the batch parity tests) vs the product's host encoder:
+    two implementations, same tiles — on ragged, empty, lower-case, non-ACGT reads and across the 64-read tile seam"""
+    _, seqs = helpers.read_fastq()
+    reads = seqs[:200] + ["", "A", "acgtnNRY" * 9, "T" * 33, "G" * 64, "C" * 65, seqs[0][:31], seqs[1][:32]] + seqs[200:260]
+    t1, l1, w1 = pa.encode_reads_host(reads)
+    t2, l2, w2 = helpers.pack_reads_tiles(reads)
+    assert w1 == w2 and np.array_equal(l1, l2) and np.array_equal(t1, t2)
+    t3, _, _ = helpers.pack_reads_tiles(reads, 4)                                  # explicit words per read
+    t4, _, _ = pa.encode_reads_host(reads, 4)
+    assert np.array_equal(t3, t4)
+    assert [int(x) for x in helpers.pack_reads_tiles(["ACGT"])[0][:1]] == [0b11100100]
+
+
 def test_simulator_is_a_pure_function_of_seed_and_index(built, small_index):
     tx = pa.Txome.from_host_index(small_index(24))
     a, la = tx.simulate_host(100, 1, 1000)
