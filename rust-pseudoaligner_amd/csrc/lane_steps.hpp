@@ -332,6 +332,45 @@ PA_HD void restart_lists(Lane& s, uint32_t k) {
 }
 
 // ---------------------------------------------------------------------------------------------- SEEK
+// One dictionary probe of find_kmer_match (:91-114), K <= 32, in the three pieces the kernel interleaves with other work:
+//   seek_issue     k-mer -> bucket, the 16-byte fingerprint load goes out
+//   seek_cands / seek_entry   fingerprints -> candidate slots, the dependent 12-byte entry load (same line) goes out
+//   seek_complete  verification of the other 33 key bits, further candidates (rare), the lane's next state
+struct SeekProbe {
+    const uint32_t* linew;   // the bucket line
+    U4 fp;                   // its four fingerprints
+    uint32_t klo, khi;       // the k-mer
+};
+PA_HD void seek_issue(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekProbe& q) {
+    const uint64_t kmer = read_window(rd, l_kp(s)) & ix.kmask;      // read_seq.get_kmer(kmer_pos) (:93)
+    uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + l_probe(s);
+    if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
+    q.linew = ix.table + (uint64_t)b * BUCKET_WORDS;
+    q.fp = *reinterpret_cast<const U4*>(q.linew);
+    q.klo = (uint32_t)kmer;
+    q.khi = (uint32_t)(kmer >> 32);
+}
+// entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j: the slots whose fingerprint (low 31 key bits) matches.
+// Two keys of one bucket can share their low 31 bits (low-complexity sequence): every matching slot is tried.
+PA_HD uint32_t seek_cands(const SeekProbe& q) {
+    const uint32_t want = q.klo & 0x7FFFFFFFu;
+    return (q.fp.x == want ? 1u : 0u) | (q.fp.y == want ? 2u : 0u) | (q.fp.z == want ? 4u : 0u) | (q.fp.w == want ? 8u : 0u);
+}
+PA_HD U3 seek_entry(const SeekProbe& q, uint32_t cand) {            // entry of the first candidate (no candidate: entry 0, ignored)
+    return *reinterpret_cast<const U3*>(q.linew + 4 + 3 * (cand ? pa_ctz32(cand) : 0u));
+}
+PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe);
+PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand, U3 e) {
+    const uint32_t top = q.klo >> 31;
+    uint32_t h = NO_HANDLE, off = 0;
+    while (cand) {                                                  // almost always exactly one candidate on a hit
+        cand &= cand - 1;
+        if (e.x == q.khi && (e.z >> 31) == top) { h = e.y; off = e.z & 0x7FFFFFFFu; cand = 0; }
+        else if (cand) e = *reinterpret_cast<const U3*>(q.linew + 4 + 3 * pa_ctz32(cand));
+    }
+    seek_finish(s, K, h, off, ((q.fp.x | q.fp.y | q.fp.z | q.fp.w) >> 31) == 0, l_probe(s));
+}
+
 // what a probe found -> the lane's next state (the tail of find_kmer_match and of :118-129)
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe) {
     const uint32_t L = l_L(s), kp = l_kp(s);
@@ -383,24 +422,11 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
         seek_finish(s, K, h0 ? v0.x : h1 ? v1.x : NO_HANDLE, h0 ? v0.y : v1.y, v0.x != NO_HANDLE && v1.x != NO_HANDLE, probe);
         return;
     }
-    const uint64_t kmer = read_window(rd, kp) & ix.kmask;           // read_seq.get_kmer(kmer_pos) (:93)
-    uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + probe;
-    if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
-    const uint32_t* linew = ix.table + (uint64_t)b * BUCKET_WORDS;
-    const U4 fp = *reinterpret_cast<const U4*>(linew);
-    const uint32_t klo = (uint32_t)kmer, khi = (uint32_t)(kmer >> 32);
-    const uint32_t want = klo & 0x7FFFFFFFu, top = klo >> 31;
-    // entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j: fetch the one whose fingerprint matches (same line).
-    // Two keys of one bucket can share their low 31 bits (low-complexity sequence): every matching slot is tried.
-    uint32_t cand = (fp.x == want ? 1u : 0u) | (fp.y == want ? 2u : 0u) | (fp.z == want ? 4u : 0u) | (fp.w == want ? 8u : 0u);
-    uint32_t h = NO_HANDLE, off = 0;
-    while (cand) {                                                  // almost always exactly one candidate on a hit
-        const uint32_t j = pa_ctz32(cand);
-        cand &= cand - 1;
-        const U3 e = *reinterpret_cast<const U3*>(linew + 4 + 3 * j);
-        if (e.x == khi && (e.z >> 31) == top) { h = e.y; off = e.z & 0x7FFFFFFFu; cand = 0; }
-    }
-    seek_finish(s, K, h, off, ((fp.x | fp.y | fp.z | fp.w) >> 31) == 0, probe);
+    SeekProbe q;
+    seek_issue(s, ix, rd, q);
+    uint32_t cand = seek_cands(q);
+    const U3 e = seek_entry(q, cand);
+    seek_complete(s, K, q, cand, e);
 }
 
 // ---------------------------------------------------------------------------------------------- FWD
@@ -408,22 +434,37 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
 // words, issued together). Fast mode compares up to 128 bases by counting mismatches only; when a node visit would
 // exceed its mismatch budget nothing is consumed and the lane switches to careful mode, which walks the same node 32
 // bases per call and locates the breaking base exactly as the reference's loop does (:236-255).
+struct FwdLoad {     // what fwd_issue leaves in flight: the node header and the sequence words this step can need
+    U4 h0, h1, h2;
+    Q2 s01, s23, s45;
+};
+PA_HD void fwd_issue(const Lane& s, const DevIndexView& ix, FwdLoad& f) {
+    const uint32_t K = ix.k, L = l_L(s);
+    const bool fresh = l_flags(s) & F_FRESH;
+    const uint32_t ro0 = fresh ? l_off(s) + K : (s.rr & 0xFFFFFFu);   // ref_offset (:227)
+    const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
+    const U4* hp = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)s.h * BLOB_GRANULE);   // dbg.get_node (:210)
+    f.h0 = hp[0]; f.h1 = hp[1]; f.h2 = hp[2];
+    const Q2* sq2 = reinterpret_cast<const Q2*>(node_seq(ix, s.h) + (ro0 >> 5));
+    // sequence words this step can need, known before the header arrives: the node visit compares at most the rest of the
+    // read (fresh) / of the visit (continued), 128 bases per step; words beyond are not fetched (each may be another line)
+    const uint32_t most = pa_min(fresh ? L - kp0 : (s.rm & 0xFFFFu), 128u), nwords = ((ro0 & 31) + most + 31) >> 5;
+    const Q2 zero2{0, 0};
+    f.s01 = sq2[0];
+    f.s23 = nwords > 2 ? sq2[1] : zero2;
+    f.s45 = nwords > 4 ? sq2[2] : zero2;
+}
+
 template <bool TRACE = false>
-PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
+PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed, const FwdLoad& f) {
     const uint32_t K = ix.k, L = l_L(s);
     const uint32_t fl = l_flags(s);
     const bool fresh = fl & F_FRESH, careful = fl & F_CAREFUL;
     const uint32_t ro0 = fresh ? l_off(s) + K : (s.rr & 0xFFFFFFu);   // ref_offset (:227)
     const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
-    const Hdr hd = load_hdr(ix, s.h);                                 // dbg.get_node (:210)
-    const Q2* sq2 = reinterpret_cast<const Q2*>(node_seq(ix, s.h) + (ro0 >> 5));
+    const Hdr hd{f.h0.x & 0xFFFFFFu, f.h0.x >> 24, f.h0.y, f.h0.z, f.h0.w, f.h1.x, f.h1.y, f.h1.z, f.h1.w, f.h2.x, f.h2.y, f.h2.z, f.h2.w};
     uint32_t rem = s.rm & 0xFFFFu, snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
-    // sequence words this step can need, known before the header arrives: the node visit compares at most the rest of the
-    // read (fresh) / of the visit (continued), 128 bases per step; words beyond are not fetched (each may be another line)
-    const uint32_t most = pa_min(fresh ? L - kp0 : rem, 128u), nwords = ((ro0 & 31) + most + 31) >> 5;
-    const Q2 zero2{0, 0};
-    const Q2 s01 = sq2[0], s23 = nwords > 2 ? sq2[1] : zero2, s45 = nwords > 4 ? sq2[2] : zero2;
-    const uint64_t a[5] = {s01.a, s01.b, s23.a, s23.b, s45.a};
+    const uint64_t a[5] = {f.s01.a, f.s01.b, f.s23.a, f.s23.b, f.s45.a};
     if (fresh) {
         cov += K;                                                     // :216
         if (push_node<TRACE>(s, cols, ix, hd, s.h)) {                 // nodes.push (:219)
@@ -486,6 +527,15 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
     s.rr = (ro0 + matched) | (snp << 24);
     s.rm = (s.rm & 0xFFFF0000u) | rem;
     s.of = off | (nfl << 24);
+}
+
+// Forward search (:209-301): one call = enter/continue one node (one dependent fetch of the node header + sequence
+// words, issued together)
+template <bool TRACE = false>
+PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
+    FwdLoad f;
+    fwd_issue(s, ix, f);
+    fwd_finish<TRACE>(s, ix, rd, cols, allowed, f);
 }
 
 // ---------------------------------------------------------------------------------------------- LEFT

@@ -3,6 +3,14 @@ from pathlib import Path
 
 import pytest
 
+# torch ships its own ROCm runtime libraries: when the product library (linked against /opt/rocm) initialises HIP first, a
+# later `import torch` finds no GPU ("No HIP GPUs are available"). Importing torch before anything touches HIP makes both
+# share one runtime, whatever subset of the test modules is collected.
+try:
+    import torch  # noqa: F401
+except ImportError:   # the CPU tier of a host without torch still runs the non-distributed tests
+    torch = None
+
 ROOT = Path(__file__).resolve().parent.parent
 for p in (str(ROOT), str(ROOT / "tests")):
     if p not in sys.path:

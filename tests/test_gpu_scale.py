@@ -176,7 +176,7 @@ def test_config5_two_million_reads_bit_exact(txome, big):
     (src/pseudoaligner.rs:287-299), left extension incl. the offset-0 quirk (:124-205, :129), empty and novel classes"""
     host, aligner, oracle = big(31)
     ctr, want = _bit_exact_with_counts(txome, host, aligner, oracle, 31, 150, 4, 10000, 2_000_000, 0, "config 5, 2 M reads")
-    assert ctr["reseeks"] > 100_000 and ctr["left_extensions"] > 100_000              # the paths this config exists for
+    assert ctr["reseeks"] > 50_000 and ctr["left_extensions"] > 50_000                # the paths this config exists for
     assert want[-3] > 0 and want[-2] > 0                                              # novel and empty classes do occur
 
 
