@@ -245,6 +245,41 @@ uint64_t pa_counts_len(const pa_index* idx);
 int pa_counts_accumulate_device(pa_index* idx, const pa_read_result* d_results, const uint32_t* d_arena,
                                 const uint32_t* d_colour, uint64_t n_reads, uint64_t* d_counts, void* stream);
 
+/* ---------------- novel classes + the reduction over GPUs ---------------- */
+/* The dense table counts every result that is no index class in ONE slot (counts[num_classes]). A pa_overflow keeps WHICH
+ * id sets those were, keyed by content, on the GPU: attach one to an index and every pa_map_count_batch_device launch files
+ * its novel results there (a small follow-up kernel on the same stream). The reduction unit over GPUs is then
+ *   dense table      -> pa_counts_allreduce  (RCCL all-reduce, sum of u64[pa_counts_len])
+ *   overflow tables  -> pa_overflow_allgather (RCCL all-gather of the serialised tables, merged by content on every rank)
+ * and sum(counts of the merged overflow records) == counts[num_classes] of the reduced dense table.
+ * Serialised form (u32 words): [0] = records, [1] = words used (this header included), then per record
+ * {len, count low, count high, ids[len]}; merged tables are ordered lexicographically by id list (canonical).
+ * max_classes / max_ids size the table (distinct novel classes, sum of their lengths); running out is reported by
+ * pa_overflow_fetch / pa_overflow_allgather as PA_ERR_ARENA_FULL, never silently. */
+typedef struct pa_overflow pa_overflow;
+int pa_overflow_create(int device, uint64_t max_classes, uint64_t max_ids, pa_overflow** out);
+void pa_overflow_destroy(pa_overflow* ovf);
+int pa_overflow_reset(pa_overflow* ovf, void* stream);
+int pa_index_set_overflow(pa_index* idx, pa_overflow* ovf);   /* NULL detaches; the table must outlive its attachment */
+/* this GPU's table, serialised and canonical, on the host (library-owned until the next call on ovf) */
+int pa_overflow_fetch(pa_overflow* ovf, void* stream, const uint32_t** words, uint64_t* n_words);
+/* host-side merge of serialised tables (what every rank does with the gathered buffers); out may be NULL to size */
+int pa_overflow_merge(const uint32_t* const* bufs, const uint64_t* n_words, int nbufs, uint32_t* out, uint64_t out_cap,
+                      uint64_t* out_words);
+
+/* RCCL communicator, one rank per GPU (xGMI). The 128-byte id comes from ONE rank (pa_comm_unique_id) and reaches the
+ * others through whatever the host already has (MPI, a file, torch.distributed ...). RCCL is bound at run time: without
+ * librccl these calls fail with PA_ERR_UNSUPPORTED, everything else works. comm == NULL means "one GPU": the reduce is a
+ * no-op and the gather is pa_overflow_fetch. */
+typedef struct pa_comm pa_comm;
+int pa_comm_unique_id(uint8_t id[128]);
+int pa_comm_create(int device, int nranks, int rank, const uint8_t id[128], pa_comm** out);
+void pa_comm_destroy(pa_comm* comm);
+int pa_comm_rank(const pa_comm* comm);
+int pa_comm_size(const pa_comm* comm);
+int pa_counts_allreduce(pa_index* idx, uint64_t* d_counts, pa_comm* comm, void* stream);   /* in place, asynchronous on stream */
+int pa_overflow_allgather(pa_overflow* ovf, pa_comm* comm, void* stream, const uint32_t** words, uint64_t* n_words);
+
 /* ---------------- synthetic workloads (BASELINE.json configs; deterministic, counter-based) ------------- */
 /* GENCODE-like transcriptome: returns a host index-less transcript set. */
 typedef struct pa_txome pa_txome;

@@ -17,12 +17,12 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _build
-from ._ffi import (PA_DEFAULT_ALLOWED_MISMATCHES, PA_MAPPED_BIT, PA_READ_COVERAGE_THRESHOLD, FlatIndex, IndexStats, PaError,
-                   ReadResult, check, lib, vp)
+from ._ffi import (PA_DEFAULT_ALLOWED_MISMATCHES, PA_ERR_ARENA_FULL, PA_MAPPED_BIT, PA_OK, PA_READ_COVERAGE_THRESHOLD, FlatIndex,
+                   IndexStats, PaError, ReadResult, check, lib, vp)
 
 __all__ = ["HostIndex", "Txome", "Pseudoaligner", "build_index", "process_reads", "PaError", "lib", "concat_reads",
            "gather_classes", "unpack_tiles", "RESULT_DTYPE", "PA_MAPPED_BIT", "PA_DEFAULT_ALLOWED_MISMATCHES",
-           "PA_READ_COVERAGE_THRESHOLD", "PA_CLASS_REF"]
+           "PA_READ_COVERAGE_THRESHOLD", "PA_CLASS_REF", "Overflow", "Comm", "parse_overflow", "serialise_overflow", "overflow_merge"]
 
 PA_CLASS_REF = 0x80000000
 RESULT_DTYPE = np.dtype([("coverage", "<u4"), ("mismatches", "<u4"), ("class_off", "<u4"), ("class_len", "<u4")])
@@ -346,6 +346,15 @@ class Pseudoaligner:
     def counts_len(self) -> int:
         return lib().pa_counts_len(self._h)
 
+    def set_overflow(self, overflow: Optional["Overflow"]) -> None:
+        """attach the table that remembers WHICH novel classes the fused count launches met (None detaches)"""
+        check(lib().pa_index_set_overflow(self._h, overflow._h if overflow else None))
+        self._overflow = overflow   # keep it alive while attached
+
+    def counts_allreduce(self, d_counts: int, comm: Optional["Comm"], stream: int = 0) -> None:
+        """RCCL all-reduce (sum) of the dense count table, in place"""
+        check(lib().pa_counts_allreduce(self._h, d_counts, comm._h if comm else None, stream or None))
+
     def counts_accumulate_device(self, d_results: int, d_arena: int, d_colour: int, n_reads: int, d_counts: int, stream: int = 0) -> None:
         check(lib().pa_counts_accumulate_device(self._h, d_results, d_arena, d_colour or None, n_reads, d_counts, stream or None))
 
@@ -356,6 +365,107 @@ class Pseudoaligner:
         try:
             if self._h:
                 lib().pa_index_destroy(self._h)
+                self._h = vp()
+        except Exception:
+            pass
+
+
+def parse_overflow(words: np.ndarray) -> dict:
+    """serialised overflow table (include/pseudoaligner_amd.h) -> {tuple(ids): count}"""
+    out = {}
+    if len(words) < 2:
+        return out
+    p = 2
+    for _ in range(int(words[0])):
+        n = int(words[p])
+        out[tuple(int(x) for x in words[p + 3:p + 3 + n])] = int(words[p + 1]) | (int(words[p + 2]) << 32)
+        p += 3 + n
+    assert p == int(words[1]), "overflow table: header says %d words, records end at %d" % (int(words[1]), p)
+    return out
+
+
+def serialise_overflow(classes: dict) -> np.ndarray:
+    """{tuple(ids): count} -> the serialised form (canonical order), e.g. to feed pa_overflow_merge"""
+    w = [0, 0]
+    for ids in sorted(classes):
+        c = int(classes[ids])
+        w += [len(ids), c & 0xFFFFFFFF, c >> 32] + list(ids)
+    w[0], w[1] = len(classes), len(w)
+    return np.array(w, dtype=np.uint32)
+
+
+def overflow_merge(buffers: Sequence[np.ndarray]) -> np.ndarray:
+    """pa_overflow_merge: serialised tables of several GPUs -> one canonical table (host side)"""
+    bufs = [np.ascontiguousarray(b, dtype=np.uint32) for b in buffers]
+    ptrs = (C.c_void_p * max(len(bufs), 1))(*[b.ctypes.data for b in bufs])
+    sizes = (C.c_uint64 * max(len(bufs), 1))(*[len(b) for b in bufs])
+    need = C.c_uint64()
+    rc = lib().pa_overflow_merge(ptrs, sizes, len(bufs), None, 0, C.byref(need))
+    if rc not in (PA_OK, PA_ERR_ARENA_FULL):
+        check(rc)
+    out = np.zeros(max(need.value, 2), dtype=np.uint32)
+    check(lib().pa_overflow_merge(ptrs, sizes, len(bufs), out.ctypes.data, len(out), C.byref(need)))
+    return out[: need.value]
+
+
+class Overflow:
+    """Per-GPU table of the NOVEL classes (results that are no index class), keyed by content."""
+
+    def __init__(self, device: int = 0, max_classes: int = 1 << 20, max_ids: int = 1 << 24):
+        h = vp()
+        check(lib().pa_overflow_create(device, max_classes, max_ids, C.byref(h)))
+        self._h = h
+
+    def reset(self, stream: int = 0) -> None:
+        check(lib().pa_overflow_reset(self._h, stream or None))
+
+    def fetch(self, stream: int = 0) -> np.ndarray:
+        w, n = vp(), C.c_uint64()
+        check(lib().pa_overflow_fetch(self._h, stream or None, C.byref(w), C.byref(n)))
+        return _np_view(w.value, n.value, np.uint32).copy()
+
+    def allgather(self, comm: Optional["Comm"], stream: int = 0) -> np.ndarray:
+        w, n = vp(), C.c_uint64()
+        check(lib().pa_overflow_allgather(self._h, comm._h if comm else None, stream or None, C.byref(w), C.byref(n)))
+        return _np_view(w.value, n.value, np.uint32).copy()
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().pa_overflow_destroy(self._h)
+                self._h = vp()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator owned by the library: one rank per GPU."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        check(lib().pa_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, device: int, nranks: int, rank: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = vp()
+        check(lib().pa_comm_create(device, nranks, rank, buf, C.byref(h)))
+        self._h = h
+
+    @property
+    def rank(self) -> int:
+        return lib().pa_comm_rank(self._h)
+
+    @property
+    def size(self) -> int:
+        return lib().pa_comm_size(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().pa_comm_destroy(self._h)
                 self._h = vp()
         except Exception:
             pass

@@ -13,7 +13,7 @@ CSRC = PKG / "csrc"
 PRODUCT_SO = PKG / "libpseudoaligner_amd.so"
 
 HOST_SOURCES = ["host_index.cpp", "dbg_build.cpp", "device_flatten.cpp", "synth.cpp", "fastq.cpp"]
-HIP_SOURCES = ["kernels.hip", "map_pool.hip", "device_index.hip"]
+HIP_SOURCES = ["kernels.hip", "map_pool.hip", "device_index.hip", "collective.hip"]
 
 
 def _stale(target: Path, sources) -> bool:
@@ -43,7 +43,7 @@ def build_product(force: bool = False) -> Path:
     deps = srcs + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
     if force or _stale(PRODUCT_SO, deps):
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-               "-Wall", "-Wno-unused-function", "-x", "hip"] + [str(s) for s in srcs] + ["-o", str(PRODUCT_SO)]
+               "-Wall", "-Wno-unused-function", "-x", "hip"] + [str(s) for s in srcs] + ["-ldl", "-o", str(PRODUCT_SO)]
         _run(cmd)
     return PRODUCT_SO
 

@@ -80,6 +80,19 @@ SIGNATURES = {
     "pa_process_reads": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]),
     "pa_counts_len": (C.c_uint64, [vp]),
     "pa_counts_accumulate_device": (C.c_int, [vp, vp, vp, vp, C.c_uint64, vp, vp]),
+    "pa_overflow_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
+    "pa_overflow_destroy": (None, [vp]),
+    "pa_overflow_reset": (C.c_int, [vp, vp]),
+    "pa_index_set_overflow": (C.c_int, [vp, vp]),
+    "pa_overflow_fetch": (C.c_int, [vp, vp, C.POINTER(vp), u64p]),
+    "pa_overflow_merge": (C.c_int, [vp, vp, C.c_int, vp, C.c_uint64, u64p]),
+    "pa_comm_unique_id": (C.c_int, [vp]),
+    "pa_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "pa_comm_destroy": (None, [vp]),
+    "pa_comm_rank": (C.c_int, [vp]),
+    "pa_comm_size": (C.c_int, [vp]),
+    "pa_counts_allreduce": (C.c_int, [vp, vp, vp, vp]),
+    "pa_overflow_allgather": (C.c_int, [vp, vp, vp, C.POINTER(vp), u64p]),
     "pa_txome_synthesize": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(vp)]),
     "pa_txome_from_host_index": (C.c_int, [vp, C.POINTER(vp)]),
     "pa_txome_from_fasta": (C.c_int, [C.c_char_p, C.POINTER(vp)]),

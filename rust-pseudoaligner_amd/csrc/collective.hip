@@ -1,0 +1,440 @@
+// The multi-GPU side of the class-count table:
+//   * pa_overflow — the per-GPU table of NOVEL classes: results that are no index class are counted in ONE slot of the dense
+//     table (counts[num_classes]); which id sets they were is kept here, keyed by content, so that the reduction over GPUs
+//     loses nothing: dense table -> all-reduce (sum), overflow tables -> all-gather + merge by content;
+//   * pa_comm — an RCCL communicator (one rank per GPU, xGMI) owned by the library, so that a host without torch (the Rust
+//     pipeline of north_star) can run the final reduce: pa_counts_allreduce, pa_overflow_allgather.
+// RCCL is bound at run time (dlopen of librccl.so.1): the library loads, and maps reads, on a host without RCCL; the
+// collective entry points then fail with PA_ERR_UNSUPPORTED and say why.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "kernel_utils.hpp"
+#include "kernels.hpp"
+#include "pa_common.hpp"
+
+using namespace pa;
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) return fail(PA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));  \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ overflow table
+// Device layout: open addressing over `cap` slots (power of two):
+//   keys[cap]   u64  0 = free, else the content hash of the id list with bit 63 forced
+//   meta[cap]   {u32 pool_off, u32 len, u64 count, u32 ready, u32 pad} (24 bytes as 6 u32)
+//   pool[pool_cap] u32 the id lists, ctl[0] = pool top, ctl[1] = status, ctl[2] = export cursor, ctl[3] = entries
+// Two lanes that insert the same new class at the same moment may both create an entry (a reader can see the other's ids
+// late); entries are merged by content at export time, so the exported table is exact either way.
+struct pa_overflow {
+    int device = 0;
+    uint64_t cap = 0, pool_cap = 0;
+    unsigned long long* d_keys = nullptr;
+    uint32_t* d_meta = nullptr;
+    uint32_t* d_pool = nullptr;
+    unsigned long long* d_ctl = nullptr;   // [0] pool top, [1] status, [2] export cursor, [3] entries, [4] novel-list length of the launch in flight
+    uint32_t* d_novel = nullptr;           // {arena offset, length} of every novel result of the launch in flight
+    uint64_t novel_cap = 0;                // pairs
+    uint32_t* d_export = nullptr;          // serialised records (export_cap u32)
+    uint64_t export_cap = 0;
+    std::vector<uint32_t> h_export, h_merged;
+    std::mutex mu;
+};
+
+namespace {
+
+constexpr uint32_t OVF_META_WORDS = 6;
+constexpr unsigned long long OVF_STATUS_TABLE_FULL = 1, OVF_STATUS_POOL_FULL = 2, OVF_STATUS_LIST_FULL = 4, OVF_STATUS_EXPORT_FULL = 8;
+
+__global__ __launch_bounds__(256) void pa_overflow_insert_kernel(const uint32_t* __restrict__ novel, const unsigned long long* __restrict__ n_ptr,
+                                                                 uint64_t novel_cap, const uint32_t* __restrict__ arena,
+                                                                 unsigned long long* keys, uint32_t* meta, uint32_t* pool, unsigned long long* ctl,
+                                                                 uint64_t cap, uint64_t pool_cap) {
+    unsigned long long n = *n_ptr;
+    if (n > novel_cap) n = novel_cap;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t off = novel[2 * i], len = novel[2 * i + 1];
+        const uint32_t* ids = arena + off;
+        const unsigned long long h = list_hash_dev(ids, len) | (1ull << 63);
+        uint64_t slot = (h * 0x9e3779b97f4a7c15ull) >> 20 & (cap - 1);
+        bool done = false;
+        for (uint64_t probes = 0; !done && probes < cap;) {
+            unsigned long long k = __hip_atomic_load(keys + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == 0) {
+                k = atomicCAS(keys + slot, 0ull, h);
+                if (k == 0) {   // this lane owns the new entry: ids into the pool, then publish
+                    const unsigned long long po = atomicAdd(ctl + 0, (unsigned long long)len);
+                    uint32_t* m = meta + slot * OVF_META_WORDS;
+                    if (po + len > pool_cap) {
+                        atomicOr(ctl + 1, OVF_STATUS_POOL_FULL);
+                        m[0] = 0xFFFFFFFFu;
+                    } else {
+                        for (uint32_t t = 0; t < len; ++t) pool[po + t] = ids[t];
+                        m[0] = (uint32_t)po;
+                    }
+                    m[1] = len;
+                    m[2] = 1;
+                    m[3] = 0;
+                    atomicAdd(ctl + 3, 1ull);
+                    __threadfence();
+                    __hip_atomic_store(m + 4, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    done = true;
+                    continue;
+                }
+            }
+            if (k == h) {
+                uint32_t* m = meta + slot * OVF_META_WORDS;
+                if (__hip_atomic_load(m + 4, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) continue;   // being written: look again
+                const uint32_t po = __hip_atomic_load(m + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool same = __hip_atomic_load(m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == len && po != 0xFFFFFFFFu;
+                for (uint32_t t = 0; same && t < len; ++t) same = __hip_atomic_load(pool + po + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ids[t];
+                if (same) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(m + 2), 1ull);
+                    done = true;
+                    continue;
+                }
+            }
+            slot = (slot + 1) & (cap - 1);
+            ++probes;
+        }
+        if (!done) atomicOr(ctl + 1, OVF_STATUS_TABLE_FULL);
+    }
+}
+
+// serialised form (u32 words): [0] records, [1] words used incl. this header, then per record {len, count lo, count hi, ids[len]}
+__global__ __launch_bounds__(256) void pa_overflow_export_kernel(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ meta,
+                                                                 const uint32_t* __restrict__ pool, unsigned long long* ctl, uint64_t cap,
+                                                                 uint32_t* out, uint64_t out_cap) {
+    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= cap || keys[slot] == 0) return;
+    const uint32_t* m = meta + slot * OVF_META_WORDS;
+    const uint32_t po = m[0], len = m[1];
+    if (po == 0xFFFFFFFFu) return;   // the pool was full: reported through the status word
+    const unsigned long long pos = atomicAdd(ctl + 2, (unsigned long long)(3 + len));
+    if (pos + 3 + len > out_cap) { atomicOr(ctl + 1, OVF_STATUS_EXPORT_FULL); return; }
+    out[pos] = len;
+    out[pos + 1] = m[2];
+    out[pos + 2] = m[3];
+    for (uint32_t t = 0; t < len; ++t) out[pos + 3 + t] = pool[po + t];
+    atomicAdd(out, 1u);   // header word 0 = records (word 1 = words used, written by the host side of the export)
+}
+
+int merge_serialised(const uint32_t* const* bufs, const uint64_t* n_words, int nbufs, std::vector<uint32_t>& out) {
+    std::map<std::vector<uint32_t>, unsigned long long> acc;   // ordered: the merged table is canonical (lexicographic by id list)
+    for (int b = 0; b < nbufs; ++b) {
+        const uint32_t* w = bufs[b];
+        const uint64_t nw = n_words[b];
+        if (nw == 0 || (nw >= 2 && w[0] == 0 && w[1] == 0)) continue;   // nothing, or nothing but padding
+        if (nw < 2 || w[1] > nw || w[1] < 2) return fail(PA_ERR_FORMAT, "overflow buffer %d: bad header", b);
+        uint64_t p = 2;
+        for (uint32_t r = 0; r < w[0]; ++r) {
+            if (p + 3 > w[1] || p + 3 + w[p] > w[1]) return fail(PA_ERR_FORMAT, "overflow buffer %d: record %u runs past the end", b, r);
+            const uint32_t len = w[p];
+            acc[std::vector<uint32_t>(w + p + 3, w + p + 3 + len)] += (unsigned long long)w[p + 1] | ((unsigned long long)w[p + 2] << 32);
+            p += 3 + len;
+        }
+    }
+    out.assign(2, 0);
+    for (const auto& kv : acc) {
+        out.push_back((uint32_t)kv.first.size());
+        out.push_back((uint32_t)kv.second);
+        out.push_back((uint32_t)(kv.second >> 32));
+        out.insert(out.end(), kv.first.begin(), kv.first.end());
+    }
+    if (acc.size() > 0xFFFFFFFFull || out.size() > 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "merged overflow table too large");
+    out[0] = (uint32_t)acc.size();
+    out[1] = (uint32_t)out.size();
+    return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ RCCL, bound at run time
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+enum { ncclSum = 0, ncclMax = 2, ncclUint32 = 3, ncclUint64 = 5 };   // rccl.h: ncclRedOp_t / ncclDataType_t
+
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.so) break;
+        }
+        if (!r.so) { r.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(r.so, n); if (!p && r.why.empty()) r.why = std::string("librccl lacks ") + n; return p; };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return r;
+}
+
+int rccl_ready() {
+    Rccl& r = rccl();
+    if (!r.why.empty()) return fail(PA_ERR_UNSUPPORTED, "RCCL is not usable: %s", r.why.c_str());
+    return PA_OK;
+}
+
+#define NCCL_TRY(expr)                                                                                                  \
+    do {                                                                                                                \
+        ncclResult_t _r = (expr);                                                                                       \
+        if (_r != 0) return fail(PA_ERR_HIP, "%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(_r) : "?"); \
+    } while (0)
+
+}  // namespace
+
+struct pa_comm {
+    int device = 0, nranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+    unsigned long long* d_scalar = nullptr;   // one u64 for the size exchange of the overflow gather
+};
+
+// hooks for device_index.hip: what the map launch needs to know about an attached overflow table
+namespace pa {
+
+int overflow_prepare_launch(pa_overflow* o, uint64_t n_reads, MapParams& p, hipStream_t stream) {
+    const uint64_t want = n_reads / 4 + 4096;
+    if (o->novel_cap < want) {
+        if (o->d_novel) HIP_TRY(hipFree(o->d_novel));
+        o->d_novel = nullptr;
+        o->novel_cap = 0;
+        HIP_TRY(hipMalloc(&o->d_novel, want * 8));
+        o->novel_cap = want;
+    }
+    HIP_TRY(hipMemsetAsync(o->d_ctl + 4, 0, 8, stream));
+    p.novel_list = o->d_novel;
+    p.novel_ctr = o->d_ctl + 4;
+    p.novel_status = o->d_ctl + 1;
+    p.novel_cap = o->novel_cap;
+    return PA_OK;
+}
+
+int overflow_after_map(pa_overflow* o, const uint32_t* d_arena, hipStream_t stream) {
+    hipLaunchKernelGGL(pa_overflow_insert_kernel, dim3(1024), dim3(256), 0, stream, o->d_novel, o->d_ctl + 4, o->novel_cap, d_arena, o->d_keys,
+                       o->d_meta, o->d_pool, o->d_ctl, o->cap, o->pool_cap);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PA_ERR_HIP, "overflow insert launch: %s", hipGetErrorString(e));
+    return PA_OK;
+}
+
+int overflow_device(const pa_overflow* o) { return o->device; }
+
+}  // namespace pa
+
+extern "C" {
+
+int pa_overflow_create(int device, uint64_t max_classes, uint64_t max_ids, pa_overflow** out) {
+    if (!out || max_classes == 0 || max_ids == 0) return fail(PA_ERR_INVALID_ARG, "bad argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PA_ERR_NO_DEVICE, "no HIP device available; this library has no CPU fallback");
+    if (device < 0 || device >= n) return fail(PA_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
+    if (max_ids > 0xFFFFFFF0ull) return fail(PA_ERR_UNSUPPORTED, "at most 2^32-16 ids in an overflow table");
+    HIP_TRY(hipSetDevice(device));
+    pa_overflow* o = new (std::nothrow) pa_overflow();
+    if (!o) return fail(PA_ERR_OOM, "out of memory");
+    o->device = device;
+    uint64_t cap = 1024;
+    while (cap < 2 * max_classes) cap <<= 1;   // load <= 0.5
+    o->cap = cap;
+    o->pool_cap = max_ids;
+    o->export_cap = 2 + 3 * max_classes + max_ids + 3 * 1024;   // room for a few duplicate entries (merged by content)
+    hipError_t e = hipMalloc(&o->d_keys, cap * 8);
+    if (e == hipSuccess) e = hipMalloc(&o->d_meta, cap * OVF_META_WORDS * 4);
+    if (e == hipSuccess) e = hipMalloc(&o->d_pool, max_ids * 4);
+    if (e == hipSuccess) e = hipMalloc(&o->d_ctl, 64);
+    if (e == hipSuccess) e = hipMalloc(&o->d_export, o->export_cap * 4);
+    if (e == hipSuccess) e = hipMemset(o->d_keys, 0, cap * 8);
+    if (e == hipSuccess) e = hipMemset(o->d_meta, 0, cap * OVF_META_WORDS * 4);
+    if (e == hipSuccess) e = hipMemset(o->d_ctl, 0, 64);
+    if (e != hipSuccess) {
+        pa_overflow_destroy(o);
+        return fail(PA_ERR_OOM, "overflow table (%llu slots, %llu ids): %s", (unsigned long long)cap, (unsigned long long)max_ids, hipGetErrorString(e));
+    }
+    *out = o;
+    return PA_OK;
+}
+
+void pa_overflow_destroy(pa_overflow* o) {
+    if (!o) return;
+    (void)hipSetDevice(o->device);
+    for (void* p : {(void*)o->d_keys, (void*)o->d_meta, (void*)o->d_pool, (void*)o->d_ctl, (void*)o->d_novel, (void*)o->d_export})
+        if (p) (void)hipFree(p);
+    delete o;
+}
+
+int pa_overflow_reset(pa_overflow* o, void* stream) {
+    if (!o) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> g(o->mu);
+    HIP_TRY(hipSetDevice(o->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(o->d_keys, 0, o->cap * 8, st));
+    HIP_TRY(hipMemsetAsync(o->d_meta, 0, o->cap * OVF_META_WORDS * 4, st));
+    HIP_TRY(hipMemsetAsync(o->d_ctl, 0, 64, st));
+    return PA_OK;
+}
+
+// serialise the table on the device; *n_words = words used (header included). Leaves the records in o->d_export.
+static int export_locked(pa_overflow* o, hipStream_t st, uint64_t* n_words) {
+    HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipMemsetAsync(o->d_export, 0, 8, st));
+    const unsigned long long two = 2;
+    HIP_TRY(hipMemcpyAsync(o->d_ctl + 2, &two, 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(pa_overflow_export_kernel, dim3((uint32_t)((o->cap + 255) / 256)), dim3(256), 0, st, o->d_keys, o->d_meta, o->d_pool, o->d_ctl,
+                       o->cap, o->d_export, o->export_cap);
+    HIP_TRY(hipGetLastError());
+    unsigned long long ctl[4];
+    HIP_TRY(hipMemcpyAsync(ctl, o->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctl[1] & OVF_STATUS_LIST_FULL) return fail(PA_ERR_ARENA_FULL, "overflow: more novel results in one launch than its list holds (a quarter of the reads)");
+    if (ctl[1] & OVF_STATUS_TABLE_FULL) return fail(PA_ERR_ARENA_FULL, "overflow table full: more than %llu distinct novel classes", (unsigned long long)(o->cap / 2));
+    if (ctl[1] & OVF_STATUS_POOL_FULL) return fail(PA_ERR_ARENA_FULL, "overflow id pool full: %llu ids needed, %llu available", ctl[0], (unsigned long long)o->pool_cap);
+    if (ctl[1] & OVF_STATUS_EXPORT_FULL) return fail(PA_ERR_INTERNAL, "overflow export buffer too small");
+    const uint32_t words = (uint32_t)ctl[2];
+    HIP_TRY(hipMemcpyAsync(o->d_export + 1, &words, 4, hipMemcpyHostToDevice, st));   // header word 1 = words used
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_words = ctl[2];
+    return PA_OK;
+}
+
+int pa_overflow_fetch(pa_overflow* o, void* stream, const uint32_t** words, uint64_t* n_words) {
+    if (!o || !words || !n_words) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> g(o->mu);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint64_t nw = 0;
+    const int rc = export_locked(o, st, &nw);
+    if (rc != PA_OK) return rc;
+    o->h_export.resize(nw);
+    HIP_TRY(hipMemcpy(o->h_export.data(), o->d_export, nw * 4, hipMemcpyDeviceToHost));
+    const uint32_t* one[1] = {o->h_export.data()};
+    const int rc2 = merge_serialised(one, &nw, 1, o->h_merged);   // canonical order, duplicate entries folded
+    if (rc2 != PA_OK) return rc2;
+    *words = o->h_merged.data();
+    *n_words = o->h_merged.size();
+    return PA_OK;
+}
+
+int pa_overflow_merge(const uint32_t* const* bufs, const uint64_t* n_words, int nbufs, uint32_t* out, uint64_t out_cap, uint64_t* out_words) {
+    if (nbufs < 0 || (nbufs && (!bufs || !n_words)) || !out_words) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::vector<uint32_t> m;
+    const int rc = merge_serialised(bufs, n_words, nbufs, m);
+    if (rc != PA_OK) return rc;
+    *out_words = m.size();
+    if (m.size() > out_cap) return fail(PA_ERR_ARENA_FULL, "merged overflow table needs %zu words", m.size());
+    if (out) memcpy(out, m.data(), m.size() * 4);
+    return PA_OK;
+}
+
+// ---- communicator ----
+int pa_comm_unique_id(uint8_t id[128]) {
+    if (!id) return fail(PA_ERR_INVALID_ARG, "null argument");
+    const int rc = rccl_ready();
+    if (rc != PA_OK) return rc;
+    ncclUniqueId u;
+    NCCL_TRY(rccl().GetUniqueId(&u));
+    memcpy(id, u.internal, 128);
+    return PA_OK;
+}
+
+int pa_comm_create(int device, int nranks, int rank, const uint8_t id[128], pa_comm** out) {
+    if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(PA_ERR_INVALID_ARG, "bad argument");
+    const int rc = rccl_ready();
+    if (rc != PA_OK) return rc;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PA_ERR_NO_DEVICE, "no HIP device available; this library has no CPU fallback");
+    if (device < 0 || device >= n) return fail(PA_ERR_INVALID_ARG, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    pa_comm* c = new (std::nothrow) pa_comm();
+    if (!c) return fail(PA_ERR_OOM, "out of memory");
+    c->device = device;
+    c->nranks = nranks;
+    c->rank = rank;
+    ncclUniqueId u;
+    memcpy(u.internal, id, 128);
+    ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
+    if (r != 0) { delete c; return fail(PA_ERR_HIP, "ncclCommInitRank(%d of %d): %s", rank, nranks, rccl().GetErrorString(r)); }
+    if (hipMalloc(&c->d_scalar, 8) != hipSuccess) { rccl().CommDestroy(c->comm); delete c; return fail(PA_ERR_OOM, "hipMalloc"); }
+    *out = c;
+    return PA_OK;
+}
+
+void pa_comm_destroy(pa_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm) rccl().CommDestroy(c->comm);
+    if (c->d_scalar) (void)hipFree(c->d_scalar);
+    delete c;
+}
+
+int pa_comm_rank(const pa_comm* c) { return c ? c->rank : 0; }
+int pa_comm_size(const pa_comm* c) { return c ? c->nranks : 1; }
+
+int pa_counts_allreduce(pa_index* idx, uint64_t* d_counts, pa_comm* comm, void* stream) {
+    if (!idx || !d_counts) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (!comm) return PA_OK;   // one GPU: the local table is the global one
+    HIP_TRY(hipSetDevice(comm->device));
+    NCCL_TRY(rccl().AllReduce(d_counts, d_counts, (size_t)pa_counts_len(idx), ncclUint64, ncclSum, comm->comm, static_cast<hipStream_t>(stream)));
+    return PA_OK;
+}
+
+int pa_overflow_allgather(pa_overflow* o, pa_comm* comm, void* stream, const uint32_t** words, uint64_t* n_words) {
+    if (!o || !words || !n_words) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (!comm || comm->nranks == 1) {
+        if (!comm) return pa_overflow_fetch(o, stream, words, n_words);
+    }
+    std::lock_guard<std::mutex> g(o->mu);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint64_t nw = 0;
+    int rc = export_locked(o, st, &nw);
+    if (rc != PA_OK) return rc;
+    // every rank sends the same number of words: the largest table (all-reduce max of one u64), zero padded
+    unsigned long long mine = nw, most = 0;
+    HIP_TRY(hipMemcpyAsync(comm->d_scalar, &mine, 8, hipMemcpyHostToDevice, st));
+    NCCL_TRY(rccl().AllReduce(comm->d_scalar, comm->d_scalar, 1, ncclUint64, ncclMax, comm->comm, st));
+    HIP_TRY(hipMemcpyAsync(&most, comm->d_scalar, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (most > o->export_cap) return fail(PA_ERR_ARENA_FULL, "overflow gather: a rank holds %llu words, this rank's buffer holds %llu (create the tables with equal capacities)",
+                                          most, (unsigned long long)o->export_cap);
+    if (most > nw) HIP_TRY(hipMemsetAsync(o->d_export + nw, 0, (most - nw) * 4, st));
+    uint32_t* d_all = nullptr;
+    HIP_TRY(hipMalloc(&d_all, (size_t)most * 4 * comm->nranks));
+    ncclResult_t r = rccl().AllGather(o->d_export, d_all, (size_t)most, ncclUint32, comm->comm, st);
+    if (r != 0) { (void)hipFree(d_all); return fail(PA_ERR_HIP, "ncclAllGather: %s", rccl().GetErrorString(r)); }
+    std::vector<uint32_t> all((size_t)most * comm->nranks);
+    hipError_t e = hipMemcpyAsync(all.data(), d_all, all.size() * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_all);
+    if (e != hipSuccess) return fail(PA_ERR_HIP, "overflow gather copy: %s", hipGetErrorString(e));
+    std::vector<const uint32_t*> bufs(comm->nranks);
+    std::vector<uint64_t> sizes(comm->nranks, most);
+    for (int i = 0; i < comm->nranks; ++i) bufs[i] = all.data() + (size_t)i * most;
+    rc = merge_serialised(bufs.data(), sizes.data(), comm->nranks, o->h_merged);
+    if (rc != PA_OK) return rc;
+    *words = o->h_merged.data();
+    *n_words = o->h_merged.size();
+    return PA_OK;
+}
+
+}  // extern "C"

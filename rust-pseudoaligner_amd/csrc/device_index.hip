@@ -63,6 +63,7 @@ struct pa_index {
     DevBuf spill, trace, xcd_counts;
     uint32_t last_grid = 0;
     uint64_t last_arena_cap = 0;
+    pa_overflow* ovf = nullptr;   // attached overflow table of novel classes (collective.hip), not owned
     // host-buffer convenience path
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
     std::vector<uint32_t> h_class_ids;
@@ -287,6 +288,11 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     p.class_table_size = idx->class_table_size;
     p.pool_slots = slots;
     p.dbg = env_int("PA_MAP_STATS", 0) ? idx->ctl.as<unsigned long long>() + 2 : nullptr;
+    p.ablate = (uint32_t)env_int("PA_MAP_ABLATE", 0);
+    if (d_counts && idx->ovf) {   // novel results of this launch are listed for the overflow table
+        rc = overflow_prepare_launch(idx->ovf, n_reads, p, stream);
+        if (rc != PA_OK) return rc;
+    }
     p.trace = d_nodes ? idx->trace.as<uint32_t>() : nullptr;
     p.nodes_out = d_nodes;
     p.nodes_len = d_nodes_len;
@@ -298,6 +304,10 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     if (d_counts) {
         const int e2 = launch_counts_fold(p.xcd_counts, p.xcd_stride, p.counts, counts_len, stream);
         if (e2) return fail(PA_ERR_HIP, "count fold launch: %s", hipGetErrorString((hipError_t)e2));
+        if (idx->ovf) {
+            rc = overflow_after_map(idx->ovf, d_arena, stream);
+            if (rc != PA_OK) return rc;
+        }
     }
     return PA_OK;
 }
@@ -307,14 +317,15 @@ static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_
     struct { unsigned long long top; uint32_t status; uint32_t pad; } ctl;
     HIP_TRY(hipMemcpy(&ctl, idx->ctl.p, 16, hipMemcpyDeviceToHost));
     if (env_int("PA_MAP_STATS", 0)) {
-        unsigned long long d[3 * ST_COUNT];
+        constexpr uint32_t NS = ST_COUNT + 4;   // ST_NSTAT of map_pool.hip: one entry per state, the dual iterations, the forward step in three parts
+        unsigned long long d[3 * NS];
         HIP_TRY(hipMemcpy(d, idx->ctl.as<unsigned long long>() + 2, sizeof d, hipMemcpyDeviceToHost));
-        static const char* names[ST_COUNT] = {"refill", "seek", "fwd", "left", "pick+pop", "store+push", "fin_light", "fin_scan", "fin_coop", "fin_bits", "fin_novel"};
+        static const char* names[NS] = {"refill", "seek", "fwd", "left", "pick+pop", "store+push", "fin_light", "fin_scan", "fin_coop", "fin_bits", "fin_novel", "fwd+seek", "fwd:issue", "fwd:wait", "fwd:compute"};
         fprintf(stderr, "[pa map stats] grid=%u", idx->last_grid);
-        for (uint32_t i = 0; i < ST_COUNT; ++i)
+        for (uint32_t i = 0; i < NS; ++i)
             if (d[i])
-                fprintf(stderr, " %s: %llu iters x %.1f lanes, %.0f ticks/iter;", names[i], d[i], (double)d[ST_COUNT + i] / (double)d[i],
-                        (double)d[2 * ST_COUNT + i] / (double)d[i]);
+                fprintf(stderr, " %s: %llu iters x %.1f lanes, %.0f ticks/iter;", names[i], d[i], (double)d[NS + i] / (double)d[i],
+                        (double)d[2 * NS + i] / (double)d[i]);
         fprintf(stderr, "\n");
     }
     // the counter includes every wave's partly used chunk and may run past the caller's arena without any allocation having
@@ -489,6 +500,14 @@ int pa_map_read_to_nodes(pa_index* idx, const uint8_t* ascii, uint32_t len, uint
 int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads, uint32_t allowed_mismatches,
                        pa_read_result* results, uint32_t* nodes_flat, uint32_t nodes_stride, uint32_t* nodes_len) {
     return map_batch_host(idx, ascii, offsets, n_reads, allowed_mismatches, results, nullptr, nullptr, nodes_flat, nodes_stride, nodes_len);
+}
+
+int pa_index_set_overflow(pa_index* idx, pa_overflow* ovf) {
+    if (!idx) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (ovf && overflow_device(ovf) != idx->device) return fail(PA_ERR_INVALID_ARG, "overflow table lives on device %d, the index on device %d", overflow_device(ovf), idx->device);
+    std::lock_guard<std::mutex> g(idx->mu);
+    idx->ovf = ovf;
+    return PA_OK;
 }
 
 // ---- counts ----

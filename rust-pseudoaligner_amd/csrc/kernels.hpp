@@ -11,6 +11,7 @@ constexpr uint32_t PA_ARENA_CHUNK = 1024;       // u32 entries a wave reserves p
 constexpr uint32_t PA_COUNT_REPLICAS = 8;        // XCDs of an MI355X
 constexpr uint32_t PA_STATUS_ARENA_FULL = 1u;
 constexpr uint32_t PA_STATUS_SPILL_OVERFLOW = 2u;
+constexpr unsigned long long PA_NOVEL_LIST_FULL = 4ull;   // OVF_STATUS_LIST_FULL of collective.hip
 
 struct MapParams {
     DevIndexView ix;
@@ -38,8 +39,16 @@ struct MapParams {
     uint32_t xcd_stride;
     const uint32_t* class_table;
     uint64_t class_table_size;
+    // optional (with the fused count table): {arena offset, length} of every result that is NO index class goes on this list;
+    // pa_overflow_insert_kernel files them by content in the per-GPU overflow table afterwards (collective.hip)
+    uint32_t* novel_list;
+    unsigned long long* novel_ctr;     // results listed so far (may run past novel_cap: then novel_status gets PA_NOVEL_LIST_FULL)
+    unsigned long long* novel_status;
+    uint64_t novel_cap;                // pairs
     // optional scheduler statistics (PA_MAP_STATS): [ST_COUNT] iterations, [ST_COUNT] slots served, [ST_COUNT] clock ticks per state
     unsigned long long* dbg;
+    uint32_t ablate;           // A/B knob (PA_MAP_ABLATE; 0 in production): 1 = window-mode results are not stored, 2 = no class counts,
+                               // 4 = no dual (forward + probe) iterations, 8 = output steps do not refill the slots they free
     // trace launches only (pa_map_read_to_nodes): per-lane scratch, per-read node lists (stride spill_cap) and lengths
     uint32_t* trace;
     uint32_t* nodes_out;
@@ -59,5 +68,10 @@ int launch_simulate(const uint64_t* packed, const uint64_t* tx_start, const uint
                     uint32_t* lens, hipStream_t stream);
 int launch_count(const pa_read_result* results, const uint32_t* arena, const uint32_t* colour, uint64_t n, const DevIndexView& ix,
                  const uint32_t* class_table, uint64_t class_table_size, unsigned long long* counts, hipStream_t stream);
+
+// overflow table hooks (collective.hip)
+int overflow_prepare_launch(pa_overflow* o, uint64_t n_reads, MapParams& p, hipStream_t stream);
+int overflow_after_map(pa_overflow* o, const uint32_t* d_arena, hipStream_t stream);
+int overflow_device(const pa_overflow* o);
 
 }  // namespace pa

@@ -47,6 +47,9 @@ __device__ __forceinline__ DevIndexView view_of(karg_ptr p) {   // member-wise: 
     return v;
 }
 
+constexpr uint32_t ST_NSTAT = ST_COUNT + 4;   // statistics entries: one per state, the dual (forward + probe) iterations, and the plain forward step
+                                               // split into issue / wait / compute (PA_MAP_STATS only)
+constexpr uint32_t ST_DUAL = ST_COUNT;
 constexpr uint32_t POOL_FIXED = 768;   // per wave: arena chunk {cur, end} (16 B), statistics, count cache (64 x {class, count})
 constexpr uint32_t COUNT_CACHE_PERIOD = 128;   // output steps between two flushes of the count cache
 constexpr uint32_t LIST_ROW_HDR = 12;  // list mode row: refs[4], lens[4], cids[4], then (ref, len, class id, -) quads
@@ -153,6 +156,24 @@ __device__ __forceinline__ uint32_t queue_of(Lane& s) {
     return st == ST_NONE ? (uint32_t)ST_F_BITS : st;   // unmapped reads share the output queue
 }
 
+// a free slot takes read `rid`: packed words from the tile into LDS (lanes of consecutive reads: coalesced), fresh lane state
+__device__ __forceinline__ void refill_slot(Lane& s, uint64_t rid, uint32_t slot, karg_ptr p, lds_u64 rd, lds_u32 wc, uint32_t S, uint32_t wpr,
+                                            uint32_t K) {
+    uint32_t L = p->lens[rid];
+    if (L > wpr * 32) L = wpr * 32;
+    const uint64_t* src = p->tiles + ((rid >> 6) * wpr) * 64 + (rid & 63);
+    for (uint32_t w0 = 0; w0 < wpr; w0 += 8) {   // eight words in flight per round trip
+        uint64_t v[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) v[i] = w0 + i < wpr ? src[(uint64_t)(w0 + i) * 64] : 0ull;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i)
+            if (w0 + i < wpr) rd[(w0 + i) * S + slot] = v[i];
+    }
+    lane_start(s, (uint32_t)rid, L, K);
+    wc[2 * slot + 1] = (uint32_t)rid;
+}
+
 constexpr uint32_t SLOT_FIXED_BYTES = 32 + 16 + 8 + ST_COUNT;   // lane state, class windows, {class id, read id}, one queue byte per state
 
 }  // namespace
@@ -176,8 +197,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     const uint32_t wave_bytes = (POOL_FIXED + S * (8 * wpr + SLOT_FIXED_BYTES) + 15) & ~15u;
     uint8_t* const wbase = smem + wave_in_block * wave_bytes;
     const lds_u64w chunk = (lds_u64w)wbase;
-    const lds_u32 dbg = (lds_u32)(wbase + 16);                            // [0..ST_COUNT) iterations, [ST_COUNT..2*ST_COUNT) slots served
-    const lds_u64w dbg_clk = (lds_u64w)(wbase + 16 + 8 * ST_COUNT + 8);   // wall ticks per state
+    const lds_u32 dbg = (lds_u32)(wbase + 16);                            // [0..ST_NSTAT) iterations, [ST_NSTAT..2*ST_NSTAT) slots served; entry ST_COUNT = dual iterations
+    const lds_u64w dbg_clk = (lds_u64w)(wbase + 16 + 8 * ST_NSTAT);        // wall ticks per state
     // count cache: 64 direct-mapped {count slot, count} pairs. A class that many reads of this wave hit (a highly expressed
     // gene) is counted in LDS and reaches the replica table once per flush; without it a handful of hot classes serialise
     // the L2 atomics (7 classes: 0.5 ms -> 6.8 ms per 10 M reads)
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     const lds_v4 win = (lds_v4)(wbase + POOL_FIXED + (8 * wpr + 32) * S); // {base1, mask1, base2, mask2}
     const lds_u32 wc = (lds_u32)(wbase + POOL_FIXED + (8 * wpr + 48) * S);   // {class id, read id} per slot
     const lds_u8 q = (lds_u8)(wbase + POOL_FIXED + (8 * wpr + 56) * S);
-    if (lane < 60) ((lds_u32)wbase)[lane] = 0;
+    if (lane < 64) ((lds_u32)wbase)[lane] = 0;
     ctag[lane] = NO_CLASS;
     ccnt[lane] = 0;
     uint32_t out_steps = 0;
@@ -252,18 +273,29 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         PA_CONSIDER(ST_EMPTY, nrefill)
 #undef PA_CONSIDER
         if (best == 0) break;
-        const uint32_t n = best < 64 ? best : 64;
+        // DUAL iteration: a forward step and a dictionary probe are each one dependent round trip and touch different parts
+        // of the memory system (node blobs: MALL / L2; dictionary: HBM). When both queues hold work the wave pops BOTH, lets
+        // the probe's fingerprint load and the node fetch go out back to back, and does the probe's arithmetic while the
+        // node lines are on their way: two round trips in flight per wave instead of one (K <= 32: the two-word dictionary
+        // has no dependent second load to hide).
+        const uint32_t n_seek_q = PA_CNT(ST_SEEK), n_fwd_q = PA_CNT(ST_FWD);
+        const bool dual = (sel == ST_FWD || sel == ST_SEEK) && K <= 32 && n_seek_q != 0 && n_fwd_q != 0 && !(p.ablate & 4u);
+        if (dual) sel = ST_FWD;
+        const uint32_t n = dual ? (n_fwd_q < 64 ? n_fwd_q : 64) : best < 64 ? best : 64;
+        const uint32_t n2 = dual ? (n_seek_q < 64 ? n_seek_q : 64) : 0u;   // lanes of the second (SEEK) batch
         if (p.dbg && lane == 0) {
-            dbg[sel] += 1;
-            dbg[ST_COUNT + sel] += n;
+            dbg[dual ? ST_DUAL : sel] += 1;
+            dbg[ST_NSTAT + (dual ? ST_DUAL : sel)] += n + n2;
         }
         const unsigned long long t_sec = p.dbg ? __builtin_readcyclecounter() : 0ull;
 
-        // ---- 2. pop n slots
-        cntv -= lane == sel ? n : 0u;
+        // ---- 2. pop n slots (and n2 slots of the SEEK queue)
+        cntv -= (lane == sel ? n : 0u) + (lane == ST_SEEK ? n2 : 0u);
         const uint32_t qbase = PA_CNT(sel);
         const bool active = lane < n;
         const uint32_t slot = active ? (uint32_t)q[sel * S + qbase + lane] : 0u;
+        const bool active2 = lane < n2;
+        const uint32_t slot2 = active2 ? (uint32_t)q[ST_SEEK * S + PA_CNT(ST_SEEK) + lane] : 0u;
         const uint32_t gslot = wave * S + slot;
         Lane s;
         {
@@ -277,30 +309,65 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                           (uint32_t*)(row + LIST_ROW_HDR), spill_cap - LIST_ROW_HDR,
                           TRACE ? (uint32_t*)((glb_u32w)p.trace + (uint64_t)gslot * spill_cap) : nullptr};
 
+        uint32_t nq2 = 0xFFu;   // DUAL: the queue the second batch's slot goes to
         const unsigned long long t_pop = p.dbg ? __builtin_readcyclecounter() : 0ull;
         // ---- 3. the step
         if (sel == ST_EMPTY) {   // REFILL: free slots take the next reads of this wave's range (coalesced: lane = consecutive read)
-            if (active) {
-                const uint64_t rid = next + lane;
-                uint32_t L = p.lens[rid];
-                if (L > wpr * 32) L = wpr * 32;
-                const uint64_t* src = p.tiles + ((rid >> 6) * wpr) * 64 + (rid & 63);
-                for (uint32_t w0 = 0; w0 < wpr; w0 += 8) {   // eight words in flight per round trip
-                    uint64_t v[8];
-#pragma unroll
-                    for (uint32_t i = 0; i < 8; ++i) v[i] = w0 + i < wpr ? src[(uint64_t)(w0 + i) * 64] : 0ull;
-#pragma unroll
-                    for (uint32_t i = 0; i < 8; ++i)
-                        if (w0 + i < wpr) rd[(w0 + i) * S + slot] = v[i];
-                }
-                lane_start(s, (uint32_t)rid, L, K);
-                wc[2 * slot + 1] = (uint32_t)rid;
-            }
+            if (active) refill_slot(s, next + lane, slot, kp, rd, wc, S, wpr, K);
             next += n;
         } else if (sel == ST_SEEK) {
             if (active) seek_step(s, ix, rr);
         } else if (sel == ST_FWD) {
-            if (active) fwd_step<TRACE>(s, ix, rr, cols, allowed);
+            if (!dual) {
+                if (!p.dbg) {
+                    if (active) fwd_step<TRACE>(s, ix, rr, cols, allowed);
+                } else {   // statistics build of the same step: where does its time go?
+                    FwdLoad fl;
+                    if (active) fwd_issue(s, ix, fl);
+                    const unsigned long long t1 = __builtin_readcyclecounter();
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned long long t2 = __builtin_readcyclecounter();
+                    if (active) {
+                        if (!TRACE && fwd_fast_ok(s, fl)) fwd_finish_fast(s, ix, rr, cols, allowed, fl);
+                        else fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
+                    }
+                    const unsigned long long t3 = __builtin_readcyclecounter();
+                    if (lane == 0) {
+                        dbg[ST_COUNT + 1] += 1; dbg[ST_COUNT + 2] += 1; dbg[ST_COUNT + 3] += 1;
+                        dbg_clk[ST_COUNT + 1] += t1 - t_pop; dbg_clk[ST_COUNT + 2] += t2 - t1; dbg_clk[ST_COUNT + 3] += t3 - t2;
+                    }
+                }
+            } else {
+                // Straight-line issue: every lane executes every load (a lane without a slot carries an all-zero state: blob 0,
+                // bucket of whatever slot 0 holds), so that the number of loads in flight is a constant and the waits below are
+                // exact: vmcnt(6) for the fingerprints, vmcnt(1) for the node, vmcnt(0) for the entry.
+                Lane s2;
+                {
+                    const u32x4 a = stv[2 * slot2], b = stv[2 * slot2 + 1];
+                    s2.lk = active2 ? a.x : 0u; s2.cm = active2 ? a.y : 0u; s2.h = active2 ? a.z : 0u; s2.of = active2 ? a.w : 0u;
+                    s2.rr = active2 ? b.x : 0u; s2.rm = active2 ? b.y : 0u; s2.ph = active2 ? b.z : 0u; s2.nc = active2 ? b.w : 0u;
+                    s2.rid = 0;   // (not used by the probe; the slot keeps its read id in `wc`)
+                }
+                if (!active) { s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0; }
+                const ReadRef rr2{(const uint64_t*)(rd + slot2), S, wpr};
+                SeekProbe pq;
+                FwdLoad fl;
+                seek_issue(s2, ix, rr2, pq);                           // fingerprints of the bucket (HBM)
+                fwd_issue(s, ix, fl);                                  // node header + sequence words (MALL / L2)
+                __builtin_amdgcn_sched_barrier(0);                     // (left alone the scheduler finishes the probe first and only then issues the node loads)
+                const uint32_t cand = seek_cands(pq);
+                const U3 ent = seek_entry(pq, cand);                   // the probe's dependent load: same line, now in the L1 / L2
+                if (active) {
+                    if (!TRACE && fwd_fast_ok(s, fl)) fwd_finish_fast(s, ix, rr, cols, allowed, fl);
+                    else fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
+                }
+                if (active2) {
+                    seek_complete(s2, K, pq, cand, ent);
+                    stv[2 * slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
+                    stv[2 * slot2 + 1] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};
+                }
+                nq2 = active2 ? queue_of(s2) : 0xFFu;
+            }
         } else if (sel == ST_LEFT) {
             if (active) left_step<TRACE>(s, ix, rr, cols, allowed);
         } else if (sel == ST_F_BITS) {
@@ -315,12 +382,13 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                     l_set_st(s, ST_F_NOVEL);
                 } else {
                     const bool is_ref = mapped && count != 0;
-                    ((glb_v4w)p.results)[s.rid] = mapped ? u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, is_ref ? PA_CLASS_REF | cand : 0u, count}
-                                                         : u32x4{0u, 0u, 0u, 0u};
+                    if (!(p.ablate & 1u))
+                        ((glb_v4w)p.results)[s.rid] = mapped ? u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, is_ref ? PA_CLASS_REF | cand : 0u, count}
+                                                             : u32x4{0u, 0u, 0u, 0u};
                     trace_out<TRACE>(s, mapped, gslot, kp);
                     const glb_u32w colour_out = (glb_u32w)p.colour_out;
                     if (colour_out) colour_out[s.rid] = is_ref ? cand : NO_CLASS;
-                    if (xcounts) {
+                    if (xcounts && !(p.ablate & 2u)) {
                         const uint32_t cslot = !mapped ? ix.num_classes + 2 : count == 0 ? ix.num_classes + 1 : cand;
                         const uint32_t hs = (cslot * 0x9E3779B1u) >> 26;
                         const uint32_t old = atomicCAS((uint32_t*)(ctag + hs), NO_CLASS, cslot);
@@ -328,6 +396,17 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                         else atomicAdd((uint32_t*)(xcounts + cslot), 1u);
                     }
                     s.lk = 0;   // ST_EMPTY
+                }
+            }
+            // ... and the slots that just became free take the wave's next reads in the same step (the tile loads are in
+            // flight together with the result stores: one wait instead of an output step and a refill step)
+            {
+                const uint64_t freed = __ballot(active && s.lk == 0);
+                const uint32_t nfree = (uint32_t)__popcll(freed);
+                const uint32_t take = (uint32_t)(left < (uint64_t)nfree ? left : (uint64_t)nfree);
+                if (take && !(p.ablate & 8u)) {
+                    if (active && s.lk == 0 && rank_in(freed) < take) refill_slot(s, next + rank_in(freed), slot, kp, rd, wc, S, wpr, K);
+                    next += take;
                 }
             }
             if (xcounts && (++out_steps % COUNT_CACHE_PERIOD) == 0) {   // flush: hot classes re-enter at once, squatters leave
@@ -373,6 +452,24 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 if (colour_out) colour_out[s.rid] = colour;
                 if (xcounts) atomicAdd((uint32_t*)(xcounts + (colour == NO_CLASS ? ix.num_classes : colour)), 1u);
                 s.lk = 0;   // ST_EMPTY
+            }
+            if (p.novel_list) {   // a class no index class equals: remember where its ids are (one atomic per step)
+                const bool rec = active && colour == NO_CLASS && (lists || my_off + cnt_alloc <= p.arena_cap);
+                const uint64_t m = __ballot(rec);
+                if (m) {
+                    const uint32_t first = (uint32_t)(__ffsll((unsigned long long)m) - 1);
+                    unsigned long long base = 0;
+                    if (lane == first) base = atomicAdd(p.novel_ctr, (unsigned long long)__popcll(m));
+                    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), (int)first) << 32) |
+                           (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+                    if (rec) {
+                        const unsigned long long at = base + rank_in(m);
+                        if (at < p.novel_cap) {
+                            ((glb_u32w)p.novel_list)[2 * at] = lists ? s.h : (uint32_t)my_off;
+                            ((glb_u32w)p.novel_list)[2 * at + 1] = lists ? s.rr : count;
+                        } else atomicOr(p.novel_status, PA_NOVEL_LIST_FULL);
+                    }
+                }
             }
         } else if (sel == ST_F_SCAN) {
             // List mode, base list of <= 8 ids, other lists of any number and length: ONE LIST PER LANE. The waiting reads
@@ -591,16 +688,20 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             stv[2 * slot] = u32x4{s.lk, s.cm, s.h, s.of};
             stv[2 * slot + 1] = u32x4{s.rr, s.rm, s.ph, s.nc};
         }
-        for (uint64_t todo = __ballot(active); todo;) {   // one round per queue that receives slots (usually two or three)
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)nq, (int)(__ffsll((unsigned long long)todo) - 1));
-            const uint64_t m = __ballot(nq == t);
-            if (nq == t) q[t * S + PA_CNT(t) + rank_in(m)] = (uint8_t)slot;
-            cntv += lane == t ? (uint32_t)__popcll(m) : 0u;
+        for (uint64_t todo = __ballot(active), todo2 = __ballot(active2); todo | todo2;) {   // one round per queue that receives slots (usually two or three)
+            const uint32_t t = todo ? (uint32_t)__builtin_amdgcn_readlane((int)nq, (int)(__ffsll((unsigned long long)todo) - 1))
+                                    : (uint32_t)__builtin_amdgcn_readlane((int)nq2, (int)(__ffsll((unsigned long long)todo2) - 1));
+            const uint64_t m = __ballot(nq == t), m2 = __ballot(nq2 == t);
+            const uint32_t base = PA_CNT(t), c1 = (uint32_t)__popcll(m);
+            if (nq == t) q[t * S + base + rank_in(m)] = (uint8_t)slot;
+            if (nq2 == t) q[t * S + base + c1 + rank_in(m2)] = (uint8_t)slot2;
+            cntv += lane == t ? c1 + (uint32_t)__popcll(m2) : 0u;
             todo &= ~m;
+            todo2 &= ~m2;
         }
         if (p.dbg && lane == 0) {   // [ST_ISECT] = pick + pop, [ST_NONE] = store + push (statistics only)
             const unsigned long long t_end = __builtin_readcyclecounter();
-            dbg_clk[sel] += t_end - t_sec;
+            dbg_clk[dual ? ST_DUAL : sel] += t_end - t_sec;
             dbg[ST_ISECT] += 1;
             dbg_clk[ST_ISECT] += t_pop - t_sec;
             dbg[ST_NONE] += 1;
@@ -611,8 +712,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         const uint32_t t = ctag[lane], c = ccnt[lane];
         if (t != NO_CLASS && c) atomicAdd((uint32_t*)(xcounts + t), c);
     }
-    if (p.dbg && lane < 2 * ST_COUNT) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
-    if (p.dbg && lane < ST_COUNT) atomicAdd(p.dbg + 2 * ST_COUNT + lane, dbg_clk[lane]);
+    if (p.dbg && lane < 2 * ST_NSTAT) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
+    if (p.dbg && lane < ST_NSTAT) atomicAdd(p.dbg + 2 * ST_NSTAT + lane, dbg_clk[lane]);
 #undef PA_CNT
 #undef p
 }

@@ -325,6 +325,21 @@ def counts_reference(results, coff, cids, host_index):
     return counts
 
 
+def novel_reference(results, coff, cids, host_index):
+    """Checker for the overflow table (pa_overflow_*): {tuple(ids): reads} over the mapped reads whose non-empty class is
+    NO index class — the reads the dense table lumps into counts[num_classes]."""
+    a = host_index.arrays()
+    off = a["ec_offset"].astype(np.int64)
+    known = {tuple(a["ec_ids"][off[c]:off[c + 1]].tolist()) for c in range(a["num_classes"])}
+    mapped = (results["mismatches"] >> 31).astype(bool) if "mapped" not in results.dtype.names else results["mapped"].astype(bool)
+    out = {}
+    for i in np.flatnonzero(mapped & (results["class_len"] > 0)):
+        ids = tuple(cids[int(coff[i]):int(coff[i + 1])].tolist())
+        if ids not in known:
+            out[ids] = out.get(ids, 0) + 1
+    return out
+
+
 def counts_reference_fast(results, coff, cids, host_index):
     """counts_reference for millions of reads: reads are grouped by (class length, 64-bit content hash), every group is checked
     id by id against its first member (so a hash collision cannot merge two classes), and only one dictionary lookup per

@@ -26,8 +26,18 @@ def shard_counts(rank, world, port, n_total, ret):
     r = helpers.Emu(host, 2).map_tiles(tiles, lens, 4)
     counts = torch.from_numpy(helpers.counts_reference(r["results"], r["coff"], r["ids"], host))
     dist.all_reduce(counts)                                    # the one exchange step of the path
+    # ... and its second half: the novel classes (one slot of the dense table) travel as serialised overflow tables,
+    # all-gathered at a common size and merged by content on every rank (pa_overflow_allgather does this over RCCL)
+    mine = pa.serialise_overflow(helpers.novel_reference(r["results"], r["coff"], r["ids"], host))
+    size = torch.tensor([len(mine)])
+    dist.all_reduce(size, op=dist.ReduceOp.MAX)
+    padded = torch.zeros(int(size.item()), dtype=torch.int64)
+    padded[: len(mine)] = torch.from_numpy(mine.astype(np.int64))
+    gathered = [torch.zeros_like(padded) for _ in range(world)]
+    dist.all_gather(gathered, padded)
+    merged = pa.overflow_merge([g.numpy().astype(np.uint32) for g in gathered])
     if rank == 0:
-        ret.put(counts.numpy().copy())
+        ret.put((counts.numpy().copy(), merged))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +59,7 @@ def test_sharded_counts_equal_single_process(built):
     procs = [ctx.Process(target=shard_counts, args=(r, 2, port, n_total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    reduced = q.get(timeout=500)
+    reduced, merged = q.get(timeout=500)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -59,3 +69,22 @@ def test_sharded_counts_equal_single_process(built):
     r = helpers.Emu(host).map_tiles(tiles, lens, 4)
     whole = helpers.counts_reference(r["results"], r["coff"], r["ids"], host)
     assert np.array_equal(reduced, whole) and reduced.sum() == n_total
+    novel = helpers.novel_reference(r["results"], r["coff"], r["ids"], host)
+    assert pa.parse_overflow(merged) == novel and sum(novel.values()) == whole[-3] and len(novel) > 0
+    assert np.array_equal(merged, pa.serialise_overflow(novel))                   # canonical: independent of the rank count
+
+
+def test_overflow_merge_semantics(built):
+    pa = helpers.pa
+    a = pa.serialise_overflow({(1, 2, 3): 5, (7,): 2})
+    b = pa.serialise_overflow({(1, 2, 3): 1 << 33, (9, 10): 4})
+    padded = np.concatenate([b, np.zeros(7, np.uint32)])                          # gathered buffers are zero padded to a common size
+    m = pa.overflow_merge([a, padded, np.zeros(0, np.uint32), np.zeros(5, np.uint32)])
+    assert pa.parse_overflow(m) == {(1, 2, 3): (1 << 33) + 5, (7,): 2, (9, 10): 4}
+    assert np.array_equal(m, pa.overflow_merge([padded, a]))                      # order of the ranks does not matter
+    assert np.array_equal(pa.overflow_merge([m]), m)                              # idempotent
+    assert pa.parse_overflow(pa.overflow_merge([])) == {}
+    bad = a.copy()
+    bad[2] = 1000                                                                 # a record that runs past the end
+    with pytest.raises(pa.PaError):
+        pa.overflow_merge([bad])

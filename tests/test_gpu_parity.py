@@ -379,3 +379,90 @@ def test_full_size_batch_properties(aligners):
     a.map_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, 2, d_col.data_ptr())
     a.map_finish()
     assert (int(res[:, 3].sum().item()), int(res[:, 0].sum().item())) == checksum1
+
+
+def _map_with_overflow(a, ovf, reads, allowed, repeats=1):
+    """fused count launches with an overflow table attached -> (dense table, overflow dict)"""
+    import torch
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    dev = torch.device("cuda", 0)
+    d_tiles, d_lens = torch.from_numpy(tiles.view(np.int64)).to(dev), torch.from_numpy(np.asarray(lens, np.uint32).view(np.int32)).to(dev)
+    n = len(reads)
+    cap = a.arena_hint(n)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    a.set_overflow(ovf)
+    for _ in range(repeats):
+        a.map_count_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, d_counts.data_ptr(), allowed)
+        a.map_finish()
+    return d_counts
+
+
+@pytest.mark.parametrize("seed,big", [(1, False), (4, False), (7, False), (0, True), (2, True)])
+def test_overflow_table_holds_the_novel_classes(tmp_path, seed, big):
+    """the dense table lumps every result that is no index class into ONE slot; the overflow table attached to the
+    index must hold exactly those id sets with their read counts (oracle histogram), also across repeated launches"""
+    host, k, reads, clean, allowed = helpers.random_txome_case(seed, tmp_path, big=big)
+    if host is None:
+        pytest.skip("every transcript is shorter than k")
+    a = pa.Pseudoaligner(host)
+    ovf = pa.Overflow(0, 1 << 14, 1 << 20)
+    d_counts = _map_with_overflow(a, ovf, reads, allowed, repeats=2)
+    o_res, o_coff, o_ids, _ = helpers.Oracle(host).map_reads(clean, allowed, 4)
+    want = helpers.novel_reference(o_res, o_coff, o_ids, host)
+    got = pa.parse_overflow(ovf.fetch())
+    assert got == {ids: 2 * c for ids, c in want.items()}
+    counts = d_counts.cpu().numpy()
+    assert int(counts[-3]) == sum(got.values()) and np.array_equal(counts, 2 * helpers.counts_reference(o_res, o_coff, o_ids, host))
+    assert np.array_equal(ovf.fetch(), pa.serialise_overflow(got))               # canonical order
+    ovf.reset()
+    assert pa.parse_overflow(ovf.fetch()) == {}
+    a.set_overflow(None)
+
+
+def test_overflow_capacity_is_reported(tmp_path):
+    host, k, reads, clean, allowed = helpers.random_txome_case(0, tmp_path, big=True)
+    a = pa.Pseudoaligner(host)
+    want = helpers.novel_reference(*helpers.Oracle(host).map_reads(clean, allowed, 4)[:3], host)
+    assert len(want) > 8
+    tiny = pa.Overflow(0, 4, 16)                                                 # room for far fewer classes / ids than occur
+    _map_with_overflow(a, tiny, reads, allowed)
+    with pytest.raises(pa.PaError) as e:
+        tiny.fetch()
+    assert e.value.code == pa._ffi.PA_ERR_ARENA_FULL
+    a.set_overflow(None)
+
+
+def test_rccl_world_of_one_reduces_counts_and_overflow(aligners):
+    """the product's own collective entry points (pa_comm_*, pa_counts_allreduce, pa_overflow_allgather) over RCCL with a
+    communicator of ONE rank (all a 1-GPU box offers): the reduce must leave the table as it is, the gather must return this
+    GPU's canonical overflow table"""
+    import torch
+    a = aligners(24)
+    tx = pa.Txome.from_host_index(a.host)
+    n, wpr = 200_000, 4
+    dev = torch.device("cuda", 0)
+    h_tiles, h_lens = tx.simulate_host(100, 11, n, 30000, 0, wpr)                # 3 % substitutions: plenty of novel classes
+    d_tiles = torch.from_numpy(h_tiles.view(np.int64)).to(dev)
+    d_lens = torch.from_numpy(h_lens.view(np.int32)).to(dev)
+    cap = a.arena_hint(n)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    ovf = pa.Overflow(0, 1 << 16, 1 << 22)
+    a.set_overflow(ovf)
+    a.map_count_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, d_counts.data_ptr(), 2)
+    a.map_finish()
+    before = d_counts.cpu().numpy().copy()
+    comm = pa.Comm(0, 1, 0, pa.Comm.unique_id())
+    assert (comm.rank, comm.size) == (0, 1)
+    a.counts_allreduce(d_counts.data_ptr(), comm)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts.cpu().numpy(), before)
+    gathered = ovf.allgather(comm)
+    assert np.array_equal(gathered, ovf.fetch()) and np.array_equal(gathered, ovf.allgather(None))
+    o_res, o_coff, o_ids, _ = helpers.Oracle(a.host).map_tiles(h_tiles, h_lens, wpr, 2, 8)
+    want = helpers.novel_reference(o_res, o_coff, o_ids, a.host)
+    assert pa.parse_overflow(gathered) == want and sum(want.values()) == int(before[-3]) > 0
+    a.set_overflow(None)
