@@ -103,6 +103,11 @@ int pa_host_index_build_packed(const uint64_t* packed, const uint64_t* tx_start,
 /* wrap caller arrays (deep copy) — the import path for an index exported from the Rust side. */
 int pa_host_index_from_flat(const pa_flat_index* flat, pa_host_index** out);
 int pa_host_index_view(const pa_host_index* h, pa_flat_index* view);   /* pointers valid until destroy */
+/* The diff tool of the interchange (an index exported from the Rust side vs the one built here from the same FASTA):
+ * 0 = equivalent, 1 = different, 2 = undecided (node sets differ and the k-mer level check would exceed max_kmers),
+ * < 0 error. Node / class numbering and node order are free; compared are the nodes as a set of (sequence, extension bits,
+ * class id LIST) and, when only unitig break points differ, the k-mer -> id-list map. `report` gets one line of text. */
+int pa_host_index_compare(const pa_host_index* a, const pa_host_index* b, uint64_t max_kmers, char* report, size_t report_cap);
 int pa_host_index_save(const pa_host_index* h, const char* path);      /* own little-endian container, not bincode */
 int pa_host_index_load(const char* path, pa_host_index** out);
 /* transcript metadata: tx_names (:31) and the gene of each transcript (:32) */

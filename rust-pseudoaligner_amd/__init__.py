@@ -85,6 +85,12 @@ class HostIndex:
     def save(self, path: str) -> None:
         check(lib().pa_host_index_save(self._h, str(path).encode()))
 
+    def compare(self, other: "HostIndex", max_kmers: int = 1 << 26) -> Tuple[int, str]:
+        """pa_host_index_compare: (0 equivalent | 1 different | 2 undecided, one line of explanation)"""
+        buf = C.create_string_buffer(512)
+        rc = check(lib().pa_host_index_compare(self._h, other._h, max_kmers, buf, len(buf)))
+        return rc, buf.value.decode()
+
     def flat(self) -> FlatIndex:
         f = FlatIndex()
         check(lib().pa_host_index_view(self._h, C.byref(f)))

@@ -49,6 +49,7 @@ SIGNATURES = {
     "pa_host_index_build_packed": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]),
     "pa_host_index_from_flat": (C.c_int, [C.POINTER(FlatIndex), C.POINTER(vp)]),
     "pa_host_index_view": (C.c_int, [vp, C.POINTER(FlatIndex)]),
+    "pa_host_index_compare": (C.c_int, [vp, vp, C.c_uint64, C.c_char_p, C.c_size_t]),
     "pa_host_index_save": (C.c_int, [vp, C.c_char_p]),
     "pa_host_index_load": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "pa_host_index_num_transcripts": (C.c_uint32, [vp]),
@@ -118,7 +119,10 @@ _lib = None
 
 
 def library_path() -> Path:
-    return _build.PRODUCT_SO
+    """the in-tree product library; PA_PRODUCT_SO (A/B runs of bench.py against an older build, tools/baseline) overrides it"""
+    import os
+    alt = os.environ.get("PA_PRODUCT_SO")
+    return Path(alt) if alt else _build.PRODUCT_SO
 
 
 def lib() -> C.CDLL:
@@ -131,6 +135,8 @@ def lib() -> C.CDLL:
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         handle = C.CDLL(str(path))
         for name, (res, args) in SIGNATURES.items():
+            if path != _build.PRODUCT_SO and not hasattr(handle, name):
+                continue                 # an older build under PA_PRODUCT_SO may lack newer entry points
             fn = getattr(handle, name)   # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args

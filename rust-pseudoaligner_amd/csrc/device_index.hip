@@ -216,14 +216,14 @@ static int pool_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t
     for (; per_cu >= 1; --per_cu) {
         const size_t per_wave = cu_lds / (size_t)per_cu / (PA_MAP_BLOCK / 64);
         const size_t per_slot = pool_slot_bytes(wpr);
-        if (per_wave < 768 + 64 * per_slot + 16) continue;
-        S = (uint32_t)((per_wave - 768 - 16) / per_slot) & ~1u;
+        if (per_wave < pool_fixed_bytes() + 64 * per_slot + 16) continue;
+        S = (uint32_t)((per_wave - pool_fixed_bytes() - 16) / per_slot);
         break;
     }
     if (S < 64) return fail(PA_ERR_UNSUPPORTED, "reads of %u words do not fit the LDS of a compute unit", wpr);
-    if (S > 256) S = 256;
+    if (S > pool_max_slots()) S = pool_max_slots();
     const int want = env_int("PA_POOL_SLOTS", 0);
-    if (want >= 64 && (uint32_t)want <= S) S = (uint32_t)want & ~1u;
+    if (want >= 64 && (uint32_t)want <= S) S = (uint32_t)want;
     *slots = S;
     *lds = pool_lds_bytes(wpr, S);
     int occ = 0;
@@ -320,7 +320,7 @@ static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_
         constexpr uint32_t NS = ST_COUNT + 4;   // ST_NSTAT of map_pool.hip: one entry per state, the dual iterations, the forward step in three parts
         unsigned long long d[3 * NS];
         HIP_TRY(hipMemcpy(d, idx->ctl.as<unsigned long long>() + 2, sizeof d, hipMemcpyDeviceToHost));
-        static const char* names[NS] = {"refill", "seek", "fwd", "left", "pick+pop", "store+push", "fin_light", "fin_scan", "fin_coop", "fin_bits", "fin_novel", "fwd+seek", "fwd:issue", "fwd:wait", "fwd:compute"};
+        static const char* names[NS] = {"refill", "seek", "fwd", "left", "pick+pop", "store+push", "fin_light", "fin_scan", "fin_coop", "fin_bits", "fin_novel", "fwd+seek", "fwd:issue", "fwd:wait", "fwd:wait+compute"};
         fprintf(stderr, "[pa map stats] grid=%u", idx->last_grid);
         for (uint32_t i = 0; i < NS; ++i)
             if (d[i])

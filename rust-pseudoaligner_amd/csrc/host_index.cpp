@@ -225,6 +225,89 @@ int pa_host_index_from_flat(const pa_flat_index* f, pa_host_index** out) {
     return PA_OK;
 }
 
+// ---- index comparison (the diff tool of the interchange: an index exported from the Rust side vs the one built here) ----
+// Node ids, class ids and node order are arbitrary in both builders; what a read can observe is, per k-mer, the id LIST of
+// its class, and per node its sequence and extension bits. Level 1 compares the nodes as a set of (sequence, exts, id
+// list); when the node sets differ (unitig break points of a k-mer cycle are not pinned by any reference test) level 2
+// compares the k-mer -> id-list map, which is break-point independent.
+namespace {
+
+struct IndexDigest {
+    std::unordered_map<std::string, uint64_t> nodes;   // packed sequence + exts byte -> hash of the class's id list
+    std::unordered_map<std::string, uint64_t> kmers;   // packed k-mer -> hash of the class's id list (level 2 only)
+};
+
+uint64_t ids_hash(const HostIndex& x, uint32_t colour) {
+    uint64_t h = 0x243f6a8885a308d3ull;
+    for (uint64_t i = x.ec_offset[colour]; i < x.ec_offset[colour + 1]; ++i) h = mix64(h ^ x.ec_ids[i]) + 0x9e3779b97f4a7c15ull;
+    return h ^ (x.ec_offset[colour + 1] - x.ec_offset[colour]);
+}
+
+std::string bases_key(const uint64_t* seq, uint64_t start, uint32_t len) {
+    std::string k((len + 3) / 4, '\0');
+    for (uint32_t i = 0; i < len; ++i) k[i >> 2] = (char)(k[i >> 2] | (get_base(seq, start + i) << (2 * (i & 3))));
+    k.push_back((char)(len & 3));
+    return k;
+}
+
+void digest_nodes(const HostIndex& x, IndexDigest& d) {
+    for (size_t n = 0; n < x.node_len.size(); ++n) {
+        std::string key = bases_key(x.node_seq.data(), x.node_start[n], x.node_len[n]);
+        key.push_back((char)x.node_exts[n]);
+        d.nodes[key] = ids_hash(x, x.node_colour[n]);
+    }
+}
+
+void digest_kmers(const HostIndex& x, IndexDigest& d) {
+    for (size_t n = 0; n < x.node_len.size(); ++n) {
+        const uint64_t h = ids_hash(x, x.node_colour[n]);
+        for (uint32_t o = 0; o + x.k <= x.node_len[n]; ++o) d.kmers[bases_key(x.node_seq.data(), x.node_start[n] + o, x.k)] = h;
+    }
+}
+
+}  // namespace
+
+int pa_host_index_compare(const pa_host_index* a, const pa_host_index* b, uint64_t max_kmers, char* report, size_t report_cap) {
+    if (!a || !b) return fail(PA_ERR_INVALID_ARG, "null argument");
+    auto say = [&](const char* fmt, auto... args) {
+        if (report && report_cap) snprintf(report, report_cap, fmt, args...);
+    };
+    const HostIndex &x = a->h, &y = b->h;
+    if (x.k != y.k) { say("k differs: %u vs %u", x.k, y.k); return 1; }
+    IndexDigest dx, dy;
+    digest_nodes(x, dx);
+    digest_nodes(y, dy);
+    if (dx.nodes.size() != x.node_len.size() || dy.nodes.size() != y.node_len.size()) { say("an index holds the same node twice"); return 1; }
+    uint64_t missing = 0, other_class = 0;
+    for (const auto& kv : dx.nodes) {
+        const auto it = dy.nodes.find(kv.first);
+        if (it == dy.nodes.end()) ++missing;
+        else if (it->second != kv.second) ++other_class;
+    }
+    if (missing == 0 && other_class == 0 && dx.nodes.size() == dy.nodes.size()) {
+        say("identical: %zu nodes (sequence, extensions, class id lists), %zu / %zu classes", dx.nodes.size(), x.ec_offset.size() - 1, y.ec_offset.size() - 1);
+        return 0;
+    }
+    if (other_class) { say("%llu nodes carry a different class (id list)", (unsigned long long)other_class); return 1; }
+    // node sets differ: are the k-mer -> class maps equal (different unitig break points only)?
+    uint64_t kx = 0, ky = 0;
+    for (size_t n = 0; n < x.node_len.size(); ++n) kx += x.node_len[n] - x.k + 1;
+    for (size_t n = 0; n < y.node_len.size(); ++n) ky += y.node_len[n] - y.k + 1;
+    if (kx != ky) { say("%llu vs %llu k-mers (%llu nodes only in the first index)", (unsigned long long)kx, (unsigned long long)ky, (unsigned long long)missing); return 1; }
+    if (kx > max_kmers) { say("node sets differ (%llu nodes only in the first index) and the k-mer level check needs %llu k-mers (limit %llu)",
+                              (unsigned long long)missing, (unsigned long long)kx, (unsigned long long)max_kmers); return 2; }
+    digest_kmers(x, dx);
+    digest_kmers(y, dy);
+    uint64_t kdiff = 0;
+    for (const auto& kv : dx.kmers) {
+        const auto it = dy.kmers.find(kv.first);
+        if (it == dy.kmers.end() || it->second != kv.second) ++kdiff;
+    }
+    if (kdiff || dx.kmers.size() != dy.kmers.size()) { say("%llu k-mers are missing or carry a different class", (unsigned long long)kdiff); return 1; }
+    say("equivalent: same k-mer -> class map over %zu k-mers; unitig break points differ (%zu vs %zu nodes)", dx.kmers.size(), dx.nodes.size(), dy.nodes.size());
+    return 0;
+}
+
 int pa_host_index_view(const pa_host_index* h, pa_flat_index* v) {
     if (!h || !v) return fail(PA_ERR_INVALID_ARG, "null argument");
     const HostIndex& x = h->h;

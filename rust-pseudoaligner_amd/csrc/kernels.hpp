@@ -57,6 +57,8 @@ struct MapParams {
 
 // the map kernel (map_pool.hip)
 size_t pool_slot_bytes(uint32_t wpr);   // LDS bytes per read slot
+size_t pool_fixed_bytes();              // LDS bytes per wave besides the slots
+uint32_t pool_max_slots();              // slots a wave can schedule
 size_t pool_lds_bytes(uint32_t wpr, uint32_t slots);
 int launch_map_pool(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream);
 int pool_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu);

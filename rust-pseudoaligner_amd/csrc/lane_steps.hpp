@@ -531,89 +531,13 @@ PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, 
     s.of = off | (nfl << 24);
 }
 
-// The common case of fwd_finish — window mode, count mode (not careful), a class that has windows — as ONE basic block:
-// every decision is a select, nothing diverges, so a wave runs it at the cost of its ~170 instructions instead of the ~30
-// exec-masked regions of the general text. fwd_fast_ok tells (per lane, once the header is there) whether it applies; the
-// result is bit-for-bit what fwd_finish computes (tests/emu runs both through fwd_step).
-PA_HD bool fwd_fast_ok(const Lane& s, const FwdLoad& f) {
-    const uint32_t fl = l_flags(s);
-    return !(fl & (F_LISTS | F_CAREFUL)) && (!(fl & F_FRESH) || f.h2.y != 0);   // h2.y = cmask: 0 = the class has no windows (list mode restart)
-}
-PA_HD void fwd_finish_fast(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed, const FwdLoad& f) {
-    const uint32_t K = ix.k, L = l_L(s);
-    const uint32_t fl = l_flags(s);
-    const bool fresh = fl & F_FRESH;
-    const uint32_t ro0 = fresh ? l_off(s) + K : (s.rr & 0xFFFFFFu);   // ref_offset (:227)
-    const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
-    const uint32_t len = f.h0.x & 0xFFFFFFu, exts = f.h0.x >> 24, cid = f.h0.y;
-    const uint32_t cmin = f.h2.x, cmask = f.h2.y, cmin2 = f.h2.z, cmask2 = f.h2.w;
-    // nodes.push (:219), window mode: the running intersection AND this class's windows (push_node, without its branches)
-    {
-        const U4 w = *reinterpret_cast<const U4*>(cols.win);
-        const uint32_t cand0 = cols.wcand[0];
-        const bool first = l_ncol(s) == 0;
-        const uint32_t m1 = w.y & (window_at(w.x, cmin, cmask) | window_at(w.x, cmin2, cmask2));
-        const uint32_t m2 = w.w & (window_at(w.z, cmin, cmask) | window_at(w.z, cmin2, cmask2));
-        const bool is_this = pa_popc32(m1) + pa_popc32(m2) == pa_popc32(cmask) + pa_popc32(cmask2);   // this class is a subset of all before: it IS the result
-        const uint32_t cand1 = is_this ? cid : (m1 == w.y && m2 == w.w) ? cand0 : NO_CLASS;
-        U4 nw;
-        nw.x = fresh && first ? cmin : w.x;
-        nw.y = !fresh ? w.y : first ? cmask : m1;
-        nw.z = fresh && first ? cmin2 : w.z;
-        nw.w = !fresh ? w.w : first ? cmask2 : m2;
-        *reinterpret_cast<U4*>(cols.win) = nw;
-        cols.wcand[0] = !fresh ? cand0 : first ? cid : cand1;
-    }
-    const uint32_t nc = fresh ? (s.nc & ~0xFFFu) | 1u : s.nc;
-    uint32_t cov = l_cov(s) + (fresh ? K : 0u), mism = l_mism(s);     // :216
-    uint32_t rem = fresh ? pa_min(L - kp0, len - ro0) : (s.rm & 0xFFFFu);   // max_matchable_pos (:222-231)
-    uint32_t snp = fresh ? 0u : s.rr >> 24;                           // :235
-    const uint32_t sh_a = (ro0 & 31) * 2, sh_r = (kp0 & 31) * 2, rw = kp0 >> 5;
-    uint64_t r[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) r[i] = read_word(rd, rw + i);         // all LDS reads in flight together
-    const uint64_t a[5] = {f.s01.a, f.s01.b, f.s23.a, f.s23.b, f.s45.a};   // (words that were not needed hold other words of the node: masked by n)
-    const uint32_t n = pa_min(rem, 128u);
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const uint32_t done = 32u * c, nn = n > done ? pa_min(n - done, 32u) : 0u;
-        cnt += pa_popc64(diff_mask(funnel(r[c], r[c + 1], sh_r) ^ funnel(a[c], a[c + 1], sh_a), nn));
-    }
-    const bool ok = snp + cnt <= allowed;                             // else: over budget somewhere in these bases, redo carefully
-    const uint32_t matched = ok ? n : 0u;
-    snp += ok ? cnt : 0u;
-    mism += ok ? cnt : 0u;
-    const uint32_t kp = kp0 + matched;                                // :257
-    cov += matched;                                                   // :254
-    rem -= matched;
-    const bool finished = ok && rem == 0;                             // node visit finished
-    const uint32_t bi = (kp >> 5) - rw;                               // the word of r[] that holds base kp (kp - kp0 <= 128)
-    const uint64_t bw = bi == 0 ? r[0] : bi == 1 ? r[1] : bi == 2 ? r[2] : bi == 3 ? r[3] : r[4];
-    const uint32_t b = (uint32_t)(bw >> ((kp & 31) * 2)) & 3u;        // :265 (only looked at when kp < L)
-    const bool has = (exts >> b) & 1u;                                // :267
-    const bool at_end = kp >= L;                                      // :259-261
-    const bool hop = finished && !at_end && has;
-    const uint32_t edge = b == 0 ? f.h1.x : b == 1 ? f.h1.y : b == 2 ? f.h1.z : f.h1.w;   // r_edges()[index].0 (:275-278)
-    const uint32_t st = !finished || hop ? (uint32_t)ST_FWD : (at_end || kp > L - K) ? (uint32_t)ST_ISECT : (uint32_t)ST_SEEK;   // :287-293
-    const uint32_t nfl = (fl & ~F_FRESH) | (ok ? 0u : (uint32_t)F_CAREFUL) | (hop ? (uint32_t)F_FRESH : 0u);
-    s.h = hop ? edge : s.h;
-    s.lk = l_pack_lk(L, hop ? kp - (K - 1) : kp, st);                 // :282
-    s.cm = (cov - (hop ? K - 1 : 0u)) | (mism << 16);                 // :283
-    s.rr = (ro0 + matched) | (snp << 24);
-    s.rm = (s.rm & 0xFFFF0000u) | rem;
-    s.of = (hop ? 0u : l_off(s)) | (nfl << 24);                       // :279
-    s.nc = nc;
-}
-
 // Forward search (:209-301): one call = enter/continue one node (one dependent fetch of the node header + sequence
 // words, issued together)
 template <bool TRACE = false>
 PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
     FwdLoad f;
     fwd_issue(s, ix, f);
-    if (!TRACE && fwd_fast_ok(s, f)) fwd_finish_fast(s, ix, rd, cols, allowed, f);
-    else fwd_finish<TRACE>(s, ix, rd, cols, allowed, f);
+    fwd_finish<TRACE>(s, ix, rd, cols, allowed, f);
 }
 
 // ---------------------------------------------------------------------------------------------- LEFT

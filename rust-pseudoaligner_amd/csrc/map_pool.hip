@@ -3,17 +3,18 @@
 // The per-read state machine of lane_steps.hpp has data-dependent length (node visits per read are heavy-tailed) and
 // several kinds of step (dictionary probe, node visit, left extension, class intersection, output). Running it with one
 // fixed read per lane leaves most lanes idle in every step: the lanes of a wave are never all in the same state.
-// Here a wave owns a POOL of S read slots (S > 64, 116 at 150 bp) that lives in LDS — packed read, 32-byte lane state,
-// class windows — and one byte queue per state. Each iteration the wave
-//     1. picks a queue (one that holds a full wave of 64 slots, preferring the states nearest to completion; otherwise
-//        the longest one), pops up to 64 slot ids from it and loads their lane state from LDS,
+// Here a wave owns a POOL of S read slots (S > 64: 128 at 150 bp) that lives in LDS — packed read, 32-byte lane state,
+// class windows — and ONE state byte per slot. Each iteration the wave
+//     1. counts the slots in every state (ballots over the state bytes: lane i watches slots i and i + 64), picks a state
+//        (one that fills a wave of 64, preferring the states nearest to completion; otherwise the most populated one),
+//        compacts the first 64 slots in that state into its lanes and loads their lane state from LDS,
 //     2. runs that state's step for all of them (one dependent HBM round trip; every lane does the same thing),
-//     3. stores the lane state back and pushes every slot onto the queue of its new state.
-// Rare states simply wait in their queue until enough of them have gathered, so they are executed at full width too.
+//     3. stores the lane state back and writes every slot's new state byte.
+// Rare states simply wait until enough slots have gathered in them, so they are executed at full width too.
 // Nothing is shared between waves: no locks, no barriers, no atomics besides the arena chunk grab and the count table.
 //
-// LDS per wave (S slots, wpr words per read):   [768 B fixed: arena chunk, statistics, count cache | rd u64[wpr][S] |
-//                                                 st {u32 x 8}[S] | win {u32 x 4}[S] | {class id, read id}[S] | q u8[ST_COUNT][S]]
+// LDS per wave (S slots, wpr words per read):   [960 B fixed: arena chunk, statistics, count cache, state bytes, pop list |
+//                                                 rd u64[wpr][S] | st {u32 x 8}[S] | win {u32 x 4}[S] | {class id, read id}[S]]
 // HBM per slot: a row of spill_cap u32 that holds the class lists of a read in list mode (lane_steps.hpp, ColRef) and,
 // in TRACE builds, a second row with the visited node ids.
 #include <hip/hip_runtime.h>
@@ -28,6 +29,7 @@ namespace {
 typedef __attribute__((address_space(3))) uint64_t* lds_u64;
 typedef __attribute__((address_space(3))) uint32_t* lds_u32;
 typedef __attribute__((address_space(3))) uint8_t* lds_u8;
+typedef __attribute__((address_space(3))) uint16_t* lds_u16;
 typedef __attribute__((address_space(3))) unsigned long long* lds_u64w;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4* lds_v4;
@@ -50,7 +52,8 @@ __device__ __forceinline__ DevIndexView view_of(karg_ptr p) {   // member-wise: 
 constexpr uint32_t ST_NSTAT = ST_COUNT + 4;   // statistics entries: one per state, the dual (forward + probe) iterations, and the plain forward step
                                                // split into issue / wait / compute (PA_MAP_STATS only)
 constexpr uint32_t ST_DUAL = ST_COUNT;
-constexpr uint32_t POOL_FIXED = 768;   // per wave: arena chunk {cur, end} (16 B), statistics, count cache (64 x {class, count})
+constexpr uint32_t POOL_FIXED = 960;   // per wave: arena chunk {cur, end} (16 B), statistics, count cache (64 x {class, count}), state bytes (128 B), pop list (64 B)
+constexpr uint32_t POOL_MAX_SLOTS = 128;   // every lane watches the state bytes of two slots (lane, lane + 64)
 constexpr uint32_t COUNT_CACHE_PERIOD = 128;   // output steps between two flushes of the count cache
 constexpr uint32_t LIST_ROW_HDR = 12;  // list mode row: refs[4], lens[4], cids[4], then (ref, len, class id, -) quads
 
@@ -174,7 +177,7 @@ __device__ __forceinline__ void refill_slot(Lane& s, uint64_t rid, uint32_t slot
     wc[2 * slot + 1] = (uint32_t)rid;
 }
 
-constexpr uint32_t SLOT_FIXED_BYTES = 32 + 16 + 8 + ST_COUNT;   // lane state, class windows, {class id, read id}, one queue byte per state
+constexpr uint32_t SLOT_FIXED_BYTES = 32 + 16 + 8;   // lane state, class windows, {class id, read id} (the state byte lives in the fixed area)
 
 }  // namespace
 
@@ -207,12 +210,17 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     const lds_v4 stv = (lds_v4)(wbase + POOL_FIXED + 8 * wpr * S);        // two vectors per slot
     const lds_v4 win = (lds_v4)(wbase + POOL_FIXED + (8 * wpr + 32) * S); // {base1, mask1, base2, mask2}
     const lds_u32 wc = (lds_u32)(wbase + POOL_FIXED + (8 * wpr + 48) * S);   // {class id, read id} per slot
-    const lds_u8 q = (lds_u8)(wbase + POOL_FIXED + (8 * wpr + 56) * S);
+    // Scheduling state: ONE byte per slot = the state the slot waits in (0xFF: no such slot), laid out so that lane i reads the
+    // bytes of slots i and i + 64 with one 16-bit load. There are no queues: every iteration the lanes look at their two
+    // bytes, ballots give the population of every state, and the batch of a step is "the first 64 slots in that state"
+    // (compacted through the 64-byte pop list). A slot changes state by ONE byte store.
+    const lds_u8 sb = (lds_u8)(wbase + 768);
+    const lds_u8 poplist = (lds_u8)(wbase + 896);
     if (lane < 64) ((lds_u32)wbase)[lane] = 0;
     ctag[lane] = NO_CLASS;
     ccnt[lane] = 0;
     uint32_t out_steps = 0;
-    for (uint32_t i = lane; i < S; i += 64) q[ST_EMPTY * S + i] = (uint8_t)i;
+    ((lds_u16)sb)[lane] = (uint16_t)((lane < S ? (uint32_t)ST_EMPTY : 0xFFu) | ((lane + 64 < S ? (uint32_t)ST_EMPTY : 0xFFu) << 8));
 
     // Work distribution: chunks of up to 16 tiles (1024 reads). Chunk w is wave w's first one; further chunks come from a
     // global counter, so that the waves finish together whatever their reads cost (a static split left the chip 9 % idle
@@ -232,8 +240,18 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (PA_COUNT_REPLICAS - 1);
     const glb_u32w xcounts = p.counts ? (glb_u32w)p.xcd_counts + (uint64_t)xcc * p.xcd_stride : (glb_u32w) nullptr;
 
-    uint32_t cntv = lane == ST_EMPTY ? S : 0u;   // queue lengths: lane t holds the length of queue t
-#define PA_CNT(t) ((uint32_t)__builtin_amdgcn_readlane((int)cntv, (int)(t)))
+#define PA_CNT(t) ((uint32_t)__popcll(__ballot(st_lo == (t))) + (uint32_t)__popcll(__ballot(st_hi == (t))))
+    // the first nn slots in state t, one per lane (lanes >= nn: slot 0)
+#define PA_POP(t, nn, out)                                                                         \
+    {                                                                                              \
+        const uint64_t m0_ = __ballot(st_lo == (t)), m1_ = __ballot(st_hi == (t));                 \
+        const uint32_t r1_ = (uint32_t)__popcll(m0_) + rank_in(m1_);                               \
+        if (st_lo == (t)) poplist[rank_in(m0_)] = (uint8_t)lane;                                   \
+        if (st_hi == (t) && r1_ < 64) poplist[r1_] = (uint8_t)(lane + 64);                         \
+        asm volatile("" ::: "memory");                                                             \
+        out = lane < (nn) ? (uint32_t)poplist[lane] : 0u;                                          \
+        asm volatile("" ::: "memory");                                                             \
+    }
 
     for (;;) {
         asm volatile("" : "+s"(kp) : : "memory");   // also: slots and queues in LDS change hands between lanes every iteration
@@ -256,7 +274,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 if (end > p.n_reads) end = p.n_reads;
             }
         }
-        // ---- 1. pick a queue: the first one (states nearest to completion first) that fills a wave, else the longest
+        // ---- 1. pick a state: the first one (states nearest to completion first) that fills a wave, else the most populated
+        const uint32_t st2 = (uint32_t)((lds_u16)sb)[lane];
+        const uint32_t st_lo = st2 & 0xFFu, st_hi = st2 >> 8;
         const uint64_t left = end - next;
         const uint32_t nempty = PA_CNT(ST_EMPTY);
         const uint32_t nrefill = (uint32_t)(left < (uint64_t)nempty ? left : (uint64_t)nempty);
@@ -290,12 +310,11 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         const unsigned long long t_sec = p.dbg ? __builtin_readcyclecounter() : 0ull;
 
         // ---- 2. pop n slots (and n2 slots of the SEEK queue)
-        cntv -= (lane == sel ? n : 0u) + (lane == ST_SEEK ? n2 : 0u);
-        const uint32_t qbase = PA_CNT(sel);
         const bool active = lane < n;
-        const uint32_t slot = active ? (uint32_t)q[sel * S + qbase + lane] : 0u;
+        uint32_t slot, slot2 = 0;
+        PA_POP(sel, n, slot)
         const bool active2 = lane < n2;
-        const uint32_t slot2 = active2 ? (uint32_t)q[ST_SEEK * S + PA_CNT(ST_SEEK) + lane] : 0u;
+        if (dual) PA_POP((uint32_t)ST_SEEK, n2, slot2)
         const uint32_t gslot = wave * S + slot;
         Lane s;
         {
@@ -318,55 +337,39 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         } else if (sel == ST_SEEK) {
             if (active) seek_step(s, ix, rr);
         } else if (sel == ST_FWD) {
-            if (!dual) {
-                if (!p.dbg) {
-                    if (active) fwd_step<TRACE>(s, ix, rr, cols, allowed);
-                } else {   // statistics build of the same step: where does its time go?
-                    FwdLoad fl;
-                    if (active) fwd_issue(s, ix, fl);
-                    const unsigned long long t1 = __builtin_readcyclecounter();
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned long long t2 = __builtin_readcyclecounter();
-                    if (active) {
-                        if (!TRACE && fwd_fast_ok(s, fl)) fwd_finish_fast(s, ix, rr, cols, allowed, fl);
-                        else fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
-                    }
-                    const unsigned long long t3 = __builtin_readcyclecounter();
-                    if (lane == 0) {
-                        dbg[ST_COUNT + 1] += 1; dbg[ST_COUNT + 2] += 1; dbg[ST_COUNT + 3] += 1;
-                        dbg_clk[ST_COUNT + 1] += t1 - t_pop; dbg_clk[ST_COUNT + 2] += t2 - t1; dbg_clk[ST_COUNT + 3] += t3 - t2;
-                    }
-                }
-            } else {
-                // Straight-line issue: every lane executes every load (a lane without a slot carries an all-zero state: blob 0,
-                // bucket of whatever slot 0 holds), so that the number of loads in flight is a constant and the waits below are
-                // exact: vmcnt(6) for the fingerprints, vmcnt(1) for the node, vmcnt(0) for the entry.
-                Lane s2;
-                {
-                    const u32x4 a = stv[2 * slot2], b = stv[2 * slot2 + 1];
-                    s2.lk = active2 ? a.x : 0u; s2.cm = active2 ? a.y : 0u; s2.h = active2 ? a.z : 0u; s2.of = active2 ? a.w : 0u;
-                    s2.rr = active2 ? b.x : 0u; s2.rm = active2 ? b.y : 0u; s2.ph = active2 ? b.z : 0u; s2.nc = active2 ? b.w : 0u;
-                    s2.rid = 0;   // (not used by the probe; the slot keeps its read id in `wc`)
-                }
-                if (!active) { s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0; }
-                const ReadRef rr2{(const uint64_t*)(rd + slot2), S, wpr};
-                SeekProbe pq;
-                FwdLoad fl;
-                seek_issue(s2, ix, rr2, pq);                           // fingerprints of the bucket (HBM)
-                fwd_issue(s, ix, fl);                                  // node header + sequence words (MALL / L2)
-                __builtin_amdgcn_sched_barrier(0);                     // (left alone the scheduler finishes the probe first and only then issues the node loads)
-                const uint32_t cand = seek_cands(pq);
-                const U3 ent = seek_entry(pq, cand);                   // the probe's dependent load: same line, now in the L1 / L2
-                if (active) {
-                    if (!TRACE && fwd_fast_ok(s, fl)) fwd_finish_fast(s, ix, rr, cols, allowed, fl);
-                    else fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
-                }
-                if (active2) {
-                    seek_complete(s2, K, pq, cand, ent);
-                    stv[2 * slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
-                    stv[2 * slot2 + 1] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};
-                }
-                nq2 = active2 ? queue_of(s2) : 0xFFu;
+            // One text for the plain forward step and the DUAL iteration (n2 = 0: the probe half runs on all-zero states and is
+            // thrown away). Straight-line issue: every lane executes every load (a lane without a slot carries an all-zero state:
+            // blob 0, bucket of whatever slot 0 holds) and nothing branches between the loads and their first use, so that the
+            // number of loads in flight is a constant and the waits are exact: vmcnt(6) for the fingerprints, then the node, then
+            // the entry.
+            Lane s2;
+            {
+                const u32x4 a = stv[2 * slot2], b = stv[2 * slot2 + 1];
+                s2.lk = active2 ? a.x : 0u; s2.cm = active2 ? a.y : 0u; s2.h = active2 ? a.z : 0u; s2.of = active2 ? a.w : 0u;
+                s2.rr = active2 ? b.x : 0u; s2.rm = active2 ? b.y : 0u; s2.ph = active2 ? b.z : 0u; s2.nc = active2 ? b.w : 0u;
+                s2.rid = 0;   // (not used by the probe; the slot keeps its read id in `wc`)
+            }
+            if (!active) { s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0; }
+            const ReadRef rr2{(const uint64_t*)(rd + slot2), S, wpr};
+            SeekProbe pq;
+            FwdLoad fl;
+            seek_issue(s2, ix, rr2, pq);                               // fingerprints of the bucket (HBM)
+            fwd_issue(s, ix, fl);                                      // node header + sequence words (MALL / L2)
+            __builtin_amdgcn_sched_barrier(0);                         // (left alone the scheduler finishes the probe first and only then issues the node loads)
+            const uint32_t cand = seek_cands(pq);
+            const U3 ent = seek_entry(pq, cand);                       // the probe's dependent load: same line, now in the L1 / L2
+            const unsigned long long t1 = p.dbg ? __builtin_readcyclecounter() : 0ull;
+            if (active) fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
+            if (p.dbg && lane == 0) {   // statistics only: issue | wait + compute of the forward half
+                const unsigned long long t3 = __builtin_readcyclecounter();
+                dbg[ST_COUNT + 1] += 1; dbg[ST_COUNT + 3] += 1;
+                dbg_clk[ST_COUNT + 1] += t1 - t_pop; dbg_clk[ST_COUNT + 3] += t3 - t1;
+            }
+            if (active2) {
+                seek_complete(s2, K, pq, cand, ent);
+                stv[2 * slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
+                stv[2 * slot2 + 1] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};
+                nq2 = queue_of(s2);
             }
         } else if (sel == ST_LEFT) {
             if (active) left_step<TRACE>(s, ix, rr, cols, allowed);
@@ -688,17 +691,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             stv[2 * slot] = u32x4{s.lk, s.cm, s.h, s.of};
             stv[2 * slot + 1] = u32x4{s.rr, s.rm, s.ph, s.nc};
         }
-        for (uint64_t todo = __ballot(active), todo2 = __ballot(active2); todo | todo2;) {   // one round per queue that receives slots (usually two or three)
-            const uint32_t t = todo ? (uint32_t)__builtin_amdgcn_readlane((int)nq, (int)(__ffsll((unsigned long long)todo) - 1))
-                                    : (uint32_t)__builtin_amdgcn_readlane((int)nq2, (int)(__ffsll((unsigned long long)todo2) - 1));
-            const uint64_t m = __ballot(nq == t), m2 = __ballot(nq2 == t);
-            const uint32_t base = PA_CNT(t), c1 = (uint32_t)__popcll(m);
-            if (nq == t) q[t * S + base + rank_in(m)] = (uint8_t)slot;
-            if (nq2 == t) q[t * S + base + c1 + rank_in(m2)] = (uint8_t)slot2;
-            cntv += lane == t ? c1 + (uint32_t)__popcll(m2) : 0u;
-            todo &= ~m;
-            todo2 &= ~m2;
-        }
+        if (active) sb[2 * (slot & 63u) + (slot >> 6)] = (uint8_t)nq;        // the slot's new state: one byte
+        if (active2) sb[2 * (slot2 & 63u) + (slot2 >> 6)] = (uint8_t)nq2;
         if (p.dbg && lane == 0) {   // [ST_ISECT] = pick + pop, [ST_NONE] = store + push (statistics only)
             const unsigned long long t_end = __builtin_readcyclecounter();
             dbg_clk[dual ? ST_DUAL : sel] += t_end - t_sec;
@@ -715,6 +709,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     if (p.dbg && lane < 2 * ST_NSTAT) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
     if (p.dbg && lane < ST_NSTAT) atomicAdd(p.dbg + 2 * ST_NSTAT + lane, dbg_clk[lane]);
 #undef PA_CNT
+#undef PA_POP
 #undef p
 }
 
@@ -739,6 +734,8 @@ int launch_counts_fold(uint32_t* xcd_counts, uint32_t xcd_stride, unsigned long 
 }
 
 size_t pool_slot_bytes(uint32_t wpr) { return 8 * (size_t)wpr + SLOT_FIXED_BYTES; }
+size_t pool_fixed_bytes() { return POOL_FIXED; }
+uint32_t pool_max_slots() { return POOL_MAX_SLOTS; }
 
 size_t pool_lds_bytes(uint32_t wpr, uint32_t slots) {
     const size_t wave_bytes = (POOL_FIXED + (size_t)slots * pool_slot_bytes(wpr) + 15) & ~(size_t)15;

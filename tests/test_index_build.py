@@ -250,3 +250,87 @@ def test_mappability(tmp_path):
             assert float(txt) == x and "e" not in txt.lower()
             # Rust's `{}`: the shortest digits that round-trip ("1", "0.5", "0.3333333333333333")
             assert txt == (repr(x)[:-2] if repr(x).endswith(".0") else repr(x)) or "e" in repr(x)
+
+
+def _flat_from(arr, k, num_tx):
+    """a FlatIndex over numpy arrays (kept alive by the returned tuple), as an exporter on the Rust side would fill it"""
+    f = pa._ffi.FlatIndex()
+    keep = {n: np.ascontiguousarray(arr[n]) for n in ("node_seq", "node_start", "node_len", "node_exts", "node_colour", "ec_offset", "ec_ids")}
+    f.k, f.num_nodes, f.num_classes, f.num_transcripts = k, len(keep["node_len"]), len(keep["ec_offset"]) - 1, num_tx
+    f.seq_bases = int(keep["node_start"][-1])
+    for n, v in keep.items():
+        setattr(f, n, v.ctypes.data)
+    f.node_redge = f.node_ledge = None
+    return f, keep
+
+
+def _repack_nodes(a, order, split=None):
+    """node arrays of `a` in a new order (and, optionally, node `split` cut into two nodes that overlap by k-1 bases — a
+    different unitig break point for the same k-mers)"""
+    k = a["k"]
+    seqs, exts, colour = [], [], []
+    for n in order:
+        st, ln = int(a["node_start"][n]), int(a["node_len"][n])
+        bases = [(int(a["node_seq"][(st + i) >> 5]) >> (2 * ((st + i) & 31))) & 3 for i in range(ln)]
+        if n == split:
+            cut = ln // 2
+            left, right = bases[:cut + k - 1], bases[cut:]
+            seqs += [left, right]
+            exts += [(int(a["node_exts"][n]) & 0xF0) | (1 << right[k - 1]), (int(a["node_exts"][n]) & 0x0F) | (16 << left[len(left) - k])]
+            colour += [int(a["node_colour"][n])] * 2
+        else:
+            seqs.append(bases)
+            exts.append(int(a["node_exts"][n]))
+            colour.append(int(a["node_colour"][n]))
+    start = np.zeros(len(seqs) + 1, np.uint64)
+    start[1:] = np.cumsum([len(s) for s in seqs])
+    words = np.zeros((int(start[-1]) + 31) // 32 + 2, np.uint64)
+    flat = np.array([b for s in seqs for b in s], np.uint64)
+    idx = np.arange(len(flat))
+    np.bitwise_or.at(words, idx >> 5, flat << ((idx & 31) * 2).astype(np.uint64))
+    return dict(node_seq=words, node_start=start, node_len=np.array([len(s) for s in seqs], np.uint32), node_exts=np.array(exts, np.uint8),
+                node_colour=np.array(colour, np.uint32))
+
+
+def test_index_compare_is_numbering_and_break_point_independent(built, tmp_path):
+    """pa_host_index_compare, the diff tool of the index interchange: an index with its nodes in another order
+    and its classes renumbered is identical; one with a unitig cut at another place is equivalent (k-mer level); one with a
+    changed id list / a lost node is different"""
+    fa = tmp_path / "t.fa"
+    _, seqs = helpers.read_fasta()
+    fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i // 2, s) for i, s in enumerate(seqs[:12])))
+    host = pa.HostIndex.build_fasta(str(fa), 20, 2)
+    a = host.arrays()
+    rng = np.random.RandomState(3)
+    order = rng.permutation(a["num_nodes"])
+    perm = rng.permutation(a["num_classes"])                       # class c is renumbered perm[c]
+    off = a["ec_offset"].astype(np.int64)
+    lists = [a["ec_ids"][off[c]:off[c + 1]] for c in range(a["num_classes"])]
+    new_lists = [None] * a["num_classes"]
+    for c, l in enumerate(lists):
+        new_lists[perm[c]] = l
+    ec_offset = np.zeros(a["num_classes"] + 1, np.uint64)
+    ec_offset[1:] = np.cumsum([len(l) for l in new_lists])
+    base = dict(ec_offset=ec_offset, ec_ids=np.concatenate(new_lists).astype(np.uint32))
+
+    def imported(nodes, classes=base):
+        arr = dict(nodes, **classes)
+        arr["node_colour"] = perm[nodes["node_colour"]].astype(np.uint32)
+        f, keep = _flat_from(arr, a["k"], a["num_transcripts"])
+        return pa.HostIndex.from_flat(f)
+
+    rc, why = host.compare(imported(_repack_nodes(a, order)))
+    assert rc == 0 and why.startswith("identical"), why
+    long_node = int(np.argmax(a["node_len"]))
+    rc, why = host.compare(imported(_repack_nodes(a, order, split=long_node)))
+    assert rc == 0 and why.startswith("equivalent"), why
+    rc, why = host.compare(imported(_repack_nodes(a, order, split=long_node)), max_kmers=10)
+    assert rc == 2, why                                            # undecided: the k-mer level check was not allowed
+    wrong = dict(base, ec_ids=base["ec_ids"].copy())
+    single = next(c for c in range(a["num_classes"]) if ec_offset[c + 1] - ec_offset[c] == 1)
+    wrong["ec_ids"][int(ec_offset[single])] = (int(wrong["ec_ids"][int(ec_offset[single])]) + 1) % a["num_transcripts"]   # one id list changed
+    rc, why = host.compare(imported(_repack_nodes(a, order), wrong))
+    assert rc == 1 and "different class" in why, why
+    rc, why = host.compare(imported(_repack_nodes(a, order[:-1])))
+    assert rc == 1, why                                            # a node (its k-mers) is missing
+    assert host.compare(pa.HostIndex.build_fasta(str(fa), 21, 2))[0] == 1
