@@ -1,0 +1,191 @@
+/* A plain-C client of include/pseudoaligner_amd.h that calls EVERY entry point of the header once, with the argument types a
+ * foreign binding (integration/rust/src/amd_ffi.rs, rust-pseudoaligner_amd/_ffi.py) assumes. Compiled by __graft_entry__.build()
+ * with gcc -Wall -Werror against the header, so a drifting prototype is a build error, not a run-time surprise; run by the
+ * tests: without a GPU the host half runs and every device entry point must fail with PA_ERR_NO_DEVICE (no CPU fallback),
+ * with a GPU the whole sequence runs on a toy transcriptome.
+ *   usage: abi_check <fasta> <fastq> <scratch dir>          exit code 0 = every call behaved
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pseudoaligner_amd.h"
+
+static int failures = 0;
+#define EXPECT(cond)                                                                      \
+    do {                                                                                  \
+        if (!(cond)) { fprintf(stderr, "abi_check: %s:%d: %s (last error: %s)\n", __FILE__, __LINE__, #cond, pa_last_error()); ++failures; } \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 4) { fprintf(stderr, "usage: %s <fasta> <fastq> <scratch dir>\n", argv[0]); return 2; }
+    const char *fasta = argv[1], *fastq = argv[2], *dir = argv[3];
+    char path[1024], report[256];
+
+    /* ---- host half ---- */
+    EXPECT(pa_abi_version() == PA_ABI_VERSION);
+    EXPECT(pa_last_error() != NULL);
+    const int ndev = pa_device_count();
+    pa_host_index *h = NULL, *h2 = NULL, *h3 = NULL, *h4 = NULL;
+    EXPECT(pa_host_index_build_fasta(fasta, 20, 2, &h) == PA_OK && h);
+    if (!h) return 1;
+    pa_flat_index flat;
+    EXPECT(pa_host_index_view(h, &flat) == PA_OK && flat.k == 20 && flat.num_nodes > 0);
+    EXPECT(pa_host_index_from_flat(&flat, &h2) == PA_OK);
+    EXPECT(pa_host_index_compare(h, h2, 1u << 20, report, sizeof report) == 0);
+    snprintf(path, sizeof path, "%s/abi_check.idx", dir);
+    EXPECT(pa_host_index_save(h, path) == PA_OK);
+    EXPECT(pa_host_index_load(path, &h3) == PA_OK);
+    const uint32_t ntx = pa_host_index_num_transcripts(h);
+    EXPECT(ntx == flat.num_transcripts && pa_host_index_tx_name(h, 0) != NULL && pa_host_index_tx_gene(h, 0) != NULL);
+    uint32_t ngenes = 0;
+    uint32_t* tx_gene = (uint32_t*)calloc(ntx ? ntx : 1, 4);
+    EXPECT(pa_host_index_genes(h, tx_gene, &ngenes) == PA_OK && ngenes >= 1 && pa_host_index_gene_name(h, 0) != NULL);
+    const uint64_t counts_len = (uint64_t)flat.num_classes + 3;
+    uint64_t* counts = (uint64_t*)calloc(counts_len, 8);
+    uint64_t* gene_counts = (uint64_t*)calloc(ngenes + 1, 8);
+    counts[0] = 5;
+    EXPECT(pa_counts_collapse_genes(h, counts, counts_len, gene_counts) == PA_OK);
+    uint64_t* mult = (uint64_t*)calloc((size_t)ntx * PA_MAPPABILITY_COUNTS_LEN, 8);
+    EXPECT(pa_host_index_mappability(h, mult, NULL) == PA_OK);
+    snprintf(path, sizeof path, "%s/abi_check_mappability.tsv", dir);
+    EXPECT(pa_write_mappability_tsv(h, path) == PA_OK);
+    const uint64_t *packed = NULL, *tx_start = NULL;
+    uint32_t ntx2 = 0;
+    EXPECT(pa_host_index_transcripts(h, &packed, &tx_start, &ntx2) == PA_OK && ntx2 == ntx);
+    EXPECT(pa_host_index_build_packed(packed, tx_start, ntx2, 20, 1, &h4) == PA_OK);
+    EXPECT(pa_host_index_compare(h, h4, 1u << 20, report, sizeof report) == 0);
+
+    const uint8_t ascii[] = "ACGTACGTACGTTTGACCAGTNNAC";
+    const uint64_t offsets[3] = {0, 12, 25};
+    const uint32_t wpr = pa_words_per_read(13);
+    EXPECT(wpr == 1 && pa_tiles_words(2, wpr) == 64);
+    uint64_t tiles[64];
+    uint32_t lens[2];
+    EXPECT(pa_encode_reads_host(ascii, offsets, 2, wpr, tiles, lens) == PA_OK && lens[0] == 12 && lens[1] == 13);
+
+    pa_txome *tx = NULL, *tx2 = NULL, *tx3 = NULL;
+    EXPECT(pa_txome_synthesize(50, 120, 7, &tx) == PA_OK);
+    EXPECT(pa_txome_from_host_index(h, &tx2) == PA_OK);
+    EXPECT(pa_txome_from_fasta(fasta, &tx3) == PA_OK);
+    EXPECT(pa_txome_view(tx2, &packed, &tx_start, &ntx2) == PA_OK && ntx2 == ntx);
+    const uint64_t nsim = 256;
+    const uint32_t sim_wpr = pa_words_per_read(60);
+    uint64_t* sim_tiles = (uint64_t*)calloc(pa_tiles_words(nsim, sim_wpr), 8);
+    uint32_t* sim_lens = (uint32_t*)calloc(nsim, 4);
+    EXPECT(pa_simulate_reads_host(tx2, 60, 1, 10000, 0, nsim, sim_wpr, sim_tiles, sim_lens) == PA_OK && sim_lens[0] == 60);
+
+    const uint32_t ovf_a[] = {1, 7, 2, 3, 0, 4, 9}, ovf_b[] = {1, 7, 2, 1, 0, 4, 9};
+    const uint32_t* bufs[2] = {ovf_a, ovf_b};
+    const uint64_t nwords[2] = {7, 7};
+    uint32_t merged[16];
+    uint64_t merged_words = 0;
+    EXPECT(pa_overflow_merge(bufs, nwords, 2, merged, 16, &merged_words) == PA_OK && merged_words == 7 && merged[3] == 4);
+
+    /* ---- device half: with a GPU it runs, without one every entry point refuses (there is no CPU fallback) ---- */
+    pa_index* idx = NULL;
+    int rc = pa_index_create(&flat, 0, &idx);
+    if (ndev < 1) {
+        void *p = NULL, *ev = NULL;
+        pa_overflow* o = NULL;
+        pa_txome_device* td = NULL;
+        EXPECT(rc == PA_ERR_NO_DEVICE && idx == NULL);
+        EXPECT(pa_device_malloc(0, 64, &p) == PA_ERR_NO_DEVICE);
+        EXPECT(pa_overflow_create(0, 16, 64, &o) == PA_ERR_NO_DEVICE);
+        EXPECT(pa_txome_upload(tx2, 60, 0, &td) == PA_ERR_NO_DEVICE);
+        EXPECT(pa_event_create(&ev) < 0);
+        printf("abi_check: host half ok, no device: %d failures\n", failures);
+    } else {
+        EXPECT(rc == PA_OK && idx);
+        pa_index_stats st;
+        EXPECT(pa_index_get_stats(idx, &st) == PA_OK && st.k == 20 && st.num_nodes == flat.num_nodes);
+        EXPECT(pa_counts_len(idx) == counts_len);
+        /* single reads and host batches */
+        const char* ex1 = "GGCTGTCAACCAGTCCATAGGCAGGGCCATCAGGCACCAAAGGGATTCTGCCAGCATAGT";
+        uint32_t cls[64], ncls = 0, cov = 0, mm = 0, nodes[256], nn = 0;
+        rc = pa_map_read(idx, (const uint8_t*)ex1, 60, cls, 64, &ncls, &cov);
+        EXPECT(rc == 0 || (rc == 1 && cov <= 60));
+        EXPECT(pa_map_read_with_mismatch(idx, (const uint8_t*)ex1, 60, 2, cls, 64, &ncls, &cov, &mm) >= 0);
+        EXPECT(pa_map_read_to_nodes(idx, (const uint8_t*)ex1, 60, 2, nodes, 256, &nn, &cov, &mm) >= 0);
+        pa_read_result res[2];
+        uint64_t coff[3];
+        const uint32_t* cids = NULL;
+        EXPECT(pa_map_batch(idx, ascii, offsets, 2, 2, res, coff, &cids) == PA_OK);
+        uint32_t nodes_flat[2 * 64], nodes_len[2];
+        EXPECT(pa_map_batch_nodes(idx, ascii, offsets, 2, 2, res, nodes_flat, 64, nodes_len) == PA_OK);
+        snprintf(path, sizeof path, "%s/abi_check_tuples.txt", dir);
+        uint64_t nreads = 0, nflag = 0;
+        EXPECT(pa_process_reads(idx, fastq, path, 2, &nreads, &nflag) == PA_OK && nreads > 0);
+        /* device-resident batch: simulate on the device, map with the fused count table, overflow table, RCCL world of one */
+        pa_txome_device* td = NULL;
+        EXPECT(pa_txome_upload(tx2, 60, 0, &td) == PA_OK);
+        void *d_tiles = NULL, *d_lens = NULL, *d_res = NULL, *d_arena = NULL, *d_counts = NULL, *d_colour = NULL, *d_ascii = NULL, *d_off = NULL;
+        const uint64_t arena_cap = pa_map_arena_hint(idx, nsim);
+        EXPECT(pa_device_malloc(0, pa_tiles_words(nsim, sim_wpr) * 8, &d_tiles) == PA_OK);
+        EXPECT(pa_device_malloc(0, nsim * 4, &d_lens) == PA_OK && pa_device_malloc(0, nsim * sizeof(pa_read_result), &d_res) == PA_OK);
+        EXPECT(pa_device_malloc(0, arena_cap * 4, &d_arena) == PA_OK && pa_device_malloc(0, counts_len * 8, &d_counts) == PA_OK);
+        EXPECT(pa_device_malloc(0, nsim * 4, &d_colour) == PA_OK && pa_device_malloc(0, 64, &d_ascii) == PA_OK && pa_device_malloc(0, 64, &d_off) == PA_OK);
+        EXPECT(pa_memset_device(d_counts, 0, counts_len * 8, NULL) == PA_OK);
+        void *ev0 = NULL, *ev1 = NULL;
+        float ms = -1.0f;
+        EXPECT(pa_event_create(&ev0) == PA_OK && pa_event_create(&ev1) == PA_OK);
+        EXPECT(pa_simulate_reads_device(td, 1, 10000, 0, nsim, sim_wpr, (uint64_t*)d_tiles, (uint32_t*)d_lens, NULL) == PA_OK);
+        pa_overflow* ovf = NULL;
+        EXPECT(pa_overflow_create(0, 1024, 1 << 16, &ovf) == PA_OK && pa_index_set_overflow(idx, ovf) == PA_OK);
+        EXPECT(pa_event_record(ev0, NULL) == PA_OK);
+        EXPECT(pa_map_count_batch_device(idx, (const uint64_t*)d_tiles, (const uint32_t*)d_lens, nsim, sim_wpr, 2, (pa_read_result*)d_res,
+                                         (uint32_t*)d_arena, arena_cap, (uint64_t*)d_counts, NULL) == PA_OK);
+        EXPECT(pa_event_record(ev1, NULL) == PA_OK);
+        uint64_t used = 0, need = 0;
+        EXPECT(pa_map_finish(idx, NULL, &used, &need) == PA_OK);
+        EXPECT(pa_event_elapsed_ms(ev0, ev1, &ms) == PA_OK && ms >= 0.0f);
+        EXPECT(pa_map_batch_device(idx, (const uint64_t*)d_tiles, (const uint32_t*)d_lens, nsim, sim_wpr, 2, (pa_read_result*)d_res, (uint32_t*)d_arena,
+                                   arena_cap, (uint32_t*)d_colour, NULL) == PA_OK);
+        EXPECT(pa_map_finish(idx, NULL, &used, &need) == PA_OK);
+        EXPECT(pa_counts_accumulate_device(idx, (const pa_read_result*)d_res, (const uint32_t*)d_arena, (const uint32_t*)d_colour, nsim, (uint64_t*)d_counts, NULL) == PA_OK);
+        EXPECT(pa_stream_synchronize(NULL) == PA_OK);
+        uint64_t* h_counts = (uint64_t*)calloc(counts_len, 8);
+        EXPECT(pa_memcpy_d2h(h_counts, d_counts, counts_len * 8, NULL) == PA_OK);
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < counts_len; ++i) total += h_counts[i];
+        EXPECT(total == 2 * nsim);                                   /* counted once by the fused launch, once by the count kernel */
+        const uint32_t* words = NULL;
+        uint64_t nw = 0;
+        EXPECT(pa_overflow_fetch(ovf, NULL, &words, &nw) == PA_OK && nw >= 2 && words[1] == nw);
+        uint8_t id[128];
+        pa_comm* comm = NULL;
+        if (pa_comm_unique_id(id) == PA_OK) {                        /* RCCL present: a world of one */
+            EXPECT(pa_comm_create(0, 1, 0, id, &comm) == PA_OK && pa_comm_rank(comm) == 0 && pa_comm_size(comm) == 1);
+            EXPECT(pa_counts_allreduce(idx, (uint64_t*)d_counts, comm, NULL) == PA_OK);
+            EXPECT(pa_overflow_allgather(ovf, comm, NULL, &words, &nw) == PA_OK && words[1] == nw);
+            pa_comm_destroy(comm);
+        } else {
+            EXPECT(pa_counts_allreduce(idx, (uint64_t*)d_counts, NULL, NULL) == PA_OK);
+            EXPECT(pa_overflow_allgather(ovf, NULL, NULL, &words, &nw) == PA_OK);
+            EXPECT(pa_comm_rank(NULL) == 0 && pa_comm_size(NULL) == 1);
+        }
+        EXPECT(pa_overflow_reset(ovf, NULL) == PA_OK && pa_index_set_overflow(idx, NULL) == PA_OK);
+        pa_overflow_destroy(ovf);
+        /* the encode kernel */
+        EXPECT(pa_memcpy_h2d(d_ascii, ascii, 25, NULL) == PA_OK && pa_memcpy_h2d(d_off, offsets, 24, NULL) == PA_OK);
+        EXPECT(pa_encode_reads_device(idx, (const uint8_t*)d_ascii, (const uint64_t*)d_off, 2, wpr, (uint64_t*)d_tiles, (uint32_t*)d_lens, NULL) == PA_OK);
+        uint64_t t2[64];
+        EXPECT(pa_memcpy_d2h(t2, d_tiles, sizeof t2, NULL) == PA_OK && memcmp(t2, tiles, sizeof t2) == 0);
+        EXPECT(pa_event_destroy(ev0) == PA_OK && pa_event_destroy(ev1) == PA_OK);
+        void* bufs_d[] = {d_tiles, d_lens, d_res, d_arena, d_counts, d_colour, d_ascii, d_off};
+        for (size_t i = 0; i < sizeof bufs_d / sizeof *bufs_d; ++i) EXPECT(pa_device_free(bufs_d[i]) == PA_OK);
+        pa_txome_device_destroy(td);
+        pa_index_destroy(idx);
+        free(h_counts);
+        printf("abi_check: host and device halves ok on %d device(s): %d failures\n", ndev, failures);
+    }
+    pa_txome_destroy(tx);
+    pa_txome_destroy(tx2);
+    pa_txome_destroy(tx3);
+    pa_host_index_destroy(h);
+    pa_host_index_destroy(h2);
+    pa_host_index_destroy(h3);
+    pa_host_index_destroy(h4);
+    free(tx_gene); free(counts); free(gene_counts); free(mult); free(sim_tiles); free(sim_lens);
+    return failures ? 1 : 0;
+}

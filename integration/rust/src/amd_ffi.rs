@@ -1,0 +1,86 @@
+//! `extern "C"` binding of include/pseudoaligner_amd.h — the part of the C ABI a Rust host needs for
+//! `Pseudoaligner::map_read` / `process_reads` (src/pseudoaligner.rs:381-384, :420-514), the fused class-count table and the
+//! reduction over GPUs. Field order and widths mirror the header exactly; `integration/c/abi_check.c` compiles the same
+//! declarations from C against the header (this file cannot be compiled in the image of this repository: no rustc).
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const PA_OK: c_int = 0;
+pub const PA_ERR_ARENA_FULL: c_int = -7;
+pub const PA_MAPPED_BIT: u32 = 0x8000_0000;
+pub const PA_CLASS_REF: u32 = 0x8000_0000;
+pub const PA_MAX_ARENA_ENTRIES: u64 = 0x7FFF_FFFF;
+
+#[repr(C)]
+pub struct PaFlatIndex {            // pa_flat_index
+    pub k: u32, pub num_nodes: u32, pub num_classes: u32, pub num_transcripts: u32,
+    pub seq_bases: u64,
+    pub node_seq: *const u64, pub node_start: *const u64, pub node_len: *const u32,
+    pub node_exts: *const u8, pub node_colour: *const u32,
+    pub ec_offset: *const u64, pub ec_ids: *const u32,
+    pub node_redge: *const u32, pub node_ledge: *const u32,   // may be null: the library derives the edges
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default, Debug)]
+pub struct PaReadResult { pub coverage: u32, pub mismatches: u32, pub class_off: u32, pub class_len: u32 }
+
+#[repr(C)] pub struct PaIndex { _private: [u8; 0] }
+#[repr(C)] pub struct PaHostIndex { _private: [u8; 0] }
+#[repr(C)] pub struct PaOverflow { _private: [u8; 0] }
+#[repr(C)] pub struct PaComm { _private: [u8; 0] }
+
+extern "C" {
+    pub fn pa_abi_version() -> u32;
+    pub fn pa_last_error() -> *const c_char;
+    pub fn pa_device_count() -> c_int;
+
+    // index: flat form of `pub struct Pseudoaligner<K>` (src/pseudoaligner.rs:26-33) -> GPU
+    pub fn pa_index_create(flat: *const PaFlatIndex, device: c_int, out: *mut *mut PaIndex) -> c_int;
+    pub fn pa_index_destroy(idx: *mut PaIndex);
+    pub fn pa_host_index_from_flat(flat: *const PaFlatIndex, out: *mut *mut PaHostIndex) -> c_int;
+    pub fn pa_host_index_build_fasta(fasta_path: *const c_char, k: u32, num_threads: c_int, out: *mut *mut PaHostIndex) -> c_int;
+    pub fn pa_host_index_save(h: *const PaHostIndex, path: *const c_char) -> c_int;
+    pub fn pa_host_index_compare(a: *const PaHostIndex, b: *const PaHostIndex, max_kmers: u64, report: *mut c_char, report_cap: usize) -> c_int;
+    pub fn pa_host_index_destroy(h: *mut PaHostIndex);
+
+    // map_read / process_reads
+    pub fn pa_map_batch(idx: *mut PaIndex, ascii: *const u8, offsets: *const u64, n_reads: u64, allowed_mismatches: u32,
+                        results: *mut PaReadResult, class_offsets: *mut u64, class_ids: *mut *const u32) -> c_int;
+    pub fn pa_map_read(idx: *mut PaIndex, ascii: *const u8, len: u32, class_buf: *mut u32, class_cap: u32,
+                       class_len: *mut u32, coverage: *mut u32) -> c_int;
+    pub fn pa_map_read_with_mismatch(idx: *mut PaIndex, ascii: *const u8, len: u32, allowed_mismatches: u32, class_buf: *mut u32,
+                                     class_cap: u32, class_len: *mut u32, coverage: *mut u32, mismatches: *mut u32) -> c_int;
+    pub fn pa_process_reads(idx: *mut PaIndex, fastq_path: *const c_char, out_path: *const c_char, num_threads: c_int,
+                            n_reads: *mut u64, n_flagged: *mut u64) -> c_int;
+
+    // device-resident batches + the fused class-count table
+    pub fn pa_words_per_read(max_read_len: u32) -> u32;
+    pub fn pa_tiles_words(n_reads: u64, words_per_read: u32) -> usize;
+    pub fn pa_encode_reads_device(idx: *const PaIndex, d_ascii: *const u8, d_offsets: *const u64, n_reads: u64, words_per_read: u32,
+                                  d_tiles: *mut u64, d_lens: *mut u32, stream: *mut c_void) -> c_int;
+    pub fn pa_map_count_batch_device(idx: *mut PaIndex, d_tiles: *const u64, d_lens: *const u32, n_reads: u64,
+                                     words_per_read: u32, allowed_mismatches: u32, d_results: *mut PaReadResult,
+                                     d_arena: *mut u32, arena_cap: u64, d_counts: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn pa_map_finish(idx: *mut PaIndex, stream: *mut c_void, arena_used: *mut u64, arena_needed: *mut u64) -> c_int;
+    pub fn pa_map_arena_hint(idx: *const PaIndex, n_reads: u64) -> u64;
+    pub fn pa_counts_len(idx: *const PaIndex) -> u64;
+
+    // novel classes + the reduction over GPUs
+    pub fn pa_overflow_create(device: c_int, max_classes: u64, max_ids: u64, out: *mut *mut PaOverflow) -> c_int;
+    pub fn pa_overflow_destroy(ovf: *mut PaOverflow);
+    pub fn pa_index_set_overflow(idx: *mut PaIndex, ovf: *mut PaOverflow) -> c_int;
+    pub fn pa_overflow_fetch(ovf: *mut PaOverflow, stream: *mut c_void, words: *mut *const u32, n_words: *mut u64) -> c_int;
+    pub fn pa_comm_unique_id(id: *mut u8) -> c_int;                               // 128 bytes
+    pub fn pa_comm_create(device: c_int, nranks: c_int, rank: c_int, id: *const u8, out: *mut *mut PaComm) -> c_int;
+    pub fn pa_comm_destroy(comm: *mut PaComm);
+    pub fn pa_counts_allreduce(idx: *mut PaIndex, d_counts: *mut u64, comm: *mut PaComm, stream: *mut c_void) -> c_int;
+    pub fn pa_overflow_allgather(ovf: *mut PaOverflow, comm: *mut PaComm, stream: *mut c_void, words: *mut *const u32, n_words: *mut u64) -> c_int;
+
+    // plumbing for hosts without a HIP binding of their own
+    pub fn pa_device_malloc(device: c_int, bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn pa_device_free(p: *mut c_void) -> c_int;
+    pub fn pa_memcpy_h2d(dst: *mut c_void, src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn pa_memcpy_d2h(dst: *mut c_void, src: *const c_void, bytes: usize, stream: *mut c_void) -> c_int;
+    pub fn pa_memset_device(dst: *mut c_void, value: c_int, bytes: usize, stream: *mut c_void) -> c_int;
+}

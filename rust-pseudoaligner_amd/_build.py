@@ -48,6 +48,19 @@ def build_product(force: bool = False) -> Path:
     return PRODUCT_SO
 
 
+ABI_CHECK_SRC = ROOT / "integration" / "c" / "abi_check.c"
+ABI_CHECK_BIN = ROOT / "integration" / "c" / "abi_check"
+
+
+def build_abi_check(force: bool = False) -> Path:
+    """gcc -Wall -Werror: the plain-C client that calls every entry point of include/pseudoaligner_amd.h (type check of the
+    header from C; the tests run it)"""
+    if force or _stale(ABI_CHECK_BIN, [ABI_CHECK_SRC, ROOT / "include" / "pseudoaligner_amd.h", PRODUCT_SO]):
+        _run(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"), str(ABI_CHECK_SRC), "-L", str(PKG),
+              "-lpseudoaligner_amd", "-Wl,-rpath," + str(PKG), "-Wl,-rpath,$ORIGIN/../../rust-pseudoaligner_amd", "-o", str(ABI_CHECK_BIN)])
+    return ABI_CHECK_BIN
+
+
 if __name__ == "__main__":
     import sys
     print(build_product("--force" in sys.argv))

@@ -106,3 +106,31 @@ def test_counts_reference_definition(small_index):
     counts = helpers.counts_reference(res, coff, cids, host)
     nc = host.arrays()["num_classes"]
     assert counts.sum() == 2000 and counts[nc + 2] == int((res["mapped"] == 0).sum())
+
+
+def _header_functions():
+    import re
+    h = (helpers.ROOT / "include" / "pseudoaligner_amd.h").read_text()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(m.group(1) for m in re.finditer(r"\b(pa_\w+)\s*\([^;{]*\)\s*;", h)))
+
+
+def test_c_client_calls_every_entry_point(built, tmp_path):
+    """integration/c/abi_check.c: compiled with gcc -Wall -Werror against the header (a prototype that drifts from what a
+    foreign binding assumes does not build) and run: host half everywhere, device half on a GPU box"""
+    import re
+    import subprocess
+    exe = helpers._build.build_abi_check()
+    src = (helpers.ROOT / "integration" / "c" / "abi_check.c").read_text()
+    missing = [f for f in _header_functions() if f + "(" not in src]
+    assert not missing, "abi_check.c does not call: %s" % missing
+    rust = (helpers.ROOT / "integration" / "rust" / "src" / "amd_ffi.rs").read_text()
+    unknown = [f for f in re.findall(r"pub fn (pa_\w+)\(", rust) if f not in _header_functions()]
+    assert not unknown, "amd_ffi.rs binds symbols the header does not declare: %s" % unknown
+    out = subprocess.run([str(exe), str(helpers.FASTA), str(helpers.FASTQ), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 failures" in out.stdout
+    if pa.lib().pa_device_count() < 1:
+        assert "no device" in out.stdout
+    else:
+        assert "device halves ok" in out.stdout

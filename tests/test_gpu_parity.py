@@ -466,3 +466,12 @@ def test_rccl_world_of_one_reduces_counts_and_overflow(aligners):
     want = helpers.novel_reference(o_res, o_coff, o_ids, a.host)
     assert pa.parse_overflow(gathered) == want and sum(want.values()) == int(before[-3]) > 0
     a.set_overflow(None)
+
+
+def test_c_client_of_the_header_runs_its_device_half(tmp_path):
+    """integration/c/abi_check.c (plain C, every entry point of the header once) on the GPU: maps, counts, overflow table, RCCL
+    world of one, encode kernel — the call sequence a Rust host would make, without Python in between"""
+    import subprocess
+    exe = helpers._build.build_abi_check()
+    out = subprocess.run([str(exe), str(helpers.FASTA), str(helpers.FASTQ), str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "device halves ok" in out.stdout and "0 failures" in out.stdout, out.stdout + out.stderr
