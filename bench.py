@@ -66,6 +66,7 @@ def main() -> None:
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg (pinned tiles -> records on the host), an extra report at N=1")
     ap.add_argument("--separate-count", action="store_true", help="class counts in their own kernel instead of fused into the map kernel")
     ap.add_argument("--index-cache", default="", help="optional path to save/load the host index container")
     args = ap.parse_args()
@@ -103,6 +104,19 @@ def main() -> None:
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    # the reduce of the count table goes through the PRODUCT's collective (pa_counts_allreduce: RCCL over xGMI, communicator
+    # owned by the library; the 128-byte id travels over torch.distributed's store, which is only the bootstrap here).
+    # torch.distributed.all_reduce (the same RCCL underneath) is the spare if the library cannot open a communicator.
+    comm = None
+    if world > 1 and backend == "nccl":
+        try:
+            box = [pa.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = pa.Comm(local_rank, world, rank, box[0])
+        except Exception as e:   # noqa: BLE001
+            log("pa_comm_create failed (%r): reducing through torch.distributed" % (e,))
+            comm = None
 
     wl = WORKLOADS[args.workload]
     k, read_len, ppm = wl["k"], wl["read_len"], wl["ppm"]
@@ -194,8 +208,10 @@ def main() -> None:
     t_start = time.perf_counter()
     for i in range(K):
         used, _ = step(W + i, i)
-    if dist is not None:
-        dist.all_reduce(counts)          # RCCL reduce of the eq-class count table over xGMI
+    if comm is not None:
+        aligner.counts_allreduce(counts.data_ptr(), comm, stream)   # RCCL reduce of the eq-class count table over xGMI (product ABI)
+    elif dist is not None:
+        dist.all_reduce(counts)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -223,8 +239,62 @@ def main() -> None:
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "reads_per_step_per_gpu": B, "read_len": read_len, "k": k,
                    "transcripts": txome.num_transcripts, "kmers": int(st.num_kmers), "index_bytes": int(st.bytes_total),
-                   "parallelism": "reads sharded over %d GPU(s), index replicated, RCCL all-reduce of class counts" % n_gpus},
+                   "parallelism": "reads sharded over %d GPU(s), index replicated, RCCL all-reduce of class counts (%s)" %
+                                  (n_gpus, "pa_counts_allreduce" if comm is not None else "torch.distributed" if world > 1 else "one GPU: no reduce")},
     }
+
+    # ---- SURVEY §8d's wall-clock leg (extra keys, never `value`): the same batch from PINNED HOST tiles to per-read records +
+    # count table back on the host. Chunks alternate between two streams of the one index handle: H2D of chunk i+1 and D2H
+    # of chunk i-1 overlap the kernel of chunk i; the link (PCIe Gen5 x16, 63 GB/s per direction), not the kernel, bounds it.
+    if n_gpus == 1 and not args.no_e2e:
+        try:
+            b = W % n_batches
+            chunk = min(B, 10_000_000)
+            n_chunks = (B + chunk - 1) // chunk
+            words = pa.lib().pa_tiles_words
+            h_tiles = torch.empty(tile_words, dtype=torch.int64, pin_memory=True)
+            h_lens = torch.empty(B, dtype=torch.int32, pin_memory=True)
+            h_results = torch.empty(B * 4, dtype=torch.int32, pin_memory=True)
+            h_counts = torch.empty(aligner.counts_len(), dtype=torch.int64, pin_memory=True)
+            h_tiles.copy_(tiles[b]); h_lens.copy_(lens[b])
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            stage = [dict(tiles=torch.empty(words(chunk, wpr), dtype=torch.int64, device=dev), lens=torch.empty(chunk, dtype=torch.int32, device=dev),
+                          res=torch.empty(chunk * 4, dtype=torch.int32, device=dev), arena=torch.empty(aligner.arena_hint(chunk), dtype=torch.int32, device=dev),
+                          busy=False) for _ in range(2)]
+            e_counts = torch.zeros(aligner.counts_len(), dtype=torch.int64, device=dev)
+            arena_ids = 0
+            torch.cuda.synchronize()
+            t_e2e = time.perf_counter()
+            for c in range(n_chunks):
+                st, S = stage[c % 2], streams[c % 2]
+                lo, nn = c * chunk, min(chunk, B - c * chunk)          # chunk is a multiple of 64: tile aligned
+                if st["busy"]:
+                    arena_ids += aligner.map_finish(S.cuda_stream)[0]   # the stream's previous chunk is done (its records are on the host)
+                with torch.cuda.stream(S):
+                    st["tiles"][: words(nn, wpr)].copy_(h_tiles[(lo // 64) * wpr * 64: (lo // 64) * wpr * 64 + words(nn, wpr)], non_blocking=True)
+                    st["lens"][:nn].copy_(h_lens[lo: lo + nn], non_blocking=True)
+                    aligner.map_count_batch_device(st["tiles"].data_ptr(), st["lens"].data_ptr(), nn, wpr, st["res"].data_ptr(), st["arena"].data_ptr(),
+                                                   st["arena"].numel(), e_counts.data_ptr(), 2, S.cuda_stream)
+                    h_results[lo * 4: (lo + nn) * 4].copy_(st["res"][: nn * 4], non_blocking=True)
+                st["busy"] = True
+            for i in range(2):
+                if stage[i]["busy"]:
+                    arena_ids += aligner.map_finish(streams[i].cuda_stream)[0]
+            h_counts.copy_(e_counts)
+            torch.cuda.synchronize()
+            e2e_s = time.perf_counter() - t_e2e
+            assert os.environ.get("PA_MAP_ABLATE") or int(h_counts.sum()) == B
+            h2d_bytes = B * (wpr * 8 + 4)
+            out["e2e_reads_per_s"] = B / e2e_s
+            out["e2e_pcie_frac"] = h2d_bytes / e2e_s / 63e9
+            out["e2e"] = {"ms": 1000.0 * e2e_s, "chunks": n_chunks, "reads_per_chunk": chunk, "streams": 2, "h2d_bytes": h2d_bytes,
+                          "d2h_bytes": B * 16 + 8 * aligner.counts_len(), "novel_class_ids_left_on_device": int(arena_ids),
+                          "what": "pinned host 2-bit tiles -> H2D || kernel || D2H of the 16-byte records on two streams of one index handle "
+                                  "-> records + count table on the host; link = PCIe Gen5 x16, 63 GB/s per direction"}
+            del h_tiles, h_lens, h_results, stage
+        except Exception as e:   # the leg is a report, not the benchmark: never lose the bench line over it
+            log("e2e leg failed: %r" % (e,))
+            out["e2e_error"] = repr(e)
 
     if rank == 0:
         # ---- checker + CPU baseline (oracle = C port of the reference path), outside the timed region ----

@@ -191,9 +191,11 @@ int pa_encode_reads_host(const uint8_t* ascii, const uint64_t* offsets, uint64_t
  *   d_arena    [arena_cap] u32: ids of the classes that are not index classes, referenced by (class_off, class_len)
  *   d_colour   optional [n_reads] u32: equivalence-class id of the result when it equals an index class
  *              reached by the read, 0xFFFFFFFF otherwise (input of pa_counts_accumulate_device); may be NULL
- * Asynchronous on `stream`; completion status is fetched with pa_map_finish (which synchronises the stream). Launches on
- * ONE index handle share its control block and scratch: issue them on one stream, or call pa_map_finish in between
- * (several handles are independent). */
+ * Asynchronous on `stream`; completion status is fetched with pa_map_finish(idx, stream, ...) (which synchronises that
+ * stream). The index is immutable and shareable: launches on DIFFERENT streams — from one host thread or several — run
+ * concurrently (every stream gets its own control block, spill rows and count replicas inside the handle; two launches may
+ * accumulate into one d_counts). Launches on ONE stream are ordered by the stream and share a control block: call
+ * pa_map_finish between them if you need each launch's own status / arena use. */
 int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads,
                         uint32_t words_per_read, uint32_t allowed_mismatches, pa_read_result* d_results,
                         uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour, void* stream);

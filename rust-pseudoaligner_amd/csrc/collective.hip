@@ -40,9 +40,7 @@ struct pa_overflow {
     unsigned long long* d_keys = nullptr;
     uint32_t* d_meta = nullptr;
     uint32_t* d_pool = nullptr;
-    unsigned long long* d_ctl = nullptr;   // [0] pool top, [1] status, [2] export cursor, [3] entries, [4] novel-list length of the launch in flight
-    uint32_t* d_novel = nullptr;           // {arena offset, length} of every novel result of the launch in flight
-    uint64_t novel_cap = 0;                // pairs
+    unsigned long long* d_ctl = nullptr;   // [0] pool top, [1] status, [2] export cursor, [3] entries
     uint32_t* d_export = nullptr;          // serialised records (export_cap u32)
     uint64_t export_cap = 0;
     std::vector<uint32_t> h_export, h_merged;
@@ -215,26 +213,13 @@ struct pa_comm {
 // hooks for device_index.hip: what the map launch needs to know about an attached overflow table
 namespace pa {
 
-int overflow_prepare_launch(pa_overflow* o, uint64_t n_reads, MapParams& p, hipStream_t stream) {
-    const uint64_t want = n_reads / 4 + 4096;
-    if (o->novel_cap < want) {
-        if (o->d_novel) HIP_TRY(hipFree(o->d_novel));
-        o->d_novel = nullptr;
-        o->novel_cap = 0;
-        HIP_TRY(hipMalloc(&o->d_novel, want * 8));
-        o->novel_cap = want;
-    }
-    HIP_TRY(hipMemsetAsync(o->d_ctl + 4, 0, 8, stream));
-    p.novel_list = o->d_novel;
-    p.novel_ctr = o->d_ctl + 4;
-    p.novel_status = o->d_ctl + 1;
-    p.novel_cap = o->novel_cap;
-    return PA_OK;
-}
+void overflow_launch_params(pa_overflow* o, MapParams& p) { p.novel_status = o->d_ctl + 1; }
 
-int overflow_after_map(pa_overflow* o, const uint32_t* d_arena, hipStream_t stream) {
-    hipLaunchKernelGGL(pa_overflow_insert_kernel, dim3(1024), dim3(256), 0, stream, o->d_novel, o->d_ctl + 4, o->novel_cap, d_arena, o->d_keys,
-                       o->d_meta, o->d_pool, o->d_ctl, o->cap, o->pool_cap);
+// files the novel results a launch listed (per stream: device_index.hip) in the table; same stream, right behind the launch
+int overflow_after_map(pa_overflow* o, const uint32_t* novel_list, const unsigned long long* novel_ctr, uint64_t novel_cap, const uint32_t* d_arena,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(pa_overflow_insert_kernel, dim3(1024), dim3(256), 0, stream, novel_list, novel_ctr, novel_cap, d_arena, o->d_keys, o->d_meta,
+                       o->d_pool, o->d_ctl, o->cap, o->pool_cap);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(PA_ERR_HIP, "overflow insert launch: %s", hipGetErrorString(e));
     return PA_OK;
@@ -280,7 +265,7 @@ int pa_overflow_create(int device, uint64_t max_classes, uint64_t max_ids, pa_ov
 void pa_overflow_destroy(pa_overflow* o) {
     if (!o) return;
     (void)hipSetDevice(o->device);
-    for (void* p : {(void*)o->d_keys, (void*)o->d_meta, (void*)o->d_pool, (void*)o->d_ctl, (void*)o->d_novel, (void*)o->d_export})
+    for (void* p : {(void*)o->d_keys, (void*)o->d_meta, (void*)o->d_pool, (void*)o->d_ctl, (void*)o->d_export})
         if (p) (void)hipFree(p);
     delete o;
 }

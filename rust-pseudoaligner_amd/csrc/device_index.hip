@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -49,6 +51,15 @@ uint64_t list_hash_host(const uint32_t* v, uint32_t n) {   // must equal list_ha
 
 }  // namespace
 
+struct LaunchCtx {
+    std::mutex mu;
+    DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status, [12..15] tile counter, [16..] statistics, [448..455] novel results listed
+    DevBuf spill, trace, xcd_counts, novel;
+    uint32_t last_grid = 0;
+    uint64_t last_arena_cap = 0;
+    void release() { for (DevBuf* b : {&ctl, &spill, &trace, &xcd_counts, &novel}) b->release(); }
+};
+
 struct pa_index {
     int device = 0;
     int num_cus = 0;
@@ -57,13 +68,12 @@ struct pa_index {
          *d_class_table = nullptr, *d_wtable = nullptr;
     uint64_t class_table_size = 0;
     pa_index_stats stats{};
-    // per-launch scratch (one batch in flight per index handle; calls are serialised by `mu`)
-    std::mutex mu;
-    DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status, [12..15] tile counter, [16..] statistics
-    DevBuf spill, trace, xcd_counts;
-    uint32_t last_grid = 0;
-    uint64_t last_arena_cap = 0;
+    // per-launch scratch: one context per stream the caller launches on, so that launches on different streams (from one or
+    // several host threads) run concurrently; launches on ONE stream share a context and are ordered by the stream
+    std::mutex mu;                // guards `ctxs` and `ovf`
+    std::map<hipStream_t, std::unique_ptr<LaunchCtx>> ctxs;
     pa_overflow* ovf = nullptr;   // attached overflow table of novel classes (collective.hip), not owned
+    std::mutex hmu;               // the host-buffer convenience path (b_* below) is one batch at a time
     // host-buffer convenience path
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
     std::vector<uint32_t> h_class_ids;
@@ -111,7 +121,8 @@ void pa_index_destroy(pa_index* idx) {
     (void)hipSetDevice(idx->device);
     for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table, idx->d_wtable})
         if (p) (void)hipFree(p);
-    for (DevBuf* b : {&idx->ctl, &idx->spill, &idx->trace, &idx->xcd_counts, &idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
+    for (auto& kv : idx->ctxs) kv.second->release();
+    for (DevBuf* b : {&idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
                       &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})
         b->release();
     delete idx;
@@ -151,7 +162,6 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     if (rc == PA_OK) rc = upload(fd.class_len.data(), fd.class_len.size() * 4, &idx->d_class_len);
     if (rc == PA_OK) rc = upload(ctab.data(), ctab.size() * 4, &idx->d_class_table);
     if (rc == PA_OK) rc = upload(fd.wtable.data(), fd.wtable.size() * 4, &idx->d_wtable);
-    if (rc == PA_OK) rc = idx->ctl.ensure(1024);
     if (rc != PA_OK) { pa_index_destroy(idx); return rc; }
     idx->class_table_size = ctab.size();
     idx->dv = fd.host_view();
@@ -238,7 +248,22 @@ static int pool_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t
     return PA_OK;
 }
 
-static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads, uint32_t wpr,
+// the launch context of a stream (created on first use)
+static int ctx_of(pa_index* idx, hipStream_t stream, LaunchCtx** out) {
+    std::lock_guard<std::mutex> g(idx->mu);
+    auto it = idx->ctxs.find(stream);
+    if (it == idx->ctxs.end()) {
+        std::unique_ptr<LaunchCtx> c(new (std::nothrow) LaunchCtx());
+        if (!c) return fail(PA_ERR_OOM, "out of memory");
+        const int rc = c->ctl.ensure(1024);
+        if (rc != PA_OK) return rc;
+        it = idx->ctxs.emplace(stream, std::move(c)).first;
+    }
+    *out = it->second.get();
+    return PA_OK;
+}
+
+static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads, uint32_t wpr,
                              uint32_t allowed, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour,
                              uint64_t* d_counts, uint32_t* d_nodes, uint32_t* d_nodes_len, hipStream_t stream) {
     if (n_reads >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "at most 2^32-2 reads per batch");
@@ -250,10 +275,10 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     if (rc != PA_OK) return rc;
     const uint32_t spill_cap = spill_cap_of(wpr);
     const size_t lanes = (size_t)grid * (PA_MAP_BLOCK / 64) * slots;
-    rc = idx->spill.ensure(lanes * spill_cap * 4);
+    rc = cx->spill.ensure(lanes * spill_cap * 4);
     if (rc != PA_OK) return rc;
-    if (d_nodes) { rc = idx->trace.ensure(lanes * spill_cap * 4); if (rc != PA_OK) return rc; }
-    HIP_TRY(hipMemsetAsync(idx->ctl.p, 0, 512, stream));
+    if (d_nodes) { rc = cx->trace.ensure(lanes * spill_cap * 4); if (rc != PA_OK) return rc; }
+    HIP_TRY(hipMemsetAsync(cx->ctl.p, 0, 512, stream));
     MapParams p{};
     p.ix = idx->dv;
     p.tiles = d_tiles;
@@ -266,62 +291,69 @@ static int map_launch_locked(pa_index* idx, const uint64_t* d_tiles, const uint3
     // bit 31 of class_off means "class by reference" (PA_CLASS_REF): offsets handed out by the arena must stay below 2^31
     p.arena_cap = arena_cap > PA_MAX_ARENA_ENTRIES ? PA_MAX_ARENA_ENTRIES : arena_cap;
     p.colour_out = d_colour;
-    p.arena_top = idx->ctl.as<unsigned long long>();
-    p.status = idx->ctl.as<uint32_t>() + 2;
-    p.tile_ctr = idx->ctl.as<uint32_t>() + 3;
-    p.spill = idx->spill.as<uint32_t>();
+    p.arena_top = cx->ctl.as<unsigned long long>();
+    p.status = cx->ctl.as<uint32_t>() + 2;
+    p.tile_ctr = cx->ctl.as<uint32_t>() + 3;
+    p.spill = cx->spill.as<uint32_t>();
     p.spill_cap = spill_cap;
     p.counts = reinterpret_cast<unsigned long long*>(d_counts);
     const uint64_t counts_len = (uint64_t)idx->stats.num_classes + 3;
     const uint32_t xcd_stride = (uint32_t)((counts_len + 63) / 64 * 64);
     if (d_counts) {   // per-XCD replicas of the table, zero on entry (the fold kernel clears what it adds)
         const size_t need = (size_t)PA_COUNT_REPLICAS * xcd_stride * 4;
-        if (idx->xcd_counts.bytes < need) {
-            rc = idx->xcd_counts.ensure(need);
+        if (cx->xcd_counts.bytes < need) {
+            rc = cx->xcd_counts.ensure(need);
             if (rc != PA_OK) return rc;
-            HIP_TRY(hipMemsetAsync(idx->xcd_counts.p, 0, idx->xcd_counts.bytes, stream));
+            HIP_TRY(hipMemsetAsync(cx->xcd_counts.p, 0, cx->xcd_counts.bytes, stream));
         }
-        p.xcd_counts = idx->xcd_counts.as<uint32_t>();
+        p.xcd_counts = cx->xcd_counts.as<uint32_t>();
         p.xcd_stride = xcd_stride;
     }
     p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
     p.class_table_size = idx->class_table_size;
     p.pool_slots = slots;
-    p.dbg = env_int("PA_MAP_STATS", 0) ? idx->ctl.as<unsigned long long>() + 2 : nullptr;
+    p.dbg = env_int("PA_MAP_STATS", 0) ? cx->ctl.as<unsigned long long>() + 2 : nullptr;
     p.ablate = (uint32_t)env_int("PA_MAP_ABLATE", 0);
-    if (d_counts && idx->ovf) {   // novel results of this launch are listed for the overflow table
-        rc = overflow_prepare_launch(idx->ovf, n_reads, p, stream);
+    pa_overflow* ovf = nullptr;
+    { std::lock_guard<std::mutex> g(idx->mu); ovf = idx->ovf; }
+    if (d_counts && ovf) {   // novel results of this launch are listed (per stream) for the overflow table
+        const uint64_t want = n_reads / 4 + 4096;
+        rc = cx->novel.ensure(want * 8);
         if (rc != PA_OK) return rc;
+        p.novel_list = cx->novel.as<uint32_t>();
+        p.novel_ctr = cx->ctl.as<unsigned long long>() + 56;
+        p.novel_cap = want;
+        overflow_launch_params(ovf, p);
     }
-    p.trace = d_nodes ? idx->trace.as<uint32_t>() : nullptr;
+    p.trace = d_nodes ? cx->trace.as<uint32_t>() : nullptr;
     p.nodes_out = d_nodes;
     p.nodes_len = d_nodes_len;
-    idx->last_grid = grid;
-    idx->last_arena_cap = p.arena_cap;
+    cx->last_grid = grid;
+    cx->last_arena_cap = p.arena_cap;
     if (n_reads == 0) return PA_OK;
     const int e = launch_map_pool(p, grid, lds, stream);
     if (e) return fail(PA_ERR_HIP, "map launch (grid %u, lds %zu): %s", grid, lds, hipGetErrorString((hipError_t)e));
     if (d_counts) {
         const int e2 = launch_counts_fold(p.xcd_counts, p.xcd_stride, p.counts, counts_len, stream);
         if (e2) return fail(PA_ERR_HIP, "count fold launch: %s", hipGetErrorString((hipError_t)e2));
-        if (idx->ovf) {
-            rc = overflow_after_map(idx->ovf, d_arena, stream);
+        if (ovf) {
+            rc = overflow_after_map(ovf, p.novel_list, p.novel_ctr, p.novel_cap, d_arena, stream);
             if (rc != PA_OK) return rc;
         }
     }
     return PA_OK;
 }
 
-static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_used, uint64_t* arena_needed) {
+static int map_finish_locked(pa_index* idx, LaunchCtx* cx, hipStream_t stream, uint64_t* arena_used, uint64_t* arena_needed) {
     HIP_TRY(hipStreamSynchronize(stream));
     struct { unsigned long long top; uint32_t status; uint32_t pad; } ctl;
-    HIP_TRY(hipMemcpy(&ctl, idx->ctl.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&ctl, cx->ctl.p, 16, hipMemcpyDeviceToHost));
     if (env_int("PA_MAP_STATS", 0)) {
         constexpr uint32_t NS = ST_COUNT + 4;   // ST_NSTAT of map_pool.hip: one entry per state, the dual iterations, the forward step in three parts
         unsigned long long d[3 * NS];
-        HIP_TRY(hipMemcpy(d, idx->ctl.as<unsigned long long>() + 2, sizeof d, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(d, cx->ctl.as<unsigned long long>() + 2, sizeof d, hipMemcpyDeviceToHost));
         static const char* names[NS] = {"refill", "seek", "fwd", "left", "pick+pop", "store+push", "fin_light", "fin_scan", "fin_coop", "fin_bits", "fin_novel", "fwd+seek", "fwd:issue", "fwd:wait", "fwd:wait+compute"};
-        fprintf(stderr, "[pa map stats] grid=%u", idx->last_grid);
+        fprintf(stderr, "[pa map stats] grid=%u", cx->last_grid);
         for (uint32_t i = 0; i < NS; ++i)
             if (d[i])
                 fprintf(stderr, " %s: %llu iters x %.1f lanes, %.0f ticks/iter;", names[i], d[i], (double)d[NS + i] / (double)d[i],
@@ -330,7 +362,7 @@ static int map_finish_locked(pa_index* idx, hipStream_t stream, uint64_t* arena_
     }
     // the counter includes every wave's partly used chunk and may run past the caller's arena without any allocation having
     // crossed its end: what may be copied back is min(top, capacity); `needed` is the capacity that would have sufficed
-    if (arena_used) *arena_used = ctl.top < idx->last_arena_cap ? ctl.top : idx->last_arena_cap;
+    if (arena_used) *arena_used = ctl.top < cx->last_arena_cap ? ctl.top : cx->last_arena_cap;
     if (arena_needed) *arena_needed = ctl.top;
     if (ctl.status & PA_STATUS_SPILL_OVERFLOW) return fail(PA_ERR_INTERNAL, "colour spill buffer overflow (should be impossible)");
     if (ctl.status & PA_STATUS_ARENA_FULL) return fail(PA_ERR_ARENA_FULL, "class arena too small: %llu entries needed", ctl.top);
@@ -341,9 +373,12 @@ int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* 
                         uint32_t allowed_mismatches, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap,
                         uint32_t* d_colour, void* stream) {
     if (!idx || (n_reads && (!d_tiles || !d_lens || !d_results || !d_arena))) return fail(PA_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
+    LaunchCtx* cx = nullptr;
+    const int rc0 = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
+    if (rc0 != PA_OK) return rc0;
+    std::lock_guard<std::mutex> g(cx->mu);
     HIP_TRY(hipSetDevice(idx->device));
-    return map_launch_locked(idx, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, d_colour,
+    return map_launch_locked(idx, cx, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, d_colour,
                              nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -351,17 +386,23 @@ int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint
                               uint32_t allowed_mismatches, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap,
                               uint64_t* d_counts, void* stream) {
     if (!idx || !d_counts || (n_reads && (!d_tiles || !d_lens || !d_results || !d_arena))) return fail(PA_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
+    LaunchCtx* cx = nullptr;
+    const int rc0 = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
+    if (rc0 != PA_OK) return rc0;
+    std::lock_guard<std::mutex> g(cx->mu);
     HIP_TRY(hipSetDevice(idx->device));
-    return map_launch_locked(idx, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, nullptr,
+    return map_launch_locked(idx, cx, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, nullptr,
                              d_counts, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed) {
     if (!idx) return fail(PA_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
+    LaunchCtx* cx = nullptr;
+    const int rc0 = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
+    if (rc0 != PA_OK) return rc0;
+    std::lock_guard<std::mutex> g(cx->mu);
     HIP_TRY(hipSetDevice(idx->device));
-    return map_finish_locked(idx, static_cast<hipStream_t>(stream), arena_used, arena_needed);
+    return map_finish_locked(idx, cx, static_cast<hipStream_t>(stream), arena_used, arena_needed);
 }
 
 uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads) {
@@ -375,7 +416,11 @@ static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* o
                           pa_read_result* results, uint64_t* class_offsets, const uint32_t** class_ids, uint32_t* nodes_flat,
                           uint32_t nodes_stride_cap, uint32_t* nodes_len) {
     if (!idx || !offsets || (n && !ascii) || !results) return fail(PA_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> g(idx->mu);
+    std::lock_guard<std::mutex> hg(idx->hmu);
+    LaunchCtx* cx = nullptr;
+    const int rc0 = ctx_of(idx, nullptr, &cx);
+    if (rc0 != PA_OK) return rc0;
+    std::lock_guard<std::mutex> g(cx->mu);
     HIP_TRY(hipSetDevice(idx->device));
     uint64_t maxlen = 1;
     for (uint64_t i = 0; i < n; ++i) {
@@ -409,10 +454,10 @@ static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* o
     uint64_t cap = pa_map_arena_hint(idx, n), used = 0, need = 0;
     for (int attempt = 0;; ++attempt) {
         if ((rc = idx->b_arena.ensure(cap * 4))) return rc;
-        rc = map_launch_locked(idx, idx->b_tiles.as<uint64_t>(), idx->b_lens.as<uint32_t>(), n, wpr, allowed,
+        rc = map_launch_locked(idx, cx, idx->b_tiles.as<uint64_t>(), idx->b_lens.as<uint32_t>(), n, wpr, allowed,
                                idx->b_results.as<pa_read_result>(), idx->b_arena.as<uint32_t>(), cap, nullptr, nullptr, d_nodes, d_nodes_len, st);
         if (rc != PA_OK) return rc;
-        rc = map_finish_locked(idx, st, &used, &need);
+        rc = map_finish_locked(idx, cx, st, &used, &need);
         if (rc == PA_ERR_ARENA_FULL && attempt < 3) { cap = need + need / 8 + 4096; continue; }
         if (rc != PA_OK) return rc;
         break;

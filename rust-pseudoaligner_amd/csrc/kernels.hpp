@@ -72,8 +72,9 @@ int launch_count(const pa_read_result* results, const uint32_t* arena, const uin
                  const uint32_t* class_table, uint64_t class_table_size, unsigned long long* counts, hipStream_t stream);
 
 // overflow table hooks (collective.hip)
-int overflow_prepare_launch(pa_overflow* o, uint64_t n_reads, MapParams& p, hipStream_t stream);
-int overflow_after_map(pa_overflow* o, const uint32_t* d_arena, hipStream_t stream);
+void overflow_launch_params(pa_overflow* o, MapParams& p);   // where a full novel list is reported
+int overflow_after_map(pa_overflow* o, const uint32_t* novel_list, const unsigned long long* novel_ctr, uint64_t novel_cap, const uint32_t* d_arena,
+                       hipStream_t stream);
 int overflow_device(const pa_overflow* o);
 
 }  // namespace pa

@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) void pa_counts_fold_kernel(uint32_t* __restric
         const uint32_t v = rep[(uint64_t)r * stride + c];
         if (v) { sum += v; rep[(uint64_t)r * stride + c] = 0; }
     }
-    if (sum) counts[c] += sum;
+    if (sum) atomicAdd(counts + c, sum);   // (launches on two streams may fold into one table at the same time)
 }
 
 int launch_counts_fold(uint32_t* xcd_counts, uint32_t xcd_stride, unsigned long long* counts, uint64_t len, hipStream_t stream) {

@@ -475,3 +475,51 @@ def test_c_client_of_the_header_runs_its_device_half(tmp_path):
     exe = helpers._build.build_abi_check()
     out = subprocess.run([str(exe), str(helpers.FASTA), str(helpers.FASTQ), str(tmp_path)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "device halves ok" in out.stdout and "0 failures" in out.stdout, out.stdout + out.stderr
+
+
+def test_concurrent_launches_on_two_streams_from_two_threads(aligners):
+    """"pa_map_batch callable concurrently from multiple host threads (one stream each)": two threads, two streams,
+    ONE index handle, ONE count table; every launch's records and the summed table equal the sequential results"""
+    import threading
+    import torch
+    a = aligners(24)
+    tx = pa.Txome.from_host_index(a.host)
+    n, wpr, rounds = 400_000, 4, 4
+    dev = torch.device("cuda", 0)
+    d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    inputs, want_res = [], []
+    for t in range(2):
+        h_tiles, h_lens = tx.simulate_host(100, 21 + t, n, 15000, 0, wpr)
+        inputs.append((torch.from_numpy(h_tiles.view(np.int64)).to(dev), torch.from_numpy(h_lens.view(np.int32)).to(dev)))
+        want_res.append(helpers.Oracle(a.host).map_tiles(h_tiles, h_lens, wpr, 2, 8))
+    torch.cuda.synchronize()
+    out, errors = [None, None], []
+
+    def worker(t):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            cap = a.arena_hint(n)
+            d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+            d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+            for _ in range(rounds):
+                a.map_count_batch_device(inputs[t][0].data_ptr(), inputs[t][1].data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap,
+                                         d_counts.data_ptr(), 2, s.cuda_stream)
+                used, _ = a.map_finish(s.cuda_stream)
+            out[t] = (d_res.cpu().numpy().view(pa.RESULT_DTYPE), d_arena[: max(used, 1)].cpu().numpy().view(np.uint32))
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    torch.cuda.synchronize()
+    want_counts = np.zeros(a.counts_len(), np.int64)
+    for t in range(2):
+        o_res, o_coff, o_ids, _ = want_res[t]
+        coff, cids = pa.gather_classes(out[t][0], out[t][1], a.host)
+        helpers.assert_same_as_oracle(out[t][0], coff, cids, o_res, o_coff, o_ids, "thread %d" % t)
+        want_counts += rounds * helpers.counts_reference_fast(o_res, o_coff, o_ids, a.host)
+    assert np.array_equal(d_counts.cpu().numpy(), want_counts)
