@@ -48,7 +48,9 @@ extern "C" {
 #define PA_NO_EDGE 0xFFFFFFFFu
 #define PA_MIN_K 8u
 #define PA_MAX_K 64u                     /* one or two 64-bit words per k-mer (Kmer20..Kmer32, Kmer48, Kmer64 of the debruijn crate) */
-#define PA_MAX_READ_LEN 2048u
+#define PA_MAX_READ_LEN 16383u           /* 14-bit read positions; the reference has no limit (its validate_dbg maps whole transcripts,
+                                            src/build_index.rs:309: up to 16 355 bases in test/gencode_small.fa) */
+#define PA_MAX_SIM_READ_LEN 2048u        /* pa_simulate_reads_*: longest synthetic read */
 
 typedef enum pa_status {
     PA_OK = 0,

@@ -15,7 +15,7 @@ PA_ERR_ARENA_FULL = -7
 PA_MAPPED_BIT = 0x80000000
 PA_DEFAULT_ALLOWED_MISMATCHES = 2
 PA_READ_COVERAGE_THRESHOLD = 32
-PA_MAX_READ_LEN = 2048
+PA_MAX_READ_LEN = 16383
 
 
 class PaError(RuntimeError):

@@ -267,13 +267,18 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
                              uint32_t allowed, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour,
                              uint64_t* d_counts, uint32_t* d_nodes, uint32_t* d_nodes_len, hipStream_t stream) {
     if (n_reads >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "at most 2^32-2 reads per batch");
-    if (wpr == 0 || wpr > PA_MAX_READ_LEN / 32) return fail(PA_ERR_UNSUPPORTED, "words_per_read %u outside [1,%u]", wpr, PA_MAX_READ_LEN / 32);
+    if (wpr == 0 || wpr > (PA_MAX_READ_LEN + 31) / 32) return fail(PA_ERR_UNSUPPORTED, "words_per_read %u outside [1,%u]", wpr, (PA_MAX_READ_LEN + 31) / 32);
     uint32_t grid = 0;
     size_t lds = 0;
     uint32_t slots = 64;
     int rc = pool_geometry(idx, n_reads, wpr, &grid, &lds, &slots);
     if (rc != PA_OK) return rc;
     const uint32_t spill_cap = spill_cap_of(wpr);
+    {   // long reads: rows of many KB per slot; fewer workgroups keep the scratch at a few GB (throughput of such batches is not the point)
+        const size_t per_block = (size_t)(PA_MAP_BLOCK / 64) * slots * spill_cap * 4 * (d_nodes ? 2 : 1);
+        const size_t budget = (size_t)6 << 30;
+        if ((size_t)grid * per_block > budget) grid = (uint32_t)std::max<size_t>(1, budget / per_block);
+    }
     const size_t lanes = (size_t)grid * (PA_MAP_BLOCK / 64) * slots;
     rc = cx->spill.ensure(lanes * spill_cap * 4);
     if (rc != PA_OK) return rc;
@@ -577,7 +582,7 @@ struct pa_txome_device {
 };
 
 int pa_txome_upload(const pa_txome* t, uint32_t read_len, int device, pa_txome_device** out) {
-    if (!t || !out || read_len == 0 || read_len > PA_MAX_READ_LEN) return fail(PA_ERR_INVALID_ARG, "bad argument");
+    if (!t || !out || read_len == 0 || read_len > PA_MAX_SIM_READ_LEN) return fail(PA_ERR_INVALID_ARG, "bad argument");
     int rc = use_device(device);
     if (rc != PA_OK) return rc;
     std::vector<uint64_t> cum;

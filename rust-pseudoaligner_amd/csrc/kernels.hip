@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void pa_simulate_kernel(const uint64_t* __rest
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t ntiles = (n_reads + 63) >> 6;
     if (i >= ntiles * 64) return;
-    uint64_t words[PA_MAX_READ_LEN / 32 + 1];
+    uint64_t words[PA_MAX_SIM_READ_LEN / 32 + 1];
     const uint32_t nw = (read_len + 31) / 32;
     uint64_t* dst = tiles + ((i >> 6) * wpr) * 64 + (i & 63);
     if (i < n_reads) {

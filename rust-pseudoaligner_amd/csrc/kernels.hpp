@@ -8,6 +8,7 @@ namespace pa {
 
 constexpr uint32_t PA_MAP_BLOCK = 256;          // 4 independent waves per workgroup, no barriers
 constexpr uint32_t PA_ARENA_CHUNK = 1024;       // u32 entries a wave reserves per global atomic
+constexpr uint32_t PA_LDS_READ_WORDS = 16;        // reads of up to 512 bases live in LDS while they are mapped, longer ones stay in their HBM tile
 constexpr uint32_t PA_COUNT_REPLICAS = 8;        // XCDs of an MI355X
 constexpr uint32_t PA_STATUS_ARENA_FULL = 1u;
 constexpr uint32_t PA_STATUS_SPILL_OVERFLOW = 2u;

@@ -27,10 +27,10 @@ enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVE
 constexpr uint32_t NO_CLASS = 0xFFFFFFFFu;
 constexpr uint32_t LDS_CLASSES = 4;   // list mode: distinct classes kept inline (one 16-byte vector each of refs, lengths, class ids)
 
-// Packed state of a read (9 words). Limits: read length <= 2048 (PA_MAX_READ_LEN; 12 bits hold 0..4095), node length < 2^24.
+// Packed state of a read (9 words). Limits: read length <= 16383 (PA_MAX_READ_LEN; 14 bits), node length < 2^24.
 struct Lane {
     uint32_t rid;
-    uint32_t lk;    // L (bits 0..11) | kmer_pos (12..23) | state (24..27)                  (:70, :79)
+    uint32_t lk;    // L (bits 0..13) | kmer_pos (14..27) | state (28..31)                  (:70, :79)
     uint32_t cm;    // read_coverage (0..15) | mismatch_count (16..31)                      (:71-72)
     uint32_t h;     // node_id of the forward search as a blob handle                       (:118-121)
     uint32_t of;    // kmer_offset (0..23) | flags (24..31)
@@ -40,16 +40,16 @@ struct Lane {
     uint32_t nc;    // distinct classes collected (0..11) | dictionary probe index (12..15) | TRACE: nodes.len() (16..31)
 };
 
-PA_HD uint32_t l_st(const Lane& s) { return (s.lk >> 24) & 15u; }
-PA_HD void l_set_st(Lane& s, uint32_t st) { s.lk = (s.lk & 0x00FFFFFFu) | (st << 24); }
+PA_HD uint32_t l_st(const Lane& s) { return s.lk >> 28; }
+PA_HD void l_set_st(Lane& s, uint32_t st) { s.lk = (s.lk & 0x0FFFFFFFu) | (st << 28); }
 PA_HD uint32_t l_flags(const Lane& s) { return s.of >> 24; }
 PA_HD void l_or_flags(Lane& s, uint32_t f) { s.of |= f << 24; }
 PA_HD void l_clr_flags(Lane& s, uint32_t f) { s.of &= ~(f << 24); }
 PA_HD uint32_t l_off(const Lane& s) { return s.of & 0xFFFFFFu; }
-PA_HD uint32_t l_L(const Lane& s) { return s.lk & 0xFFFu; }
-PA_HD uint32_t l_kp(const Lane& s) { return (s.lk >> 12) & 0xFFFu; }
-PA_HD void l_set_kp(Lane& s, uint32_t kp) { s.lk = (s.lk & 0xFF000FFFu) | (kp << 12); }
-PA_HD uint32_t l_pack_lk(uint32_t L, uint32_t kp, uint32_t st) { return L | (kp << 12) | (st << 24); }
+PA_HD uint32_t l_L(const Lane& s) { return s.lk & 0x3FFFu; }
+PA_HD uint32_t l_kp(const Lane& s) { return (s.lk >> 14) & 0x3FFFu; }
+PA_HD void l_set_kp(Lane& s, uint32_t kp) { s.lk = (s.lk & 0xF0003FFFu) | (kp << 14); }
+PA_HD uint32_t l_pack_lk(uint32_t L, uint32_t kp, uint32_t st) { return L | (kp << 14) | (st << 28); }
 PA_HD uint32_t l_cov(const Lane& s) { return s.cm & 0xFFFFu; }
 PA_HD uint32_t l_mism(const Lane& s) { return s.cm >> 16; }
 PA_HD uint32_t l_ncol(const Lane& s) { return s.nc & 0xFFFu; }
@@ -309,7 +309,7 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
         c.cids[n] = hd.cid;
     } else {
         const uint32_t o = 4 * (n - LDS_CLASSES);
-        if (o + 3 >= c.spill_cap) { l_or_flags(s, F_SPILL_OVERFLOW); return false; }
+        if (o + 3 >= c.spill_cap || n >= 0xFFEu) { l_or_flags(s, F_SPILL_OVERFLOW); return false; }   // (the class counter has 12 bits)
         c.spill[o] = hd.ec_ref;
         c.spill[o + 1] = hd.ec_len;
         c.spill[o + 2] = hd.cid;

@@ -160,18 +160,21 @@ __device__ __forceinline__ uint32_t queue_of(Lane& s) {
 }
 
 // a free slot takes read `rid`: packed words from the tile into LDS (lanes of consecutive reads: coalesced), fresh lane state
+template <bool GREAD>
 __device__ __forceinline__ void refill_slot(Lane& s, uint64_t rid, uint32_t slot, karg_ptr p, lds_u64 rd, lds_u32 wc, uint32_t S, uint32_t wpr,
                                             uint32_t K) {
     uint32_t L = p->lens[rid];
     if (L > wpr * 32) L = wpr * 32;
-    const uint64_t* src = p->tiles + ((rid >> 6) * wpr) * 64 + (rid & 63);
-    for (uint32_t w0 = 0; w0 < wpr; w0 += 8) {   // eight words in flight per round trip
-        uint64_t v[8];
+    if (!GREAD) {
+        const uint64_t* src = p->tiles + ((rid >> 6) * wpr) * 64 + (rid & 63);
+        for (uint32_t w0 = 0; w0 < wpr; w0 += 8) {   // eight words in flight per round trip
+            uint64_t v[8];
 #pragma unroll
-        for (uint32_t i = 0; i < 8; ++i) v[i] = w0 + i < wpr ? src[(uint64_t)(w0 + i) * 64] : 0ull;
+            for (uint32_t i = 0; i < 8; ++i) v[i] = w0 + i < wpr ? src[(uint64_t)(w0 + i) * 64] : 0ull;
 #pragma unroll
-        for (uint32_t i = 0; i < 8; ++i)
-            if (w0 + i < wpr) rd[(w0 + i) * S + slot] = v[i];
+            for (uint32_t i = 0; i < 8; ++i)
+                if (w0 + i < wpr) rd[(w0 + i) * S + slot] = v[i];
+        }
     }
     lane_start(s, (uint32_t)rid, L, K);
     wc[2 * slot + 1] = (uint32_t)rid;
@@ -181,7 +184,10 @@ constexpr uint32_t SLOT_FIXED_BYTES = 32 + 16 + 8;   // lane state, class window
 
 }  // namespace
 
-template <bool TRACE>
+// GREAD: reads too long for the LDS (more than PA_LDS_READ_WORDS words: long transcripts mapped onto their own graph,
+// src/build_index.rs:309) stay in their HBM tile and every step fetches the words it needs from there; a slot then holds
+// only state, windows and ids.
+template <bool TRACE, bool GREAD>
 __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapParams p_arg) {
     // The ~50 words of parameters are NOT kept in registers across the loop (the allocator would spill most of them to
     // VGPR lanes and pay a v_readlane + hazard nops at every use): each iteration re-reads what its step needs from the
@@ -196,8 +202,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     const uint32_t wave = blockIdx.x * waves_per_block + wave_in_block;
     const uint32_t nwaves = gridDim.x * waves_per_block;
     const uint32_t S = p.pool_slots, wpr = p.wpr;
+    const uint32_t lwpr = GREAD ? 0u : wpr;   // words of a read kept in LDS
 
-    const uint32_t wave_bytes = (POOL_FIXED + S * (8 * wpr + SLOT_FIXED_BYTES) + 15) & ~15u;
+    const uint32_t wave_bytes = (POOL_FIXED + S * (8 * lwpr + SLOT_FIXED_BYTES) + 15) & ~15u;
     uint8_t* const wbase = smem + wave_in_block * wave_bytes;
     const lds_u64w chunk = (lds_u64w)wbase;
     const lds_u32 dbg = (lds_u32)(wbase + 16);                            // [0..ST_NSTAT) iterations, [ST_NSTAT..2*ST_NSTAT) slots served; entry ST_COUNT = dual iterations
@@ -207,9 +214,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     // the L2 atomics (7 classes: 0.5 ms -> 6.8 ms per 10 M reads)
     const lds_u32 ctag = (lds_u32)(wbase + 256), ccnt = (lds_u32)(wbase + 512);
     const lds_u64 rd = (lds_u64)(wbase + POOL_FIXED);
-    const lds_v4 stv = (lds_v4)(wbase + POOL_FIXED + 8 * wpr * S);        // two vectors per slot
-    const lds_v4 win = (lds_v4)(wbase + POOL_FIXED + (8 * wpr + 32) * S); // {base1, mask1, base2, mask2}
-    const lds_u32 wc = (lds_u32)(wbase + POOL_FIXED + (8 * wpr + 48) * S);   // {class id, read id} per slot
+    const lds_v4 stv = (lds_v4)(wbase + POOL_FIXED + 8 * lwpr * S);        // two vectors per slot
+    const lds_v4 win = (lds_v4)(wbase + POOL_FIXED + (8 * lwpr + 32) * S); // {base1, mask1, base2, mask2}
+    const lds_u32 wc = (lds_u32)(wbase + POOL_FIXED + (8 * lwpr + 48) * S);   // {class id, read id} per slot
     // Scheduling state: ONE byte per slot = the state the slot waits in (0xFF: no such slot), laid out so that lane i reads the
     // bytes of slots i and i + 64 with one 16-bit load. There are no queues: every iteration the lanes look at their two
     // bytes, ballots give the population of every state, and the batch of a step is "the first 64 slots in that state"
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             s.lk = a.x; s.cm = a.y; s.h = a.z; s.of = a.w; s.rr = b.x; s.rm = b.y; s.ph = b.z; s.nc = b.w;
             s.rid = wc[2 * slot + 1];
         }
-        const ReadRef rr{(const uint64_t*)(rd + slot), S, wpr};
+        const ReadRef rr = GREAD ? ReadRef{p.tiles + ((uint64_t)(s.rid >> 6) * wpr) * 64 + (s.rid & 63), 64u, wpr} : ReadRef{(const uint64_t*)(rd + slot), S, wpr};
         const glb_u32w row = (glb_u32w)p.spill + (uint64_t)gslot * spill_cap;
         const ColRef cols{(uint32_t*)&win[slot], (uint32_t*)(wc + 2 * slot), (uint32_t*)row, (uint32_t*)(row + 4), (uint32_t*)(row + 8),
                           (uint32_t*)(row + LIST_ROW_HDR), spill_cap - LIST_ROW_HDR,
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         const unsigned long long t_pop = p.dbg ? __builtin_readcyclecounter() : 0ull;
         // ---- 3. the step
         if (sel == ST_EMPTY) {   // REFILL: free slots take the next reads of this wave's range (coalesced: lane = consecutive read)
-            if (active) refill_slot(s, next + lane, slot, kp, rd, wc, S, wpr, K);
+            if (active) refill_slot<GREAD>(s, next + lane, slot, kp, rd, wc, S, wpr, K);
             next += n;
         } else if (sel == ST_SEEK) {
             if (active) seek_step(s, ix, rr);
@@ -350,7 +357,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 s2.rid = 0;   // (not used by the probe; the slot keeps its read id in `wc`)
             }
             if (!active) { s.lk = s.cm = s.h = s.of = s.rr = s.rm = s.ph = s.nc = 0; }
-            const ReadRef rr2{(const uint64_t*)(rd + slot2), S, wpr};
+            const uint32_t rid2 = GREAD && active2 ? wc[2 * slot2 + 1] : 0u;   // (a lane without a slot probes with read 0)
+            const ReadRef rr2 = GREAD ? ReadRef{p.tiles + ((uint64_t)(rid2 >> 6) * wpr) * 64 + (rid2 & 63), 64u, wpr} : ReadRef{(const uint64_t*)(rd + slot2), S, wpr};
             SeekProbe pq;
             FwdLoad fl;
             seek_issue(s2, ix, rr2, pq);                               // fingerprints of the bucket (HBM)
@@ -408,7 +416,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 const uint32_t nfree = (uint32_t)__popcll(freed);
                 const uint32_t take = (uint32_t)(left < (uint64_t)nfree ? left : (uint64_t)nfree);
                 if (take && !(p.ablate & 8u)) {
-                    if (active && s.lk == 0 && rank_in(freed) < take) refill_slot(s, next + rank_in(freed), slot, kp, rd, wc, S, wpr, K);
+                    if (active && s.lk == 0 && rank_in(freed) < take) refill_slot<GREAD>(s, next + rank_in(freed), slot, kp, rd, wc, S, wpr, K);
                     next += take;
                 }
             }
@@ -733,7 +741,7 @@ int launch_counts_fold(uint32_t* xcd_counts, uint32_t xcd_stride, unsigned long 
     return (int)hipGetLastError();
 }
 
-size_t pool_slot_bytes(uint32_t wpr) { return 8 * (size_t)wpr + SLOT_FIXED_BYTES; }
+size_t pool_slot_bytes(uint32_t wpr) { return 8 * (size_t)(wpr > PA_LDS_READ_WORDS ? 0 : wpr) + SLOT_FIXED_BYTES; }   // longer reads stay in HBM
 size_t pool_fixed_bytes() { return POOL_FIXED; }
 uint32_t pool_max_slots() { return POOL_MAX_SLOTS; }
 
@@ -742,19 +750,25 @@ size_t pool_lds_bytes(uint32_t wpr, uint32_t slots) {
     return wave_bytes * (PA_MAP_BLOCK / 64);
 }
 
-int launch_map_pool(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
-    const void* fn = p.trace ? reinterpret_cast<const void*>(&pa_map_pool_kernel<true>) : reinterpret_cast<const void*>(&pa_map_pool_kernel<false>);
+template <bool TRACE, bool GREAD>
+static int launch_one(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(&pa_map_pool_kernel<TRACE, GREAD>);
     if (lds_bytes > 48 * 1024) {   // opt in to more than the default dynamic LDS limit
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    if (p.trace) hipLaunchKernelGGL((pa_map_pool_kernel<true>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
-    else hipLaunchKernelGGL((pa_map_pool_kernel<false>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
+    hipLaunchKernelGGL((pa_map_pool_kernel<TRACE, GREAD>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
     return (int)hipGetLastError();
 }
 
+int launch_map_pool(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
+    const bool gread = p.wpr > PA_LDS_READ_WORDS;
+    if (p.trace) return gread ? launch_one<true, true>(p, grid, lds_bytes, stream) : launch_one<true, false>(p, grid, lds_bytes, stream);
+    return gread ? launch_one<false, true>(p, grid, lds_bytes, stream) : launch_one<false, false>(p, grid, lds_bytes, stream);
+}
+
 int pool_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu) {
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(&pa_map_pool_kernel<false>),
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(&pa_map_pool_kernel<false, false>),
                                                              PA_MAP_BLOCK, lds_bytes);
 }
 

@@ -134,6 +134,7 @@ int pa_simulate_reads_host(const pa_txome* t, uint32_t read_len, uint64_t seed, 
                            uint64_t n_reads, uint32_t words_per_read, uint64_t* tiles, uint32_t* lens) {
     if (!t || !tiles || !lens) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (read_len == 0 || words_per_read < (read_len + 31) / 32) return fail(PA_ERR_INVALID_ARG, "words_per_read too small");
+    if (read_len > PA_MAX_SIM_READ_LEN) return fail(PA_ERR_INVALID_ARG, "synthetic reads are at most %u bases", PA_MAX_SIM_READ_LEN);
     std::vector<uint64_t> cum;
     synth::build_cum(t->t.tx_start.data(), t->t.num_tx(), read_len, cum);
     const uint64_t total = cum.back();
@@ -141,7 +142,7 @@ int pa_simulate_reads_host(const pa_txome* t, uint32_t read_len, uint64_t seed, 
     const uint64_t ntiles = (n_reads + 63) / 64;
     std::memset(tiles, 0, ntiles * words_per_read * 64 * sizeof(uint64_t));
     for (uint64_t i = 0; i < n_reads; ++i) {
-        uint64_t words[PA_MAX_READ_LEN / 32 + 1];
+        uint64_t words[PA_MAX_SIM_READ_LEN / 32 + 1];
         synth::simulate_read(t->t.packed.data(), t->t.tx_start.data(), cum.data(), t->t.num_tx(), total, read_len, seed,
                              sub_rate_ppm, first_read + i, words);
         const uint64_t tile = i >> 6, r = i & 63;

@@ -154,20 +154,40 @@ def test_long_reads_and_max_length(aligners):
     _, seqs = helpers.read_fasta()
     reads = [s[:2048] for s in seqs if len(s) >= 300][:300] + [s[:600] for s in seqs if len(s) >= 600][:300]
     gpu_vs_oracle(a, reads, 2, "long reads")
+    # reads beyond 512 bases stay in their HBM tile while they are mapped (the other kernel variant): with errors, ragged
+    rng = np.random.RandomState(11)
+    longer = []
+    for s in [s for s in seqs if len(s) >= 1200][:120]:
+        r = list(s[: rng.randint(513, min(len(s), 9000) + 1)])
+        for j in rng.randint(0, len(r), len(r) // 150):
+            r[j] = "ACGT"[rng.randint(4)]
+        longer.append("".join(r))
+    gpu_vs_oracle(a, longer + [seqs[0][:40], "", seqs[1][:700]], 2, "reads kept in HBM")
+    top = max(seqs, key=len)
+    assert len(top) > 16000
+    gpu_vs_oracle(a, [(top * 2)[:16383]], 2, "PA_MAX_READ_LEN")
     with pytest.raises(pa.PaError):
-        a.map_batch(["A" * 2049])                                                # beyond PA_MAX_READ_LEN
+        a.map_batch(["A" * 16384])                                               # beyond PA_MAX_READ_LEN
 
 
 def test_self_mapping_of_transcripts(aligners):
-    """validate_dbg part 2 (src/build_index.rs:300-367) through the GPU for every transcript that fits a read tile"""
+    """validate_dbg part 2 (src/build_index.rs:300-367) through the GPU for EVERY transcript (up to 16 355 bases: reads that
+    long stay in HBM while they are mapped), incl. the node traces of the longest ones"""
     a = aligners(20)
     _, seqs = helpers.read_fasta()
-    idx = [i for i, s in enumerate(seqs) if 20 <= len(s) <= 2048]
+    idx = [i for i, s in enumerate(seqs) if len(s) >= 20]
+    assert max(len(seqs[i]) for i in idx) > 16000 and len(idx) == sum(len(s) >= 20 for s in seqs)
     res, coff, cids = a.map_batch([seqs[i] for i in idx])
     for j, i in enumerate(idx):
         assert res["mismatches"][j] >> 31 == 1 and res["coverage"][j] == len(seqs[i])
         cls = cids[int(coff[j]):int(coff[j + 1])].tolist()
         assert (i in cls) if len(cls) > 1 else cls == [i]
+    o = helpers.Oracle(a.host)
+    longest = sorted(idx, key=lambda i: -len(seqs[i]))[:3]
+    r, nodes, nlen = a.map_batch_nodes([seqs[i] for i in longest])
+    for j, i in enumerate(longest):
+        rc, _, cov, _, onodes = o.map_read(seqs[i])
+        assert rc == 1 and nodes[j][: nlen[j]].tolist() == onodes and r["coverage"][j] == cov
 
 
 def test_node_traces_match_map_read_to_nodes(aligners):
