@@ -43,7 +43,7 @@ def build_product(force: bool = False) -> Path:
     deps = srcs + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
     if force or _stale(PRODUCT_SO, deps):
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-               "-Wall", "-Wno-unused-function", "-x", "hip"] + [str(s) for s in srcs] + ["-ldl", "-o", str(PRODUCT_SO)]
+               "-Wall", "-Wno-unused-function", "-x", "hip"] + [str(s) for s in srcs] + ["-ldl", "-lz", "-o", str(PRODUCT_SO)]
         _run(cmd)
     return PRODUCT_SO
 

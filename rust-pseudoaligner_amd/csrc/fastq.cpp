@@ -17,6 +17,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -246,17 +247,43 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     if (fd < 0) return fail(PA_ERR_IO, "cannot open %s: %s", fastq_path, strerror(errno));
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); return fail(PA_ERR_IO, "cannot stat %s: %s", fastq_path, strerror(errno)); }
-    const uint64_t fsize = (uint64_t)st.st_size;
+    uint64_t fsize = (uint64_t)st.st_size;
     const char* data = nullptr;
-    if (fsize) {
+    std::vector<char> inflated;   // a gzip'ed FASTQ (utils::open_with_gz, src/utils.rs:45-57) is inflated into memory first
+    bool mapped = false;
+    unsigned char magic[2] = {0, 0};
+    const bool gz = fsize >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (gz) {
+        gzFile g = gzdopen(dup(fd), "rb");   // every member of a multi-member file, like flate2's MultiGzDecoder
+        if (!g) { close(fd); return fail(PA_ERR_IO, "cannot read %s as gzip", fastq_path); }
+        (void)gzbuffer(g, 1 << 20);
+        inflated.resize(std::max<uint64_t>(fsize * 4, 1 << 20));
+        uint64_t have = 0;
+        for (;;) {
+            if (have == inflated.size()) inflated.resize(inflated.size() * 2);
+            const int got = gzread(g, inflated.data() + have, (unsigned)std::min<uint64_t>(inflated.size() - have, 1u << 30));
+            if (got < 0) { int e = 0; const char* why = gzerror(g, &e); gzclose(g); close(fd); return fail(PA_ERR_FORMAT, "%s: corrupt gzip stream: %s", fastq_path, why); }
+            if (got == 0) break;
+            have += (uint64_t)got;
+        }
+        {
+            int e = Z_OK;
+            const char* why = gzerror(g, &e);   // a truncated member hands out what it has and reports Z_BUF_ERROR
+            if (e != Z_OK && e != Z_STREAM_END) { const int rc_ = fail(PA_ERR_FORMAT, "%s: corrupt gzip stream: %s", fastq_path, why); gzclose(g); close(fd); return rc_; }
+        }
+        gzclose(g);
+        fsize = have;
+        data = inflated.data();
+    } else if (fsize) {
         void* m = mmap(nullptr, fsize, PROT_READ, MAP_PRIVATE, fd, 0);
         if (m == MAP_FAILED) { close(fd); return fail(PA_ERR_IO, "cannot map %s: %s", fastq_path, strerror(errno)); }
         (void)madvise(m, fsize, MADV_SEQUENTIAL);
         data = (const char*)m;
+        mapped = true;
     }
     close(fd);
     FILE* out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
-    if (!out) { if (data) munmap((void*)data, fsize); return fail(PA_ERR_IO, "cannot create %s: %s", out_path, strerror(errno)); }
+    if (!out) { if (mapped) munmap((void*)data, fsize); return fail(PA_ERR_IO, "cannot create %s: %s", out_path, strerror(errno)); }
     // a private 4 MiB stdio buffer only for a file this function opened (and closes before the buffer dies); the process-wide
     // stdout keeps its own buffering: handing it a function-local buffer would leave it dangling after the return
     std::vector<char> obuf(out != stdout ? (size_t)1 << 22 : 0);
@@ -527,7 +554,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     const bool wrote = writer.finish();
     if (rc == PA_OK && !wrote) rc = fail(PA_ERR_IO, "short write to %s", out_path);
     for (BatchCtx& c : ctx) c.release();
-    if (data) munmap((void*)data, fsize);
+    if (mapped) munmap((void*)data, fsize);
     if (out != stdout) { if (fclose(out) != 0 && rc == PA_OK) rc = fail(PA_ERR_IO, "close %s: %s", out_path, strerror(errno)); }
     else fflush(stdout);
     if (n_reads_out) *n_reads_out = reported;

@@ -301,6 +301,18 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
             got = out.read_text().splitlines()
             assert n == len(ids) and got == want, (name, batch, threads)
             assert flagged == sum(1 for w in want if w.startswith("(true"))
+    # gzip input (utils::open_with_gz, src/utils.rs:45-57), also as two concatenated members
+    import gzip
+    gzp = tmp_path / "plain.fq.gz"
+    text = variants["plain"].encode()
+    gzp.write_bytes(gzip.compress(text[: len(text) // 2]) + gzip.compress(text[len(text) // 2:]))
+    monkeypatch.setenv("PA_INGEST_BATCH", "1024")
+    n, flagged = pa.process_reads(str(gzp), a, str(out), 4)
+    assert n == len(ids) and out.read_text().splitlines() == want
+    broken = tmp_path / "broken.fq.gz"
+    broken.write_bytes(gzp.read_bytes()[:2000])
+    with pytest.raises(pa.PaError):
+        pa.process_reads(str(broken), a, str(out), 2)
     empty = tmp_path / "empty.fq"
     empty.write_text("")
     assert pa.process_reads(str(empty), a, str(out), 4) == (0, 0) and out.read_text() == ""
