@@ -254,6 +254,16 @@ uint64_t pa_counts_len(const pa_index* idx);
 int pa_counts_accumulate_device(pa_index* idx, const pa_read_result* d_results, const uint32_t* d_arena,
                                 const uint32_t* d_colour, uint64_t n_reads, uint64_t* d_counts, void* stream);
 
+/* Per-barcode (single-cell) counts, SURVEY.md §8f.3 (the reference's stated purpose, README.md:3): d_barcode[i] = index of the
+ * cell barcode of read i (assigned by the host from the barcode read / whitelist). Output = the sparse matrix
+ * (barcode, column) -> reads as sorted unique keys (barcode << 32 | column) with their counts, columns as in the dense
+ * table (class id, pa_counts_len-3.. = novel / empty / unmapped). d_keys / d_vals are caller-owned device arrays of n_reads
+ * entries (the worst case); *n_entries (host) receives the number of non-zero cells. barcode_bits: bits of the barcode
+ * index that can be set (0 = all 32; fewer bits = fewer sort passes). Synchronous on `stream`. */
+int pa_counts_by_barcode_device(pa_index* idx, const pa_read_result* d_results, const uint32_t* d_arena,
+                                const uint32_t* d_barcode, uint64_t n_reads, uint32_t barcode_bits, uint64_t* d_keys,
+                                uint32_t* d_vals, uint64_t* n_entries, void* stream);
+
 /* ---------------- novel classes + the reduction over GPUs ---------------- */
 /* The dense table counts every result that is no index class in ONE slot (counts[num_classes]). A pa_overflow keeps WHICH
  * id sets those were, keyed by content, on the GPU: attach one to an index and every pa_map_count_batch_device launch files

@@ -144,6 +144,18 @@ int main(int argc, char** argv) {
         EXPECT(pa_map_finish(idx, NULL, &used, &need) == PA_OK);
         EXPECT(pa_counts_accumulate_device(idx, (const pa_read_result*)d_res, (const uint32_t*)d_arena, (const uint32_t*)d_colour, nsim, (uint64_t*)d_counts, NULL) == PA_OK);
         EXPECT(pa_stream_synchronize(NULL) == PA_OK);
+        {   /* per-barcode counts: four cells' worth of barcodes over the same records */
+            void *d_bc = NULL, *d_keys = NULL, *d_vals = NULL;
+            uint32_t* bc = (uint32_t*)calloc(nsim, 4);
+            for (uint64_t i = 0; i < nsim; ++i) bc[i] = (uint32_t)(i & 3);
+            uint64_t cells = 0;
+            EXPECT(pa_device_malloc(0, nsim * 4, &d_bc) == PA_OK && pa_device_malloc(0, nsim * 8, &d_keys) == PA_OK && pa_device_malloc(0, nsim * 4, &d_vals) == PA_OK);
+            EXPECT(pa_memcpy_h2d(d_bc, bc, nsim * 4, NULL) == PA_OK);
+            EXPECT(pa_counts_by_barcode_device(idx, (const pa_read_result*)d_res, (const uint32_t*)d_arena, (const uint32_t*)d_bc, nsim, 2, (uint64_t*)d_keys,
+                                               (uint32_t*)d_vals, &cells, NULL) == PA_OK && cells >= 4 && cells <= nsim);
+            EXPECT(pa_device_free(d_bc) == PA_OK && pa_device_free(d_keys) == PA_OK && pa_device_free(d_vals) == PA_OK);
+            free(bc);
+        }
         uint64_t* h_counts = (uint64_t*)calloc(counts_len, 8);
         EXPECT(pa_memcpy_d2h(h_counts, d_counts, counts_len * 8, NULL) == PA_OK);
         uint64_t total = 0;

@@ -352,6 +352,13 @@ class Pseudoaligner:
     def counts_len(self) -> int:
         return lib().pa_counts_len(self._h)
 
+    def counts_by_barcode_device(self, d_results: int, d_arena: int, d_barcode: int, n_reads: int, d_keys: int, d_vals: int,
+                                 barcode_bits: int = 0, stream: int = 0) -> int:
+        """sparse (barcode, class) -> reads matrix as sorted keys (barcode << 32 | column) + counts; returns the number of cells"""
+        n = C.c_uint64()
+        check(lib().pa_counts_by_barcode_device(self._h, d_results, d_arena, d_barcode, n_reads, barcode_bits, d_keys, d_vals, C.byref(n), stream or None))
+        return n.value
+
     def set_overflow(self, overflow: Optional["Overflow"]) -> None:
         """attach the table that remembers WHICH novel classes the fused count launches met (None detaches)"""
         check(lib().pa_index_set_overflow(self._h, overflow._h if overflow else None))

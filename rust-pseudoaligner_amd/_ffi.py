@@ -81,6 +81,7 @@ SIGNATURES = {
     "pa_process_reads": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]),
     "pa_counts_len": (C.c_uint64, [vp]),
     "pa_counts_accumulate_device": (C.c_int, [vp, vp, vp, vp, C.c_uint64, vp, vp]),
+    "pa_counts_by_barcode_device": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, u64p, vp]),
     "pa_overflow_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(vp)]),
     "pa_overflow_destroy": (None, [vp]),
     "pa_overflow_reset": (C.c_int, [vp, vp]),

@@ -552,6 +552,14 @@ int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offs
     return map_batch_host(idx, ascii, offsets, n_reads, allowed_mismatches, results, nullptr, nullptr, nodes_flat, nodes_stride, nodes_len);
 }
 
+int pa_counts_by_barcode_device(pa_index* idx, const pa_read_result* d_results, const uint32_t* d_arena, const uint32_t* d_barcode, uint64_t n_reads,
+                                uint32_t barcode_bits, uint64_t* d_keys, uint32_t* d_vals, uint64_t* n_entries, void* stream) {
+    if (!idx || !n_entries || (n_reads && (!d_results || !d_arena || !d_barcode || !d_keys || !d_vals))) return fail(PA_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(idx->device));
+    return barcode_counts(idx->dv, static_cast<const uint32_t*>(idx->d_class_table), idx->class_table_size, d_results, d_arena, d_barcode, n_reads,
+                          barcode_bits, d_keys, d_vals, n_entries, static_cast<hipStream_t>(stream));
+}
+
 int pa_index_set_overflow(pa_index* idx, pa_overflow* ovf) {
     if (!idx) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (ovf && overflow_device(ovf) != idx->device) return fail(PA_ERR_INVALID_ARG, "overflow table lives on device %d, the index on device %d", overflow_device(ovf), idx->device);

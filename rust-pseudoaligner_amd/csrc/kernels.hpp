@@ -72,6 +72,11 @@ int launch_simulate(const uint64_t* packed, const uint64_t* tx_start, const uint
 int launch_count(const pa_read_result* results, const uint32_t* arena, const uint32_t* colour, uint64_t n, const DevIndexView& ix,
                  const uint32_t* class_table, uint64_t class_table_size, unsigned long long* counts, hipStream_t stream);
 
+// per-barcode counts (barcode_counts.hip)
+int barcode_counts(const DevIndexView& ix, const uint32_t* class_table, uint64_t class_table_size, const pa_read_result* d_results,
+                   const uint32_t* d_arena, const uint32_t* d_barcode, uint64_t n, uint32_t barcode_bits, uint64_t* d_keys, uint32_t* d_vals,
+                   uint64_t* n_entries, hipStream_t stream);
+
 // overflow table hooks (collective.hip)
 void overflow_launch_params(pa_overflow* o, MapParams& p);   // where a full novel list is reported
 int overflow_after_map(pa_overflow* o, const uint32_t* novel_list, const unsigned long long* novel_ctr, uint64_t novel_cap, const uint32_t* d_arena,

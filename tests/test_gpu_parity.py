@@ -555,3 +555,46 @@ def test_concurrent_launches_on_two_streams_from_two_threads(aligners):
         helpers.assert_same_as_oracle(out[t][0], coff, cids, o_res, o_coff, o_ids, "thread %d" % t)
         want_counts += rounds * helpers.counts_reference_fast(o_res, o_coff, o_ids, a.host)
     assert np.array_equal(d_counts.cpu().numpy(), want_counts)
+
+
+def test_per_barcode_counts_equal_the_histogram(aligners):
+    """SURVEY §8f.3 (single-cell use, README.md:3): the sparse (barcode, class) -> reads matrix from the GPU (keys sorted,
+    barcode << 32 | column) equals the histogram of (barcode, column) built from the oracle's per-read results"""
+    import torch
+    a = aligners(24)
+    tx = pa.Txome.from_host_index(a.host)
+    n, wpr, ncells = 300_000, 4, 700
+    dev = torch.device("cuda", 0)
+    h_tiles, h_lens = tx.simulate_host(100, 31, n, 20000, 0, wpr)
+    rng = np.random.RandomState(8)
+    barcode = rng.randint(0, ncells, n).astype(np.uint32)
+    d_tiles = torch.from_numpy(h_tiles.view(np.int64)).to(dev)
+    d_lens = torch.from_numpy(h_lens.view(np.int32)).to(dev)
+    d_bc = torch.from_numpy(barcode.view(np.int32)).to(dev)
+    cap = a.arena_hint(n)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+    a.map_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, 2, 0)
+    a.map_finish()
+    d_keys = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_vals = torch.zeros(n, dtype=torch.int32, device=dev)
+    cells = a.counts_by_barcode_device(d_res.data_ptr(), d_arena.data_ptr(), d_bc.data_ptr(), n, d_keys.data_ptr(), d_vals.data_ptr(), 10)
+    keys = d_keys[:cells].cpu().numpy().view(np.uint64)
+    vals = d_vals[:cells].cpu().numpy().view(np.uint32)
+    # the checker: column of every read from the oracle's classes
+    o_res, o_coff, o_ids, _ = helpers.Oracle(a.host).map_tiles(h_tiles, h_lens, wpr, 2, 8)
+    arr = a.host.arrays()
+    off = arr["ec_offset"].astype(np.int64)
+    nc = arr["num_classes"]
+    table = {tuple(arr["ec_ids"][off[c]:off[c + 1]].tolist()): c for c in range(nc)}
+    col = np.zeros(n, np.uint64)
+    for i in range(n):
+        if not o_res["mapped"][i]:
+            col[i] = nc + 2
+        elif o_res["class_len"][i] == 0:
+            col[i] = nc + 1
+        else:
+            col[i] = table.get(tuple(o_ids[int(o_coff[i]):int(o_coff[i + 1])].tolist()), nc)
+    want_keys, want_vals = np.unique((barcode.astype(np.uint64) << np.uint64(32)) | col, return_counts=True)
+    assert np.array_equal(keys, want_keys) and np.array_equal(vals, want_vals.astype(np.uint32)) and int(vals.sum()) == n
+    assert a.counts_by_barcode_device(d_res.data_ptr(), d_arena.data_ptr(), d_bc.data_ptr(), 0, d_keys.data_ptr(), d_vals.data_ptr()) == 0
