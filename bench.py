@@ -321,8 +321,8 @@ def main() -> None:
         achieved = bytes_per_read * B / (kernel_avg_ms * 1e-3) / 1e9
         traffic = None   # HBM bytes per launch from committed rocprofv3 PMC passes of this same workload (bench.py cannot run PMC itself)
         try:
-            pmc = json.load(open(ROOT / "profiles" / "latest_pmc.json"))
-            if pmc.get("workload") == args.workload and pmc.get("reads_per_launch") == B:
+            pmc = json.load(open(ROOT / "profiles" / "latest_pmc.json"))["workloads"][args.workload]
+            if pmc.get("reads_per_launch") == B:
                 traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0
         except (OSError, ValueError, KeyError):
             pass
