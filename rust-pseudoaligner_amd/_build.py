@@ -37,14 +37,33 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: the product library cannot be built")
 
 
+OBJ_DIR = PKG / "_build"   # per-source objects (git-ignored): only what changed is recompiled
+
+
+def _deps_of(src: Path):
+    """the source plus every header it can see (all of csrc/*.hpp and the public header: coarse, always safe)"""
+    return [src] + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
+
+
 def build_product(force: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950: HIP kernels + C ABI + host runtime -> libpseudoaligner_amd.so"""
+    """hipcc --offload-arch=gfx950: HIP kernels + C ABI + host runtime -> libpseudoaligner_amd.so (one object per source,
+    compiled in parallel, then linked)"""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [CSRC / s for s in HOST_SOURCES + HIP_SOURCES]
-    deps = srcs + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
-    if force or _stale(PRODUCT_SO, deps):
-        cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-               "-Wall", "-Wno-unused-function", "-x", "hip"] + [str(s) for s in srcs] + ["-ldl", "-lz", "-o", str(PRODUCT_SO)]
-        _run(cmd)
+    OBJ_DIR.mkdir(exist_ok=True)
+    hipcc = hipcc_path()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function"]
+    jobs = []
+    for s in srcs:
+        obj = OBJ_DIR / (s.name + ".o")
+        if force or _stale(obj, _deps_of(s)):
+            jobs.append([hipcc] + flags + ["-x", "hip", "-c", str(s), "-o", str(obj)])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(_run, jobs))
+    objs = [OBJ_DIR / (s.name + ".o") for s in srcs]
+    if jobs or _stale(PRODUCT_SO, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + [str(o) for o in objs] + ["-ldl", "-lz", "-o", str(PRODUCT_SO)])
     return PRODUCT_SO
 
 

@@ -255,8 +255,11 @@ PA_HD uint32_t window_class(const DevIndexView& ix, uint32_t b1, uint32_t m1, ui
 
 // mask of the window (base c, mask n) expressed relative to base b
 PA_HD uint32_t window_at(uint32_t b, uint32_t c, uint32_t n) {
-    const uint32_t up = c - b, down = b - c;
-    return up < CLASS_WINDOW ? n << up : down < CLASS_WINDOW ? n >> down : 0u;
+    // one 64-bit shift instead of two branches: n sits in the upper half of a 64-bit value, d = 32 + b - c moves it down;
+    // d in [1, 63] covers both directions (c - b < 32: up; b - c < 32: down), anything else leaves nothing in the low half
+    const uint32_t d = CLASS_WINDOW + b - c;
+    const uint32_t r = (uint32_t)(((uint64_t)n << 32) >> (d & 63u));
+    return d - 1u < 63u ? r : 0u;
 }
 
 // nodes.push(node_id) (:199, :219): fold the node's class into the lane's record. Returns true when the read has to

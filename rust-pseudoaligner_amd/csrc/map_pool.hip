@@ -187,7 +187,9 @@ constexpr uint32_t SLOT_FIXED_BYTES = 32 + 16 + 8;   // lane state, class window
 // GREAD: reads too long for the LDS (more than PA_LDS_READ_WORDS words: long transcripts mapped onto their own graph,
 // src/build_index.rs:309) stay in their HBM tile and every step fetches the words it needs from there; a slot then holds
 // only state, windows and ids.
-template <bool TRACE, bool GREAD>
+// DBG: the statistics (PA_MAP_STATS) and ablation (PA_MAP_ABLATE) build of the same text; the production build has neither the
+// clock reads nor the parameter loads they need.
+template <bool TRACE, bool GREAD, bool DBG>
 __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapParams p_arg) {
     // The ~50 words of parameters are NOT kept in registers across the loop (the allocator would spill most of them to
     // VGPR lanes and pay a v_readlane + hazard nops at every use): each iteration re-reads what its step needs from the
@@ -195,6 +197,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
     karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     (void)p_arg;
 #define p (*kp)
+#define PA_DBG (DBG && p.dbg)
+#define PA_ABLATE(bit) (DBG && (p.ablate & (bit)))
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = lane_id();
     const uint32_t wave_in_block = threadIdx.x >> 6;
@@ -289,13 +293,19 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         const uint32_t nrefill = (uint32_t)(left < (uint64_t)nempty ? left : (uint64_t)nempty);
         uint32_t best = 0, sel = ST_EMPTY;
 #define PA_CONSIDER(t, c) { const uint32_t c_ = (c); if (best < 64 && c_ > best) { best = c_; sel = (t); } }
-        PA_CONSIDER(ST_F_NOVEL, PA_CNT(ST_F_NOVEL))
-        PA_CONSIDER(ST_F_COOP, PA_CNT(ST_F_COOP))
-        PA_CONSIDER(ST_F_SCAN, PA_CNT(ST_F_SCAN))
-        PA_CONSIDER(ST_F_LIGHT, PA_CNT(ST_F_LIGHT))
+        // the five rare states (left extension, the list-mode tiers, the content lookup) are only counted when some slot is in one
+        // of them: one ballot instead of ten in most iterations (the order of consideration is the same either way)
+        constexpr uint32_t RARE = (1u << ST_LEFT) | (1u << ST_F_LIGHT) | (1u << ST_F_SCAN) | (1u << ST_F_COOP) | (1u << ST_F_NOVEL);
+        const bool any_rare = __ballot((((RARE >> (st_lo & 31u)) | (RARE >> (st_hi & 31u))) & 1u) != 0) != 0;   // (0xFF, no slot: bit 31, not rare)
+        if (any_rare) {
+            PA_CONSIDER(ST_F_NOVEL, PA_CNT(ST_F_NOVEL))
+            PA_CONSIDER(ST_F_COOP, PA_CNT(ST_F_COOP))
+            PA_CONSIDER(ST_F_SCAN, PA_CNT(ST_F_SCAN))
+            PA_CONSIDER(ST_F_LIGHT, PA_CNT(ST_F_LIGHT))
+        }
         PA_CONSIDER(ST_F_BITS, PA_CNT(ST_F_BITS))
         PA_CONSIDER(ST_FWD, PA_CNT(ST_FWD))
-        PA_CONSIDER(ST_LEFT, PA_CNT(ST_LEFT))
+        if (any_rare) PA_CONSIDER(ST_LEFT, PA_CNT(ST_LEFT))
         PA_CONSIDER(ST_SEEK, PA_CNT(ST_SEEK))
         PA_CONSIDER(ST_EMPTY, nrefill)
 #undef PA_CONSIDER
@@ -306,15 +316,15 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         // node lines are on their way: two round trips in flight per wave instead of one (K <= 32: the two-word dictionary
         // has no dependent second load to hide).
         const uint32_t n_seek_q = PA_CNT(ST_SEEK), n_fwd_q = PA_CNT(ST_FWD);
-        const bool dual = (sel == ST_FWD || sel == ST_SEEK) && K <= 32 && n_seek_q != 0 && n_fwd_q != 0 && !(p.ablate & 4u);
+        const bool dual = (sel == ST_FWD || sel == ST_SEEK) && K <= 32 && n_seek_q != 0 && n_fwd_q != 0 && !PA_ABLATE(4u);
         if (dual) sel = ST_FWD;
         const uint32_t n = dual ? (n_fwd_q < 64 ? n_fwd_q : 64) : best < 64 ? best : 64;
         const uint32_t n2 = dual ? (n_seek_q < 64 ? n_seek_q : 64) : 0u;   // lanes of the second (SEEK) batch
-        if (p.dbg && lane == 0) {
+        if (PA_DBG && lane == 0) {
             dbg[dual ? ST_DUAL : sel] += 1;
             dbg[ST_NSTAT + (dual ? ST_DUAL : sel)] += n + n2;
         }
-        const unsigned long long t_sec = p.dbg ? __builtin_readcyclecounter() : 0ull;
+        const unsigned long long t_sec = PA_DBG ? __builtin_readcyclecounter() : 0ull;
 
         // ---- 2. pop n slots (and n2 slots of the SEEK queue)
         const bool active = lane < n;
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                           TRACE ? (uint32_t*)((glb_u32w)p.trace + (uint64_t)gslot * spill_cap) : nullptr};
 
         uint32_t nq2 = 0xFFu;   // DUAL: the queue the second batch's slot goes to
-        const unsigned long long t_pop = p.dbg ? __builtin_readcyclecounter() : 0ull;
+        const unsigned long long t_pop = PA_DBG ? __builtin_readcyclecounter() : 0ull;
         // ---- 3. the step
         if (sel == ST_EMPTY) {   // REFILL: free slots take the next reads of this wave's range (coalesced: lane = consecutive read)
             if (active) refill_slot<GREAD>(s, next + lane, slot, kp, rd, wc, S, wpr, K);
@@ -366,9 +376,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             __builtin_amdgcn_sched_barrier(0);                         // (left alone the scheduler finishes the probe first and only then issues the node loads)
             const uint32_t cand = seek_cands(pq);
             const U3 ent = seek_entry(pq, cand);                       // the probe's dependent load: same line, now in the L1 / L2
-            const unsigned long long t1 = p.dbg ? __builtin_readcyclecounter() : 0ull;
+            const unsigned long long t1 = PA_DBG ? __builtin_readcyclecounter() : 0ull;
             if (active) fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
-            if (p.dbg && lane == 0) {   // statistics only: issue | wait + compute of the forward half
+            if (PA_DBG && lane == 0) {   // statistics only: issue | wait + compute of the forward half
                 const unsigned long long t3 = __builtin_readcyclecounter();
                 dbg[ST_COUNT + 1] += 1; dbg[ST_COUNT + 3] += 1;
                 dbg_clk[ST_COUNT + 1] += t1 - t_pop; dbg_clk[ST_COUNT + 3] += t3 - t1;
@@ -393,13 +403,13 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                     l_set_st(s, ST_F_NOVEL);
                 } else {
                     const bool is_ref = mapped && count != 0;
-                    if (!(p.ablate & 1u))
+                    if (!PA_ABLATE(1u))
                         ((glb_v4w)p.results)[s.rid] = mapped ? u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, is_ref ? PA_CLASS_REF | cand : 0u, count}
                                                              : u32x4{0u, 0u, 0u, 0u};
                     trace_out<TRACE>(s, mapped, gslot, kp);
                     const glb_u32w colour_out = (glb_u32w)p.colour_out;
                     if (colour_out) colour_out[s.rid] = is_ref ? cand : NO_CLASS;
-                    if (xcounts && !(p.ablate & 2u)) {
+                    if (xcounts && !PA_ABLATE(2u)) {
                         const uint32_t cslot = !mapped ? ix.num_classes + 2 : count == 0 ? ix.num_classes + 1 : cand;
                         const uint32_t hs = (cslot * 0x9E3779B1u) >> 26;
                         const uint32_t old = atomicCAS((uint32_t*)(ctag + hs), NO_CLASS, cslot);
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
                 const uint64_t freed = __ballot(active && s.lk == 0);
                 const uint32_t nfree = (uint32_t)__popcll(freed);
                 const uint32_t take = (uint32_t)(left < (uint64_t)nfree ? left : (uint64_t)nfree);
-                if (take && !(p.ablate & 8u)) {
+                if (take && !PA_ABLATE(8u)) {
                     if (active && s.lk == 0 && rank_in(freed) < take) refill_slot<GREAD>(s, next + rank_in(freed), slot, kp, rd, wc, S, wpr, K);
                     next += take;
                 }
@@ -692,7 +702,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
             }
         }
 
-        const unsigned long long t_step = p.dbg ? __builtin_readcyclecounter() : 0ull;
+        const unsigned long long t_step = PA_DBG ? __builtin_readcyclecounter() : 0ull;
         // ---- 4. store the lane state, push every slot onto the queue of its new state
         const uint32_t nq = active ? queue_of(s) : 0xFFu;
         if (active) {
@@ -701,7 +711,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         }
         if (active) sb[2 * (slot & 63u) + (slot >> 6)] = (uint8_t)nq;        // the slot's new state: one byte
         if (active2) sb[2 * (slot2 & 63u) + (slot2 >> 6)] = (uint8_t)nq2;
-        if (p.dbg && lane == 0) {   // [ST_ISECT] = pick + pop, [ST_NONE] = store + push (statistics only)
+        if (PA_DBG && lane == 0) {   // [ST_ISECT] = pick + pop, [ST_NONE] = store + push (statistics only)
             const unsigned long long t_end = __builtin_readcyclecounter();
             dbg_clk[dual ? ST_DUAL : sel] += t_end - t_sec;
             dbg[ST_ISECT] += 1;
@@ -714,10 +724,12 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapP
         const uint32_t t = ctag[lane], c = ccnt[lane];
         if (t != NO_CLASS && c) atomicAdd((uint32_t*)(xcounts + t), c);
     }
-    if (p.dbg && lane < 2 * ST_NSTAT) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
-    if (p.dbg && lane < ST_NSTAT) atomicAdd(p.dbg + 2 * ST_NSTAT + lane, dbg_clk[lane]);
+    if (PA_DBG && lane < 2 * ST_NSTAT) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
+    if (PA_DBG && lane < ST_NSTAT) atomicAdd(p.dbg + 2 * ST_NSTAT + lane, dbg_clk[lane]);
 #undef PA_CNT
 #undef PA_POP
+#undef PA_DBG
+#undef PA_ABLATE
 #undef p
 }
 
@@ -750,25 +762,26 @@ size_t pool_lds_bytes(uint32_t wpr, uint32_t slots) {
     return wave_bytes * (PA_MAP_BLOCK / 64);
 }
 
-template <bool TRACE, bool GREAD>
+template <bool TRACE, bool GREAD, bool DBG>
 static int launch_one(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
-    const void* fn = reinterpret_cast<const void*>(&pa_map_pool_kernel<TRACE, GREAD>);
+    const void* fn = reinterpret_cast<const void*>(&pa_map_pool_kernel<TRACE, GREAD, DBG>);
     if (lds_bytes > 48 * 1024) {   // opt in to more than the default dynamic LDS limit
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((pa_map_pool_kernel<TRACE, GREAD>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
+    hipLaunchKernelGGL((pa_map_pool_kernel<TRACE, GREAD, DBG>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
     return (int)hipGetLastError();
 }
 
 int launch_map_pool(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
     const bool gread = p.wpr > PA_LDS_READ_WORDS;
-    if (p.trace) return gread ? launch_one<true, true>(p, grid, lds_bytes, stream) : launch_one<true, false>(p, grid, lds_bytes, stream);
-    return gread ? launch_one<false, true>(p, grid, lds_bytes, stream) : launch_one<false, false>(p, grid, lds_bytes, stream);
+    if (p.trace) return gread ? launch_one<true, true, false>(p, grid, lds_bytes, stream) : launch_one<true, false, false>(p, grid, lds_bytes, stream);
+    if (gread) return launch_one<false, true, false>(p, grid, lds_bytes, stream);
+    return (p.dbg || p.ablate) ? launch_one<false, false, true>(p, grid, lds_bytes, stream) : launch_one<false, false, false>(p, grid, lds_bytes, stream);
 }
 
 int pool_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu) {
-    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(&pa_map_pool_kernel<false, false>),
+    return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void*>(&pa_map_pool_kernel<false, false, false>),
                                                              PA_MAP_BLOCK, lds_bytes);
 }
 
