@@ -102,6 +102,13 @@ int pa_host_index_build_fasta(const char* fasta_path, uint32_t k, int num_thread
 /* same from already packed transcripts: tx_start[num_tx+1] base offsets into `packed`. */
 int pa_host_index_build_packed(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx,
                                uint32_t k, int num_threads, pa_host_index** out);
+/* The same two builders with the graph construction on HIP device `device` (k-mer enumeration, radix sort,
+ * colour interning, unitig compaction by pointer jumping — csrc/index_build.hip). The result is the SAME index, array for
+ * array, as the CPU builders give (src/build_index.rs:27-91 semantics; numbering as in csrc/dbg_build.cpp).
+ * PA_ERR_NO_DEVICE without a GPU; PA_ERR_UNSUPPORTED beyond 2^24 transcripts or 2^32 k-mer occurrences. */
+int pa_host_index_build_fasta_device(const char* fasta_path, uint32_t k, int device, pa_host_index** out);
+int pa_host_index_build_packed_device(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx,
+                                      uint32_t k, int device, pa_host_index** out);
 /* wrap caller arrays (deep copy) — the import path for an index exported from the Rust side. */
 int pa_host_index_from_flat(const pa_flat_index* flat, pa_host_index** out);
 int pa_host_index_view(const pa_host_index* h, pa_flat_index* view);   /* pointers valid until destroy */

@@ -94,9 +94,20 @@ int main(int argc, char** argv) {
         EXPECT(pa_overflow_create(0, 16, 64, &o) == PA_ERR_NO_DEVICE);
         EXPECT(pa_txome_upload(tx2, 60, 0, &td) == PA_ERR_NO_DEVICE);
         EXPECT(pa_event_create(&ev) < 0);
+        pa_host_index* hg = NULL;
+        EXPECT(pa_host_index_build_fasta_device(fasta, 20, 0, &hg) == PA_ERR_NO_DEVICE && hg == NULL);
+        EXPECT(pa_host_index_build_packed_device(packed, tx_start, ntx2, 20, 0, &hg) == PA_ERR_NO_DEVICE && hg == NULL);
         printf("abi_check: host half ok, no device: %d failures\n", failures);
     } else {
         EXPECT(rc == PA_OK && idx);
+        /* the graph built on the GPU is the graph the CPU builder gives */
+        pa_host_index *hg = NULL, *hg2 = NULL;
+        EXPECT(pa_host_index_build_fasta_device(fasta, 20, 0, &hg) == PA_OK && hg);
+        EXPECT(pa_host_index_compare(h, hg, 1u << 20, report, sizeof report) == 0);
+        EXPECT(pa_host_index_build_packed_device(packed, tx_start, ntx2, 20, 0, &hg2) == PA_OK && hg2);
+        EXPECT(pa_host_index_compare(h, hg2, 1u << 20, report, sizeof report) == 0);
+        pa_host_index_destroy(hg);
+        pa_host_index_destroy(hg2);
         pa_index_stats st;
         EXPECT(pa_index_get_stats(idx, &st) == PA_OK && st.k == 20 && st.num_nodes == flat.num_nodes);
         EXPECT(pa_counts_len(idx) == counts_len);

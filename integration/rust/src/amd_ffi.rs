@@ -40,6 +40,7 @@ extern "C" {
     pub fn pa_index_destroy(idx: *mut PaIndex);
     pub fn pa_host_index_from_flat(flat: *const PaFlatIndex, out: *mut *mut PaHostIndex) -> c_int;
     pub fn pa_host_index_build_fasta(fasta_path: *const c_char, k: u32, num_threads: c_int, out: *mut *mut PaHostIndex) -> c_int;
+    pub fn pa_host_index_build_fasta_device(fasta_path: *const c_char, k: u32, device: c_int, out: *mut *mut PaHostIndex) -> c_int;
     pub fn pa_host_index_save(h: *const PaHostIndex, path: *const c_char) -> c_int;
     pub fn pa_host_index_compare(a: *const PaHostIndex, b: *const PaHostIndex, max_kmers: u64, report: *mut c_char, report_cap: usize) -> c_int;
     pub fn pa_host_index_destroy(h: *mut PaHostIndex);

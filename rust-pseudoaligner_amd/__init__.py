@@ -70,6 +70,26 @@ class HostIndex:
         packed, tx_start = txome.arrays()
         return cls.build_packed(packed, tx_start, k, num_threads)
 
+    # the same index with the graph construction on the GPU (csrc/index_build.hip)
+    @classmethod
+    def build_fasta_device(cls, fasta_path: str, k: int, device: int = 0) -> "HostIndex":
+        h = vp()
+        check(lib().pa_host_index_build_fasta_device(str(fasta_path).encode(), k, device, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def build_packed_device(cls, packed: np.ndarray, tx_start: np.ndarray, k: int, device: int = 0) -> "HostIndex":
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        tx_start = np.ascontiguousarray(tx_start, dtype=np.uint64)
+        h = vp()
+        check(lib().pa_host_index_build_packed_device(packed.ctypes.data, tx_start.ctypes.data, len(tx_start) - 1, k, device, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_txome_device(cls, txome: "Txome", k: int, device: int = 0) -> "HostIndex":
+        packed, tx_start = txome.arrays()
+        return cls.build_packed_device(packed, tx_start, k, device)
+
     @classmethod
     def from_flat(cls, flat: FlatIndex) -> "HostIndex":
         h = vp()

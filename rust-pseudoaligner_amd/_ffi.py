@@ -47,6 +47,8 @@ SIGNATURES = {
     "pa_last_error": (C.c_char_p, []),
     "pa_host_index_build_fasta": (C.c_int, [C.c_char_p, C.c_uint32, C.c_int, C.POINTER(vp)]),
     "pa_host_index_build_packed": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]),
+    "pa_host_index_build_fasta_device": (C.c_int, [C.c_char_p, C.c_uint32, C.c_int, C.POINTER(vp)]),
+    "pa_host_index_build_packed_device": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]),
     "pa_host_index_from_flat": (C.c_int, [C.POINTER(FlatIndex), C.POINTER(vp)]),
     "pa_host_index_view": (C.c_int, [vp, C.POINTER(FlatIndex)]),
     "pa_host_index_compare": (C.c_int, [vp, vp, C.c_uint64, C.c_char_p, C.c_size_t]),

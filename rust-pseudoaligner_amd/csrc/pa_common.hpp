@@ -117,6 +117,8 @@ struct Txome {
 
 // dbg_build.cpp
 int build_graph(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx, uint32_t k, int threads, HostIndex& out);
+// index_build.hip: the same graph built on HIP device `device`
+int build_graph_device(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx, uint32_t k, int device, HostIndex& out);
 // fasta.cpp
 int read_fasta(const char* path, Txome& out);
 
