@@ -718,3 +718,43 @@ int build_graph_device(const uint64_t* packed, const uint64_t* tx_start, uint32_
 }
 
 }  // namespace pa
+
+using namespace pa;
+
+// ---- C ABI (include/pseudoaligner_amd.h) ----
+extern "C" {
+
+int pa_host_index_build_packed_device(const uint64_t* packed, const uint64_t* tx_start, uint32_t num_tx, uint32_t k, int device,
+                                      pa_host_index** out) {
+    if (!packed || !tx_start || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    pa_host_index* h = new (std::nothrow) pa_host_index();
+    if (!h) return fail(PA_ERR_OOM, "out of memory");
+    try {
+        int rc = build_graph_device(packed, tx_start, num_tx, k, device, h->h);
+        if (rc != PA_OK) { delete h; return rc; }
+        const uint64_t nb = tx_start[num_tx];
+        h->h.tx_packed.assign(packed, packed + (nb + 31) / 32);
+        h->h.tx_packed.push_back(0);
+        h->h.tx_packed.push_back(0);
+        h->h.tx_start.assign(tx_start, tx_start + num_tx + 1);
+    } catch (const std::bad_alloc&) {
+        delete h;
+        return fail(PA_ERR_OOM, "out of memory while building the index");
+    }
+    *out = h;
+    return PA_OK;
+}
+
+int pa_host_index_build_fasta_device(const char* fasta_path, uint32_t k, int device, pa_host_index** out) {
+    if (!fasta_path || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    Txome t;
+    int rc = read_fasta(fasta_path, t);
+    if (rc != PA_OK) return rc;
+    rc = pa_host_index_build_packed_device(t.packed.data(), t.tx_start.data(), t.num_tx(), k, device, out);
+    if (rc != PA_OK) return rc;
+    (*out)->h.tx_names = std::move(t.names);
+    (*out)->h.tx_genes = std::move(t.genes);
+    return PA_OK;
+}
+
+}  // extern "C"
