@@ -69,6 +69,7 @@ def main() -> None:
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg (pinned tiles -> records on the host), an extra report at N=1")
     ap.add_argument("--separate-count", action="store_true", help="class counts in their own kernel instead of fused into the map kernel")
     ap.add_argument("--index-cache", default="", help="optional path to save/load the host index container")
+    ap.add_argument("--cpu-build", action="store_true", help="build the index with the CPU builder instead of the GPU builder")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,32 +128,27 @@ def main() -> None:
         txome = pa.Txome.synthesize(wl["genes"], wl["transcripts"], wl["txome_seed"])
     log("transcriptome: %d transcripts (%.1f s)" % (txome.num_transcripts, time.time() - t0))
 
-    # ---- index: CPU build on rank 0 (north_star: index construction stays on the CPU), shared through a file ----
+    # ---- index: built on this rank's GPU (csrc/index_build.hip: the same index, array for array, as the CPU builder gives; every rank
+    # builds its own copy in well under a second, so nothing is handed over between ranks). --cpu-build takes the CPU builder.
     t0 = time.time()
-    cache = args.index_cache or ("/tmp/pa_bench_%s_k%d_%d.idx" % (args.workload, k, os.getppid()) if world > 1 else "")
-    host = None
-    if cache and os.path.exists(cache) and args.index_cache:
-        host = pa.HostIndex.load(cache)
-    elif rank == 0:
-        host = pa.HostIndex.from_txome(txome, k, 0)
-        if cache:
-            host.save(cache + ".tmp")
-            os.replace(cache + ".tmp", cache)
-    barrier()
-    if host is None:
-        host = pa.HostIndex.load(cache)
-    log("host index ready (%.1f s)" % (time.time() - t0))
+    host, how = None, "GPU builder"
+    if args.index_cache and os.path.exists(args.index_cache):
+        host, how = pa.HostIndex.load(args.index_cache), "cache file"
+    else:
+        how = "CPU builder" if args.cpu_build else how
+        host = pa.HostIndex.from_txome(txome, k, 0) if args.cpu_build else pa.HostIndex.from_txome_device(txome, k, local_rank)
+        if args.index_cache and rank == 0:
+            host.save(args.index_cache + ".tmp")
+            os.replace(args.index_cache + ".tmp", args.index_cache)
+    t_build = time.time() - t0
+    log("host index ready (%.1f s, %s)" % (t_build, how))
     t0 = time.time()
     aligner = pa.Pseudoaligner(host, local_rank)
     st = aligner.stats()
+    t_create = time.time() - t0
     log("device index: %d k-mers, %d nodes, %d classes, %.2f GB in HBM (%.1f s)" %
-        (st.num_kmers, st.num_nodes, st.num_classes, st.bytes_total / 1e9, time.time() - t0))
+        (st.num_kmers, st.num_nodes, st.num_classes, st.bytes_total / 1e9, t_create))
     barrier()
-    if world > 1 and rank == 0 and not args.index_cache and cache:
-        try:
-            os.remove(cache)
-        except OSError:
-            pass
 
     # ---- resident inputs: distinct batches of packed reads in HBM, generated on the device ----
     B, K, W = args.batch or wl["batch"], args.steps, args.warmup
@@ -238,7 +234,7 @@ def main() -> None:
         "ms_per_step": 1000.0 * elapsed / max(K, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": "%s: %s" % (args.workload, wl["desc"]), "reads_per_step_per_gpu": B, "read_len": read_len, "k": k,
-                   "transcripts": txome.num_transcripts, "kmers": int(st.num_kmers), "index_bytes": int(st.bytes_total),
+                   "transcripts": txome.num_transcripts, "kmers": int(st.num_kmers), "index_bytes": int(st.bytes_total), "index_build_s": round(t_build, 3), "index_upload_s": round(t_create, 3),
                    "parallelism": "reads sharded over %d GPU(s), index replicated, RCCL all-reduce of class counts (%s)" %
                                   (n_gpus, "pa_counts_allreduce" if comm is not None else "torch.distributed" if world > 1 else "one GPU: no reduce")},
     }

@@ -140,7 +140,7 @@ struct Dict<uint64_t> {   // host-side builder/reader of the bucket lines descri
 }  // namespace
 
 template <class KT>
-static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out) {
+static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool device_dict) {
     if (threads < 1) threads = 1;
     const uint32_t k = f.k, N = f.num_nodes;
     out = FlatDevice();
@@ -234,7 +234,14 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out) {
         }
     };
     Dict<KT> dict{nullptr, 0};
-    for (double load = Dict<KT>::LOAD;; load *= 0.75) {
+    if (device_dict) {   // the GPU fills the dictionary and derives the edges (index_fill.hip)
+        out.node_kcum.resize((size_t)N + 1);
+        out.node_kcum[0] = 0;
+        for (uint32_t i = 0; i < N; ++i) out.node_kcum[i + 1] = out.node_kcum[i] + (f.node_len[i] - k + 1);
+        out.have_redge = f.node_redge != nullptr;
+        out.have_ledge = f.node_ledge != nullptr;
+    }
+    for (double load = Dict<KT>::LOAD; !device_dict; load *= 0.75) {
         out.nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (Dict<KT>::SLOTS * load)) + 1);
         if (out.nbuckets >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "dictionary exceeds 2^32 buckets");
         out.table.assign(out.nbuckets * BUCKET_WORDS, FP_EMPTY);
@@ -287,24 +294,24 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out) {
                     if (f.node_redge) {
                         const uint32_t t = f.node_redge[4 * i + base];
                         if (t < N) re = out.handle[t];
-                    } else {
+                    } else if (!device_dict) {
                         // find_link(last.extend_right(b), Dir::Right): node whose FIRST k-mer it is (offset 0)
                         uint32_t h, off;
                         if (dict.find((last >> 2) | ((KT)base << topshift), h, off) && off == 0) re = h;
                     }
-                    if (re == NO_HANDLE) dangling.store((uint32_t)i);
+                    if (re == NO_HANDLE && (f.node_redge || !device_dict)) dangling.store((uint32_t)i);
                 }
                 if (f.node_exts[i] & (1u << (4 + base))) {
                     if (f.node_ledge) {
                         const uint32_t t = f.node_ledge[4 * i + base];
                         if (t < N) le = out.handle[t];
-                    } else {
+                    } else if (!device_dict) {
                         // find_link(first.extend_left(b), Dir::Left): node whose LAST k-mer it is
                         // (that it IS the last k-mer is verified below, once every header has been written)
                         uint32_t h, off;
                         if (dict.find(((first << 2) | base) & mask, h, off)) le = h;
                     }
-                    if (le == NO_HANDLE) dangling.store((uint32_t)i);
+                    if (le == NO_HANDLE && (f.node_ledge || !device_dict)) dangling.store((uint32_t)i);
                 }
                 hd[4 + base] = re;
                 out.ledge[4ull * out.handle[i] + base] = le;
@@ -314,7 +321,7 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out) {
     if (dangling.load() != NO_HANDLE)
         return fail(PA_ERR_FORMAT, "node %u has an extension bit without a terminal neighbour k-mer (missing link)", dangling.load());
     // left-edge targets must be entered at their LAST k-mer (offset len-k): check now that every header exists
-    if (!f.node_ledge) {
+    if (!f.node_ledge && !device_dict) {
         par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
             for (uint64_t i = a; i < b; ++i) {
                 const KT first = KmerOps<KT>::get(node_seq, f.node_start[i], k);
@@ -333,9 +340,9 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out) {
     return PA_OK;
 }
 
-int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out) {
+int flatten_for_device(const pa_flat_index& f, int threads, FlatDevice& out, bool device_dict) {
     if (f.k < PA_MIN_K || f.k > PA_MAX_K) return fail(PA_ERR_UNSUPPORTED, "k=%u outside [%u,%u]", f.k, PA_MIN_K, PA_MAX_K);
-    return f.k <= 32 ? flatten_t<uint64_t>(f, threads, out) : flatten_t<u128>(f, threads, out);
+    return f.k <= 32 ? flatten_t<uint64_t>(f, threads, out, device_dict) : flatten_t<u128>(f, threads, out, device_dict);
 }
 
 }  // namespace pa

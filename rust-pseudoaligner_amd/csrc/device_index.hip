@@ -135,7 +135,9 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     FlatDevice fd;
     int threads = usable_threads();
     if (threads < 1) threads = 1;
-    rc = flatten_for_device(*flat, threads, fd);
+    // classes, window table, blob layout on the host; the dictionary (3.3 GB at config 3) and the edges are built on the GPU
+    // from the uploaded blobs (index_fill.hip) — nothing of the table exists on the host or crosses PCIe
+    rc = flatten_for_device(*flat, threads, fd, /*device_dict=*/true);
     if (rc != PA_OK) return rc;
 
     // class-list hash table for the count kernel: open addressing of class ids keyed by the hash of the id list
@@ -153,9 +155,9 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) idx->num_cus = prop.multiProcessorCount;
     if (idx->num_cus <= 0) idx->num_cus = 256;
-    rc = upload(fd.table.data(), fd.table.size() * 4, &idx->d_table);
-    if (rc == PA_OK) rc = upload(fd.blobs.data(), fd.blobs.size(), &idx->d_blobs);
+    rc = upload(fd.blobs.data(), fd.blobs.size(), &idx->d_blobs);
     if (rc == PA_OK) rc = upload(fd.ledge.data(), fd.ledge.size() * 4, &idx->d_ledge);
+    if (rc == PA_OK) rc = device_fill_index(fd, idx->d_blobs, idx->d_ledge, &idx->d_table, &fd.nbuckets);
     if (rc == PA_OK) rc = upload(fd.nid_of_handle.data(), fd.nid_of_handle.size() * 4, &idx->d_nid);
     if (rc == PA_OK) rc = upload(fd.ec.data(), fd.ec.size() * 4, &idx->d_ec);
     if (rc == PA_OK) rc = upload(fd.class_ref.data(), fd.class_ref.size() * 4, &idx->d_class_ref);
@@ -178,7 +180,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     pa_index_stats& s = idx->stats;
     s.num_kmers = fd.num_kmers;
     s.table_slots = fd.nbuckets * SLOTS_PER_BUCKET;
-    s.bytes_table = fd.table.size() * 4;
+    s.bytes_table = fd.nbuckets * BUCKET_WORDS * 4;
     s.bytes_graph = fd.blobs.size() + fd.ledge.size() * 4 + fd.nid_of_handle.size() * 4;
     s.bytes_classes = (fd.ec.size() + fd.class_ref.size() + fd.class_len.size() + ctab.size() + fd.wtable.size()) * 4;
     s.bytes_total = s.bytes_table + s.bytes_graph + s.bytes_classes;

@@ -1,0 +1,254 @@
+// pa_index_create's device side: the k-mer dictionary is filled, verified and used to derive the node edges ON the GPU, from
+// the node blobs already resident in HBM — nothing of the 3.3 GB table (config 3) is built on the host or crosses PCIe.
+//
+// Replaces make_dbg_index (src/build_index.rs:182-221: boomphf MPHF + (node id, offset) scatter over every k-mer of every
+// node) and the edge resolution the debruijn crate does by hashing at every hop (Node::r_edges / l_edges):
+//   pa_fill_insert_kernel   one thread per k-mer of the graph: bucket of the k-mer, compare-and-swap on the first free
+//                           fingerprint (k <= 32) / handle word (k > 32) of the line, then the entry words — the same lines
+//                           the host flattener (device_flatten.cpp, kept for the CPU-only test tier) writes
+//   pa_fill_verify_kernel   every k-mer is looked up again: it must come back as (its node, its offset) — a k-mer that
+//                           occurs twice in the graph does not — within the 15 overflow buckets the mapping kernel follows
+//   pa_fill_edges_kernel    one thread per node: the four right neighbours of its last k-mer must be FIRST k-mers (offset 0),
+//                           the four left neighbours of its first k-mer LAST k-mers (offset len - k) of their nodes
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "device_flatten.hpp"
+#include "lane_steps.hpp"
+#include "pa_common.hpp"
+
+namespace pa {
+namespace {
+
+#define FILL_HIP(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(PA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+__device__ __forceinline__ uint64_t win32(const uint64_t* w, uint32_t pos) {
+    const uint32_t i = pos >> 5, s = (pos & 31) * 2;
+    return s ? (w[i] >> s) | (w[i + 1] << (64 - s)) : w[i];
+}
+
+template <class KT> struct FillOps;
+template <> struct FillOps<uint64_t> {
+    static constexpr uint32_t SLOTS = SLOTS_PER_BUCKET;
+    static constexpr double LOAD = 0.5;
+    __host__ __device__ static uint64_t mask(uint32_t k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1); }
+    __device__ static uint64_t get(const uint64_t* seq, uint32_t o, uint32_t k) { return win32(seq, o) & mask(k); }
+    __device__ static uint32_t bucket(uint64_t km, uint32_t nbuckets) { return pa_bucket(km, nbuckets); }
+    __device__ static bool try_insert(uint32_t* line, uint64_t km, uint32_t handle, uint32_t off) {
+        const uint32_t klo = (uint32_t)km, want = klo & 0x7FFFFFFFu;
+        for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i)
+            if (atomicCAS(line + i, FP_EMPTY, want) == FP_EMPTY) {
+                line[4 + 3 * i] = (uint32_t)(km >> 32);
+                line[5 + 3 * i] = handle;
+                line[6 + 3 * i] = off | (klo & 0x80000000u);
+                return true;
+            }
+        return false;
+    }
+    // 1 found, 0 absent (a line with a free slot ends the probe sequence), 2 keep probing
+    __device__ static int look(const uint32_t* line, uint64_t km, uint32_t& handle, uint32_t& off) {
+        const uint32_t klo = (uint32_t)km, want = klo & 0x7FFFFFFFu, khi = (uint32_t)(km >> 32);
+        bool full = true;
+        for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i) {
+            const uint32_t fp = line[i];
+            if (fp == FP_EMPTY) { full = false; continue; }
+            if (fp == want && line[4 + 3 * i] == khi && (line[6 + 3 * i] >> 31) == (klo >> 31)) {
+                handle = line[5 + 3 * i];
+                off = line[6 + 3 * i] & 0x7FFFFFFFu;
+                return 1;
+            }
+        }
+        return full ? 2 : 0;
+    }
+};
+template <> struct FillOps<u128> {
+    static constexpr uint32_t SLOTS = 2;
+    static constexpr double LOAD = 1.0 / 3.0;
+    __host__ __device__ static u128 mask(uint32_t k) { return k >= 64 ? ~(u128)0 : (((u128)1 << (2 * k)) - 1); }
+    __device__ static u128 get(const uint64_t* seq, uint32_t o, uint32_t k) {
+        return ((u128)(win32(seq, o + 32) & FillOps<uint64_t>::mask(k - 32)) << 64) | win32(seq, o);
+    }
+    __device__ static uint32_t bucket(u128 km, uint32_t nbuckets) { return __umulhi((uint32_t)(pa_mix128((uint64_t)km, (uint64_t)(km >> 64)) >> 32), nbuckets); }
+    __device__ static bool try_insert(uint32_t* line, u128 km, uint32_t handle, uint32_t off) {
+        for (uint32_t i = 0; i < 2; ++i)
+            if (atomicCAS(line + 8 * i + 4, NO_HANDLE, handle) == NO_HANDLE) {
+                line[8 * i] = (uint32_t)km; line[8 * i + 1] = (uint32_t)(km >> 32);
+                line[8 * i + 2] = (uint32_t)(km >> 64); line[8 * i + 3] = (uint32_t)(km >> 96);
+                line[8 * i + 5] = off;
+                return true;
+            }
+        return false;
+    }
+    __device__ static int look(const uint32_t* line, u128 km, uint32_t& handle, uint32_t& off) {
+        bool full = true;
+        for (uint32_t i = 0; i < 2; ++i) {
+            if (line[8 * i + 4] == NO_HANDLE) { full = false; continue; }
+            if (line[8 * i] == (uint32_t)km && line[8 * i + 1] == (uint32_t)(km >> 32) && line[8 * i + 2] == (uint32_t)(km >> 64) &&
+                line[8 * i + 3] == (uint32_t)(km >> 96)) {
+                handle = line[8 * i + 4];
+                off = line[8 * i + 5];
+                return 1;
+            }
+        }
+        return full ? 2 : 0;
+    }
+};
+
+template <class KT>
+__device__ __forceinline__ bool dict_find(const uint32_t* table, uint32_t nbuckets, KT km, uint32_t& handle, uint32_t& off, uint32_t& probes) {
+    uint32_t b = FillOps<KT>::bucket(km, nbuckets);
+    for (probes = 0; probes < nbuckets; ++probes) {
+        const int r = FillOps<KT>::look(table + (uint64_t)b * BUCKET_WORDS, km, handle, off);
+        if (r != 2) return r == 1;
+        if (++b == nbuckets) b = 0;
+    }
+    return false;
+}
+
+__device__ __forceinline__ const uint64_t* blob_seq(const uint8_t* blobs, uint32_t handle) {
+    return reinterpret_cast<const uint64_t*>(blobs + (uint64_t)handle * BLOB_GRANULE + BLOB_HDR_BYTES);
+}
+
+// node of the g-th k-mer of the graph: the last i with kcum[i] <= g
+__device__ __forceinline__ uint32_t node_of_kmer(const uint64_t* kcum, uint32_t num_nodes, uint64_t g) {
+    uint32_t lo = 0, hi = num_nodes - 1;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        if (kcum[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+template <class KT>
+__global__ __launch_bounds__(256) void pa_fill_insert_kernel(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ handle, const uint64_t* __restrict__ kcum,
+                                                             uint32_t num_nodes, uint64_t nk, uint32_t k, uint32_t* table, uint32_t nbuckets) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nk) return;
+    const uint32_t i = node_of_kmer(kcum, num_nodes, g), o = (uint32_t)(g - kcum[i]), h = handle[i];
+    const KT km = FillOps<KT>::get(blob_seq(blobs, h), o, k);
+    uint32_t b = FillOps<KT>::bucket(km, nbuckets);
+    for (;;) {   // load <= 1/2 (1/3): a free slot exists
+        if (FillOps<KT>::try_insert(table + (uint64_t)b * BUCKET_WORDS, km, h, o)) return;
+        if (++b == nbuckets) b = 0;
+    }
+}
+
+// flags[0] = a node one of whose k-mers does not come back as itself (a k-mer that occurs twice in the graph), else NO_HANDLE;
+// flags[1] = 1 when some k-mer sits more than 15 buckets from home
+template <class KT>
+__global__ __launch_bounds__(256) void pa_fill_verify_kernel(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ handle, const uint64_t* __restrict__ kcum,
+                                                             uint32_t num_nodes, uint64_t nk, uint32_t k, const uint32_t* __restrict__ table, uint32_t nbuckets,
+                                                             uint32_t* __restrict__ flags) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nk) return;
+    const uint32_t i = node_of_kmer(kcum, num_nodes, g), o = (uint32_t)(g - kcum[i]), h = handle[i];
+    const KT km = FillOps<KT>::get(blob_seq(blobs, h), o, k);
+    uint32_t fh = 0, fo = 0, probes = 0;
+    if (!dict_find<KT>(table, nbuckets, km, fh, fo, probes) || fh != h || fo != o) atomicMin(flags, i);
+    if (probes > 15) flags[1] = 1;
+}
+
+// flags[2] = a node with an extension bit but no terminal neighbour k-mer, flags[3] = a node whose left neighbour k-mer is
+// not the last k-mer of its node (both NO_HANDLE when fine)
+template <class KT>
+__global__ __launch_bounds__(256) void pa_fill_edges_kernel(uint8_t* blobs, uint32_t* __restrict__ ledge, const uint32_t* __restrict__ handle, uint32_t num_nodes,
+                                                            uint32_t k, const uint32_t* __restrict__ table, uint32_t nbuckets, bool need_r, bool need_l,
+                                                            uint32_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_nodes) return;
+    const uint32_t h = handle[i];
+    uint32_t* hd = reinterpret_cast<uint32_t*>(blobs + (uint64_t)h * BLOB_GRANULE);
+    const uint32_t len = hd[0] & 0xFFFFFFu, exts = hd[0] >> 24, topshift = 2 * (k - 1);
+    const uint64_t* seq = blob_seq(blobs, h);
+    const KT first = FillOps<KT>::get(seq, 0, k), last = FillOps<KT>::get(seq, len - k, k), mask = FillOps<KT>::mask(k);
+    for (uint32_t base = 0; base < 4; ++base) {
+        uint32_t fh = 0, fo = 0, probes = 0;
+        if (need_r) {   // find_link(last.extend_right(b), Dir::Right): the node whose FIRST k-mer it is
+            uint32_t re = NO_HANDLE;
+            if (exts & (1u << base)) {
+                if (dict_find<KT>(table, nbuckets, (last >> 2) | ((KT)base << topshift), fh, fo, probes) && fo == 0) re = fh;
+                else atomicMin(flags + 2, i);
+            }
+            hd[4 + base] = re;
+        }
+        if (need_l) {   // find_link(first.extend_left(b), Dir::Left): the node whose LAST k-mer it is
+            uint32_t le = NO_HANDLE;
+            if (exts & (1u << (4 + base))) {
+                if (dict_find<KT>(table, nbuckets, ((first << 2) | (KT)base) & mask, fh, fo, probes)) {
+                    le = fh;
+                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(blobs + (uint64_t)fh * BLOB_GRANULE) & 0xFFFFFFu;   // (word 0 of a header is never written here)
+                    if (fo != tlen - k) atomicMin(flags + 3, i);
+                } else atomicMin(flags + 2, i);
+            }
+            ledge[4ull * h + base] = le;
+        }
+    }
+}
+
+template <class KT>
+int fill_t(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, uint64_t* nbuckets_out) {
+    const uint32_t N = fd.num_nodes, k = fd.k;
+    const uint64_t nk = fd.num_kmers;
+    *d_table = nullptr;
+    void *d_handle = nullptr, *d_kcum = nullptr, *d_flags = nullptr;
+    auto done = [&](int rc) {
+        for (void* p : {d_handle, d_kcum, d_flags})
+            if (p) (void)hipFree(p);
+        if (rc != PA_OK && *d_table) { (void)hipFree(*d_table); *d_table = nullptr; }
+        return rc;
+    };
+#define FILL_TRY(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(PA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
+    FILL_TRY(hipMalloc(&d_handle, (size_t)(N ? N : 1) * 4));
+    FILL_TRY(hipMalloc(&d_kcum, ((size_t)N + 1) * 8));
+    FILL_TRY(hipMalloc(&d_flags, 16));
+    if (N) FILL_TRY(hipMemcpy(d_handle, fd.handle.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    FILL_TRY(hipMemcpy(d_kcum, fd.node_kcum.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
+    uint64_t nbuckets = 0;
+    for (double load = FillOps<KT>::LOAD;; load *= 0.75) {
+        nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (FillOps<KT>::SLOTS * load)) + 1);
+        if (nbuckets >= 0xFFFFFFFFull) return done(fail(PA_ERR_UNSUPPORTED, "dictionary exceeds 2^32 buckets"));
+        if (*d_table) { (void)hipFree(*d_table); *d_table = nullptr; }
+        const hipError_t em = hipMalloc(d_table, nbuckets * BUCKET_WORDS * 4);
+        if (em != hipSuccess) { *d_table = nullptr; return done(fail(PA_ERR_OOM, "hipMalloc(%llu) for the dictionary: %s", (unsigned long long)(nbuckets * BUCKET_WORDS * 4), hipGetErrorString(em))); }
+        FILL_TRY(hipMemsetAsync(*d_table, 0xFF, nbuckets * BUCKET_WORDS * 4, nullptr));   // FP_EMPTY / NO_HANDLE in every word
+        const uint32_t init[4] = {NO_HANDLE, 0u, NO_HANDLE, NO_HANDLE};
+        FILL_TRY(hipMemcpy(d_flags, init, 16, hipMemcpyHostToDevice));
+        if (nk) {
+            const dim3 grid((uint32_t)((nk + 255) / 256));
+            hipLaunchKernelGGL(pa_fill_insert_kernel<KT>, grid, dim3(256), 0, nullptr, static_cast<const uint8_t*>(d_blobs), static_cast<const uint32_t*>(d_handle),
+                               static_cast<const uint64_t*>(d_kcum), N, nk, k, static_cast<uint32_t*>(*d_table), (uint32_t)nbuckets);
+            FILL_TRY(hipGetLastError());
+            hipLaunchKernelGGL(pa_fill_verify_kernel<KT>, grid, dim3(256), 0, nullptr, static_cast<const uint8_t*>(d_blobs), static_cast<const uint32_t*>(d_handle),
+                               static_cast<const uint64_t*>(d_kcum), N, nk, k, static_cast<const uint32_t*>(*d_table), (uint32_t)nbuckets,
+                               static_cast<uint32_t*>(d_flags));
+            FILL_TRY(hipGetLastError());
+        }
+        uint32_t flags[4];
+        FILL_TRY(hipMemcpy(flags, d_flags, 16, hipMemcpyDeviceToHost));
+        if (flags[0] != NO_HANDLE) return done(fail(PA_ERR_FORMAT, "a k-mer of node %u occurs twice in the graph", flags[0]));
+        if (!flags[1]) break;   // else: some key sits further from home than the kernel follows; a larger table
+    }
+    if (N && !(fd.have_redge && fd.have_ledge)) {
+        hipLaunchKernelGGL(pa_fill_edges_kernel<KT>, dim3((N + 255) / 256), dim3(256), 0, nullptr, static_cast<uint8_t*>(d_blobs), static_cast<uint32_t*>(d_ledge),
+                           static_cast<const uint32_t*>(d_handle), N, k, static_cast<const uint32_t*>(*d_table), (uint32_t)nbuckets, !fd.have_redge, !fd.have_ledge,
+                           static_cast<uint32_t*>(d_flags));
+        FILL_TRY(hipGetLastError());
+        uint32_t flags[4];
+        FILL_TRY(hipMemcpy(flags, d_flags, 16, hipMemcpyDeviceToHost));
+        if (flags[2] != NO_HANDLE)
+            return done(fail(PA_ERR_FORMAT, "node %u has an extension bit without a terminal neighbour k-mer (missing link)", flags[2]));
+        if (flags[3] != NO_HANDLE) return done(fail(PA_ERR_FORMAT, "node %u: left neighbour k-mer is not the last k-mer of its node", flags[3]));
+    }
+#undef FILL_TRY
+    *nbuckets_out = nbuckets;
+    return done(PA_OK);
+}
+
+}  // namespace
+
+int device_fill_index(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, uint64_t* nbuckets) {
+    return fd.k <= 32 ? fill_t<uint64_t>(fd, d_blobs, d_ledge, d_table, nbuckets) : fill_t<u128>(fd, d_blobs, d_ledge, d_table, nbuckets);
+}
+
+}  // namespace pa
