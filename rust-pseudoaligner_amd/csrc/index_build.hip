@@ -248,18 +248,24 @@ __global__ __launch_bounds__(256) void pa_ib_links_kernel(const KT* __restrict__
 // thread can observe is a true statement ("distance steps back from here is that k-mer"), so racing updates only speed it up
 __global__ __launch_bounds__(256) void pa_ib_jump_kernel(unsigned long long* __restrict__ pd, uint32_t D, uint32_t* __restrict__ unresolved) {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
     // a FIRST k-mer is (itself, distance 0). On a pure cycle the jumps can bring a pointer back to its own k-mer, but then at a
     // distance that is not 0 (it saturates instead of wrapping), so a cycle member is never taken for a first k-mer
-    const unsigned long long me = __atomic_load_n(pd + d, __ATOMIC_RELAXED);
-    if (me == ((unsigned long long)d << 32)) return;
-    const uint32_t p = (uint32_t)(me >> 32);
-    const unsigned long long up = __atomic_load_n(pd + p, __ATOMIC_RELAXED);
-    if (up == ((unsigned long long)p << 32)) return;   // p is a first k-mer: resolved
-    uint32_t dist = (uint32_t)me + (uint32_t)up;
-    if (dist < (uint32_t)me) dist = 0xFFFFFFFFu;
-    __atomic_store_n(pd + d, (up & 0xFFFFFFFF00000000ull) | dist, __ATOMIC_RELAXED);
-    atomicAdd(unresolved, 1u);
+    bool jumped = false;
+    if (d < D) {
+        const unsigned long long me = __atomic_load_n(pd + d, __ATOMIC_RELAXED);
+        if (me != ((unsigned long long)d << 32)) {
+            const uint32_t p = (uint32_t)(me >> 32);
+            const unsigned long long up = __atomic_load_n(pd + p, __ATOMIC_RELAXED);
+            if (up != ((unsigned long long)p << 32)) {   // else: p is a first k-mer, resolved
+                uint32_t dist = (uint32_t)me + (uint32_t)up;
+                if (dist < (uint32_t)me) dist = 0xFFFFFFFFu;
+                __atomic_store_n(pd + d, (up & 0xFFFFFFFF00000000ull) | dist, __ATOMIC_RELAXED);
+                jumped = true;
+            }
+        }
+    }
+    const uint64_t m = __ballot(jumped);   // one atomic per wave: a single counter hit by every thread serialises the whole pass
+    if (m && (threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(unresolved, (uint32_t)__popcll(m));
 }
 // flags: first k-mer of a unitig / member of a pure cycle (its pointer never reaches a first k-mer)
 __global__ __launch_bounds__(256) void pa_ib_classify_kernel(const unsigned long long* __restrict__ pd, uint32_t D, uint32_t* __restrict__ is_start,

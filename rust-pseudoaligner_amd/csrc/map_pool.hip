@@ -189,8 +189,11 @@ constexpr uint32_t SLOT_FIXED_BYTES = 32 + 16 + 8;   // lane state, class window
 // only state, windows and ids.
 // DBG: the statistics (PA_MAP_STATS) and ablation (PA_MAP_ABLATE) build of the same text; the production build has neither the
 // clock reads nor the parameter loads they need.
+#ifndef PA_MAP_MIN_BLOCKS
+#define PA_MAP_MIN_BLOCKS 3   // workgroups per CU the register budget is sized for (A/B builds: -DPA_MAP_MIN_BLOCKS=4)
+#endif
 template <bool TRACE, bool GREAD, bool DBG>
-__global__ __launch_bounds__(PA_MAP_BLOCK, 3) void pa_map_pool_kernel(const MapParams p_arg) {
+__global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_kernel(const MapParams p_arg) {
     // The ~50 words of parameters are NOT kept in registers across the loop (the allocator would spill most of them to
     // VGPR lanes and pay a v_readlane + hazard nops at every use): each iteration re-reads what its step needs from the
     // kernarg segment with scalar loads (scalar cache hits). The empty asm makes the pointer opaque per iteration.

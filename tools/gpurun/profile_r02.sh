@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="env $@ python $R/bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --no-e2e --index-cache /tmp/g_$wl.idx"
+B="env $@ python $R/bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --no-e2e "
 $B > $O/bench.json 2> $O/bench.err; cut -c1-400 $O/bench.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O/trace.log 2>&1; echo "trace rc=$?"
 run() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$name -- $B > $O/$name.log 2>&1; echo "$name rc=$?"; }
