@@ -167,6 +167,12 @@ PA_HD uint64_t read_window(ReadRef r, uint32_t pos) {
     const uint32_t w = pos >> 5;
     return funnel(read_word(r, w), read_word(r, w + 1), (pos & 31) * 2);
 }
+// the same when the caller only looks at bases INSIDE the read (a k-mer at kp <= L - K): the word after the last one is
+// not zeroed but re-read, one multiply instead of two
+PA_HD uint64_t read_window_in(ReadRef r, uint32_t pos) {
+    const uint32_t i0 = (pos >> 5) * r.stride, ilast = (r.wmax - 1) * r.stride;
+    return funnel(r.p[i0], r.p[pa_min(i0 + r.stride, ilast)], (pos & 31) * 2);
+}
 // 32 bases ENDING at base p (base p lands in the top 2 bits; missing low bases are zero)
 PA_HD uint64_t read_window_end(ReadRef r, uint32_t p) { return p >= 31 ? read_window(r, p - 31) : r.p[0] << (2 * (31 - p)); }
 
@@ -189,6 +195,14 @@ PA_HD uint64_t diff_mask(uint64_t x, uint32_t n) {
     hi = (hi | (hi >> 1)) & 0x55555555u;
     const uint64_t keep = n >= 32 ? ~0ull : ((1ull << (2 * n)) - 1);
     return ((uint64_t)lo | ((uint64_t)hi << 32)) & keep;
+}
+
+// the same for 1 <= n <= 32 (the callers that skip empty chunks): the keep mask is one 64-bit shift
+PA_HD uint64_t diff_mask_nz(uint64_t x, uint32_t n) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    lo = (lo | (lo >> 1)) & 0x55555555u;
+    hi = (hi | (hi >> 1)) & 0x55555555u;
+    return ((uint64_t)lo | ((uint64_t)hi << 32)) & (~0ull >> (64u - 2u * n));
 }
 
 // The body of the compare loops (:151-170 / :236-255) over n <= 32 bases given their mismatch mask (bit 2i = i-th base
@@ -345,7 +359,7 @@ struct SeekProbe {
     uint32_t klo, khi;       // the k-mer
 };
 PA_HD void seek_issue(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekProbe& q) {
-    const uint64_t kmer = read_window(rd, l_kp(s)) & ix.kmask;      // read_seq.get_kmer(kmer_pos) (:93)
+    const uint64_t kmer = read_window_in(rd, l_kp(s)) & ix.kmask;   // read_seq.get_kmer(kmer_pos) (:93); kmer_pos <= L - K
     uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + l_probe(s);
     if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
     q.linew = ix.table + (uint64_t)b * BUCKET_WORDS;
@@ -480,9 +494,15 @@ PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, 
         snp = 0;                                                      // :235
     }
     const uint32_t sh_a = (ro0 & 31) * 2, sh_r = (kp0 & 31) * 2, rw = kp0 >> 5;
+    // five read words, all LDS reads in flight together. Words beyond the read's last are NOT zeroed here (they re-read the last
+    // word): every compare below is masked to bases inside the read (n <= L - kp0), so what lies beyond is never looked at;
+    // one multiply for the first word, the others are an add and a clamp
     uint64_t r[5];
+    {
+        const uint32_t i0 = rw * rd.stride, ilast = (rd.wmax - 1) * rd.stride;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) r[i] = read_word(rd, rw + i);         // all LDS reads in flight together
+        for (uint32_t i = 0; i < 5; ++i) r[i] = rd.p[pa_min(i0 + i * rd.stride, ilast)];
+    }
     bool premature = false;
     uint32_t matched, nfl = (fl & ~F_FRESH) | (l_flags(s) & (F_SMALL_BASE | F_SPILL_OVERFLOW));   // (what push_node may just have set)
     if (!careful) {
@@ -491,7 +511,7 @@ PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const uint32_t done = 32u * c;
-            if (n > done) cnt += pa_popc64(diff_mask(funnel(r[c], r[c + 1], sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u)));
+            if (n > done) cnt += pa_popc64(diff_mask_nz(funnel(r[c], r[c + 1], sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u)));
         }
         if (snp + cnt <= allowed) {
             matched = n;
