@@ -23,6 +23,10 @@
 #include "lane_steps.hpp"
 #include "kernel_utils.hpp"
 
+#ifndef PA_RARE_MIN   // A/B builds: -DPA_RARE_MIN=0 (rare states compete by population only)
+#define PA_RARE_MIN 10u
+#endif
+
 namespace pa {
 namespace {
 
@@ -295,23 +299,32 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         const uint32_t nempty = PA_CNT(ST_EMPTY);
         const uint32_t nrefill = (uint32_t)(left < (uint64_t)nempty ? left : (uint64_t)nempty);
         uint32_t best = 0, sel = ST_EMPTY;
-#define PA_CONSIDER(t, c) { const uint32_t c_ = (c); if (best < 64 && c_ > best) { best = c_; sel = (t); } }
+        // `best` is the WEIGHT of the choice (64 and more = "fills a wave": the first such state in this order wins), `bestn` the
+        // slots it really holds. A rare state weighs as a full wave from PA_RARE_MIN slots on: slots parked in a rare state are
+        // slots the common steps cannot use (with the plain "most populated" rule the rare states only ran once they
+        // outnumbered the common ones, i.e. when a good part of the pool was parked); the best trade between a low-width rare
+        // iteration and parked slots is at 12...17 slots for the rare states of configs 3 and 5
+        uint32_t bestn = 0;
+#define PA_CONSIDER(t, c) { const uint32_t c_ = (c); if (best < 64 && c_ > best) { best = c_; bestn = c_; sel = (t); } }
+#define PA_CONSIDER_RARE(t, c) { const uint32_t c_ = (c), w_ = (PA_RARE_MIN && c_ >= PA_RARE_MIN) ? 64u + c_ : c_; \
+                                 if (best < 64 && w_ > best) { best = w_; bestn = c_; sel = (t); } }
         // the five rare states (left extension, the list-mode tiers, the content lookup) are only counted when some slot is in one
         // of them: one ballot instead of ten in most iterations (the order of consideration is the same either way)
         constexpr uint32_t RARE = (1u << ST_LEFT) | (1u << ST_F_LIGHT) | (1u << ST_F_SCAN) | (1u << ST_F_COOP) | (1u << ST_F_NOVEL);
         const bool any_rare = __ballot((((RARE >> (st_lo & 31u)) | (RARE >> (st_hi & 31u))) & 1u) != 0) != 0;   // (0xFF, no slot: bit 31, not rare)
         if (any_rare) {
-            PA_CONSIDER(ST_F_NOVEL, PA_CNT(ST_F_NOVEL))
-            PA_CONSIDER(ST_F_COOP, PA_CNT(ST_F_COOP))
-            PA_CONSIDER(ST_F_SCAN, PA_CNT(ST_F_SCAN))
-            PA_CONSIDER(ST_F_LIGHT, PA_CNT(ST_F_LIGHT))
+            PA_CONSIDER_RARE(ST_F_NOVEL, PA_CNT(ST_F_NOVEL))
+            PA_CONSIDER_RARE(ST_F_COOP, PA_CNT(ST_F_COOP))
+            PA_CONSIDER_RARE(ST_F_SCAN, PA_CNT(ST_F_SCAN))
+            PA_CONSIDER_RARE(ST_F_LIGHT, PA_CNT(ST_F_LIGHT))
         }
         PA_CONSIDER(ST_F_BITS, PA_CNT(ST_F_BITS))
         PA_CONSIDER(ST_FWD, PA_CNT(ST_FWD))
-        if (any_rare) PA_CONSIDER(ST_LEFT, PA_CNT(ST_LEFT))
+        if (any_rare) PA_CONSIDER_RARE(ST_LEFT, PA_CNT(ST_LEFT))
         PA_CONSIDER(ST_SEEK, PA_CNT(ST_SEEK))
         PA_CONSIDER(ST_EMPTY, nrefill)
 #undef PA_CONSIDER
+#undef PA_CONSIDER_RARE
         if (best == 0) break;
         // DUAL iteration: a forward step and a dictionary probe are each one dependent round trip and touch different parts
         // of the memory system (node blobs: MALL / L2; dictionary: HBM). When both queues hold work the wave pops BOTH, lets
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         const uint32_t n_seek_q = PA_CNT(ST_SEEK), n_fwd_q = PA_CNT(ST_FWD);
         const bool dual = (sel == ST_FWD || sel == ST_SEEK) && K <= 32 && n_seek_q != 0 && n_fwd_q != 0 && !PA_ABLATE(4u);
         if (dual) sel = ST_FWD;
-        const uint32_t n = dual ? (n_fwd_q < 64 ? n_fwd_q : 64) : best < 64 ? best : 64;
+        const uint32_t n = dual ? (n_fwd_q < 64 ? n_fwd_q : 64) : bestn < 64 ? bestn : 64;
         const uint32_t n2 = dual ? (n_seek_q < 64 ? n_seek_q : 64) : 0u;   // lanes of the second (SEEK) batch
         if (PA_DBG && lane == 0) {
             dbg[dual ? ST_DUAL : sel] += 1;
