@@ -23,6 +23,9 @@
 #include "lane_steps.hpp"
 #include "kernel_utils.hpp"
 
+#ifndef PA_FILL   // A/B builds: -DPA_FILL=0 (output steps do not take EMPTY slots along)
+#define PA_FILL 1
+#endif
 #ifndef PA_RARE_MIN   // A/B builds: -DPA_RARE_MIN=0 (rare states compete by population only)
 #define PA_RARE_MIN 10u
 #endif
@@ -334,7 +337,11 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         const uint32_t n_seek_q = PA_CNT(ST_SEEK), n_fwd_q = PA_CNT(ST_FWD);
         const bool dual = (sel == ST_FWD || sel == ST_SEEK) && K <= 32 && n_seek_q != 0 && n_fwd_q != 0 && !PA_ABLATE(4u);
         if (dual) sel = ST_FWD;
-        const uint32_t n = dual ? (n_fwd_q < 64 ? n_fwd_q : 64) : bestn < 64 ? bestn : 64;
+        const uint32_t n_own = dual ? (n_fwd_q < 64 ? n_fwd_q : 64) : bestn < 64 ? bestn : 64;
+        // an output step that does not fill the wave takes EMPTY slots into its idle lanes: they are refilled by the same text
+        // (slots freed by the rare finishing steps otherwise wait, parked, for a refill step of their own)
+        const uint32_t n_fill = (PA_FILL && sel == ST_F_BITS && left != 0) ? (64 - n_own < nempty ? 64 - n_own : nempty) : 0u;
+        const uint32_t n = n_own + n_fill;
         const uint32_t n2 = dual ? (n_seek_q < 64 ? n_seek_q : 64) : 0u;   // lanes of the second (SEEK) batch
         if (PA_DBG && lane == 0) {
             dbg[dual ? ST_DUAL : sel] += 1;
@@ -345,7 +352,13 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         // ---- 2. pop n slots (and n2 slots of the SEEK queue)
         const bool active = lane < n;
         uint32_t slot, slot2 = 0;
-        PA_POP(sel, n, slot)
+        PA_POP(sel, n_own, slot)
+        if (n_fill) {   // lanes n_own .. n - 1: the first n_fill EMPTY slots
+            uint32_t eslot;
+            PA_POP((uint32_t)ST_EMPTY, n_fill, eslot)
+            const uint32_t mine = (uint32_t)__shfl((int)eslot, (int)((lane - n_own) & 63u), 64);
+            if (lane >= n_own && active) slot = mine;
+        }
         const bool active2 = lane < n2;
         if (dual) PA_POP((uint32_t)ST_SEEK, n2, slot2)
         const uint32_t gslot = wave * S + slot;
@@ -354,6 +367,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             const u32x4 a = stv[2 * slot], b = stv[2 * slot + 1];
             s.lk = a.x; s.cm = a.y; s.h = a.z; s.of = a.w; s.rr = b.x; s.rm = b.y; s.ph = b.z; s.nc = b.w;
             s.rid = wc[2 * slot + 1];
+            if (n_fill && lane >= n_own) s.lk = 0;   // an EMPTY slot taken along by an output step (its stored state may be stale)
         }
         const ReadRef rr = GREAD ? ReadRef{p.tiles + ((uint64_t)(s.rid >> 6) * wpr) * 64 + (s.rid & 63), 64u, wpr} : ReadRef{(const uint64_t*)(rd + slot), S, wpr};
         const glb_u32w row = (glb_u32w)p.spill + (uint64_t)gslot * spill_cap;
@@ -410,7 +424,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         } else if (sel == ST_F_BITS) {
             // output of window-mode reads and of unmapped reads: no loads. A non-empty window that is a strict subset of
             // every class seen goes on to NOVEL (is it an index class all the same?) and is written there.
-            if (active) {
+            if (active && lane < n_own) {
                 const bool mapped = l_st(s) != ST_NONE;
                 const u32x4 w = win[slot];
                 const uint32_t cand = wc[2 * slot];
