@@ -211,7 +211,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
 #define PA_ABLATE(bit) (DBG && (p.ablate & (bit)))
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t lane = lane_id();
-    const uint32_t wave_in_block = threadIdx.x >> 6;
+    const uint32_t wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform, and the compiler should know:
+                                                                                                        // next / end / gslot arithmetic then runs on the scalar unit
     const uint32_t waves_per_block = PA_MAP_BLOCK / 64;
     const uint32_t wave = blockIdx.x * waves_per_block + wave_in_block;
     const uint32_t nwaves = gridDim.x * waves_per_block;
