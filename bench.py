@@ -245,7 +245,7 @@ def main() -> None:
     if n_gpus == 1 and not args.no_e2e:
         try:
             b = W % n_batches
-            chunk = min(B, 10_000_000)
+            chunk = min(B, 20_000_000)
             n_chunks = (B + chunk - 1) // chunk
             words = pa.lib().pa_tiles_words
             h_tiles = torch.empty(tile_words, dtype=torch.int64, pin_memory=True)
@@ -253,16 +253,19 @@ def main() -> None:
             h_results = torch.empty(B * 4, dtype=torch.int32, pin_memory=True)
             h_counts = torch.empty(aligner.counts_len(), dtype=torch.int64, pin_memory=True)
             h_tiles.copy_(tiles[b]); h_lens.copy_(lens[b])
-            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            NS = int(os.environ.get("PA_E2E_STREAMS", "3"))   # chunks in flight (one stream + one set of staging buffers each)
+            chunk = min(B, int(os.environ.get("PA_E2E_CHUNK", str(chunk))))
+            n_chunks = (B + chunk - 1) // chunk
+            streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
             stage = [dict(tiles=torch.empty(words(chunk, wpr), dtype=torch.int64, device=dev), lens=torch.empty(chunk, dtype=torch.int32, device=dev),
                           res=torch.empty(chunk * 4, dtype=torch.int32, device=dev), arena=torch.empty(aligner.arena_hint(chunk), dtype=torch.int32, device=dev),
-                          busy=False) for _ in range(2)]
+                          busy=False) for _ in range(NS)]
             e_counts = torch.zeros(aligner.counts_len(), dtype=torch.int64, device=dev)
             arena_ids = 0
             torch.cuda.synchronize()
             t_e2e = time.perf_counter()
             for c in range(n_chunks):
-                st, S = stage[c % 2], streams[c % 2]
+                st, S = stage[c % NS], streams[c % NS]
                 lo, nn = c * chunk, min(chunk, B - c * chunk)          # chunk is a multiple of 64: tile aligned
                 if st["busy"]:
                     arena_ids += aligner.map_finish(S.cuda_stream)[0]   # the stream's previous chunk is done (its records are on the host)
@@ -273,7 +276,7 @@ def main() -> None:
                                                    st["arena"].numel(), e_counts.data_ptr(), 2, S.cuda_stream)
                     h_results[lo * 4: (lo + nn) * 4].copy_(st["res"][: nn * 4], non_blocking=True)
                 st["busy"] = True
-            for i in range(2):
+            for i in range(NS):
                 if stage[i]["busy"]:
                     arena_ids += aligner.map_finish(streams[i].cuda_stream)[0]
             h_counts.copy_(e_counts)
@@ -283,9 +286,9 @@ def main() -> None:
             h2d_bytes = B * (wpr * 8 + 4)
             out["e2e_reads_per_s"] = B / e2e_s
             out["e2e_pcie_frac"] = h2d_bytes / e2e_s / 63e9
-            out["e2e"] = {"ms": 1000.0 * e2e_s, "chunks": n_chunks, "reads_per_chunk": chunk, "streams": 2, "h2d_bytes": h2d_bytes,
+            out["e2e"] = {"ms": 1000.0 * e2e_s, "chunks": n_chunks, "reads_per_chunk": chunk, "streams": NS, "h2d_bytes": h2d_bytes,
                           "d2h_bytes": B * 16 + 8 * aligner.counts_len(), "novel_class_ids_left_on_device": int(arena_ids),
-                          "what": "pinned host 2-bit tiles -> H2D || kernel || D2H of the 16-byte records on two streams of one index handle "
+                          "what": "pinned host 2-bit tiles -> H2D || kernel || D2H of the 16-byte records on several streams of one index handle "
                                   "-> records + count table on the host; link = PCIe Gen5 x16, 63 GB/s per direction"}
             del h_tiles, h_lens, h_results, stage
         except Exception as e:   # the leg is a report, not the benchmark: never lose the bench line over it
