@@ -162,6 +162,10 @@ typedef struct pa_index_stats {
 
 /* Flatten for the GPU and upload to HIP device `device`. Fails with PA_ERR_NO_DEVICE when no GPU. */
 int pa_index_create(const pa_flat_index* flat, int device, pa_index** out);
+/* The same for several GPUs of one process (`devices, ndev`): out[i] receives the handle of devices[i]; the
+ * index is replicated (reads shard over the handles, §8e). All or nothing: on failure every handle created so far is
+ * destroyed and out[] is NULL throughout. A host that runs one process per GPU calls pa_index_create instead. */
+int pa_index_create_multi(const pa_flat_index* flat, const int* devices, int ndev, pa_index** out);
 int pa_index_get_stats(const pa_index* idx, pa_index_stats* stats);
 void pa_index_destroy(pa_index* idx);
 

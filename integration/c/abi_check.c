@@ -94,12 +94,24 @@ int main(int argc, char** argv) {
         EXPECT(pa_overflow_create(0, 16, 64, &o) == PA_ERR_NO_DEVICE);
         EXPECT(pa_txome_upload(tx2, 60, 0, &td) == PA_ERR_NO_DEVICE);
         EXPECT(pa_event_create(&ev) < 0);
+        const int devs0[1] = {0};
+        pa_index* multi0[1] = {NULL};
+        EXPECT(pa_index_create_multi(&flat, devs0, 1, multi0) == PA_ERR_NO_DEVICE && multi0[0] == NULL);
         pa_host_index* hg = NULL;
         EXPECT(pa_host_index_build_fasta_device(fasta, 20, 0, &hg) == PA_ERR_NO_DEVICE && hg == NULL);
         EXPECT(pa_host_index_build_packed_device(packed, tx_start, ntx2, 20, 0, &hg) == PA_ERR_NO_DEVICE && hg == NULL);
         printf("abi_check: host half ok, no device: %d failures\n", failures);
     } else {
         EXPECT(rc == PA_OK && idx);
+        /* one call for the GPUs of a single-process host (here: the one GPU, and a refused duplicate) */
+        const int devs[2] = {0, 0};
+        pa_index* multi[2] = {NULL, NULL};
+        EXPECT(pa_index_create_multi(&flat, devs, 1, multi) == PA_OK && multi[0] != NULL);
+        pa_index_stats mst;
+        EXPECT(pa_index_get_stats(multi[0], &mst) == PA_OK && mst.num_nodes == flat.num_nodes);
+        pa_index_destroy(multi[0]);
+        multi[0] = NULL;
+        EXPECT(pa_index_create_multi(&flat, devs, 2, multi) == PA_ERR_INVALID_ARG && multi[0] == NULL && multi[1] == NULL);
         /* the graph built on the GPU is the graph the CPU builder gives */
         pa_host_index *hg = NULL, *hg2 = NULL;
         EXPECT(pa_host_index_build_fasta_device(fasta, 20, 0, &hg) == PA_OK && hg);

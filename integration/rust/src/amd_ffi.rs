@@ -37,6 +37,7 @@ extern "C" {
 
     // index: flat form of `pub struct Pseudoaligner<K>` (src/pseudoaligner.rs:26-33) -> GPU
     pub fn pa_index_create(flat: *const PaFlatIndex, device: c_int, out: *mut *mut PaIndex) -> c_int;
+    pub fn pa_index_create_multi(flat: *const PaFlatIndex, devices: *const c_int, ndev: c_int, out: *mut *mut PaIndex) -> c_int;
     pub fn pa_index_destroy(idx: *mut PaIndex);
     pub fn pa_host_index_from_flat(flat: *const PaFlatIndex, out: *mut *mut PaHostIndex) -> c_int;
     pub fn pa_host_index_build_fasta(fasta_path: *const c_char, k: u32, num_threads: c_int, out: *mut *mut PaHostIndex) -> c_int;

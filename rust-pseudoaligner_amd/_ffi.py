@@ -65,6 +65,7 @@ SIGNATURES = {
     "pa_host_index_transcripts": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), u32p]),
     "pa_host_index_destroy": (None, [vp]),
     "pa_index_create": (C.c_int, [C.POINTER(FlatIndex), C.c_int, C.POINTER(vp)]),
+    "pa_index_create_multi": (C.c_int, [C.POINTER(FlatIndex), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
     "pa_index_get_stats": (C.c_int, [vp, C.POINTER(IndexStats)]),
     "pa_index_destroy": (None, [vp]),
     "pa_tiles_words": (C.c_size_t, [C.c_uint64, C.c_uint32]),

@@ -192,6 +192,25 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     return PA_OK;
 }
 
+int pa_index_create_multi(const pa_flat_index* flat, const int* devices, int ndev, pa_index** out) {
+    if (!flat || !devices || !out || ndev < 1) return fail(PA_ERR_INVALID_ARG, "null argument or ndev < 1");
+    for (int i = 0; i < ndev; ++i) out[i] = nullptr;
+    for (int i = 0; i < ndev; ++i) {
+        for (int j = 0; j < i; ++j)
+            if (devices[j] == devices[i]) {
+                for (int t = 0; t < i; ++t) { pa_index_destroy(out[t]); out[t] = nullptr; }
+                return fail(PA_ERR_INVALID_ARG, "device %d listed twice", devices[i]);
+            }
+        const int rc = pa_index_create(flat, devices[i], &out[i]);
+        if (rc != PA_OK) {
+            const std::string why = last_error_ref();
+            for (int t = 0; t <= i; ++t) { pa_index_destroy(out[t]); out[t] = nullptr; }
+            return fail(rc, "device %d: %s", devices[i], why.c_str());
+        }
+    }
+    return PA_OK;
+}
+
 int pa_index_get_stats(const pa_index* idx, pa_index_stats* stats) {
     if (!idx || !stats) return fail(PA_ERR_INVALID_ARG, "null argument");
     *stats = idx->stats;
