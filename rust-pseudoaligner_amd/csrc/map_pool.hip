@@ -229,7 +229,10 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
     // the L2 atomics (7 classes: 0.5 ms -> 6.8 ms per 10 M reads)
     const lds_u32 ctag = (lds_u32)(wbase + 256), ccnt = (lds_u32)(wbase + 512);
     const lds_u64 rd = (lds_u64)(wbase + POOL_FIXED);
-    const lds_v4 stv = (lds_v4)(wbase + POOL_FIXED + 8 * lwpr * S);        // two vectors per slot
+    // the lane state as TWO arrays of one 16-byte vector per slot (not one array of 32-byte records: with a 32-byte stride the
+    // vectors of 64 random slots fall into 4 bank groups, with 16 bytes into 8 — half of the LDS cycles were bank conflicts)
+    const lds_v4 stA = (lds_v4)(wbase + POOL_FIXED + 8 * lwpr * S);
+    const lds_v4 stB = (lds_v4)(wbase + POOL_FIXED + (8 * lwpr + 16) * S);
     const lds_v4 win = (lds_v4)(wbase + POOL_FIXED + (8 * lwpr + 32) * S); // {base1, mask1, base2, mask2}
     const lds_u32 wc = (lds_u32)(wbase + POOL_FIXED + (8 * lwpr + 48) * S);   // {class id, read id} per slot
     // Scheduling state: ONE byte per slot = the state the slot waits in (0xFF: no such slot), laid out so that lane i reads the
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         const uint32_t gslot = wave * S + slot;
         Lane s;
         {
-            const u32x4 a = stv[2 * slot], b = stv[2 * slot + 1];
+            const u32x4 a = stA[slot], b = stB[slot];
             s.lk = a.x; s.cm = a.y; s.h = a.z; s.of = a.w; s.rr = b.x; s.rm = b.y; s.ph = b.z; s.nc = b.w;
             s.rid = wc[2 * slot + 1];
             if (n_fill && lane >= n_own) s.lk = 0;   // an EMPTY slot taken along by an output step (its stored state may be stale)
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             // the entry.
             Lane s2;
             {
-                const u32x4 a = stv[2 * slot2], b = stv[2 * slot2 + 1];
+                const u32x4 a = stA[slot2], b = stB[slot2];
                 s2.lk = active2 ? a.x : 0u; s2.cm = active2 ? a.y : 0u; s2.h = active2 ? a.z : 0u; s2.of = active2 ? a.w : 0u;
                 s2.rr = active2 ? b.x : 0u; s2.rm = active2 ? b.y : 0u; s2.ph = active2 ? b.z : 0u; s2.nc = active2 ? b.w : 0u;
                 s2.rid = 0;   // (not used by the probe; the slot keeps its read id in `wc`)
@@ -416,8 +419,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             }
             if (active2) {
                 seek_complete(s2, K, pq, cand, ent);
-                stv[2 * slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
-                stv[2 * slot2 + 1] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};
+                stA[slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
+                stB[slot2] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};
                 nq2 = queue_of(s2);
             }
         } else if (sel == ST_LEFT) {
@@ -737,8 +740,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         // ---- 4. store the lane state, push every slot onto the queue of its new state
         const uint32_t nq = active ? queue_of(s) : 0xFFu;
         if (active) {
-            stv[2 * slot] = u32x4{s.lk, s.cm, s.h, s.of};
-            stv[2 * slot + 1] = u32x4{s.rr, s.rm, s.ph, s.nc};
+            stA[slot] = u32x4{s.lk, s.cm, s.h, s.of};
+            stB[slot] = u32x4{s.rr, s.rm, s.ph, s.nc};
         }
         if (active) sb[2 * (slot & 63u) + (slot >> 6)] = (uint8_t)nq;        // the slot's new state: one byte
         if (active2) sb[2 * (slot2 & 63u) + (slot2 >> 6)] = (uint8_t)nq2;

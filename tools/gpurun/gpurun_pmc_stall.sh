@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="env $@ python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --index-cache /tmp/g.idx"
+B="env $@ python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "
 run() { name=$1; shift; timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$name -- $B > $O/$name.log 2>&1; echo "$name rc=$?"; }
 run pmc_ic SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL
 run pmc_lvl SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LEVEL_WAVES SQ_INST_LEVEL_LDS SQ_CYCLES
