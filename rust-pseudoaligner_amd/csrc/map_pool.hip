@@ -106,11 +106,22 @@ __device__ __forceinline__ void trace_out(const Lane& s, bool mapped, uint32_t g
     for (uint32_t j = 0; j < nn; ++j) out[j] = tr[j];
 }
 
+// one more read for count slot `cslot`, through the wave's count cache in LDS: 64 direct-mapped {slot, count} pairs that absorb
+// the slots many reads of the wave hit (a highly expressed class; the "novel" / "empty" / "unmapped" slots at the table's end,
+// which EVERY such read hits: straight atomics on them are one hot word per XCD) and are flushed every COUNT_CACHE_PERIOD
+// output steps; a slot whose pair is taken goes straight to the replica table
+__device__ __forceinline__ void count_cached(lds_u32 ctag, lds_u32 ccnt, glb_u32w xcounts, uint32_t cslot) {
+    const uint32_t hs = (cslot * 0x9E3779B1u) >> 26;
+    const uint32_t old = atomicCAS((uint32_t*)(ctag + hs), NO_CLASS, cslot);
+    if (old == NO_CLASS || old == cslot) atomicAdd((uint32_t*)(ccnt + hs), 1u);
+    else atomicAdd((uint32_t*)(xcounts + cslot), 1u);
+}
+
 // list mode: record + class-count update of one finished read; leaves the lane in ST_EMPTY, or in ST_F_NOVEL when the class
 // of a strict-subset result still has to be looked up by content before it can be counted
 template <bool TRACE>
 __device__ __forceinline__ void emit_record(Lane& s, uint32_t cnt, uint32_t cnt_alloc, uint64_t my_off, uint32_t base_len,
-                                            uint32_t base_colour, uint32_t gslot, karg_ptr p, glb_u32w xcounts) {
+                                            uint32_t base_colour, uint32_t gslot, karg_ptr p, glb_u32w xcounts, lds_u32 ctag, lds_u32 ccnt) {
     uint32_t colour = NO_CLASS, class_off = (uint32_t)my_off;
     bool novel = false;
     if (my_off + cnt_alloc > p->arena_cap) atomicOr(p->status, PA_STATUS_ARENA_FULL);
@@ -131,7 +142,7 @@ __device__ __forceinline__ void emit_record(Lane& s, uint32_t cnt, uint32_t cnt_
     if (colour_out) colour_out[s.rid] = colour;
     if (xcounts) {   // fused class-count table: fire-and-forget atomic
         const uint32_t num_classes = p->ix.num_classes;
-        atomicAdd((uint32_t*)(xcounts + (cnt == 0 ? num_classes + 1 : colour == NO_CLASS ? num_classes : colour)), 1u);
+        count_cached(ctag, ccnt, xcounts, cnt == 0 ? num_classes + 1 : colour == NO_CLASS ? num_classes : colour);
     }
     s.lk = 0;   // ST_EMPTY
 }
@@ -445,10 +456,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     if (colour_out) colour_out[s.rid] = is_ref ? cand : NO_CLASS;
                     if (xcounts && !PA_ABLATE(2u)) {
                         const uint32_t cslot = !mapped ? ix.num_classes + 2 : count == 0 ? ix.num_classes + 1 : cand;
-                        const uint32_t hs = (cslot * 0x9E3779B1u) >> 26;
-                        const uint32_t old = atomicCAS((uint32_t*)(ctag + hs), NO_CLASS, cslot);
-                        if (old == NO_CLASS || old == cslot) atomicAdd((uint32_t*)(ccnt + hs), 1u);
-                        else atomicAdd((uint32_t*)(xcounts + cslot), 1u);
+                        count_cached(ctag, ccnt, xcounts, cslot);
                     }
                     s.lk = 0;   // ST_EMPTY
                 }
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 }
                 const glb_u32w colour_out = (glb_u32w)p.colour_out;
                 if (colour_out) colour_out[s.rid] = colour;
-                if (xcounts) atomicAdd((uint32_t*)(xcounts + (colour == NO_CLASS ? ix.num_classes : colour)), 1u);
+                if (xcounts) count_cached(ctag, ccnt, xcounts, colour == NO_CLASS ? ix.num_classes : colour);   // (the novel slot is one word for every such read)
                 s.lk = 0;   // ST_EMPTY
             }
             if (p.novel_list) {   // a class no index class equals: remember where its ids are (one atomic per step)
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     uint32_t k = 0;
                     for (uint32_t t = my_alive; t; t &= t - 1) dst[k++] = bids[__ffs((int)t) - 1];
                 }
-                emit_record<TRACE>(s, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts);
+                emit_record<TRACE>(s, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts, ctag, ccnt);
             }
         } else if (sel == ST_F_COOP) {
             // the whole wave works on one read at a time (list mode, base list of more than 8 ids). Lane e owns base ids
@@ -702,7 +710,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 }
                 if (lane == Lr) my_count = total;
             }
-            if (active) emit_record<TRACE>(s, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts);
+            if (active) emit_record<TRACE>(s, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts, ctag, ccnt);
         } else {   // ST_F_LIGHT: list mode — pick a tier, intersect, write
             Isect is;
             is.count = 0;
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     for (int j = 0; j < 7; ++j)   // survivors straight from registers
                         if ((alive >> j) & 1u) dst[__popc(alive & ((1u << j) - 1))] = is.ids[j];
                 }
-                emit_record<TRACE>(s, cntv2, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts);
+                emit_record<TRACE>(s, cntv2, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts, ctag, ccnt);
             }
         }
 
