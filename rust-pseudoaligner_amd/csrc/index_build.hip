@@ -247,25 +247,29 @@ __global__ __launch_bounds__(256) void pa_ib_links_kernel(const KT* __restrict__
 // ---- 6. pointer jumping. In place: a (pointer, distance) pair is read and written as one 64-bit word, and any pair a
 // thread can observe is a true statement ("distance steps back from here is that k-mer"), so racing updates only speed it up
 __global__ __launch_bounds__(256) void pa_ib_jump_kernel(unsigned long long* __restrict__ pd, uint32_t D, uint32_t* __restrict__ unresolved) {
-    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     // a FIRST k-mer is (itself, distance 0). On a pure cycle the jumps can bring a pointer back to its own k-mer, but then at a
-    // distance that is not 0 (it saturates instead of wrapping), so a cycle member is never taken for a first k-mer
-    bool jumped = false;
-    if (d < D) {
+    // distance that is not 0 (it saturates instead of wrapping), so a cycle member is never taken for a first k-mer.
+    // Grid-stride, one atomic per WORKGROUP: a counter hit once per wave (1.6 M times per pass at config 3) is one hot word
+    // and was the whole cost of a pass (15 ms)
+    uint32_t mine = 0;
+    for (uint64_t d64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d64 < D; d64 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t d = (uint32_t)d64;
         const unsigned long long me = __atomic_load_n(pd + d, __ATOMIC_RELAXED);
-        if (me != ((unsigned long long)d << 32)) {
-            const uint32_t p = (uint32_t)(me >> 32);
-            const unsigned long long up = __atomic_load_n(pd + p, __ATOMIC_RELAXED);
-            if (up != ((unsigned long long)p << 32)) {   // else: p is a first k-mer, resolved
-                uint32_t dist = (uint32_t)me + (uint32_t)up;
-                if (dist < (uint32_t)me) dist = 0xFFFFFFFFu;
-                __atomic_store_n(pd + d, (up & 0xFFFFFFFF00000000ull) | dist, __ATOMIC_RELAXED);
-                jumped = true;
-            }
-        }
+        if (me == ((unsigned long long)d << 32)) continue;
+        const uint32_t p = (uint32_t)(me >> 32);
+        const unsigned long long up = __atomic_load_n(pd + p, __ATOMIC_RELAXED);
+        if (up == ((unsigned long long)p << 32)) continue;   // p is a first k-mer: resolved
+        uint32_t dist = (uint32_t)me + (uint32_t)up;
+        if (dist < (uint32_t)me) dist = 0xFFFFFFFFu;
+        __atomic_store_n(pd + d, (up & 0xFFFFFFFF00000000ull) | dist, __ATOMIC_RELAXED);
+        ++mine;
     }
-    const uint64_t m = __ballot(jumped);   // one atomic per wave: a single counter hit by every thread serialises the whole pass
-    if (m && (threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(unresolved, (uint32_t)__popcll(m));
+    __shared__ uint32_t block_sum;
+    if (threadIdx.x == 0) block_sum = 0;
+    __syncthreads();
+    if (mine) atomicAdd(&block_sum, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && block_sum) atomicAdd(unresolved, block_sum);
 }
 // flags: first k-mer of a unitig / member of a pure cycle (its pointer never reaches a first k-mer)
 __global__ __launch_bounds__(256) void pa_ib_classify_kernel(const unsigned long long* __restrict__ pd, uint32_t D, uint32_t* __restrict__ is_start,
@@ -567,7 +571,8 @@ int build_graph_device_t(const uint64_t* packed_in, const uint64_t* tx_start, ui
         uint32_t prev = NONE32;
         for (int round = 0; round < 40; ++round) {
             IB_HIP(hipMemset(cnt.p, 0, 4));
-            hipLaunchKernelGGL(pa_ib_jump_kernel, grid_of(D), dim3(256), 0, nullptr, pd.as<unsigned long long>(), D, cnt.as<uint32_t>());
+            const uint32_t jump_blocks = (uint32_t)std::min<uint64_t>(((uint64_t)D + 255) / 256, 8192);
+            hipLaunchKernelGGL(pa_ib_jump_kernel, dim3(jump_blocks), dim3(256), 0, nullptr, pd.as<unsigned long long>(), D, cnt.as<uint32_t>());
             IB_HIP(hipGetLastError());
             uint32_t now = 0;
             IB_HIP(hipMemcpy(&now, cnt.p, 4, hipMemcpyDeviceToHost));
