@@ -254,9 +254,10 @@ int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offs
  * ("-" = stdout) in INPUT order (the reference's order is completion order, :490). num_threads sizes the
  * host parse/format pool. n_reads_out/n_flagged_out may be NULL.
  * Input: plain or gzip'ed (multi-member) FASTQ in the four-line form every sequencer writes — "@id ...", sequence, "+...",
- * qualities; LF or CRLF; trailing blank lines tolerated. Records whose sequence or qualities are wrapped over several
- * lines, which bio's reader accepts, are refused with PA_ERR_FORMAT and the record number (the parallel scan finds records by
- * counting lines); so is a file that ends inside a record. Read ids are cut at the first space, as record.id() does. */
+ * qualities; LF or CRLF; trailing blank lines tolerated. A file whose records are not four lines each (sequence or qualities
+ * wrapped over several lines, which bio's reader accepts) is first rewritten into that form by a sequential pass (as many
+ * quality lines as sequence lines, as bio 1.5 reads them), then scanned in parallel like any other. PA_ERR_FORMAT with
+ * the record number for text that is no FASTQ or ends inside a record. Read ids are cut at the first space, as record.id() does. */
 int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads,
                      uint64_t* n_reads_out, uint64_t* n_flagged_out);
 

@@ -229,6 +229,57 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
 
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(PA_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
+// The parallel scan finds records by counting lines, four to a record. A file that does not have that shape — sequence or
+// qualities wrapped over several lines, which bio's fastq::Reader (the reference's reader) accepts — is first rewritten
+// into it by this sequential reader: header line '@...', sequence lines up to the line that starts with '+', then as many
+// quality lines as there were sequence lines (what bio 1.5's Reader::read does). Returns false (with the 0-based record
+// number) when the text is no FASTQ at all; trailing blank lines are tolerated as everywhere in this file.
+bool normalize_fastq(const char* d, uint64_t n, std::vector<char>& out, uint64_t& bad_rec) {
+    out.clear();
+    out.reserve(n + 16);
+    const char* p = d;
+    const char* const end = d + n;
+    auto next_line = [&](const char*& b, const char*& e) -> bool {   // [b, e) without the line break; false at the end of the text
+        if (p >= end) return false;
+        b = p;
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        e = nl ? nl : end;
+        p = nl ? nl + 1 : end;
+        if (e > b && e[-1] == '\r') --e;
+        return true;
+    };
+    uint64_t rec = 0;
+    const char *b, *e;
+    for (;;) {
+        if (!next_line(b, e)) return true;
+        if (b == e) {   // blank line: fine only if nothing but blank lines follows
+            while (next_line(b, e))
+                if (b != e) { bad_rec = rec; return false; }
+            return true;
+        }
+        if (*b != '@') { bad_rec = rec; return false; }
+        out.insert(out.end(), b, e);
+        out.push_back('\n');
+        uint64_t seq_lines = 0;
+        bool plus = false;
+        while (next_line(b, e)) {
+            if (b != e && *b == '+') { plus = true; break; }
+            out.insert(out.end(), b, e);
+            ++seq_lines;
+        }
+        if (!plus) { bad_rec = rec; return false; }   // the text ends inside a record
+        out.push_back('\n');
+        out.push_back('+');
+        out.push_back('\n');
+        for (uint64_t i = 0; i < seq_lines; ++i) {
+            if (!next_line(b, e)) break;   // (bio leaves the qualities short; the reference never looks at them)
+            out.insert(out.end(), b, e);
+        }
+        out.push_back('\n');
+        ++rec;
+    }
+}
+
 }  // namespace
 
 extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads, uint64_t* n_reads_out,
@@ -302,7 +353,10 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     std::vector<uint64_t> rec_start;
 
     // ---- scan: line breaks per byte range, then the start of every fourth line ----
-    {
+    std::vector<char> normalized;   // the text rewritten into four-line records, if it did not have that shape
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        std::atomic<uint64_t> odd_record{~0ull};   // first record whose first line lacks the '@' or whose third the '+'
+        rc = PA_OK;
         const int R = (int)std::min<uint64_t>((uint64_t)T * 4, fsize / (1 << 16) + 1);
         std::vector<uint64_t> nl((size_t)R + 1, 0);
         auto range = [&](int r, uint64_t& a, uint64_t& b) { a = fsize * (uint64_t)r / R; b = fsize * (uint64_t)(r + 1) / R; };
@@ -341,6 +395,10 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                 }
                 while (p < data + b && p < data + fsize) {
                     if (li % 4 == 0 && li / 4 < nrec) rec_start[li / 4] = (uint64_t)(p - data);
+                    if (li / 4 < nrec && ((li % 4 == 0 && *p != '@') || (li % 4 == 2 && *p != '+'))) {
+                        uint64_t cur = odd_record.load();
+                        while (li / 4 < cur && !odd_record.compare_exchange_weak(cur, li / 4)) {}
+                    }
                     const char* e = (const char*)memchr(p, '\n', (size_t)(data + fsize - p));
                     if (!e) break;
                     p = e + 1;
@@ -348,6 +406,23 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                 }
             });
         }
+        if (rc == PA_OK && odd_record.load() == ~0ull) break;   // four lines to a record, markers in place
+        if (attempt == 1) {
+            if (rc == PA_OK) rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu", fastq_path, (unsigned long long)odd_record.load());
+            break;
+        }
+        // not that shape: wrapped sequence / quality lines? rewrite and scan again
+        uint64_t bad = 0;
+        if (!normalize_fastq(data, fsize, normalized, bad)) {
+            rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu (no '@' header, or the file ends inside the record)", fastq_path, (unsigned long long)bad);
+            break;
+        }
+        if (mapped) { munmap((void*)data, fsize); mapped = false; }
+        inflated = std::vector<char>();
+        data = normalized.data();
+        fsize = normalized.size();
+        rec_start.clear();
+        nrec = 0;
     }
 
     t_scan = now() - t_begin;

@@ -290,6 +290,10 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
         "plain": "".join("@%s extra words\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in zip(ids, seqs)),
         "crlf": "".join("@%s\r\n%s\r\n+\r\n%s\r\n" % (i, s, "I" * len(s)) for i, s in zip(ids, seqs)),
     }
+    # sequence and qualities wrapped over several lines (bio's reader accepts that; the scan falls back to a sequential rewrite)
+    wrap = lambda t, w: "\n".join(t[j:j + w] for j in range(0, len(t), w)) if t else ""
+    variants["wrapped"] = "".join("@%s extra\n%s\n+\n%s\n" % (i, wrap(s, 25), wrap("I" * len(s), 25)) for i, s in zip(ids, seqs))
+    variants["wrapped_crlf_tail"] = variants["wrapped"].replace("\n", "\r\n") + "\r\n\r\n"
     variants["no_final_newline"] = variants["plain"][:-1]
     variants["trailing_blank_lines"] = variants["plain"] + "\n\n\n"
     for name, text in variants.items():
@@ -316,6 +320,12 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
     empty = tmp_path / "empty.fq"
     empty.write_text("")
     assert pa.process_reads(str(empty), a, str(out), 4) == (0, 0) and out.read_text() == ""
+    for name, text in (("noat", "r1\nACGT\n+\nIIII\n"), ("blank_inside", "@r1\nACGT\n+\nIIII\n\n@r2\nACGT\n+\nIIII\n"),
+                       ("wrapped_trunc", "@r1\nACGT\nACGT\n+\nIIII\nIIII\n@r2\nAC\nGT\n")):
+        bad = tmp_path / (name + ".fq")
+        bad.write_text(text)
+        with pytest.raises(pa.PaError):
+            pa.process_reads(str(bad), a, str(out), 2)
     trunc = tmp_path / "trunc.fq"
     trunc.write_text("@r1\nACGT\n+\nIIII\n@r2\nACGT\n")
     with pytest.raises(pa.PaError):
