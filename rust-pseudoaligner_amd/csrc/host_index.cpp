@@ -113,7 +113,8 @@ int read_fasta(const char* path, Txome& out) {
         if (line[0] == '>') {
             finish();
             have = true;
-            const size_t sp = line.find_first_of(" \t");
+            while (!line.empty() && (line.back() == ' ' || line.back() == '\t')) line.pop_back();   // record.id() of bio 1.5: header[1..].trim_end()
+            const size_t sp = line.find(' ');                                                     // .splitn(2, ' '): a tab stays part of the id
             id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
             desc = sp == std::string::npos ? std::string() : line.substr(sp + 1);
             name_hash = 0xcbf29ce484222325ull;
