@@ -26,6 +26,9 @@
 #ifndef PA_FILL   // A/B builds: -DPA_FILL=0 (output steps do not take EMPTY slots along)
 #define PA_FILL 1
 #endif
+#ifndef PA_COOP_MIN
+#define PA_COOP_MIN 2u
+#endif
 #ifndef PA_RARE_MIN   // A/B builds: -DPA_RARE_MIN=0 (rare states compete by population only)
 #define PA_RARE_MIN 10u
 #endif
@@ -324,15 +327,16 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         // iteration and parked slots is at 12...17 slots for the rare states of configs 3 and 5
         uint32_t bestn = 0;
 #define PA_CONSIDER(t, c) { const uint32_t c_ = (c); if (best < 64 && c_ > best) { best = c_; bestn = c_; sel = (t); } }
-#define PA_CONSIDER_RARE(t, c) { const uint32_t c_ = (c), w_ = (PA_RARE_MIN && c_ >= PA_RARE_MIN) ? 64u + c_ : c_; \
-                                 if (best < 64 && w_ > best) { best = w_; bestn = c_; sel = (t); } }
+#define PA_CONSIDER_RARE_MIN(t, c, mn) { const uint32_t c_ = (c), w_ = (PA_RARE_MIN && c_ >= (mn)) ? 64u + c_ : c_; \
+                                         if (best < 64 && w_ > best) { best = w_; bestn = c_; sel = (t); } }
+#define PA_CONSIDER_RARE(t, c) PA_CONSIDER_RARE_MIN(t, c, PA_RARE_MIN)
         // the five rare states (left extension, the list-mode tiers, the content lookup) are only counted when some slot is in one
         // of them: one ballot instead of ten in most iterations (the order of consideration is the same either way)
         constexpr uint32_t RARE = (1u << ST_LEFT) | (1u << ST_F_LIGHT) | (1u << ST_F_SCAN) | (1u << ST_F_COOP) | (1u << ST_F_NOVEL);
         const bool any_rare = __ballot((((RARE >> (st_lo & 31u)) | (RARE >> (st_hi & 31u))) & 1u) != 0) != 0;   // (0xFF, no slot: bit 31, not rare)
         if (any_rare) {
             PA_CONSIDER_RARE(ST_F_NOVEL, PA_CNT(ST_F_NOVEL))
-            PA_CONSIDER_RARE(ST_F_COOP, PA_CNT(ST_F_COOP))
+            PA_CONSIDER_RARE_MIN(ST_F_COOP, PA_CNT(ST_F_COOP), PA_COOP_MIN)   // (the wave takes its reads one at a time: nothing to gain from gathering them)
             PA_CONSIDER_RARE(ST_F_SCAN, PA_CNT(ST_F_SCAN))
             PA_CONSIDER_RARE(ST_F_LIGHT, PA_CNT(ST_F_LIGHT))
         }
@@ -343,6 +347,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         PA_CONSIDER(ST_EMPTY, nrefill)
 #undef PA_CONSIDER
 #undef PA_CONSIDER_RARE
+#undef PA_CONSIDER_RARE_MIN
         if (best == 0) break;
         // DUAL iteration: a forward step and a dictionary probe are each one dependent round trip and touch different parts
         // of the memory system (node blobs: MALL / L2; dictionary: HBM). When both queues hold work the wave pops BOTH, lets
