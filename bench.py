@@ -333,6 +333,7 @@ def main() -> None:
             pass
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                            "traffic": traffic, "kernel": "pa_map_pool_kernel", "kernel_ms": kernel_avg_ms,
+                           "kernel_ms_min": min(kernel_ms) if kernel_ms else None, "kernel_ms_max": max(kernel_ms) if kernel_ms else None,
                            "algorithmic_bytes_per_read": bytes_per_read, "reads_per_launch": B}
         if n_gpus == 1 and not args.no_cpu_baseline:
             rate = sample_n / max(1e-9, _time_oracle(oracle, s_tiles, s_lens, wpr, ncpu))
