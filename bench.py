@@ -153,7 +153,12 @@ def main() -> None:
     # ---- resident inputs: distinct batches of packed reads in HBM, generated on the device ----
     B, K, W = args.batch or wl["batch"], args.steps, args.warmup
     wpr = pa.lib().pa_words_per_read(read_len)
-    n_batches = max(2, min(K + W, 12, int(64e9 // (B * (wpr * 8 + 4)))))   # distinct resident batches, at most ~64 GB of HBM
+    # distinct batches resident in HBM, used in rotation (consecutive steps never see the same reads; one batch is 4.4 GB of tiles,
+    # far beyond every cache). THREE, as a streaming pipeline holds them (one being filled, one being mapped, one being drained);
+    # holding more only grows the process's HBM footprint, and beyond ~60 GB allocated every launch gets slower on this chip,
+    # whatever the extra memory holds (same box: 2 / 3 / 6 / 12 resident batches 9.85 / 9.93 / 9.97 / 10.27 ms per 100 M reads;
+    # 3 batches + an untouched 40 / 100 GB tensor: 9.71 / 10.41 ms). PA_BENCH_BATCHES overrides.
+    n_batches = max(2, min(K + W, int(os.environ.get("PA_BENCH_BATCHES", "3")), int(64e9 // (B * (wpr * 8 + 4)))))
     tile_words = pa.lib().pa_tiles_words(B, wpr)
     stream = torch.cuda.current_stream().cuda_stream
     tiles = [torch.empty(tile_words, dtype=torch.int64, device=dev) for _ in range(n_batches)]
@@ -334,6 +339,7 @@ def main() -> None:
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                            "traffic": traffic, "kernel": "pa_map_pool_kernel", "kernel_ms": kernel_avg_ms,
                            "kernel_ms_min": min(kernel_ms) if kernel_ms else None, "kernel_ms_max": max(kernel_ms) if kernel_ms else None,
+                           "kernel_ms_steps": [round(x, 3) for x in kernel_ms],
                            "algorithmic_bytes_per_read": bytes_per_read, "reads_per_launch": B}
         if n_gpus == 1 and not args.no_cpu_baseline:
             rate = sample_n / max(1e-9, _time_oracle(oracle, s_tiles, s_lens, wpr, ncpu))
