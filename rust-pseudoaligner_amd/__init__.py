@@ -28,10 +28,12 @@ PA_CLASS_REF = 0x80000000
 RESULT_DTYPE = np.dtype([("coverage", "<u4"), ("mismatches", "<u4"), ("class_off", "<u4"), ("class_len", "<u4")])
 
 
-def _np_view(ptr: int, n: int, dtype) -> np.ndarray:
+def _np_view(ptr: int, n: int, dtype, owner=None) -> np.ndarray:
+    """numpy view of library-owned memory; `owner` (the wrapper object whose handle owns it) is kept alive by the view"""
     if n == 0 or not ptr:
         return np.zeros(0, dtype=dtype)
     buf = (C.c_uint8 * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr)
+    buf._pa_owner = owner          # ndarray.base -> buf -> owner: the index cannot be destroyed under a live view
     return np.frombuffer(buf, dtype=dtype)
 
 
@@ -120,12 +122,12 @@ class HostIndex:
         """numpy views (no copy) of the flat arrays; valid while this object is alive."""
         f = self.flat()
         n, c = f.num_nodes, f.num_classes
-        ec_offset = _np_view(f.ec_offset, c + 1, np.uint64)
+        ec_offset = _np_view(f.ec_offset, c + 1, np.uint64, owner=self)
         return dict(k=f.k, num_nodes=n, num_classes=c, num_transcripts=f.num_transcripts,
-                    node_seq=_np_view(f.node_seq, (f.seq_bases + 31) // 32 + 1, np.uint64),
-                    node_start=_np_view(f.node_start, n + 1, np.uint64), node_len=_np_view(f.node_len, n, np.uint32),
-                    node_exts=_np_view(f.node_exts, n, np.uint8), node_colour=_np_view(f.node_colour, n, np.uint32),
-                    ec_offset=ec_offset, ec_ids=_np_view(f.ec_ids, int(ec_offset[-1]) if c else 0, np.uint32))
+                    node_seq=_np_view(f.node_seq, (f.seq_bases + 31) // 32 + 1, np.uint64, owner=self),
+                    node_start=_np_view(f.node_start, n + 1, np.uint64, owner=self), node_len=_np_view(f.node_len, n, np.uint32, owner=self),
+                    node_exts=_np_view(f.node_exts, n, np.uint8, owner=self), node_colour=_np_view(f.node_colour, n, np.uint32, owner=self),
+                    ec_offset=ec_offset, ec_ids=_np_view(f.ec_ids, int(ec_offset[-1]) if c else 0, np.uint32, owner=self))
 
     @property
     def k(self) -> int:
@@ -172,8 +174,8 @@ class HostIndex:
     def transcripts(self) -> Tuple[np.ndarray, np.ndarray]:
         p, s, n = vp(), vp(), C.c_uint32()
         check(lib().pa_host_index_transcripts(self._h, C.byref(p), C.byref(s), C.byref(n)))
-        tx_start = _np_view(s.value, n.value + 1, np.uint64)
-        return _np_view(p.value, (int(tx_start[-1]) + 31) // 32 + 1, np.uint64), tx_start
+        tx_start = _np_view(s.value, n.value + 1, np.uint64, owner=self)
+        return _np_view(p.value, (int(tx_start[-1]) + 31) // 32 + 1, np.uint64, owner=self), tx_start
 
     def __del__(self):
         try:
@@ -212,8 +214,8 @@ class Txome:
     def arrays(self) -> Tuple[np.ndarray, np.ndarray]:
         p, s, n = vp(), vp(), C.c_uint32()
         check(lib().pa_txome_view(self._h, C.byref(p), C.byref(s), C.byref(n)))
-        tx_start = _np_view(s.value, n.value + 1, np.uint64)
-        return _np_view(p.value, (int(tx_start[-1]) + 31) // 32 + 1, np.uint64), tx_start
+        tx_start = _np_view(s.value, n.value + 1, np.uint64, owner=self)
+        return _np_view(p.value, (int(tx_start[-1]) + 31) // 32 + 1, np.uint64, owner=self), tx_start
 
     @property
     def num_transcripts(self) -> int:
