@@ -22,8 +22,12 @@ def test_usable_cpus_is_sane():
     assert 1 <= n <= (os.cpu_count() or 1)
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    line = json.loads((ROOT / "profiles" / "r01_pool_bench.json").read_text())
+import pytest
+
+
+@pytest.mark.parametrize("name", ["r01_pool_bench.json", "r02_bench_config3.json", "r02_bench_config5.json"])
+def test_committed_bench_line_has_the_contract_fields(name):
+    line = json.loads((ROOT / "profiles" / name).read_text())
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
@@ -35,3 +39,8 @@ def test_committed_bench_line_has_the_contract_fields():
     c = line["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == line["unit"] and "sample" in c
     assert abs(line["value"] - line["config"]["reads_per_step_per_gpu"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert r["kernel_ms"] <= line["ms_per_step"] * 1.001   # the dominant kernel fits inside the step it belongs to
+    if name.startswith("r02"):   # round 2: the host-to-host leg (config 3 only) and the index set-up times ride along as extra keys
+        assert "index_build_s" in line["config"] and "kernel_ms_steps" in r and len(r["kernel_ms_steps"]) == line["steps"]
+        if "config3" in name:
+            assert line["e2e_reads_per_s"] > 0 and 0 < line["e2e_pcie_frac"] < 1
