@@ -79,6 +79,8 @@ struct pa_index {
     std::vector<uint32_t> h_class_ids;
     std::vector<uint32_t> h_ec, h_class_ref;
     std::vector<uint32_t> h_arena;
+    void* ingest_cache = nullptr;   // parked by fastq.cpp between pa_process_reads calls (guarded by `mu`)
+    void (*ingest_cache_free)(void*) = nullptr;
 };
 
 extern "C" {
@@ -113,6 +115,23 @@ void index_host_classes(const pa_index* idx, const uint32_t** ec, const uint32_t
     *class_ref = idx->h_class_ref.data();
     *device = idx->device;
 }
+void* index_take_ingest_cache(pa_index* idx) {
+    std::lock_guard<std::mutex> g(idx->mu);
+    void* c = idx->ingest_cache;
+    idx->ingest_cache = nullptr;
+    return c;
+}
+void index_put_ingest_cache(pa_index* idx, void* cache, void (*free_fn)(void*)) {
+    {
+        std::lock_guard<std::mutex> g(idx->mu);
+        if (!idx->ingest_cache) {
+            idx->ingest_cache = cache;
+            idx->ingest_cache_free = free_fn;
+            return;
+        }
+    }
+    free_fn(cache);
+}
 }  // namespace pa
 }
 
@@ -122,6 +141,7 @@ void pa_index_destroy(pa_index* idx) {
     for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table, idx->d_wtable})
         if (p) (void)hipFree(p);
     for (auto& kv : idx->ctxs) kv.second->release();
+    if (idx->ingest_cache && idx->ingest_cache_free) idx->ingest_cache_free(idx->ingest_cache);
     for (DevBuf* b : {&idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
                       &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})
         b->release();

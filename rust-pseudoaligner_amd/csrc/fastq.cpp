@@ -212,7 +212,7 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
     uint32_t* h_lens = nullptr;
     pa_read_result* h_results = nullptr;
     void *d_tiles = nullptr, *d_lens = nullptr, *d_results = nullptr, *d_arena = nullptr;
-    size_t tiles_bytes = 0, arena_entries = 0;
+    size_t tiles_bytes = 0, arena_entries = 0, reads_cap = 0;
     std::vector<uint32_t> h_arena;
     std::vector<Record> recs;
     uint64_t first = 0, n = 0;
@@ -224,6 +224,15 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
         for (void* p : {d_tiles, d_lens, d_results, d_arena})
             if (p) (void)hipFree(p);
         *this = BatchCtx();
+    }
+};
+
+struct IngestCache {   // the two batches in flight; parked on the index between calls (pa_common.hpp)
+    BatchCtx ctx[2];
+    static void destroy(void* p) {
+        IngestCache* c = static_cast<IngestCache*>(p);
+        for (BatchCtx& b : c->ctx) b.release();
+        delete c;
     }
 };
 
@@ -285,6 +294,7 @@ bool normalize_fastq(const char* d, uint64_t n, std::vector<char>& out, uint64_t
 extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads, uint64_t* n_reads_out,
                                 uint64_t* n_flagged_out) {
     if (!idx || !fastq_path || !out_path) return fail(PA_ERR_INVALID_ARG, "null argument");
+    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (num_threads < 1) num_threads = 1;
     if (n_reads_out) *n_reads_out = 0;
     if (n_flagged_out) *n_flagged_out = 0;
@@ -427,7 +437,9 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
 
     t_scan = now() - t_begin;
     // ---- batches ----
-    BatchCtx ctx[2];
+    IngestCache* cache = static_cast<IngestCache*>(index_take_ingest_cache(idx));   // buffers of the previous call, if any
+    if (!cache) cache = new IngestCache();
+    BatchCtx* const ctx = cache->ctx;
     hipStream_t stream = nullptr;
     if (rc == PA_OK && hipStreamCreate(&stream) != hipSuccess) rc = fail(PA_ERR_HIP, "hipStreamCreate failed");
     Writer writer(out);
@@ -443,16 +455,24 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
             if (c.h_tiles) (void)hipHostFree(c.h_tiles);
             if (c.d_tiles) (void)hipFree(c.d_tiles);
             c.h_tiles = nullptr; c.d_tiles = nullptr;
+            c.tiles_bytes = 0;
             HIP_OK(hipHostMalloc((void**)&c.h_tiles, want, hipHostMallocDefault));
             HIP_OK(hipMalloc(&c.d_tiles, want));
             c.tiles_bytes = want;
         }
-        if (!c.h_lens) {
-            const size_t cap_reads = std::min<uint64_t>(BATCH_READS, nrec) + 64;
+        if (n + 64 > c.reads_cap) {
+            const size_t cap_reads = std::max<uint64_t>(n, std::min<uint64_t>(BATCH_READS, nrec)) + 64;
+            if (c.h_lens) (void)hipHostFree(c.h_lens);
+            if (c.h_results) (void)hipHostFree(c.h_results);
+            if (c.d_lens) (void)hipFree(c.d_lens);
+            if (c.d_results) (void)hipFree(c.d_results);
+            c.h_lens = nullptr; c.h_results = nullptr; c.d_lens = nullptr; c.d_results = nullptr;
+            c.reads_cap = 0;
             HIP_OK(hipHostMalloc((void**)&c.h_lens, cap_reads * 4, hipHostMallocDefault));
             HIP_OK(hipHostMalloc((void**)&c.h_results, cap_reads * sizeof(pa_read_result), hipHostMallocDefault));
             HIP_OK(hipMalloc(&c.d_lens, cap_reads * 4));
             HIP_OK(hipMalloc(&c.d_results, cap_reads * sizeof(pa_read_result)));
+            c.reads_cap = cap_reads;
         }
         const uint64_t hint = pa_map_arena_hint(idx, n);
         if (hint > c.arena_entries) {
@@ -567,17 +587,28 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         return PA_OK;
     };
 
+    // Formatting runs as 4T tasks handed out dynamically, plus one that gives the text of the batches already written back
+    // to the kernel: unmapping 5 GB of page-cache mapping is 0.09 s of one thread's time, hidden here behind the others' work.
+    uint64_t unmapped_to = 0;   // bytes of the mapping already given back (page-aligned)
     auto format = [&](BatchCtx& c) {
-        TextSet* parts = writer.acquire((size_t)T);
-        std::vector<uint64_t> flags((size_t)T, 0);
-        pool.run(T, [&](int t) {
+        const int P = T * 4;
+        TextSet* parts = writer.acquire((size_t)P);
+        std::vector<uint64_t> flags((size_t)P, 0);
+        const uint64_t keep_from = mapped ? (rec_start[c.first] & ~4095ull) : 0;   // nothing before this batch is read again
+        const int extra = keep_from > unmapped_to ? 1 : 0;
+        pool.run(P + extra, [&](int task) {
+            if (task < extra) {
+                (void)munmap((void*)(data + unmapped_to), keep_from - unmapped_to);
+                return;
+            }
+            const int t = task - extra;
             TextBuf buf = std::move((*parts)[(size_t)t]);   // thread-local while filling: neighbours share cache lines in the set
             uint64_t nflag = 0;
-            const uint64_t a = c.n * (uint64_t)t / T, b = c.n * (uint64_t)(t + 1) / T;
+            const uint64_t a = c.n * (uint64_t)t / P, b = c.n * (uint64_t)(t + 1) / P;
             for (uint64_t i = a; i < b; ++i) {
                 const pa_read_result& r = c.h_results[i];
-                const bool mapped = r.mismatches & PA_MAPPED_BIT;
-                const bool flag = mapped && r.coverage >= PA_READ_COVERAGE_THRESHOLD && r.class_len == 0;   // :455
+                const bool mapped_read = r.mismatches & PA_MAPPED_BIT;
+                const bool flag = mapped_read && r.coverage >= PA_READ_COVERAGE_THRESHOLD && r.class_len == 0;   // :455
                 nflag += flag;
                 char* const base = buf.room(6 * (size_t)c.recs[i].id_len + 12 * (size_t)r.class_len + 64);
                 char* o = put_str(base, flag ? "(true, " : "(false, ");
@@ -590,7 +621,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                     o = put_u32(o, ids[j]);
                 }
                 o = put_str(o, "], ");
-                o = put_u32(o, mapped ? r.coverage : 0u);   // None -> (false, id, [], 0) (:461)
+                o = put_u32(o, mapped_read ? r.coverage : 0u);   // None -> (false, id, [], 0) (:461)
                 *o++ = ')';
                 *o++ = '\n';
                 buf.len += (size_t)(o - base);
@@ -598,6 +629,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
             flags[(size_t)t] = nflag;
             (*parts)[(size_t)t] = std::move(buf);
         });
+        if (extra) unmapped_to = keep_from;
         for (uint64_t f : flags) flagged += f;
         reported += c.n;
         while (reported >= next_report) {   // :497-503
@@ -625,13 +657,21 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     if (verbose)
         fprintf(stderr, "\n[pa ingest] %llu reads, %d threads: scan %.3f s, pack %.3f s (records %.3f, alloc %.3f, tiles %.3f), wait GPU %.3f s, launch %.3f s, format %.3f s (writer wait %.3f), total %.3f s\n",
                 (unsigned long long)nrec, T, t_scan, t_pack, t_pack_rec, t_pack_alloc, t_pack_tiles, t_finish, t_launch, t_format, t_push, now() - t_begin);
+    double t0 = now();
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    const double t_stream = now() - t0; t0 = now();
     const bool wrote = writer.finish();
+    const double t_writer = now() - t0; t0 = now();
     if (rc == PA_OK && !wrote) rc = fail(PA_ERR_IO, "short write to %s", out_path);
-    for (BatchCtx& c : ctx) c.release();
-    if (mapped) munmap((void*)data, fsize);
+    if (rc == PA_OK) index_put_ingest_cache(idx, cache, IngestCache::destroy);   // the next call starts with warm buffers
+    else IngestCache::destroy(cache);
+    if (mapped && fsize > unmapped_to) munmap((void*)(data + unmapped_to), fsize - unmapped_to);
+    const double t_unmap = now() - t0; t0 = now();
     if (out != stdout) { if (fclose(out) != 0 && rc == PA_OK) rc = fail(PA_ERR_IO, "close %s: %s", out_path, strerror(errno)); }
     else fflush(stdout);
+    if (verbose)
+        fprintf(stderr, "[pa ingest] teardown: stream %.3f s, writer %.3f s, unmap %.3f s, close %.3f s; before the scan %.3f s\n", t_stream, t_writer, t_unmap,
+                now() - t0, t_begin - t_enter);
     if (n_reads_out) *n_reads_out = reported;
     if (n_flagged_out) *n_flagged_out = flagged;
     return rc;

@@ -18,6 +18,11 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // host copy of the class records of a device index (device_index.hip): class c = ec[4 * class_ref[c] + 1 ...]; used to
 // resolve results returned by reference (PA_CLASS_REF) without a device round trip
 void index_host_classes(const pa_index* idx, const uint32_t** ec, const uint32_t** class_ref, int* device);
+// One opaque object the FASTQ driver parks on the index between calls (its pinned + device batch buffers: allocating them
+// costs more than packing a batch). take() hands it to the caller and empties the slot, so concurrent calls never share
+// it; put() stores it back (or frees it with `free_fn` when another call already parked one). pa_index_destroy frees it.
+void* index_take_ingest_cache(pa_index* idx);
+void index_put_ingest_cache(pa_index* idx, void* cache, void (*free_fn)(void*));
 
 // CPUs this process may use: hardware threads, capped by the cgroup CPU quota (a container that sees 256 CPUs may be
 // limited to 16 CPUs' worth of time; 256 threads there only add scheduling noise). host_index.cpp

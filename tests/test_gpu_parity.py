@@ -332,6 +332,31 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
         pa.process_reads(str(trunc), a, str(out), 2)
 
 
+def test_process_reads_concurrent_calls_one_index(aligners, tmp_path, monkeypatch):
+    """pa_process_reads parks its batch buffers on the index between calls (include/pseudoaligner_amd.h): calls that overlap
+    on one index each get their own set, and a later call that needs bigger batches grows the parked one"""
+    import threading
+    a = aligners(24)
+    ids, seqs = helpers.read_fastq()
+    ids, seqs = list(ids[:4000]), list(seqs[:4000])
+    want = _expected_lines(a, ids, seqs)
+    fq = tmp_path / "in.fq"
+    fq.write_text("".join("@%s\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in zip(ids, seqs)))
+    monkeypatch.setenv("PA_INGEST_BATCH", "256")
+    outs = [tmp_path / ("o%d.txt" % t) for t in range(4)]
+    got = [None] * 4
+    def run(t):
+        for _ in range(3):
+            got[t] = pa.process_reads(str(fq), a, str(outs[t]), 2)
+    th = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for t in range(4):
+        assert got[t] is not None and got[t][0] == len(ids) and outs[t].read_text().splitlines() == want, t
+    monkeypatch.setenv("PA_INGEST_BATCH", "2048")   # bigger batches than the parked buffers were sized for
+    assert pa.process_reads(str(fq), a, str(outs[0]), 3)[0] == len(ids) and outs[0].read_text().splitlines() == want
+
+
 # 12..308: seeds on which a lookup that only tried the first fingerprint match of a bucket missed k-mers (two keys of one
 # bucket sharing their low 31 bits — low-complexity sequence); found by tools/gpu_soak.py
 @pytest.mark.parametrize("seed", list(range(10)) + [12, 19, 31, 39, 48, 55, 96, 242, 278, 308])
