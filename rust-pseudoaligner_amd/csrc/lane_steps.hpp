@@ -178,9 +178,41 @@ PA_HD uint64_t read_window_end(ReadRef r, uint32_t p) { return p >= 31 ? read_wi
 
 PA_HD uint32_t read_base(ReadRef r, uint32_t pos) { return (uint32_t)(r.p[(pos >> 5) * r.stride] >> ((pos & 31) * 2)) & 3u; }
 
+// Streaming loads: every dictionary line, node blob and read word is touched by ONE read of the batch and never again, while
+// the count replicas, the window table and the hot class records are shared by all of them. PA_NT (bit 0 read words,
+// 1 result stores, 2 dictionary lines, 3 node blobs) marks the former non-temporal, so that they do not push the latter out
+// of the L2.
+#ifndef PA_NT
+#define PA_NT 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t pa_nt_u32x4 __attribute__((ext_vector_type(4)));
+PA_HD U4 ld_nt(const U4* p) {
+    const pa_nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const pa_nt_u32x4*>(p));
+    return U4{v.x, v.y, v.z, v.w};
+}
+PA_HD uint64_t ld_nt(const uint64_t* p) { return __builtin_nontemporal_load(p); }
+typedef uint64_t pa_nt_u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+PA_HD Q2 ld_nt(const Q2* p) {
+    const pa_nt_u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const pa_nt_u64x2*>(p));
+    return Q2{v.x, v.y};
+}
+typedef uint32_t pa_nt_u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+PA_HD U3 ld_nt(const U3* p) {
+    const pa_nt_u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const pa_nt_u32x3*>(p));
+    return U3{v.x, v.y, v.z};
+}
+#else
+PA_HD Q2 ld_nt(const Q2* p) { return *p; }
+PA_HD U3 ld_nt(const U3* p) { return *p; }
+PA_HD U4 ld_nt(const U4* p) { return *p; }
+PA_HD uint64_t ld_nt(const uint64_t* p) { return *p; }
+#endif
+#define PA_LD(bit, ptr) ((PA_NT & (bit)) ? ld_nt(ptr) : *(ptr))
+
 PA_HD Hdr load_hdr(const DevIndexView& ix, uint32_t h) {
     const U4* p = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)h * BLOB_GRANULE);
-    const U4 a = p[0], b = p[1], c = p[2];
+    const U4 a = PA_LD(8, p), b = PA_LD(8, p + 1), c = PA_LD(8, p + 2);
     return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
 }
 PA_HD const uint64_t* node_seq(const DevIndexView& ix, uint32_t h) {
@@ -363,7 +395,7 @@ PA_HD void seek_issue(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekPro
     uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + l_probe(s);
     if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
     q.linew = ix.table + (uint64_t)b * BUCKET_WORDS;
-    q.fp = *reinterpret_cast<const U4*>(q.linew);
+    q.fp = PA_LD(4, reinterpret_cast<const U4*>(q.linew));
     q.klo = (uint32_t)kmer;
     q.khi = (uint32_t)(kmer >> 32);
 }
@@ -374,7 +406,7 @@ PA_HD uint32_t seek_cands(const SeekProbe& q) {
     return (q.fp.x == want ? 1u : 0u) | (q.fp.y == want ? 2u : 0u) | (q.fp.z == want ? 4u : 0u) | (q.fp.w == want ? 8u : 0u);
 }
 PA_HD U3 seek_entry(const SeekProbe& q, uint32_t cand) {            // entry of the first candidate (no candidate: entry 0, ignored)
-    return *reinterpret_cast<const U3*>(q.linew + 4 + 3 * (cand ? pa_ctz32(cand) : 0u));
+    return PA_LD(4, reinterpret_cast<const U3*>(q.linew + 4 + 3 * (cand ? pa_ctz32(cand) : 0u)));
 }
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe);
 PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand, U3 e) {
@@ -461,16 +493,16 @@ PA_HD void fwd_issue(const Lane& s, const DevIndexView& ix, FwdLoad& f) {
     const uint32_t ro0 = fresh ? l_off(s) + K : (s.rr & 0xFFFFFFu);   // ref_offset (:227)
     const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
     const U4* hp = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)s.h * BLOB_GRANULE);   // dbg.get_node (:210)
-    f.h0 = hp[0]; f.h1 = hp[1]; f.h2 = hp[2];
+    f.h0 = PA_LD(8, hp); f.h1 = PA_LD(8, hp + 1); f.h2 = PA_LD(8, hp + 2);
     const Q2* sq2 = reinterpret_cast<const Q2*>(node_seq(ix, s.h) + (ro0 >> 5));
     // sequence words this step can need, known before the header arrives: the node visit compares at most the rest of the
     // read (fresh) / of the visit (continued), 128 bases per step; words beyond are not fetched (each may be another line)
     const uint32_t most = pa_min(fresh ? L - kp0 : (s.rm & 0xFFFFu), 128u), nwords = ((ro0 & 31) + most + 31) >> 5;
     // always three 16-byte sequence loads, without branches (a fixed number of loads in flight is what lets the kernel wait
     // for an OLDER load while these are still on their way); a word pair that cannot be needed re-reads the first one
-    f.s01 = sq2[0];
-    f.s23 = sq2[nwords > 2 ? 1 : 0];
-    f.s45 = sq2[nwords > 4 ? 2 : 0];
+    f.s01 = PA_LD(8, sq2);
+    f.s23 = PA_LD(8, sq2 + (nwords > 2 ? 1 : 0));
+    f.s45 = PA_LD(8, sq2 + (nwords > 4 ? 2 : 0));
 }
 
 template <bool TRACE = false>

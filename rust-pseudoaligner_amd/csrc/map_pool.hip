@@ -48,6 +48,11 @@ typedef __attribute__((address_space(1))) const u32x4* glb_v4;
 typedef __attribute__((address_space(1))) uint32_t* glb_u32w;
 typedef __attribute__((address_space(1))) const uint32_t* glb_u32;
 typedef __attribute__((address_space(1))) unsigned long long* glb_u64w;
+// the 16-byte record of the common output step (PA_NT bit 1: written once, read by nobody on the device)
+__device__ __forceinline__ void store_result(glb_v4w dst, u32x4 v) {
+    if (PA_NT & 2) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
+}
 
 typedef __attribute__((address_space(4))) const MapParams* karg_ptr;   // the kernel's parameter block in the kernarg segment
 
@@ -191,7 +196,7 @@ __device__ __forceinline__ void refill_slot(Lane& s, uint64_t rid, uint32_t slot
         for (uint32_t w0 = 0; w0 < wpr; w0 += 8) {   // eight words in flight per round trip
             uint64_t v[8];
 #pragma unroll
-            for (uint32_t i = 0; i < 8; ++i) v[i] = w0 + i < wpr ? src[(uint64_t)(w0 + i) * 64] : 0ull;
+            for (uint32_t i = 0; i < 8; ++i) v[i] = w0 + i < wpr ? PA_LD(1, src + (uint64_t)(w0 + i) * 64) : 0ull;
 #pragma unroll
             for (uint32_t i = 0; i < 8; ++i)
                 if (w0 + i < wpr) rd[(w0 + i) * S + slot] = v[i];
@@ -454,8 +459,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 } else {
                     const bool is_ref = mapped && count != 0;
                     if (!PA_ABLATE(1u))
-                        ((glb_v4w)p.results)[s.rid] = mapped ? u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, is_ref ? PA_CLASS_REF | cand : 0u, count}
-                                                             : u32x4{0u, 0u, 0u, 0u};
+                        store_result((glb_v4w)p.results + s.rid, mapped ? u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, is_ref ? PA_CLASS_REF | cand : 0u, count}
+                                                                        : u32x4{0u, 0u, 0u, 0u});
                     trace_out<TRACE>(s, mapped, gslot, kp);
                     const glb_u32w colour_out = (glb_u32w)p.colour_out;
                     if (colour_out) colour_out[s.rid] = is_ref ? cand : NO_CLASS;
