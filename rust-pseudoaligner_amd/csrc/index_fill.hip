@@ -11,6 +11,7 @@
 //   pa_fill_edges_kernel    one thread per node: the four right neighbours of its last k-mer must be FIRST k-mers (offset 0),
 //                           the four left neighbours of its first k-mer LAST k-mers (offset len - k) of their nodes
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <algorithm>
 
@@ -205,7 +206,9 @@ int fill_t(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, u
     if (N) FILL_TRY(hipMemcpy(d_handle, fd.handle.data(), (size_t)N * 4, hipMemcpyHostToDevice));
     FILL_TRY(hipMemcpy(d_kcum, fd.node_kcum.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
     uint64_t nbuckets = 0;
-    for (double load = FillOps<KT>::LOAD;; load *= 0.75) {
+    double load0 = FillOps<KT>::LOAD;
+    if (const char* v = getenv("PA_DICT_LOAD")) { const double x = atof(v); if (x > 0.01 && x <= 0.95) load0 = x; }   // A/B runs only
+    for (double load = load0;; load *= 0.75) {
         nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (FillOps<KT>::SLOTS * load)) + 1);
         if (nbuckets >= 0xFFFFFFFFull) return done(fail(PA_ERR_UNSUPPORTED, "dictionary exceeds 2^32 buckets"));
         if (*d_table) { (void)hipFree(*d_table); *d_table = nullptr; }
