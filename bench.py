@@ -203,6 +203,13 @@ def main() -> None:
 
     for i in range(W):
         step(i)
+    # the warm-up includes the reduce: the first collective on a fresh RCCL communicator sets up its channels over xGMI, which
+    # takes longer than the ten timed steps together
+    if comm is not None:
+        aligner.counts_allreduce(counts.data_ptr(), comm, stream)
+    elif dist is not None:
+        dist.all_reduce(counts)
+    torch.cuda.synchronize()
     counts.zero_()
     torch.cuda.synchronize()
     barrier()
