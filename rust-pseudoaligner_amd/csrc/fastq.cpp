@@ -14,7 +14,9 @@
 // The flag rule of :455 is kept as is (true iff coverage >= 32 and the class is EMPTY).
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <emmintrin.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -207,6 +209,53 @@ const char* line_end(const char* p, const char* end) {
     return e ? e : end;
 }
 
+// Line breaks, 64 bytes at a time (SSE2, part of every x86-64): FASTQ lines are short — a header, a '+' — and one memchr call per
+// line costs more than the bytes it looks at.
+inline uint64_t nl_mask64(const char* p) {
+    const __m128i nl = _mm_set1_epi8('\n');
+    const uint64_t m0 = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)p), nl));
+    const uint64_t m1 = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(p + 16)), nl));
+    const uint64_t m2 = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(p + 32)), nl));
+    const uint64_t m3 = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(p + 48)), nl));
+    return m0 | (m1 << 16) | (m2 << 32) | (m3 << 48);
+}
+uint64_t count_newlines(const char* d, uint64_t a, uint64_t b) {
+    uint64_t c = 0, i = a;
+    for (; i + 64 <= b; i += 64) c += (uint64_t)__builtin_popcountll(nl_mask64(d + i));
+    for (; i < b; ++i) c += d[i] == '\n';
+    return c;
+}
+// fn(position of a line break) for every line break in [from, to), in order, until fn returns false
+template <class F>
+void for_each_newline(const char* d, uint64_t from, uint64_t to, F&& fn) {
+    uint64_t i = from;
+    for (; i + 64 <= to; i += 64)
+        for (uint64_t m = nl_mask64(d + i); m; m &= m - 1)
+            if (!fn(i + (uint64_t)__builtin_ctzll(m))) return;
+    for (; i < to; ++i)
+        if (d[i] == '\n' && !fn(i)) return;
+}
+
+// sixteen bases -> 32 bits, the table of BaseLut in registers (SSE2): code = ((c >> 1) ^ (c >> 2)) & 3 is A0 C1 G2 T3 in either
+// case; every other byte becomes A like in the table
+inline uint32_t pack16(const uint8_t* p) {
+    const __m128i v = _mm_loadu_si128((const __m128i*)p);
+    __m128i t = _mm_and_si128(_mm_xor_si128(_mm_srli_epi16(v, 1), _mm_srli_epi16(v, 2)), _mm_set1_epi8(3));
+    const __m128i u = _mm_and_si128(v, _mm_set1_epi8((char)0xDF));
+    const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, _mm_set1_epi8('A')), _mm_cmpeq_epi8(u, _mm_set1_epi8('C'))),
+                                    _mm_or_si128(_mm_cmpeq_epi8(u, _mm_set1_epi8('G')), _mm_cmpeq_epi8(u, _mm_set1_epi8('T'))));
+    t = _mm_and_si128(t, ok);
+    t = _mm_and_si128(_mm_or_si128(t, _mm_srli_epi16(t, 6)), _mm_set1_epi16(0x000F));    // 2 bases per 16-bit lane
+    t = _mm_and_si128(_mm_or_si128(t, _mm_srli_epi32(t, 12)), _mm_set1_epi32(0x000000FF)); // 4 per 32-bit lane
+    t = _mm_or_si128(t, _mm_srli_epi64(t, 24));                                             // 8 per 64-bit lane (low 16 bits)
+    return ((uint32_t)_mm_cvtsi128_si32(t) & 0xFFFFu) | ((uint32_t)_mm_extract_epi16(t, 4) << 16);
+}
+
+struct RecPos {   // where a record lies in the text: found by the scan, read by the pack stage
+    uint64_t start;      // of the '@'
+    uint32_t hdr, seq;   // bytes of the header line and of the sequence line (without their line breaks)
+};
+
 struct BatchCtx {   // pinned host buffers + device buffers of one batch in flight
     uint64_t* h_tiles = nullptr;
     uint32_t* h_lens = nullptr;
@@ -229,6 +278,7 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
 
 struct IngestCache {   // the two batches in flight; parked on the index between calls (pa_common.hpp)
     BatchCtx ctx[2];
+    std::vector<RecPos> rec_pos;   // 16 bytes per record of the file: kept, or every call would page 256 MB in again
     static void destroy(void* p) {
         IngestCache* c = static_cast<IngestCache*>(p);
         for (BatchCtx& b : c->ctx) b.release();
@@ -360,7 +410,9 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     const int T = pool.size();
     int rc = PA_OK;
     uint64_t nrec = 0;
-    std::vector<uint64_t> rec_start;
+    IngestCache* cache = static_cast<IngestCache*>(index_take_ingest_cache(idx));   // buffers of the previous call, if any
+    if (!cache) cache = new IngestCache();
+    std::vector<RecPos>& rec_pos = cache->rec_pos;
 
     // ---- scan: line breaks per byte range, then the start of every fourth line ----
     std::vector<char> normalized;   // the text rewritten into four-line records, if it did not have that shape
@@ -373,12 +425,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         pool.run(R, [&](int r) {
             uint64_t a, b, c = 0;
             range(r, a, b);
-            for (const char* p = data + a; p < data + b;) {
-                const char* e = (const char*)memchr(p, '\n', (size_t)(data + b - p));
-                if (!e) break;
-                ++c;
-                p = e + 1;
-            }
+            c = count_newlines(data, a, b);
             nl[(size_t)r + 1] = c;
         });
         for (int r = 0; r < R; ++r) nl[(size_t)r + 1] += nl[(size_t)r];
@@ -390,30 +437,42 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
             rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu (file ends inside a record)", fastq_path, (unsigned long long)(content_lines / 4));
         nrec = content_lines / 4;
         if (rc == PA_OK && nrec) {
-            rec_start.assign(nrec, 0);
+            rec_pos.resize(nrec);   // (every field is written below: each line starts in exactly one range)
+            RecPos* const rp = rec_pos.data();
             pool.run(R, [&](int r) {
                 uint64_t a, b;
                 range(r, a, b);
-                // index of the first line that STARTS in [a, b)
-                uint64_t li = nl[(size_t)r];
-                const char* p = data + a;
-                if (a > 0 && data[a - 1] != '\n') {
-                    const char* e = (const char*)memchr(p, '\n', (size_t)(data + fsize - p));
-                    if (!e) return;
-                    p = e + 1;
-                    li += 1;
-                }
-                while (p < data + b && p < data + fsize) {
-                    if (li % 4 == 0 && li / 4 < nrec) rec_start[li / 4] = (uint64_t)(p - data);
-                    if (li / 4 < nrec && ((li % 4 == 0 && *p != '@') || (li % 4 == 2 && *p != '+'))) {
-                        uint64_t cur = odd_record.load();
-                        while (li / 4 < cur && !odd_record.compare_exchange_weak(cur, li / 4)) {}
+                auto odd = [&](uint64_t rec) {
+                    uint64_t cur = odd_record.load();
+                    while (rec < cur && !odd_record.compare_exchange_weak(cur, rec)) {}
+                };
+                // line li = bytes [p, e) (e = its line break, or the end of the text)
+                auto line = [&](uint64_t p, uint64_t e, uint64_t li) {
+                    const uint64_t rec = li >> 2;
+                    if (rec >= nrec) return;
+                    switch (li & 3) {
+                        case 0:
+                            rp[rec].start = p;
+                            rp[rec].hdr = (uint32_t)std::min<uint64_t>(e - p, 0xFFFFFFFFull);
+                            if (data[p] != '@') odd(rec);
+                            break;
+                        case 1: rp[rec].seq = (uint32_t)std::min<uint64_t>(e - p, 0xFFFFFFFFull); break;
+                        case 2: if (data[p] != '+') odd(rec); break;
+                        default: break;
                     }
-                    const char* e = (const char*)memchr(p, '\n', (size_t)(data + fsize - p));
-                    if (!e) break;
+                };
+                // the lines that START in [a, b): the first one begins after the first line break at or after a - 1
+                uint64_t li = nl[(size_t)r], p = a;
+                bool started = a == 0 || data[a - 1] == '\n';
+                if (!started) li += 1;   // (the line break that ends the straddling line is counted in this range or a later one)
+                for_each_newline(data, a, fsize, [&](uint64_t e) {
+                    if (!started) { started = true; p = e + 1; return p < b; }
+                    line(p, e, li);
                     p = e + 1;
                     ++li;
-                }
+                    return p < b;
+                });
+                if (started && p < b && p < fsize) line(p, fsize, li);   // a last line without a line break
             });
         }
         if (rc == PA_OK && odd_record.load() == ~0ull) break;   // four lines to a record, markers in place
@@ -431,14 +490,11 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         inflated = std::vector<char>();
         data = normalized.data();
         fsize = normalized.size();
-        rec_start.clear();
         nrec = 0;
     }
 
     t_scan = now() - t_begin;
     // ---- batches ----
-    IngestCache* cache = static_cast<IngestCache*>(index_take_ingest_cache(idx));   // buffers of the previous call, if any
-    if (!cache) cache = new IngestCache();
     BatchCtx* const ctx = cache->ctx;
     hipStream_t stream = nullptr;
     if (rc == PA_OK && hipStreamCreate(&stream) != hipSuccess) rc = fail(PA_ERR_HIP, "hipStreamCreate failed");
@@ -496,10 +552,11 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
             uint32_t mx = 0;
             for (uint64_t i = c.n * (uint64_t)t / ntask; i < c.n * (uint64_t)(t + 1) / ntask; ++i) {
                 const char* end = data + fsize;
-                const char* p = data + rec_start[c.first + i];
-                const char* l1e = line_end(p, end);
+                const RecPos& rp = rec_pos[c.first + i];   // the scan walked every line break once: nothing is searched for again
+                const char* p = data + rp.start;
+                const char* l1e = p + rp.hdr;
                 const char* l2 = l1e < end ? l1e + 1 : end;
-                const char* l2e = line_end(l2, end);
+                const char* l2e = std::min(l2 + rp.seq, end);
                 const char* l3 = l2e < end ? l2e + 1 : end;
                 if (*p != '@' || l3 >= end || *l3 != '+') {
                     uint64_t cur = bad_record.load();
@@ -550,7 +607,9 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                     for (uint32_t w = 0; w < wpr; ++w) {
                         uint64_t v = 0;
                         const uint32_t b0 = 32 * w, nbases = rec.seq_len > b0 ? std::min<uint32_t>(32, rec.seq_len - b0) : 0;
-                        for (uint32_t j = 0; j < nbases; ++j) v |= (uint64_t)BASE_LUT.v[sq[b0 + j]] << (2 * j);
+                        uint32_t j = 0;
+                        for (; j + 16 <= nbases; j += 16) v |= (uint64_t)pack16(sq + b0 + j) << (2 * j);
+                        for (; j < nbases; ++j) v |= (uint64_t)BASE_LUT.v[sq[b0 + j]] << (2 * j);
                         tw[(uint64_t)w * 64 + r] = v;
                     }
                 }
@@ -594,7 +653,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         const int P = T * 4;
         TextSet* parts = writer.acquire((size_t)P);
         std::vector<uint64_t> flags((size_t)P, 0);
-        const uint64_t keep_from = mapped ? (rec_start[c.first] & ~4095ull) : 0;   // nothing before this batch is read again
+        const uint64_t keep_from = mapped ? (rec_pos[c.first].start & ~4095ull) : 0;   // nothing before this batch is read again
         const int extra = keep_from > unmapped_to ? 1 : 0;
         pool.run(P + extra, [&](int task) {
             if (task < extra) {
@@ -605,7 +664,22 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
             TextBuf buf = std::move((*parts)[(size_t)t]);   // thread-local while filling: neighbours share cache lines in the set
             uint64_t nflag = 0;
             const uint64_t a = c.n * (uint64_t)t / P, b = c.n * (uint64_t)(t + 1) / P;
+            // classes returned by reference are two dependent random reads into tables of tens of MB (class -> record -> ids):
+            // both are prefetched a few reads ahead, or every read would wait for two cache misses
+            constexpr uint64_t PF_REF = 16, PF_IDS = 8;
             for (uint64_t i = a; i < b; ++i) {
+                if (i + PF_REF < b) {
+                    const uint32_t off = c.h_results[i + PF_REF].class_off;
+                    if (off & PA_CLASS_REF) __builtin_prefetch(h_class_ref + (off & ~PA_CLASS_REF));
+                }
+                if (i + PF_IDS < b) {
+                    const pa_read_result& q = c.h_results[i + PF_IDS];
+                    if (q.class_off & PA_CLASS_REF) {
+                        const uint32_t* ids = h_ec + 4ull * h_class_ref[q.class_off & ~PA_CLASS_REF] + 1;
+                        __builtin_prefetch(ids);
+                        if (q.class_len > 14) __builtin_prefetch(ids + 16);
+                    } else if (q.class_len) __builtin_prefetch(c.h_arena.data() + q.class_off);
+                }
                 const pa_read_result& r = c.h_results[i];
                 const bool mapped_read = r.mismatches & PA_MAPPED_BIT;
                 const bool flag = mapped_read && r.coverage >= PA_READ_COVERAGE_THRESHOLD && r.class_len == 0;   // :455
@@ -663,12 +737,19 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     const bool wrote = writer.finish();
     const double t_writer = now() - t0; t0 = now();
     if (rc == PA_OK && !wrote) rc = fail(PA_ERR_IO, "short write to %s", out_path);
+    if (cache->rec_pos.capacity() > ((size_t)64 << 20)) std::vector<RecPos>().swap(cache->rec_pos);   // (do not park more than 1 GB of it)
     if (rc == PA_OK) index_put_ingest_cache(idx, cache, IngestCache::destroy);   // the next call starts with warm buffers
     else IngestCache::destroy(cache);
     if (mapped && fsize > unmapped_to) munmap((void*)(data + unmapped_to), fsize - unmapped_to);
     const double t_unmap = now() - t0; t0 = now();
     if (out != stdout) { if (fclose(out) != 0 && rc == PA_OK) rc = fail(PA_ERR_IO, "close %s: %s", out_path, strerror(errno)); }
     else fflush(stdout);
+    if (verbose) {
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        fprintf(stderr, "[pa ingest] process CPU so far: user %.2f s, system %.2f s, minor faults %ld\n", ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec,
+                ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec, ru.ru_minflt);
+    }
     if (verbose)
         fprintf(stderr, "[pa ingest] teardown: stream %.3f s, writer %.3f s, unmap %.3f s, close %.3f s; before the scan %.3f s\n", t_stream, t_writer, t_unmap,
                 now() - t0, t_begin - t_enter);
