@@ -259,8 +259,9 @@ int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offs
  * quality lines as sequence lines, as bio 1.5 reads them), then scanned in parallel like any other. PA_ERR_FORMAT with
  * the record number for text that is no FASTQ or ends inside a record. Read ids are cut at the first space, as record.id() does.
  * The pinned host and device buffers of the two batches in flight (about 0.4 GB of each for 4 M-read batches of 150-base
- * reads) stay parked on `idx` after a successful call, so that the next file starts with warm buffers; concurrent calls on
- * one index each use their own set; pa_index_destroy frees them. */
+ * reads) and the record positions of the file (16 bytes per read, at most 1 GB of them) stay parked on `idx` after a successful
+ * call, so that the next file starts with warm buffers; concurrent calls on one index each use their own set;
+ * pa_index_destroy frees them. */
 int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads,
                      uint64_t* n_reads_out, uint64_t* n_flagged_out);
 
