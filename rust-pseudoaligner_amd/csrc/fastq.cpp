@@ -178,16 +178,57 @@ char* debug_str(char* o, const char* s, size_t n) {
     return o;
 }
 
+// decimal digits two at a time from a 200-byte table
+struct DigitPairs {
+    char d[200];
+    DigitPairs() { for (int i = 0; i < 100; ++i) { d[2 * i] = (char)('0' + i / 10); d[2 * i + 1] = (char)('0' + i % 10); } }
+};
+const DigitPairs DIGIT_PAIRS;
 char* put_u32(char* o, uint32_t v) {
     char b[10];
-    int n = 0;
-    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) *o++ = b[--n];
+    int n = 10;
+    while (v >= 100) { const uint32_t q = v / 100, r = v - q * 100; v = q; n -= 2; memcpy(b + n, DIGIT_PAIRS.d + 2 * r, 2); }
+    if (v >= 10) { n -= 2; memcpy(b + n, DIGIT_PAIRS.d + 2 * v, 2); }
+    else b[--n] = (char)('0' + v);
+    memcpy(o, b + n, (size_t)(10 - n));
+    return o + (10 - n);
+}
+
+template <size_t N>
+inline char* put_lit(char* o, const char (&lit)[N]) {   // a string literal, copied with its known length
+    memcpy(o, lit, N - 1);
+    return o + (N - 1);
+}
+char* put_str(char* o, const char* s) {
+    while (*s) *o++ = *s++;
     return o;
 }
 
-char* put_str(char* o, const char* s) {
-    while (*s) *o++ = *s++;
+// does the id need no escaping at all (the usual case)? eight bytes at a time: no byte below 0x20, none of 0x7f \\ "
+inline bool plain_text(const char* s, size_t n) {
+    const uint64_t ones = 0x0101010101010101ull, high = 0x8080808080808080ull;
+    auto haszero = [&](uint64_t x) { return (x - ones) & ~x & high; };
+    size_t i = 0;
+    uint64_t bad = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t x;
+        memcpy(&x, s + i, 8);
+        bad |= (x & high)                                   // bytes >= 0x80: left to the byte loop (which copies them)
+               | ((x - 0x20 * ones) & ~x & high)             // a byte below 0x20
+               | haszero(x ^ (0x7Full * ones)) | haszero(x ^ ((uint64_t)'\\' * ones)) | haszero(x ^ ((uint64_t)'"' * ones));
+    }
+    for (; i < n; ++i) {
+        const unsigned char c = (unsigned char)s[i];
+        bad |= (uint64_t)(c < 0x20 || c >= 0x7f || c == '\\' || c == '"');
+    }
+    return bad == 0;
+}
+inline char* debug_id(char* o, const char* s, size_t n) {
+    if (!plain_text(s, n)) return debug_str(o, s, n);
+    *o++ = '"';
+    memcpy(o, s, n);
+    o += n;
+    *o++ = '"';
     return o;
 }
 
@@ -685,16 +726,16 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                 const bool flag = mapped_read && r.coverage >= PA_READ_COVERAGE_THRESHOLD && r.class_len == 0;   // :455
                 nflag += flag;
                 char* const base = buf.room(6 * (size_t)c.recs[i].id_len + 12 * (size_t)r.class_len + 64);
-                char* o = put_str(base, flag ? "(true, " : "(false, ");
-                o = debug_str(o, data + c.recs[i].id_off, c.recs[i].id_len);
-                o = put_str(o, ", [");
+                char* o = flag ? put_lit(base, "(true, ") : put_lit(base, "(false, ");
+                o = debug_id(o, data + c.recs[i].id_off, c.recs[i].id_len);
+                o = put_lit(o, ", [");
                 const uint32_t* ids = (r.class_off & PA_CLASS_REF) ? h_ec + 4ull * h_class_ref[r.class_off & ~PA_CLASS_REF] + 1
                                                                    : c.h_arena.data() + r.class_off;
                 for (uint32_t j = 0; j < r.class_len; ++j) {
                     if (j) { *o++ = ','; *o++ = ' '; }
                     o = put_u32(o, ids[j]);
                 }
-                o = put_str(o, "], ");
+                o = put_lit(o, "], ");
                 o = put_u32(o, mapped_read ? r.coverage : 0u);   // None -> (false, id, [], 0) (:461)
                 *o++ = ')';
                 *o++ = '\n';
