@@ -337,14 +337,19 @@ def main() -> None:
         bytes_per_read = algorithmic_bytes_per_read(ctr, read_len, k)
         achieved = bytes_per_read * B / (kernel_avg_ms * 1e-3) / 1e9
         requests = None
+        raw_traffic = None
         traffic = None   # HBM bytes per launch from committed rocprofv3 PMC passes of this same workload (bench.py cannot run PMC itself)
         try:
             pmc = json.load(open(ROOT / "profiles" / "latest_pmc.json"))["workloads"][args.workload]
             if pmc.get("reads_per_launch") == B:
-                traffic = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0
+                raw = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0
+                # gfx950's FETCH_SIZE tallies a coalesced stream at half its bytes (calibrated: profiles/r02_pmc_calibration.txt; random
+                # lines, stores and atomics are exact): the other half of the streamed input (read tiles + lengths) is added back
+                traffic = raw + 0.5 * (8.0 * wpr + 4.0) * B
+                raw_traffic = raw
                 # the same traffic as 64-byte requests per second, next to what tools/microbench/gather.hip measures on MI355X
                 # for nothing but random 64-byte lines: the bound this access pattern actually runs into
-                per_launch = traffic / 64.0
+                per_launch = raw / 64.0
                 requests = {"per_read": per_launch / B, "per_s": per_launch / (kernel_avg_ms * 1e-3), "gather_hbm_per_s": 49e9,
                             "gather_mall_per_s": 57e9, "frac_of_gather_hbm": per_launch / (kernel_avg_ms * 1e-3) / 49e9,
                             "what": "(FETCH_SIZE + WRITE_SIZE) / 64 B of the committed PMC passes over this run's kernel time; ceilings: "
@@ -352,7 +357,7 @@ def main() -> None:
         except (OSError, ValueError, KeyError):
             pass
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                           "traffic": traffic, "kernel": "pa_map_pool_kernel", "kernel_ms": kernel_avg_ms,
+                           "traffic": traffic, "traffic_raw_counters": raw_traffic, "kernel": "pa_map_pool_kernel", "kernel_ms": kernel_avg_ms,
                            "kernel_ms_min": min(kernel_ms) if kernel_ms else None, "kernel_ms_max": max(kernel_ms) if kernel_ms else None,
                            "kernel_ms_steps": [round(x, 3) for x in kernel_ms],
                            "algorithmic_bytes_per_read": bytes_per_read, "reads_per_launch": B, "requests": requests}
