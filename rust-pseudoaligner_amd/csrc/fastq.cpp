@@ -473,7 +473,19 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         // trailing empty lines are tolerated: lines = line breaks before the last content byte + 1
         uint64_t tail = fsize, trailing_nl = 0;
         while (tail > 0 && (data[tail - 1] == '\n' || data[tail - 1] == '\r')) { trailing_nl += data[tail - 1] == '\n'; --tail; }
-        const uint64_t content_lines = tail ? nl[(size_t)R] - trailing_nl + 1 : 0;
+        uint64_t content_lines = tail ? nl[(size_t)R] - trailing_nl + 1 : 0;
+        if (content_lines % 4 == 3) {
+            // a last record with an EMPTY sequence: its empty quality line looks like a trailing blank line (or is missing
+            // altogether when the file ends after the '+'; bio's reader reads nothing there and hands the record out). Taken as
+            // that record when the text ends "...\n<empty line>\n+..."
+            uint64_t ls = tail;                                            // start of the last content line
+            while (ls > 0 && data[ls - 1] != '\n') --ls;
+            if (data[ls] == '+' && ls >= 2) {
+                uint64_t pe = ls - 1;                                      // the line break that ends the sequence line
+                if (pe > 0 && data[pe - 1] == '\r') --pe;
+                if (pe > 0 && data[pe - 1] == '\n') content_lines += 1;    // the sequence line is empty
+            }
+        }
         if (content_lines % 4 != 0)
             rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu (file ends inside a record)", fastq_path, (unsigned long long)(content_lines / 4));
         nrec = content_lines / 4;

@@ -305,6 +305,15 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
             got = out.read_text().splitlines()
             assert n == len(ids) and got == want, (name, batch, threads)
             assert flagged == sum(1 for w in want if w.startswith("(true"))
+    # a LAST record with an empty sequence: its empty quality line looks like a trailing blank line, or is missing altogether
+    # (bio's reader reads nothing at the end of the file and hands the record out)
+    monkeypatch.setenv("PA_INGEST_BATCH", "1024")
+    for name, ending in (("empty_last", "@last\n\n+\n\n"), ("empty_last_crlf", "@last\r\n\r\n+\r\n\r\n"), ("empty_last_no_qual", "@last\n\n+"),
+                         ("empty_last_blank_lines", "@last\n\n+\n\n\n\n")):
+        fq = tmp_path / (name + ".fq")
+        fq.write_text(variants["plain"] + ending, newline="")
+        n, flagged = pa.process_reads(str(fq), a, str(out), 3)
+        assert n == len(ids) + 1 and out.read_text().splitlines() == want + ['(false, "last", [], 0)'], name
     # gzip input (utils::open_with_gz, src/utils.rs:45-57), also as two concatenated members
     import gzip
     gzp = tmp_path / "plain.fq.gz"

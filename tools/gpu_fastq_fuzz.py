@@ -2,7 +2,7 @@
 paths) against the oracle's tuples: random slices of small.fq rewritten with random ids (quotes, backslashes, control bytes,
 tabs, trailing blanks), random read lengths (0..300: word counts change between batches), lower case / N / IUPAC letters,
 LF or CRLF, with or without a final line break, trailing blank lines, wrapped records, gzip; random batch sizes and thread
-counts. Usage (GPU box): python tools/gpu_fastq_fuzz.py [files]"""
+counts. Usage (GPU box): python tools/gpu_fastq_fuzz.py [files [first seed]]"""
 import gzip, importlib, os, sys, tempfile
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -25,11 +25,12 @@ def rust_debug(s):   # impl Debug for str, for the bytes this fuzz produces (ASC
 
 def main():
     nfiles = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     _, base = helpers.read_fastq()
     bad = 0
     aligners = {}
     with tempfile.TemporaryDirectory() as td:
-        for seed in range(nfiles):
+        for seed in range(first, first + nfiles):
             rng = np.random.default_rng(7000 + seed)
             k = (20, 24, 31)[seed % 3]
             if k not in aligners:
@@ -87,8 +88,9 @@ def main():
             if not ok:
                 bad += 1
                 print("MISMATCH seed %d (n=%d k=%d nl=%r wrap=%s gz=%s)" % (seed, n, k, nl, wrap, path.endswith(".gz")))
-                for x, y in list(zip(got, want))[:2000]:
-                    if x != y: print("   got ", x[:150]); print("   want", y[:150]); break
+                print("   lines got %d want %d, batch %s" % (len(got), len(want), os.environ["PA_INGEST_BATCH"]))
+                for j, (x, y) in enumerate(zip(got, want)):
+                    if x != y: print("   line", j, "seq len", len(seqs[j]), "\n   got ", x[:150], "\n   want", y[:150]); break
     print("fastq fuzz: %d files, mismatching %d" % (nfiles, bad))
 
 if __name__ == "__main__":
