@@ -2,6 +2,7 @@
 // (kernels.hip) from the same text so that both produce identical reads.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #if defined(__HIPCC__)
@@ -40,9 +41,13 @@ PA_SYN_HD static inline uint64_t win32(const uint64_t* w, uint64_t pos) {
 // cum[t] = number of valid read starts in transcripts < t (a transcript of length len has len-read_len+1 of them)
 static inline void build_cum(const uint64_t* tx_start, uint32_t num_tx, uint32_t read_len, std::vector<uint64_t>& cum) {
     cum.assign((size_t)num_tx + 1, 0);
+    // PA_SIM_TX_LIMIT=n (experiments only): reads are drawn from the first n transcripts, i.e. the index stays what it
+    // is but the part of it the reads touch fits the caches
+    uint32_t limit = num_tx;
+    if (const char* v = getenv("PA_SIM_TX_LIMIT")) { const long x = atol(v); if (x > 0 && (unsigned long)x < num_tx) limit = (uint32_t)x; }
     for (uint32_t t = 0; t < num_tx; ++t) {
         const uint64_t len = tx_start[t + 1] - tx_start[t];
-        cum[t + 1] = cum[t] + (len >= read_len ? len - read_len + 1 : 0);
+        cum[t + 1] = cum[t] + (t < limit && len >= read_len ? len - read_len + 1 : 0);
     }
 }
 
