@@ -265,6 +265,14 @@ int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offs
 int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads,
                      uint64_t* n_reads_out, uint64_t* n_flagged_out);
 
+/* The scan stage of pa_process_reads by itself, without a GPU: the number of records of a FASTQ file (plain, gzip'ed or with
+ * wrapped lines: same acceptance rules and errors as above) and, for the first `capacity` of them, where the record starts and
+ * how long its header line ('@' included, line break and CR excluded... the CR of a CRLF header is part of it) and its
+ * sequence are. Offsets refer to the text as scanned: *text_kind = 0 the file itself, 1 the inflated gzip stream, 2 the text
+ * rewritten into four-line records. Every output pointer but n_records may be NULL. */
+int pa_fastq_scan_host(const char* fastq_path, int num_threads, uint64_t* n_records, uint64_t* starts, uint32_t* header_len,
+                       uint32_t* seq_len, uint64_t capacity, int* text_kind);
+
 /* ---------------- equivalence-class count table (multi-GPU reduction unit) ---------------- */
 /* counts[c] += number of reads whose class equals index class c; reads with a novel (non-index)
  * non-empty class are counted in counts[num_classes] ("novel"), empty-class mapped reads in

@@ -63,6 +63,13 @@ int main(int argc, char** argv) {
     uint64_t tiles[64];
     uint32_t lens[2];
     EXPECT(pa_encode_reads_host(ascii, offsets, 2, wpr, tiles, lens) == PA_OK && lens[0] == 12 && lens[1] == 13);
+    {   /* the scan stage of process_reads, no GPU needed */
+        uint64_t nrec = 0, starts[4];
+        uint32_t hdr[4], sq[4];
+        int kind = -1;
+        EXPECT(pa_fastq_scan_host(fastq, 2, &nrec, starts, hdr, sq, 4, &kind) == PA_OK && nrec > 4 && kind == 0 && starts[0] == 0 && sq[0] > 0 &&
+               starts[1] > starts[0] + hdr[0] + sq[0]);
+    }
 
     pa_txome *tx = NULL, *tx2 = NULL, *tx3 = NULL;
     EXPECT(pa_txome_synthesize(50, 120, 7, &tx) == PA_OK);

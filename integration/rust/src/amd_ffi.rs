@@ -55,6 +55,8 @@ extern "C" {
                                      class_cap: u32, class_len: *mut u32, coverage: *mut u32, mismatches: *mut u32) -> c_int;
     pub fn pa_process_reads(idx: *mut PaIndex, fastq_path: *const c_char, out_path: *const c_char, num_threads: c_int,
                             n_reads: *mut u64, n_flagged: *mut u64) -> c_int;
+    pub fn pa_fastq_scan_host(fastq_path: *const c_char, num_threads: c_int, n_records: *mut u64, starts: *mut u64, header_len: *mut u32,
+                              seq_len: *mut u32, capacity: u64, text_kind: *mut c_int) -> c_int;
 
     // device-resident batches + the fused class-count table
     pub fn pa_words_per_read(max_read_len: u32) -> u32;

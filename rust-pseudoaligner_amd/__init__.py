@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import _build
+from . import _build, _ffi
 from ._ffi import (PA_DEFAULT_ALLOWED_MISMATCHES, PA_ERR_ARENA_FULL, PA_MAPPED_BIT, PA_OK, PA_READ_COVERAGE_THRESHOLD, FlatIndex,
                    IndexStats, PaError, ReadResult, check, lib, vp)
 
@@ -512,6 +512,17 @@ def process_reads(fastq_path: str, index: Pseudoaligner, out_path: str = "-", nu
     n, flagged = C.c_uint64(), C.c_uint64()
     check(lib().pa_process_reads(index._h, str(fastq_path).encode(), str(out_path).encode(), num_threads, C.byref(n), C.byref(flagged)))
     return n.value, flagged.value
+
+
+def fastq_scan(fastq_path: str, num_threads: int = 2) -> Tuple[np.ndarray, np.ndarray, np.ndarray, int]:
+    """pa_fastq_scan_host: the scan stage of process_reads alone (no GPU) -> (starts, header_len, seq_len, text_kind)"""
+    n, kind = C.c_uint64(), C.c_int()
+    check(lib().pa_fastq_scan_host(str(fastq_path).encode(), num_threads, C.byref(n), None, None, None, 0, C.byref(kind)))
+    starts, hdr, seq = np.zeros(n.value, np.uint64), np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint32)
+    if n.value:
+        check(lib().pa_fastq_scan_host(str(fastq_path).encode(), num_threads, C.byref(n), starts.ctypes.data_as(_ffi.u64p),
+                                       hdr.ctypes.data_as(_ffi.u32p), seq.ctypes.data_as(_ffi.u32p), len(starts), C.byref(kind)))
+    return starts, hdr, seq, kind.value
 
 
 def gather_classes(results: np.ndarray, arena: np.ndarray, index: "HostIndex") -> Tuple[np.ndarray, np.ndarray]:

@@ -380,29 +380,31 @@ bool normalize_fastq(const char* d, uint64_t n, std::vector<char>& out, uint64_t
     }
 }
 
-}  // namespace
+struct FastqText {   // the text of a FASTQ file as the scan sees it: the mapped file, an inflated gzip stream, or the rewritten records
+    const char* data = nullptr;
+    uint64_t fsize = 0;
+    bool mapped = false;
+    std::vector<char> inflated;     // a gzip'ed FASTQ (utils::open_with_gz, src/utils.rs:45-57) is inflated into memory first
+    std::vector<char> normalized;   // the text rewritten into four-line records, if it did not have that shape
+    void release() {
+        if (mapped) munmap((void*)data, fsize);
+        mapped = false;
+        data = nullptr;
+        fsize = 0;
+    }
+};
 
-extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads, uint64_t* n_reads_out,
-                                uint64_t* n_flagged_out) {
-    if (!idx || !fastq_path || !out_path) return fail(PA_ERR_INVALID_ARG, "null argument");
-    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (num_threads < 1) num_threads = 1;
-    if (n_reads_out) *n_reads_out = 0;
-    if (n_flagged_out) *n_flagged_out = 0;
-    const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
-    int device = 0;
-    index_host_classes(idx, &h_ec, &h_class_ref, &device);
-    HIP_OK(hipSetDevice(device));
-
+int open_fastq(const char* fastq_path, FastqText& t) {
+    const char*& data = t.data;
+    uint64_t& fsize = t.fsize;
+    bool& mapped = t.mapped;
+    std::vector<char>& inflated = t.inflated;
     // ---- map the file ----
     const int fd = open(fastq_path, O_RDONLY);
     if (fd < 0) return fail(PA_ERR_IO, "cannot open %s: %s", fastq_path, strerror(errno));
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); return fail(PA_ERR_IO, "cannot stat %s: %s", fastq_path, strerror(errno)); }
-    uint64_t fsize = (uint64_t)st.st_size;
-    const char* data = nullptr;
-    std::vector<char> inflated;   // a gzip'ed FASTQ (utils::open_with_gz, src/utils.rs:45-57) is inflated into memory first
-    bool mapped = false;
+    fsize = (uint64_t)st.st_size;
     unsigned char magic[2] = {0, 0};
     const bool gz = fsize >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
     if (gz) {
@@ -434,29 +436,20 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         mapped = true;
     }
     close(fd);
-    FILE* out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
-    if (!out) { if (mapped) munmap((void*)data, fsize); return fail(PA_ERR_IO, "cannot create %s: %s", out_path, strerror(errno)); }
-    // a private 4 MiB stdio buffer only for a file this function opened (and closes before the buffer dies); the process-wide
-    // stdout keeps its own buffering: handing it a function-local buffer would leave it dangling after the return
-    std::vector<char> obuf(out != stdout ? (size_t)1 << 22 : 0);
-    if (out != stdout) setvbuf(out, obuf.data(), _IOFBF, obuf.size());
+    return PA_OK;
+}
 
-    uint64_t BATCH_READS = DEFAULT_BATCH_READS;
-    if (const char* v = getenv("PA_INGEST_BATCH")) { const long long x = atoll(v); if (x >= 64) BATCH_READS = (uint64_t)x / 64 * 64; }
-    const bool verbose = getenv("PA_VERBOSE") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_scan = 0, t_pack = 0, t_finish = 0, t_launch = 0, t_format = 0, t_pack_rec = 0, t_pack_alloc = 0, t_pack_tiles = 0, t_push = 0;
-    const double t_begin = now();
-    Pool pool(num_threads);
+// Records of the text: line breaks per byte range, then what every line is (scan of pa_process_reads; pa_fastq_scan_host runs
+// it alone). rec_pos[i] = where record i lies; a text that is not in four-line shape is rewritten once and scanned again.
+int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<RecPos>& rec_pos, uint64_t& nrec) {
+    const char*& data = t.data;
+    uint64_t& fsize = t.fsize;
+    bool& mapped = t.mapped;
+    std::vector<char>& inflated = t.inflated;
+    std::vector<char>& normalized = t.normalized;
     const int T = pool.size();
     int rc = PA_OK;
-    uint64_t nrec = 0;
-    IngestCache* cache = static_cast<IngestCache*>(index_take_ingest_cache(idx));   // buffers of the previous call, if any
-    if (!cache) cache = new IngestCache();
-    std::vector<RecPos>& rec_pos = cache->rec_pos;
-
     // ---- scan: line breaks per byte range, then the start of every fourth line ----
-    std::vector<char> normalized;   // the text rewritten into four-line records, if it did not have that shape
     for (int attempt = 0; attempt < 2; ++attempt) {
         std::atomic<uint64_t> odd_record{~0ull};   // first record whose first line lacks the '@' or whose third the '+'
         rc = PA_OK;
@@ -546,6 +539,85 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         nrec = 0;
     }
 
+    return rc;
+}
+
+}  // namespace
+
+// The scan stage of pa_process_reads by itself (no GPU): how many records the text holds and where their header and sequence
+// lines lie. Offsets refer to the text as scanned: the file itself (*text_kind 0), the inflated gzip stream (1) or the text
+// rewritten into four-line records (2, wrapped input).
+extern "C" int pa_fastq_scan_host(const char* fastq_path, int num_threads, uint64_t* n_records, uint64_t* starts, uint32_t* header_len,
+                                  uint32_t* seq_len, uint64_t capacity, int* text_kind) {
+    if (!fastq_path || !n_records) return fail(PA_ERR_INVALID_ARG, "null argument");
+    *n_records = 0;
+    FastqText text;
+    int rc = open_fastq(fastq_path, text);
+    if (rc != PA_OK) return rc;
+    const bool was_gz = !text.mapped && text.fsize != 0;
+    Pool pool(num_threads < 1 ? 1 : num_threads);
+    std::vector<RecPos> rec_pos;
+    uint64_t nrec = 0;
+    rc = scan_fastq(fastq_path, text, pool, rec_pos, nrec);
+    if (rc == PA_OK) {
+        *n_records = nrec;
+        if (text_kind) *text_kind = !text.normalized.empty() ? 2 : was_gz ? 1 : 0;
+        for (uint64_t i = 0; i < nrec && i < capacity; ++i) {
+            const char* l2e = text.data + rec_pos[i].start + rec_pos[i].hdr + 1 + rec_pos[i].seq;   // a CR before the line break is not sequence
+            const bool cr = rec_pos[i].seq && l2e[-1] == '\r';
+            if (starts) starts[i] = rec_pos[i].start;
+            if (header_len) header_len[i] = rec_pos[i].hdr;
+            if (seq_len) seq_len[i] = rec_pos[i].seq - (cr ? 1u : 0u);
+        }
+    }
+    text.release();
+    return rc;
+}
+
+extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads, uint64_t* n_reads_out,
+                                uint64_t* n_flagged_out) {
+    if (!idx || !fastq_path || !out_path) return fail(PA_ERR_INVALID_ARG, "null argument");
+    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (num_threads < 1) num_threads = 1;
+    if (n_reads_out) *n_reads_out = 0;
+    if (n_flagged_out) *n_flagged_out = 0;
+    const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
+    int device = 0;
+    index_host_classes(idx, &h_ec, &h_class_ref, &device);
+    HIP_OK(hipSetDevice(device));
+
+    // ---- map the file ----
+    FastqText text;
+    {
+        const int orc = open_fastq(fastq_path, text);
+        if (orc != PA_OK) return orc;
+    }
+    const char*& data = text.data;
+    uint64_t& fsize = text.fsize;
+    bool& mapped = text.mapped;
+    FILE* out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
+    if (!out) { if (mapped) munmap((void*)data, fsize); return fail(PA_ERR_IO, "cannot create %s: %s", out_path, strerror(errno)); }
+    // a private 4 MiB stdio buffer only for a file this function opened (and closes before the buffer dies); the process-wide
+    // stdout keeps its own buffering: handing it a function-local buffer would leave it dangling after the return
+    std::vector<char> obuf(out != stdout ? (size_t)1 << 22 : 0);
+    if (out != stdout) setvbuf(out, obuf.data(), _IOFBF, obuf.size());
+
+    uint64_t BATCH_READS = DEFAULT_BATCH_READS;
+    if (const char* v = getenv("PA_INGEST_BATCH")) { const long long x = atoll(v); if (x >= 64) BATCH_READS = (uint64_t)x / 64 * 64; }
+    const bool verbose = getenv("PA_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_scan = 0, t_pack = 0, t_finish = 0, t_launch = 0, t_format = 0, t_pack_rec = 0, t_pack_alloc = 0, t_pack_tiles = 0, t_push = 0;
+    const double t_begin = now();
+    Pool pool(num_threads);
+    const int T = pool.size();
+    int rc = PA_OK;
+    uint64_t nrec = 0;
+    IngestCache* cache = static_cast<IngestCache*>(index_take_ingest_cache(idx));   // buffers of the previous call, if any
+    if (!cache) cache = new IngestCache();
+    std::vector<RecPos>& rec_pos = cache->rec_pos;
+
+    // ---- scan ----
+    rc = scan_fastq(fastq_path, text, pool, rec_pos, nrec);
     t_scan = now() - t_begin;
     // ---- batches ----
     BatchCtx* const ctx = cache->ctx;
