@@ -266,9 +266,9 @@ int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path
                      uint64_t* n_reads_out, uint64_t* n_flagged_out);
 
 /* The scan stage of pa_process_reads by itself, without a GPU: the number of records of a FASTQ file (plain, gzip'ed or with
- * wrapped lines: same acceptance rules and errors as above) and, for the first `capacity` of them, where the record starts and
- * how long its header line ('@' included, line break and CR excluded... the CR of a CRLF header is part of it) and its
- * sequence are. Offsets refer to the text as scanned: *text_kind = 0 the file itself, 1 the inflated gzip stream, 2 the text
+ * wrapped lines: same acceptance rules and errors as above) and, for the first `capacity` of them, where the record starts,
+ * how many bytes its header line has before the line feed ('@' included, and the CR of a CRLF file) and how many bases its
+ * sequence has. The sequence begins at start + header_len + 1. Offsets refer to the text as scanned: *text_kind = 0 the file itself, 1 the inflated gzip stream, 2 the text
  * rewritten into four-line records. Every output pointer but n_records may be NULL. */
 int pa_fastq_scan_host(const char* fastq_path, int num_threads, uint64_t* n_records, uint64_t* starts, uint32_t* header_len,
                        uint32_t* seq_len, uint64_t capacity, int* text_kind);
