@@ -366,6 +366,17 @@ def test_process_reads_concurrent_calls_one_index(aligners, tmp_path, monkeypatc
     assert pa.process_reads(str(fq), a, str(outs[0]), 3)[0] == len(ids) and outs[0].read_text().splitlines() == want
 
 
+def test_process_reads_fuzz(monkeypatch):
+    """tools/gpu_fastq_fuzz.py, a short run: random FASTQ files (ids with quotes / control bytes / tabs, read lengths 0..300, IUPAC
+    letters, LF / CRLF, wrapped records, gzip members, trailing blank lines) through pa_process_reads against the oracle's tuples"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_fastq_fuzz", str(helpers.ROOT / "tools" / "gpu_fastq_fuzz.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    monkeypatch.setenv("PA_INGEST_BATCH", "64")   # (the fuzz sets it per file; restored afterwards)
+    assert fuzz.run(36, 20000) == 0
+
+
 # 12..308: seeds on which a lookup that only tried the first fingerprint match of a bucket missed k-mers (two keys of one
 # bucket sharing their low 31 bits — low-complexity sequence); found by tools/gpu_soak.py
 @pytest.mark.parametrize("seed", list(range(10)) + [12, 19, 31, 39, 48, 55, 96, 242, 278, 308])

@@ -23,9 +23,7 @@ def rust_debug(s):   # impl Debug for str, for the bytes this fuzz produces (ASC
     out.append('"')
     return "".join(out)
 
-def main():
-    nfiles = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+def run(nfiles, first=0):
     _, base = helpers.read_fastq()
     bad = 0
     aligners = {}
@@ -92,6 +90,7 @@ def main():
                 for j, (x, y) in enumerate(zip(got, want)):
                     if x != y: print("   line", j, "seq len", len(seqs[j]), "\n   got ", x[:150], "\n   want", y[:150]); break
     print("fastq fuzz: %d files, mismatching %d" % (nfiles, bad))
+    return bad
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 150, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
