@@ -250,10 +250,7 @@ int pa_encode_reads_device(const pa_index* idx, const uint8_t* d_ascii, const ui
 }
 
 // ---- launch geometry ----
-static int env_int(const char* name, int dflt) {   // tuning knobs for A/B runs (documented in DESIGN.md); unset in production
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
+static int env_int(const char* name, int dflt) { return knob_int(name, dflt); }   // A/B knobs: -DPA_DEBUG_KNOBS builds only (pa_common.hpp)
 
 // u32 words of a slot's row in the spill / trace scratch: list-mode header + (ref, len, class id, -) quads for >= 2 * max
 // read length + 2 node visits; also the stride of the node lists of pa_map_batch_nodes

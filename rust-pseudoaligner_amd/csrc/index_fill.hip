@@ -207,7 +207,7 @@ int fill_t(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, u
     FILL_TRY(hipMemcpy(d_kcum, fd.node_kcum.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
     uint64_t nbuckets = 0;
     double load0 = FillOps<KT>::LOAD;
-    if (const char* v = getenv("PA_DICT_LOAD")) { const double x = atof(v); if (x > 0.01 && x <= 0.95) load0 = x; }   // A/B runs only
+    if (const char* v = knob_str("PA_DICT_LOAD")) { const double x = atof(v); if (x > 0.01 && x <= 0.95) load0 = x; }   // A/B runs only
     for (double load = load0;; load *= 0.75) {
         nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (FillOps<KT>::SLOTS * load)) + 1);
         if (nbuckets >= 0xFFFFFFFFull) return done(fail(PA_ERR_UNSUPPORTED, "dictionary exceeds 2^32 buckets"));

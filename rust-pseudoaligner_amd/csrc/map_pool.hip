@@ -118,11 +118,20 @@ __device__ __forceinline__ void trace_out(const Lane& s, bool mapped, uint32_t g
 // the slots many reads of the wave hit (a highly expressed class; the "novel" / "empty" / "unmapped" slots at the table's end,
 // which EVERY such read hits: straight atomics on them are one hot word per XCD) and are flushed every COUNT_CACHE_PERIOD
 // output steps; a slot whose pair is taken goes straight to the replica table
+// the add into this XCD's replica. A/B build -DPA_COUNT_WG=1: workgroup scope — executed in this XCD's L2 instead of being forwarded
+// to the memory side (every wave that touches replica x runs on XCD x, and the fold kernel reads after the launch has ended)
+#ifndef PA_COUNT_WG
+#define PA_COUNT_WG 0
+#endif
+__device__ __forceinline__ void replica_add(glb_u32w p, uint32_t v) {
+    if (PA_COUNT_WG) __hip_atomic_fetch_add((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicAdd((uint32_t*)p, v);
+}
 __device__ __forceinline__ void count_cached(lds_u32 ctag, lds_u32 ccnt, glb_u32w xcounts, uint32_t cslot) {
     const uint32_t hs = (cslot * 0x9E3779B1u) >> 26;
     const uint32_t old = atomicCAS((uint32_t*)(ctag + hs), NO_CLASS, cslot);
     if (old == NO_CLASS || old == cslot) atomicAdd((uint32_t*)(ccnt + hs), 1u);
-    else atomicAdd((uint32_t*)(xcounts + cslot), 1u);
+    else replica_add(xcounts + cslot, 1u);
 }
 
 // list mode: record + class-count update of one finished read; leaves the lane in ST_EMPTY, or in ST_F_NOVEL when the class
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             }
             if (xcounts && (++out_steps % COUNT_CACHE_PERIOD) == 0) {   // flush: hot classes re-enter at once, squatters leave
                 const uint32_t t = ctag[lane], c = ccnt[lane];
-                if (t != NO_CLASS && c) atomicAdd((uint32_t*)(xcounts + t), c);
+                if (t != NO_CLASS && c) replica_add(xcounts + t, c);
                 ctag[lane] = NO_CLASS;
                 ccnt[lane] = 0;
             }
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
     }
     if (xcounts) {
         const uint32_t t = ctag[lane], c = ccnt[lane];
-        if (t != NO_CLASS && c) atomicAdd((uint32_t*)(xcounts + t), c);
+        if (t != NO_CLASS && c) replica_add(xcounts + t, c);
     }
     if (PA_DBG && lane < 2 * ST_NSTAT) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
     if (PA_DBG && lane < ST_NSTAT) atomicAdd(p.dbg + 2 * ST_NSTAT + lane, dbg_clk[lane]);
@@ -829,7 +838,10 @@ int launch_map_pool(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStre
     const bool gread = p.wpr > PA_LDS_READ_WORDS;
     if (p.trace) return gread ? launch_one<true, true, false>(p, grid, lds_bytes, stream) : launch_one<true, false, false>(p, grid, lds_bytes, stream);
     if (gread) return launch_one<false, true, false>(p, grid, lds_bytes, stream);
-    return (p.dbg || p.ablate) ? launch_one<false, false, true>(p, grid, lds_bytes, stream) : launch_one<false, false, false>(p, grid, lds_bytes, stream);
+#ifdef PA_DEBUG_KNOBS   // the statistics / ablation instantiation exists in A/B builds only
+    if (p.dbg || p.ablate) return launch_one<false, false, true>(p, grid, lds_bytes, stream);
+#endif
+    return launch_one<false, false, false>(p, grid, lds_bytes, stream);
 }
 
 int pool_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu) {

@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -23,6 +24,23 @@ void index_host_classes(const pa_index* idx, const uint32_t** ec, const uint32_t
 // it; put() stores it back (or frees it with `free_fn` when another call already parked one). pa_index_destroy frees it.
 void* index_take_ingest_cache(pa_index* idx);
 void index_put_ingest_cache(pa_index* idx, void* cache, void (*free_fn)(void*));
+
+// A/B tuning knobs (PA_MAP_ABLATE, PA_MAP_STATS, PA_POOL_SLOTS, PA_MAP_BLOCKS_PER_CU, PA_DICT_LOAD, PA_SIM_TX_LIMIT) exist only
+// in builds made with -DPA_DEBUG_KNOBS (tools/build_variant.sh). The shipped library never reads them: an exported variable
+// cannot make it skip result stores or counts.
+static inline const char* knob_str(const char* name) {
+#ifdef PA_DEBUG_KNOBS
+    const char* v = getenv(name);
+    return v && *v ? v : nullptr;
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+static inline int knob_int(const char* name, int dflt) {
+    const char* v = knob_str(name);
+    return v ? atoi(v) : dflt;
+}
 
 // CPUs this process may use: hardware threads, capped by the cgroup CPU quota (a container that sees 256 CPUs may be
 // limited to 16 CPUs' worth of time; 256 threads there only add scheduling noise). host_index.cpp

@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include "pa_common.hpp"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PA_SYN_HD __host__ __device__
@@ -44,7 +46,7 @@ static inline void build_cum(const uint64_t* tx_start, uint32_t num_tx, uint32_t
     // PA_SIM_TX_LIMIT=n (experiments only): reads are drawn from the first n transcripts, i.e. the index stays what it
     // is but the part of it the reads touch fits the caches
     uint32_t limit = num_tx;
-    if (const char* v = getenv("PA_SIM_TX_LIMIT")) { const long x = atol(v); if (x > 0 && (unsigned long)x < num_tx) limit = (uint32_t)x; }
+    if (const char* v = knob_str("PA_SIM_TX_LIMIT")) { const long x = atol(v); if (x > 0 && (unsigned long)x < num_tx) limit = (uint32_t)x; }
     for (uint32_t t = 0; t < num_tx; ++t) {
         const uint64_t len = tx_start[t + 1] - tx_start[t];
         cum[t + 1] = cum[t] + (t < limit && len >= read_len ? len - read_len + 1 : 0);

@@ -35,6 +35,14 @@ def test_product_never_references_the_oracle():
         assert "pa_oracle" not in text and "oracle/" not in text and "libpa_emu" not in text, f
 
 
+def test_shipped_library_reads_no_tuning_knob(built):
+    """the A/B knobs of DESIGN.md §8 exist only in -DPA_DEBUG_KNOBS builds (tools/build_variant.sh): the shipped library does not
+    even hold their names, so an exported variable cannot make it skip result stores or counts"""
+    blob = pa._ffi.library_path().read_bytes()
+    for knob in (b"PA_MAP_ABLATE", b"PA_MAP_STATS", b"PA_POOL_SLOTS", b"PA_MAP_BLOCKS_PER_CU", b"PA_MAP_GREAD", b"PA_DICT_LOAD", b"PA_SIM_TX_LIMIT"):
+        assert knob not in blob, knob
+
+
 def test_no_gpu_means_loud_failure(built, small_index):
     if pa.lib().pa_device_count() > 0:
         pytest.skip("a GPU is present")

@@ -40,6 +40,30 @@ def test_small_fq_vs_oracle_and_fixture(aligners, k):
     assert "".join(lines) == (helpers.GOLDEN / ("small_fq_k%d.tsv" % k)).read_text()
 
 
+def test_tuning_knobs_in_the_environment_change_nothing(aligners, monkeypatch):
+    """PA_MAP_ABLATE=3 (no result stores, no counts) / PA_POOL_SLOTS / PA_MAP_STATS are read by -DPA_DEBUG_KNOBS builds only: the
+    shipped library ignores them and stays bit-exact, fused count table included"""
+    import torch
+    for k, v in (("PA_MAP_ABLATE", "3"), ("PA_POOL_SLOTS", "64"), ("PA_MAP_STATS", "1"), ("PA_MAP_BLOCKS_PER_CU", "1")):
+        monkeypatch.setenv(k, v)
+    a = aligners(24)
+    _, seqs = helpers.read_fastq()
+    res, coff, cids, _ = gpu_vs_oracle(a, seqs, 2, "small.fq K=24 with knobs exported")
+    tiles, lens, wpr = pa.encode_reads_host(seqs)
+    dev = torch.device("cuda", 0)
+    n = len(seqs)
+    d_tiles = torch.from_numpy(tiles.view(np.int64)).to(dev)
+    d_lens = torch.from_numpy(lens.view(np.int32)).to(dev)
+    cap = a.arena_hint(n)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+    a.map_count_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, d_counts.data_ptr(), 2)
+    a.map_finish()
+    want = helpers.counts_reference(*helpers.Oracle(a.host).map_reads(seqs, 2, 8)[:3], a.host)
+    assert np.array_equal(d_counts.cpu().numpy().astype(np.uint64), want.astype(np.uint64))
+
+
 def test_reference_literals_through_map_read(aligners):
     a = aligners(20)
     ex1 = "GGCTGTCAACCAGTCCATAGGCAGGGCCATCAGGCACCAAAGGGATTCTGCCAGCATAGT"          # src/build_index.rs:429-434

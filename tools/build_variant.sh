@@ -1,12 +1,17 @@
-# build tools/baseline/<name>.so = the product library with map_pool.hip compiled under extra flags (A/B runs: PA_PRODUCT_SO)
+# build tools/baseline/<name>.so = the product library compiled under extra flags, for same-box A/B runs (PA_PRODUCT_SO=...).
+# Every variant is built with -DPA_DEBUG_KNOBS: the A/B knobs of DESIGN.md §8 (PA_MAP_ABLATE, PA_MAP_STATS, PA_POOL_SLOTS, ...)
+# exist in these builds only, never in the shipped library.
 # usage: bash tools/build_variant.sh <name> [-DPA_NT=5 ...]
 set -e
 name=$1; shift
 cd "$(dirname "$0")/.."
-python -c "import __graft_entry__ as g; g.build()" > /dev/null
-mkdir -p tools/baseline _build
-obj=rust-pseudoaligner_amd/_build
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -Wall -Wno-unused-function "$@" -x hip -c rust-pseudoaligner_amd/csrc/map_pool.hip -o _build/map_pool_$name.o
-objs=$(ls $obj/*.o | grep -v map_pool.hip.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread $objs _build/map_pool_$name.o -ldl -lz -o tools/baseline/$name.so
+mkdir -p tools/baseline _build/variant_$name
+src=rust-pseudoaligner_amd/csrc
+pids=""
+for f in host_index.cpp dbg_build.cpp device_flatten.cpp synth.cpp fastq.cpp kernels.hip map_pool.hip device_index.hip collective.hip barcode_counts.hip index_build.hip index_fill.hip; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -pthread -Wall -Wno-unused-function -DPA_DEBUG_KNOBS "$@" -x hip -c $src/$f -o _build/variant_$name/$f.o &
+  pids="$pids $!"
+done
+for p in $pids; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread _build/variant_$name/*.o -ldl -lz -o tools/baseline/$name.so
 echo tools/baseline/$name.so
