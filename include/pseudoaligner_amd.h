@@ -224,6 +224,12 @@ int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint
 /* Synchronise and report: PA_OK, or PA_ERR_ARENA_FULL with *arena_needed set (re-run with a larger arena).
  * *arena_used = entries of d_arena that may hold ids (never more than the arena_cap of the launch). */
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed);
+/* Per-stream scratch: the first launch on a stream creates that stream's launch context inside the handle (control block,
+ * list-mode rows of CUs x 3 x 4 waves x 128 slots x (256 x words_per_read + 24) x 4 bytes — about 2 GB at 150 bp on a 256-CU
+ * part —, count replicas, novel list) and keeps it for later launches on the same stream. pa_index_release_stream frees
+ * it (after synchronising the stream): call it before destroying a stream you launched on; pa_index_destroy frees what
+ * is left. A host that launches from a pool of N streams holds N contexts. */
+int pa_index_release_stream(pa_index* idx, void* stream);
 /* arena capacity (u32 entries) that suffices for typical batches of n_reads; the exact need is data dependent */
 uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads);
 

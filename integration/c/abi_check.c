@@ -168,6 +168,7 @@ int main(int argc, char** argv) {
         EXPECT(pa_event_record(ev1, NULL) == PA_OK);
         uint64_t used = 0, need = 0;
         EXPECT(pa_map_finish(idx, NULL, &used, &need) == PA_OK);
+        EXPECT(pa_index_release_stream(idx, NULL) == PA_OK);   /* the null stream's launch context goes; the next launch makes a new one */
         EXPECT(pa_event_elapsed_ms(ev0, ev1, &ms) == PA_OK && ms >= 0.0f);
         EXPECT(pa_map_batch_device(idx, (const uint64_t*)d_tiles, (const uint32_t*)d_lens, nsim, sim_wpr, 2, (pa_read_result*)d_res, (uint32_t*)d_arena,
                                    arena_cap, (uint32_t*)d_colour, NULL) == PA_OK);

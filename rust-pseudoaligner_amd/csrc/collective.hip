@@ -207,7 +207,7 @@ int rccl_ready() {
 struct pa_comm {
     int device = 0, nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
-    unsigned long long* d_scalar = nullptr;   // one u64 for the size exchange of the overflow gather
+    unsigned long long* d_scalar = nullptr;   // two u64 for the size / status exchange of the overflow gather
 };
 
 // hooks for device_index.hip: what the map launch needs to know about an attached overflow table
@@ -245,7 +245,7 @@ int pa_overflow_create(int device, uint64_t max_classes, uint64_t max_ids, pa_ov
     while (cap < 2 * max_classes) cap <<= 1;   // load <= 0.5
     o->cap = cap;
     o->pool_cap = max_ids;
-    o->export_cap = 2 + 3 * max_classes + max_ids + 3 * 1024;   // room for a few duplicate entries (merged by content)
+    o->export_cap = 2 + 3 * cap + max_ids;   // a record per table slot: whatever the table can hold can be exported (TABLE_FULL / POOL_FULL are the only limits)
     hipError_t e = hipMalloc(&o->d_keys, cap * 8);
     if (e == hipSuccess) e = hipMalloc(&o->d_meta, cap * OVF_META_WORDS * 4);
     if (e == hipSuccess) e = hipMalloc(&o->d_pool, max_ids * 4);
@@ -293,7 +293,7 @@ static int export_locked(pa_overflow* o, hipStream_t st, uint64_t* n_words) {
     unsigned long long ctl[4];
     HIP_TRY(hipMemcpyAsync(ctl, o->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (ctl[1] & OVF_STATUS_LIST_FULL) return fail(PA_ERR_ARENA_FULL, "overflow: more novel results in one launch than its list holds (a quarter of the reads)");
+    if (ctl[1] & OVF_STATUS_LIST_FULL) return fail(PA_ERR_ARENA_FULL, "overflow: more novel results in one launch than its list holds");
     if (ctl[1] & OVF_STATUS_TABLE_FULL) return fail(PA_ERR_ARENA_FULL, "overflow table full: more than %llu distinct novel classes", (unsigned long long)(o->cap / 2));
     if (ctl[1] & OVF_STATUS_POOL_FULL) return fail(PA_ERR_ARENA_FULL, "overflow id pool full: %llu ids needed, %llu available", ctl[0], (unsigned long long)o->pool_cap);
     if (ctl[1] & OVF_STATUS_EXPORT_FULL) return fail(PA_ERR_INTERNAL, "overflow export buffer too small");
@@ -360,7 +360,7 @@ int pa_comm_create(int device, int nranks, int rank, const uint8_t id[128], pa_c
     memcpy(u.internal, id, 128);
     ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
     if (r != 0) { delete c; return fail(PA_ERR_HIP, "ncclCommInitRank(%d of %d): %s", rank, nranks, rccl().GetErrorString(r)); }
-    if (hipMalloc(&c->d_scalar, 8) != hipSuccess) { rccl().CommDestroy(c->comm); delete c; return fail(PA_ERR_OOM, "hipMalloc"); }
+    if (hipMalloc(&c->d_scalar, 16) != hipSuccess) { rccl().CommDestroy(c->comm); delete c; return fail(PA_ERR_OOM, "hipMalloc"); }
     *out = c;
     return PA_OK;
 }
@@ -386,36 +386,47 @@ int pa_counts_allreduce(pa_index* idx, uint64_t* d_counts, pa_comm* comm, void* 
 
 int pa_overflow_allgather(pa_overflow* o, pa_comm* comm, void* stream, const uint32_t** words, uint64_t* n_words) {
     if (!o || !words || !n_words) return fail(PA_ERR_INVALID_ARG, "null argument");
-    if (!comm || comm->nranks == 1) {
-        if (!comm) return pa_overflow_fetch(o, stream, words, n_words);
-    }
+    if (!comm || comm->nranks == 1) return pa_overflow_fetch(o, stream, words, n_words);   // one GPU: the local table is the global one
     std::lock_guard<std::mutex> g(o->mu);
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint64_t nw = 0;
-    int rc = export_locked(o, st, &nw);
-    if (rc != PA_OK) return rc;
-    // every rank sends the same number of words: the largest table (all-reduce max of one u64), zero padded
-    unsigned long long mine = nw, most = 0;
-    HIP_TRY(hipMemcpyAsync(comm->d_scalar, &mine, 8, hipMemcpyHostToDevice, st));
-    NCCL_TRY(rccl().AllReduce(comm->d_scalar, comm->d_scalar, 1, ncclUint64, ncclMax, comm->comm, st));
-    HIP_TRY(hipMemcpyAsync(&most, comm->d_scalar, 8, hipMemcpyDeviceToHost, st));
+    // A rank-local failure (table / pool / novel list full: the documented PA_ERR_ARENA_FULL) must not keep this rank out of
+    // the collectives the other ranks are about to enter — they would wait for it forever. Every rank always takes part in
+    // the exchange of {words, status}; after it all of them know the largest table and whether ANY rank failed, and all
+    // return the same error.
+    const int rc_local = export_locked(o, st, &nw);
+    const std::string why_local = rc_local != PA_OK ? last_error_ref() : std::string();
+    unsigned long long mine[2] = {rc_local == PA_OK ? nw : 0ull, (unsigned long long)(rc_local == PA_OK ? 0 : -rc_local)}, most[2] = {0, 0};
+    HIP_TRY(hipSetDevice(comm->device));
+    HIP_TRY(hipMemcpyAsync(comm->d_scalar, mine, 16, hipMemcpyHostToDevice, st));
+    NCCL_TRY(rccl().AllReduce(comm->d_scalar, comm->d_scalar, 2, ncclUint64, ncclMax, comm->comm, st));
+    HIP_TRY(hipMemcpyAsync(most, comm->d_scalar, 16, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (most > o->export_cap) return fail(PA_ERR_ARENA_FULL, "overflow gather: a rank holds %llu words, this rank's buffer holds %llu (create the tables with equal capacities)",
-                                          most, (unsigned long long)o->export_cap);
-    if (most > nw) HIP_TRY(hipMemsetAsync(o->d_export + nw, 0, (most - nw) * 4, st));
-    uint32_t* d_all = nullptr;
-    HIP_TRY(hipMalloc(&d_all, (size_t)most * 4 * comm->nranks));
-    ncclResult_t r = rccl().AllGather(o->d_export, d_all, (size_t)most, ncclUint32, comm->comm, st);
-    if (r != 0) { (void)hipFree(d_all); return fail(PA_ERR_HIP, "ncclAllGather: %s", rccl().GetErrorString(r)); }
-    std::vector<uint32_t> all((size_t)most * comm->nranks);
-    hipError_t e = hipMemcpyAsync(all.data(), d_all, all.size() * 4, hipMemcpyDeviceToHost, st);
+    if (most[1] != 0) {   // some rank failed: everybody reports it (this rank's own reason when it has one)
+        if (rc_local != PA_OK) return fail(rc_local, "%s", why_local.c_str());
+        return fail(-(int)most[1], "overflow gather: another rank could not export its table (status %d there); no rank merged anything", -(int)most[1]);
+    }
+    const uint64_t len = most[0];
+    // send buffer of the common length (the largest table), zero padded: independent of this rank's own export capacity
+    uint32_t *d_send = nullptr, *d_all = nullptr;
+    hipError_t e = hipMalloc(&d_send, (size_t)len * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_all, (size_t)len * 4 * comm->nranks);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_send, o->d_export, (size_t)nw * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && len > nw) e = hipMemsetAsync(d_send + nw, 0, (size_t)(len - nw) * 4, st);
+    // (a failed allocation here is fatal for the job: the other ranks are already in the gather)
+    if (e != hipSuccess) { (void)hipFree(d_send); (void)hipFree(d_all); return fail(PA_ERR_OOM, "overflow gather buffers (%llu words x %d ranks): %s", (unsigned long long)len, comm->nranks, hipGetErrorString(e)); }
+    ncclResult_t r = rccl().AllGather(d_send, d_all, (size_t)len, ncclUint32, comm->comm, st);
+    if (r != 0) { (void)hipFree(d_send); (void)hipFree(d_all); return fail(PA_ERR_HIP, "ncclAllGather: %s", rccl().GetErrorString(r)); }
+    std::vector<uint32_t> all((size_t)len * comm->nranks);
+    e = hipMemcpyAsync(all.data(), d_all, all.size() * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_send);
     (void)hipFree(d_all);
     if (e != hipSuccess) return fail(PA_ERR_HIP, "overflow gather copy: %s", hipGetErrorString(e));
     std::vector<const uint32_t*> bufs(comm->nranks);
-    std::vector<uint64_t> sizes(comm->nranks, most);
-    for (int i = 0; i < comm->nranks; ++i) bufs[i] = all.data() + (size_t)i * most;
-    rc = merge_serialised(bufs.data(), sizes.data(), comm->nranks, o->h_merged);
+    std::vector<uint64_t> sizes(comm->nranks, len);
+    for (int i = 0; i < comm->nranks; ++i) bufs[i] = all.data() + (size_t)i * len;
+    const int rc = merge_serialised(bufs.data(), sizes.data(), comm->nranks, o->h_merged);
     if (rc != PA_OK) return rc;
     *words = o->h_merged.data();
     *n_words = o->h_merged.size();

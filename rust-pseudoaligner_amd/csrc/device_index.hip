@@ -140,8 +140,8 @@ void pa_index_destroy(pa_index* idx) {
     (void)hipSetDevice(idx->device);
     for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table, idx->d_wtable})
         if (p) (void)hipFree(p);
+    if (idx->ingest_cache && idx->ingest_cache_free) { idx->ingest_cache_free(idx->ingest_cache); idx->ingest_cache = nullptr; }   // (releases its stream's context)
     for (auto& kv : idx->ctxs) kv.second->release();
-    if (idx->ingest_cache && idx->ingest_cache_free) idx->ingest_cache_free(idx->ingest_cache);
     for (DevBuf* b : {&idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
                       &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})
         b->release();
@@ -360,7 +360,7 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     pa_overflow* ovf = nullptr;
     { std::lock_guard<std::mutex> g(idx->mu); ovf = idx->ovf; }
     if (d_counts && ovf) {   // novel results of this launch are listed (per stream) for the overflow table
-        const uint64_t want = n_reads / 4 + 4096;
+        const uint64_t want = n_reads + 64;   // every read can end in a novel class: the list never overflows
         rc = cx->novel.ensure(want * 8);
         if (rc != PA_OK) return rc;
         p.novel_list = cx->novel.as<uint32_t>();
@@ -409,6 +409,27 @@ static int map_finish_locked(pa_index* idx, LaunchCtx* cx, hipStream_t stream, u
     if (arena_needed) *arena_needed = ctl.top;
     if (ctl.status & PA_STATUS_SPILL_OVERFLOW) return fail(PA_ERR_INTERNAL, "colour spill buffer overflow (should be impossible)");
     if (ctl.status & PA_STATUS_ARENA_FULL) return fail(PA_ERR_ARENA_FULL, "class arena too small: %llu entries needed", ctl.top);
+    return PA_OK;
+}
+
+// The launch context of `stream` (control block, list-mode rows, count replicas, novel list: about 2 GB at 150 bp on a 256-CU
+// part) is freed; the next launch on that stream creates a fresh one. Callers that create and destroy streams call this
+// before hipStreamDestroy — a context left behind would stay until pa_index_destroy and could be matched to a later stream
+// whose handle value the runtime reuses.
+int pa_index_release_stream(pa_index* idx, void* stream) {
+    if (!idx) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::unique_ptr<LaunchCtx> cx;
+    {
+        std::lock_guard<std::mutex> g(idx->mu);
+        auto it = idx->ctxs.find(static_cast<hipStream_t>(stream));
+        if (it == idx->ctxs.end()) return PA_OK;
+        cx = std::move(it->second);
+        idx->ctxs.erase(it);
+    }
+    std::lock_guard<std::mutex> g(cx->mu);   // (a launch in progress on another thread finishes first)
+    HIP_TRY(hipSetDevice(idx->device));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    cx->release();
     return PA_OK;
 }
 

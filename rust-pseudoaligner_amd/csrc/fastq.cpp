@@ -320,9 +320,17 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
 struct IngestCache {   // the two batches in flight; parked on the index between calls (pa_common.hpp)
     BatchCtx ctx[2];
     std::vector<RecPos> rec_pos;   // 16 bytes per record of the file: kept, or every call would page 256 MB in again
+    // the stream the batches run on travels with the buffers: its launch context inside the index (2 GB of list-mode rows)
+    // is then reused by the next call instead of being stranded behind a destroyed stream
+    pa_index* idx = nullptr;
+    hipStream_t stream = nullptr;
     static void destroy(void* p) {
         IngestCache* c = static_cast<IngestCache*>(p);
         for (BatchCtx& b : c->ctx) b.release();
+        if (c->stream) {
+            if (c->idx) (void)pa_index_release_stream(c->idx, c->stream);
+            (void)hipStreamDestroy(c->stream);
+        }
         delete c;
     }
 };
@@ -621,8 +629,9 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     t_scan = now() - t_begin;
     // ---- batches ----
     BatchCtx* const ctx = cache->ctx;
-    hipStream_t stream = nullptr;
-    if (rc == PA_OK && hipStreamCreate(&stream) != hipSuccess) rc = fail(PA_ERR_HIP, "hipStreamCreate failed");
+    cache->idx = idx;
+    if (rc == PA_OK && !cache->stream && hipStreamCreate(&cache->stream) != hipSuccess) { cache->stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); }
+    const hipStream_t stream = cache->stream;
     Writer writer(out);
     uint64_t flagged = 0, next_report = 1000000, reported = 0;
     const uint64_t nb = (nrec + BATCH_READS - 1) / BATCH_READS;
@@ -857,7 +866,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         fprintf(stderr, "\n[pa ingest] %llu reads, %d threads: scan %.3f s, pack %.3f s (records %.3f, alloc %.3f, tiles %.3f), wait GPU %.3f s, launch %.3f s, format %.3f s (writer wait %.3f), total %.3f s\n",
                 (unsigned long long)nrec, T, t_scan, t_pack, t_pack_rec, t_pack_alloc, t_pack_tiles, t_finish, t_launch, t_format, t_push, now() - t_begin);
     double t0 = now();
-    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    if (stream) (void)hipStreamSynchronize(stream);   // (the stream stays with the parked buffers; IngestCache::destroy releases both)
     const double t_stream = now() - t0; t0 = now();
     const bool wrote = writer.finish();
     const double t_writer = now() - t0; t0 = now();

@@ -113,8 +113,15 @@ int read_fasta(const char* path, Txome& out) {
         if (line[0] == '>') {
             finish();
             have = true;
-            while (!line.empty() && (line.back() == ' ' || line.back() == '\t')) line.pop_back();   // record.id() of bio 1.5: header[1..].trim_end()
-            const size_t sp = line.find(' ');                                                     // .splitn(2, ' '): a tab stays part of the id
+            // record.id() / desc() of bio 1.5's FASTA reader: header[1..].trim_end().splitn(2, char::is_whitespace) — the id ends at
+            // the first white-space character of ANY kind (its FASTQ reader splits on ' ' only: fastq.cpp keeps that rule). The id
+            // names the transcript AND seeds from_acgt_bytes_hashn (src/utils.rs:76), so a tab-separated header must cut the same
+            // way or the bases substituted for N differ. ASCII white space only (Unicode spaces in a FASTA header: unpinned).
+            auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\x0b' || c == '\x0c' || c == '\r' || c == '\n'; };
+            while (!line.empty() && is_ws(line.back())) line.pop_back();
+            size_t sp = 1;
+            while (sp < line.size() && !is_ws(line[sp])) ++sp;
+            if (sp >= line.size()) sp = std::string::npos;
             id = line.substr(1, sp == std::string::npos ? std::string::npos : sp - 1);
             desc = sp == std::string::npos ? std::string() : line.substr(sp + 1);
             name_hash = 0xcbf29ce484222325ull;

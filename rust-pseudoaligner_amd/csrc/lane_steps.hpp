@@ -27,7 +27,7 @@ enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVE
 constexpr uint32_t NO_CLASS = 0xFFFFFFFFu;
 constexpr uint32_t LDS_CLASSES = 4;   // list mode: distinct classes kept inline (one 16-byte vector each of refs, lengths, class ids)
 
-// Packed state of a read (9 words). Limits: read length <= 16383 (PA_MAX_READ_LEN; 14 bits), node length < 2^24.
+// Packed state of a read (9 words). Limits: read length <= 16383 (PA_MAX_READ_LEN; 14 bits: positions, class and node counters), node length < 2^24.
 struct Lane {
     uint32_t rid;
     uint32_t lk;    // L (bits 0..13) | kmer_pos (14..27) | state (28..31)                  (:70, :79)
@@ -37,7 +37,8 @@ struct Lane {
     uint32_t rr;    // FWD: ref offset in the node, LEFT: node bases still to the left (0..23) | seen_snp (24..31)
     uint32_t rm;    // bases of max_matchable_pos not yet compared (0..15) | LEFT: read bases still to the left (16..31)
     uint32_t ph;    // LEFT: prev_node_id as a blob handle                                  (:128)
-    uint32_t nc;    // distinct classes collected (0..11) | dictionary probe index (12..15) | TRACE: nodes.len() (16..31)
+    uint32_t nc;    // distinct classes collected (0..13) | dictionary probe index (14..17) | TRACE: nodes.len() (18..31)
+                    // (a read of L <= 16383 bases visits at most L nodes — every visit consumes a base — so 14 bits hold both counts)
 };
 
 PA_HD uint32_t l_st(const Lane& s) { return s.lk >> 28; }
@@ -52,9 +53,10 @@ PA_HD void l_set_kp(Lane& s, uint32_t kp) { s.lk = (s.lk & 0xF0003FFFu) | (kp <<
 PA_HD uint32_t l_pack_lk(uint32_t L, uint32_t kp, uint32_t st) { return L | (kp << 14) | (st << 28); }
 PA_HD uint32_t l_cov(const Lane& s) { return s.cm & 0xFFFFu; }
 PA_HD uint32_t l_mism(const Lane& s) { return s.cm >> 16; }
-PA_HD uint32_t l_ncol(const Lane& s) { return s.nc & 0xFFFu; }
-PA_HD uint32_t l_probe(const Lane& s) { return (s.nc >> 12) & 15u; }
-PA_HD uint32_t l_ntrace(const Lane& s) { return s.nc >> 16; }
+constexpr uint32_t NC_COL_MASK = 0x3FFFu, NC_PROBE_SHIFT = 14, NC_TRACE_SHIFT = 18;
+PA_HD uint32_t l_ncol(const Lane& s) { return s.nc & NC_COL_MASK; }
+PA_HD uint32_t l_probe(const Lane& s) { return (s.nc >> NC_PROBE_SHIFT) & 15u; }
+PA_HD uint32_t l_ntrace(const Lane& s) { return s.nc >> NC_TRACE_SHIFT; }
 
 struct ReadRef {   // the lane's packed read: word w < wmax at p[w * stride]; words from wmax on read as zero
     const uint64_t* p;
@@ -315,7 +317,7 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
     if (TRACE) {
         const uint32_t nt = l_ntrace(s);
         if (nt < c.spill_cap) c.trace[nt] = ix.nid_of_handle[handle];
-        s.nc += 1u << 16;
+        s.nc += 1u << NC_TRACE_SHIFT;
     }
     const uint32_t n = l_ncol(s);
     if (!(l_flags(s) & F_LISTS)) {                                   // window mode: AND of masks
@@ -335,7 +337,7 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
         }
         *reinterpret_cast<U4*>(c.win) = w;
         c.wcand[0] = cand;
-        s.nc = (s.nc & ~0xFFFu) | 1u;
+        s.nc = (s.nc & ~NC_COL_MASK) | 1u;
         return false;
     }
     // list mode: win = {ref of class 0, 1, 2, ref of the shortest class so far}, wcand = the shortest length (both in LDS:
@@ -358,7 +360,7 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
         c.cids[n] = hd.cid;
     } else {
         const uint32_t o = 4 * (n - LDS_CLASSES);
-        if (o + 3 >= c.spill_cap || n >= 0xFFEu) { l_or_flags(s, F_SPILL_OVERFLOW); return false; }   // (the class counter has 12 bits)
+        if (o + 3 >= c.spill_cap || n >= NC_COL_MASK) { l_or_flags(s, F_SPILL_OVERFLOW); return false; }   // (unreachable: the row holds 2 L + 3 classes, the counter L)
         c.spill[o] = hd.ec_ref;
         c.spill[o + 1] = hd.ec_len;
         c.spill[o + 2] = hd.cid;
@@ -423,7 +425,7 @@ PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand,
 // what a probe found -> the lane's next state (the tail of find_kmer_match and of :118-129)
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe) {
     const uint32_t L = l_L(s), kp = l_kp(s);
-    s.nc &= ~(15u << 12);                                           // probe index back to 0
+    s.nc &= ~(15u << NC_PROBE_SHIFT);                               // probe index back to 0
     if (h != NO_HANDLE) {                                           // Some((nid, offset)) (:106)
         s.h = h;
         const uint32_t fl = l_flags(s);
@@ -441,7 +443,7 @@ PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full,
         return;
     }
     if (full && probe < 15) {                                       // no free slot: the key may live in the next bucket
-        s.nc |= (probe + 1) << 12;
+        s.nc |= (probe + 1) << NC_PROBE_SHIFT;
         return;
     }
     const uint32_t nkp = kp + PA_SEEK_STRIDE;                       // :110

@@ -467,3 +467,21 @@ def many_classes_case(seed, tmp_path, k=11, ntx=300, read_len=1500, nreads=400, 
                 r[j] = "ACGT"[rng.randint(4)]
         reads.append("".join(r))
     return host, reads
+
+
+def thousands_of_classes_case(tmp_path, k=20, length=16383, step=3):
+    """ONE long transcript T and every suffix T[step*i:] as a transcript of its own: the k-mer at position p belongs to the
+    transcripts {i : step*i <= p}, so the colour changes every `step` positions and a read = T passes ~length/step unitigs
+    with pairwise DIFFERENT classes (5 400 for the defaults: more than the 12-bit class counter of round 2 could hold;
+    the reference has no limit). Returns (host index, [reads])."""
+    rng = np.random.RandomState(77)
+    T = "".join("ACGT"[i] for i in rng.randint(0, 4, length))
+    p = tmp_path / "suffixes.fa"
+    with open(p, "w") as f:
+        i = 0
+        while step * i + k <= length:
+            f.write(">s%d gene=G\n%s\n" % (i, T[step * i:]))
+            i += 1
+    host = pa.build_index(str(p), k, 8)
+    reads = [T, T[5000:], T[: 3 * k], T[100:9000], T[:6000] + "A" + T[6001:]]
+    return host, reads

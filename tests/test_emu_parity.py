@@ -71,6 +71,17 @@ def test_many_classes_per_read(tmp_path, ordered):
     check(host, tiles, lens, wpr, 2)
 
 
+def test_thousands_of_classes_per_read(tmp_path):
+    """a 16 383-base read that passes ~5 400 unitigs with pairwise different classes (the class counter of the lane
+    state had 12 bits and turned such a read into PA_ERR_INTERNAL for its whole batch; it has 14 now = the read length limit)"""
+    host, reads = helpers.thousands_of_classes_case(tmp_path)
+    assert host.arrays()["num_classes"] > 5000
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    r, (o_res, o_coff, o_ids, ctr) = check(host, tiles, lens, wpr, 2)
+    assert ctr["node_visits"] > 4 * 4096 // 2 and o_res["mapped"].all()
+    assert o_ids[o_coff[0]:o_coff[1]].tolist() == [0]          # only the whole transcript holds every k-mer of itself
+
+
 def test_ragged_short_and_unmappable_reads(small_index):
     host = small_index(24)
     _, seqs = helpers.read_fastq()

@@ -64,6 +64,15 @@ def test_tuning_knobs_in_the_environment_change_nothing(aligners, monkeypatch):
     assert np.array_equal(d_counts.cpu().numpy().astype(np.uint64), want.astype(np.uint64))
 
 
+def test_thousands_of_classes_per_read(tmp_path):
+    """16 383-base reads over ~5 400 unitigs with pairwise different classes: list mode far into the spill rows, the one-list-
+    per-lane scan 64 lists at a time, more classes than the 12-bit counter of round 2 could count"""
+    host, reads = helpers.thousands_of_classes_case(tmp_path)
+    a = pa.Pseudoaligner(host, 0)
+    res, coff, cids, ctr = gpu_vs_oracle(a, reads, 2, "suffix transcripts")
+    assert ctr["node_visits"] > 8000 and cids[coff[0]:coff[1]].tolist() == [0]
+
+
 def test_reference_literals_through_map_read(aligners):
     a = aligners(20)
     ex1 = "GGCTGTCAACCAGTCCATAGGCAGGGCCATCAGGCACCAAAGGGATTCTGCCAGCATAGT"          # src/build_index.rs:429-434

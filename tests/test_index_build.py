@@ -334,3 +334,25 @@ def test_index_compare_is_numbering_and_break_point_independent(built, tmp_path)
     rc, why = host.compare(imported(_repack_nodes(a, order[:-1])))
     assert rc == 1, why                                            # a node (its k-mers) is missing
     assert host.compare(pa.HostIndex.build_fasta(str(fa), 21, 2))[0] == 1
+
+
+def test_fasta_id_ends_at_any_white_space(built, tmp_path):
+    """record.id() of bio 1.5's FASTA reader cuts the header at the first white-space character of any kind: the id
+    names the transcript and seeds the bases substituted for N (from_acgt_bytes_hashn, src/utils.rs:76), so the same record
+    with a space- or a tab-separated description must give the same names AND the same packed transcript."""
+    rng = np.random.RandomState(5)
+    body = "".join("ACGT"[i] for i in rng.randint(0, 4, 300))
+    body = body[:100] + "NNNNN" + body[105:200] + "n" + body[201:]
+    texts = {"space": ">tx1 gene=G1 extra\n%s\n>tx2 gene=G1\n%s\n" % (body, body[::-1]),
+             "tab": ">tx1\tgene=G1 extra\r\n%s\r\n>tx2\tgene=G1  \t\r\n%s\r\n" % (body, body[::-1]),
+             "ff": ">tx1\x0cgene=G1 extra\n%s\n>tx2\x0bgene=G1\n%s\n" % (body, body[::-1])}
+    packed, names = {}, {}
+    for tag, text in texts.items():
+        p = tmp_path / (tag + ".fa")
+        p.write_bytes(text.encode())
+        host = pa.build_index(str(p), 20, 2)
+        names[tag] = host.tx_names()
+        packed[tag] = [a.copy() for a in host.transcripts()]
+    assert names["space"] == ["tx1", "tx2"] == names["tab"] == names["ff"]
+    for tag in ("tab", "ff"):
+        assert all(np.array_equal(x, y) for x, y in zip(packed["space"], packed[tag])), tag
