@@ -1,0 +1,301 @@
+// The equivalence-class count table (the unit the GPUs of a node reduce over RCCL) from the KEY STREAMS of a
+// mapping launch. The map kernel (map_pool.hip) appends one key per finished read — the slot of the table the read counts
+// in — to its wave's stream; the streams are fully coalesced writes (0.4 GB per 100 M reads). Here:
+//
+//   one bin  (table of <= 32768 slots, e.g. gencode_small)     pa_keys_count_kernel straight over the streams
+//   several  pa_keys_hist_kernel     keys per bin (bin = key >> 15: 32768 consecutive slots = 128 KiB of LDS counters)
+//            pa_keys_scatter_kernel  keys partitioned by bin into `sorted` (counting sort: a workgroup counts its tile's
+//                                    keys per bin in LDS, reserves the runs with one global atomic per bin, writes every
+//                                    key to its run; the lines of a run fill up inside the L2 within one tile)
+//            pa_keys_count_kernel    one LDS table per workgroup and bin: LDS atomics over its share of the bin's keys,
+//                                    then the non-zero counters are added to the caller's u64 table
+//
+// Round 2 counted inside the map kernel with one device-scope atomic per read into per-XCD replicas of the table; the table
+// (1.9 MB per replica at config 3) does not survive in an L2 that 3 GB of dictionary lines, node blobs and read tiles stream
+// through per launch, and a device-scope atomic that misses is forwarded to the memory side: 100 M random 32-byte requests
+// per 100 M reads, 8-9 % of the kernel. The same counts by sorting move 4 x 0.4 GB of coalesced traffic.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "kernels.hpp"
+#include "pa_common.hpp"
+
+namespace pa {
+namespace {
+
+constexpr uint32_t NO_KEY = 0xFFFFFFFFu;
+constexpr uint32_t MAX_BINS = 256;                       // tables of up to 8.4 M slots; beyond, keys are counted with plain atomics
+constexpr uint32_t BIN_SLOTS = 1u << PA_KEY_BIN_SHIFT;
+constexpr uint32_t CS_BLOCK = 1024;
+
+__device__ __forceinline__ uint64_t stream_len(const unsigned long long* keys_top, uint64_t keys_cap) {
+    const unsigned long long t = *keys_top;
+    return t < keys_cap ? t : keys_cap;
+}
+
+// Counting sort of the keys by bin without a single global atomic: the stream is cut into one slice per workgroup;
+//   pa_keys_hist_kernel     wg_hist[b * G + g] = keys of bin b in slice g
+//   pa_keys_scan_kernel     (one workgroup per bin) wg_base[b * G + g] = where slice g's keys of bin b go: the bin's base (the bins
+//                           before it) + the slices before g; hist[b] = the bin's total
+//   pa_keys_scatter_kernel  the same slices again: every workgroup partitions its tiles inside LDS and appends the runs at its own
+//                           cursors (LDS), writing whole lines
+// (One shared cursor per bin, bumped once per tile, is a hot word: 26 k dependent atomics per bin and launch = 0.3 ms.)
+constexpr uint32_t SC_BLOCK = 256, SC_PER = 16, SC_TILE = SC_BLOCK * SC_PER;
+constexpr uint32_t SC_MAX_GRID = 2048;   // slices (the scan kernel holds one bin's slice counts in LDS)
+
+__device__ __forceinline__ void slice_of(uint64_t n, uint32_t g, uint32_t G, uint64_t& a, uint64_t& b) {   // whole tiles
+    const uint64_t tiles = (n + SC_TILE - 1) / SC_TILE;
+    a = tiles * g / G * SC_TILE;
+    b = tiles * (g + 1) / G * SC_TILE;
+    if (b > n) b = n;
+    if (a > n) a = n;
+}
+
+__global__ __launch_bounds__(SC_BLOCK) void pa_keys_hist_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ keys_top,
+                                                                uint64_t keys_cap, uint32_t nbins, uint32_t* __restrict__ wg_hist) {
+    __shared__ uint32_t h[MAX_BINS];
+    for (uint32_t i = threadIdx.x; i < nbins; i += SC_BLOCK) h[i] = 0;
+    __syncthreads();
+    uint64_t a, b;
+    slice_of(stream_len(keys_top, keys_cap), blockIdx.x, gridDim.x, a, b);
+    const uint4* k4 = reinterpret_cast<const uint4*>(keys);   // (chunks and tiles are multiples of 4 entries: 16-byte loads)
+    for (uint64_t i = a / 4 + threadIdx.x; i < b / 4; i += SC_BLOCK) {
+        const uint4 v = k4[i];
+        if (v.x != NO_KEY) atomicAdd(&h[v.x >> PA_KEY_BIN_SHIFT], 1u);
+        if (v.y != NO_KEY) atomicAdd(&h[v.y >> PA_KEY_BIN_SHIFT], 1u);
+        if (v.z != NO_KEY) atomicAdd(&h[v.z >> PA_KEY_BIN_SHIFT], 1u);
+        if (v.w != NO_KEY) atomicAdd(&h[v.w >> PA_KEY_BIN_SHIFT], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nbins; i += SC_BLOCK) wg_hist[(uint64_t)i * gridDim.x + blockIdx.x] = h[i];
+}
+
+// blockIdx.x = bin. hist[bin] = its total; wg_base[bin * G + g] = base of the bin + slices before g. The base of a bin needs
+// the totals of the bins before it: every workgroup sums those rows itself (nbins * G words, L2-resident).
+__global__ __launch_bounds__(1024) void pa_keys_scan_kernel(const uint32_t* __restrict__ wg_hist, uint32_t G, uint32_t* __restrict__ wg_base,
+                                                            uint32_t* __restrict__ hist) {
+    __shared__ uint32_t red[1024];
+    const uint32_t bin = blockIdx.x, t = threadIdx.x;
+    uint32_t before = 0;   // keys of the bins before this one
+    for (uint64_t i = t; i < (uint64_t)bin * G; i += 1024) before += wg_hist[i];
+    red[t] = before;
+    __syncthreads();
+    for (uint32_t o = 512; o; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    const uint32_t bin_base = red[0];
+    __syncthreads();
+    // exclusive scan of this bin's G slice counts: two per thread
+    const uint32_t i0 = 2 * t, i1 = 2 * t + 1;
+    const uint32_t c0 = i0 < G ? wg_hist[(uint64_t)bin * G + i0] : 0u, c1 = i1 < G ? wg_hist[(uint64_t)bin * G + i1] : 0u;
+    red[t] = c0 + c1;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {   // Hillis-Steele inclusive scan over the pair sums
+        const uint32_t x = t >= o ? red[t - o] : 0u;
+        __syncthreads();
+        red[t] += x;
+        __syncthreads();
+    }
+    const uint32_t excl = red[t] - (c0 + c1);
+    if (i0 < G) wg_base[(uint64_t)bin * G + i0] = bin_base + excl;
+    if (i1 < G) wg_base[(uint64_t)bin * G + i1] = bin_base + excl + c0;
+    if (t == 1023) hist[bin] = red[t];
+}
+
+__global__ __launch_bounds__(SC_BLOCK) void pa_keys_scatter_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ keys_top,
+                                                                   uint64_t keys_cap, uint32_t nbins, const uint32_t* __restrict__ wg_base,
+                                                                   uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cnt[MAX_BINS], lbase[MAX_BINS], gbase[MAX_BINS], cursor[MAX_BINS], stage[SC_TILE], total;
+    for (uint32_t b = threadIdx.x; b < nbins; b += SC_BLOCK) cursor[b] = wg_base[(uint64_t)b * gridDim.x + blockIdx.x];
+    uint64_t sa, sb;
+    slice_of(stream_len(keys_top, keys_cap), blockIdx.x, gridDim.x, sa, sb);
+    for (uint64_t t0 = sa; t0 < sb; t0 += SC_TILE) {
+        for (uint32_t b = threadIdx.x; b < nbins; b += SC_BLOCK) cnt[b] = 0;
+        __syncthreads();
+        uint32_t k[SC_PER], pos[SC_PER];
+        const uint4* src = reinterpret_cast<const uint4*>(keys + t0) + threadIdx.x;
+#pragma unroll
+        for (uint32_t j = 0; j < SC_PER / 4; ++j) {   // coalesced 16-byte loads, all in flight together
+            const uint64_t i = t0 + 4ull * (j * SC_BLOCK + threadIdx.x);
+            const uint4 v = i < sb ? src[j * SC_BLOCK] : uint4{NO_KEY, NO_KEY, NO_KEY, NO_KEY};
+            k[4 * j] = v.x; k[4 * j + 1] = v.y; k[4 * j + 2] = v.z; k[4 * j + 3] = v.w;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < SC_PER; ++j) pos[j] = k[j] != NO_KEY ? atomicAdd(&cnt[k[j] >> PA_KEY_BIN_SHIFT], 1u) : 0u;   // rank inside the tile's run of that bin
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < nbins; b += SC_BLOCK) {
+            uint32_t s = 0;
+            for (uint32_t j = 0; j < b; ++j) s += cnt[j];
+            lbase[b] = s;
+            gbase[b] = cursor[b];
+            cursor[b] += cnt[b];
+            if (b == nbins - 1) total = s + cnt[b];
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < SC_PER; ++j)
+            if (k[j] != NO_KEY) stage[lbase[k[j] >> PA_KEY_BIN_SHIFT] + pos[j]] = k[j];
+        __syncthreads();
+        const uint32_t tot = total;
+        for (uint32_t i = threadIdx.x; i < tot; i += SC_BLOCK) {   // consecutive threads, consecutive words of a run; the key names its bin
+            const uint32_t key = stage[i], b = key >> PA_KEY_BIN_SHIFT;
+            sorted[gbase[b] + (i - lbase[b])] = key;
+        }
+        __syncthreads();
+    }
+}
+
+// counts[(bin << 15) + i] += occurrences of that key. Workgroup (bin, part) takes part `part` of `parts` of the bin's keys.
+// hist == nullptr: one bin, the raw streams (padding skipped).
+__global__ __launch_bounds__(CS_BLOCK) void pa_keys_count_kernel(const uint32_t* __restrict__ src, const unsigned long long* __restrict__ keys_top,
+                                                                 uint64_t keys_cap, const uint32_t* __restrict__ hist, uint32_t parts,
+                                                                 unsigned long long* __restrict__ counts, uint64_t counts_len) {
+    extern __shared__ uint32_t tab[];   // BIN_SLOTS counters (or counts_len when that is less)
+    const uint32_t bin = blockIdx.x / parts, part = blockIdx.x % parts;
+    const uint64_t slot0 = (uint64_t)bin << PA_KEY_BIN_SHIFT;
+    const uint32_t nslots = (uint32_t)(counts_len - slot0 < BIN_SLOTS ? counts_len - slot0 : BIN_SLOTS);
+    for (uint32_t i = threadIdx.x; i < nslots; i += CS_BLOCK) tab[i] = 0;
+    __syncthreads();
+    uint64_t lo = 0, n;
+    if (hist) {
+        for (uint32_t j = 0; j < bin; ++j) lo += hist[j];
+        n = hist[bin];
+    } else n = stream_len(keys_top, keys_cap);
+    const uint64_t a = lo + n * part / parts, b = lo + n * (part + 1) / parts;
+    // 16-byte loads, four in flight per thread (one dependent round trip per iteration otherwise); the few keys before the
+    // first and after the last aligned quad go one by one
+    const uint64_t a4 = (a + 3) & ~3ull, b4 = b & ~3ull;
+    if (a4 >= b4) {
+        for (uint64_t i = a + threadIdx.x; i < b; i += CS_BLOCK) { const uint32_t k = src[i]; if (k != NO_KEY) atomicAdd(&tab[k & (BIN_SLOTS - 1)], 1u); }
+    } else {
+        if (a + threadIdx.x < a4) { const uint32_t k = src[a + threadIdx.x]; if (k != NO_KEY) atomicAdd(&tab[k & (BIN_SLOTS - 1)], 1u); }
+        if (b4 + threadIdx.x < b) { const uint32_t k = src[b4 + threadIdx.x]; if (k != NO_KEY) atomicAdd(&tab[k & (BIN_SLOTS - 1)], 1u); }
+        const uint4* q = reinterpret_cast<const uint4*>(src);
+        constexpr uint32_t DEPTH = 4;
+        for (uint64_t i0 = a4 / 4; i0 < b4 / 4; i0 += (uint64_t)DEPTH * CS_BLOCK) {
+            uint4 v[DEPTH];
+#pragma unroll
+            for (uint32_t j = 0; j < DEPTH; ++j) {
+                const uint64_t i = i0 + (uint64_t)j * CS_BLOCK + threadIdx.x;
+                v[j] = i < b4 / 4 ? q[i] : uint4{NO_KEY, NO_KEY, NO_KEY, NO_KEY};
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < DEPTH; ++j) {
+                if (v[j].x != NO_KEY) atomicAdd(&tab[v[j].x & (BIN_SLOTS - 1)], 1u);
+                if (v[j].y != NO_KEY) atomicAdd(&tab[v[j].y & (BIN_SLOTS - 1)], 1u);
+                if (v[j].z != NO_KEY) atomicAdd(&tab[v[j].z & (BIN_SLOTS - 1)], 1u);
+                if (v[j].w != NO_KEY) atomicAdd(&tab[v[j].w & (BIN_SLOTS - 1)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nslots; i += CS_BLOCK) {
+        const uint32_t c = tab[i];
+        if (c) atomicAdd(counts + slot0 + i, (unsigned long long)c);   // (launches on several streams may count into one table)
+    }
+}
+
+// tables beyond MAX_BINS bins: plain atomics per key
+__global__ __launch_bounds__(256) void pa_keys_count_direct_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ keys_top,
+                                                                   uint64_t keys_cap, unsigned long long* __restrict__ counts) {
+    const uint64_t n = stream_len(keys_top, keys_cap);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = keys[i];
+        if (k != NO_KEY) atomicAdd(counts + k, 1ull);
+    }
+}
+
+#ifdef PA_DEBUG_KNOBS
+// A/B experiment (PA_COUNT_MODE=1): no sort — every key is one workgroup-scope atomic into this XCD's replica of the table, executed
+// in that XCD's L2 (nothing but the key stream passes through the L2 in this kernel, so the replica stays resident), and a fold
+// kernel adds the eight replicas into the caller's table. Prices the L2's atomic rate against the three-kernel sort.
+__global__ __launch_bounds__(256) void pa_keys_count_l2_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ keys_top, uint64_t keys_cap,
+                                                               uint32_t* __restrict__ rep, uint64_t stride) {
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID
+    uint32_t* mine = rep + (uint64_t)xcc * stride;
+    const uint64_t n4 = stream_len(keys_top, keys_cap) / 4;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t* k4 = reinterpret_cast<const u32x4_t*>(keys);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
+        const u32x4_t v = __builtin_nontemporal_load(k4 + i);
+        if (v.x != NO_KEY) __hip_atomic_fetch_add(mine + v.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v.y != NO_KEY) __hip_atomic_fetch_add(mine + v.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v.z != NO_KEY) __hip_atomic_fetch_add(mine + v.z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v.w != NO_KEY) __hip_atomic_fetch_add(mine + v.w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+__global__ __launch_bounds__(256) void pa_keys_fold_kernel(uint32_t* __restrict__ rep, uint64_t stride, unsigned long long* __restrict__ counts, uint64_t len) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= len) return;
+    unsigned long long sum = 0;
+    for (uint32_t r = 0; r < 8; ++r) {
+        const uint32_t v = rep[r * stride + c];
+        if (v) { sum += v; rep[r * stride + c] = 0; }
+    }
+    if (sum) atomicAdd(counts + c, sum);
+}
+#endif
+
+}  // namespace
+
+// a wave wastes at most 63 entries of every chunk it takes (append_keys pads when fewer than a step's keys are left) and
+// leaves one chunk partly used at its exit
+uint64_t key_stream_capacity(uint64_t n_reads, uint32_t nwaves) {
+    return (n_reads / (PA_KEY_CHUNK - 63) + nwaves + 1) * PA_KEY_CHUNK;
+}
+
+size_t count_keys_ctl_bytes(uint64_t counts_len) {
+    const uint64_t nbins = (counts_len + BIN_SLOTS - 1) >> PA_KEY_BIN_SHIFT;
+    return (MAX_BINS + 2 * (size_t)std::min<uint64_t>(nbins, MAX_BINS) * SC_MAX_GRID) * 4;
+}
+
+int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top, uint64_t keys_cap, uint32_t* sorted, uint32_t* ctl,
+                      unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream) {
+    if (counts_len == 0) return 0;
+    const uint64_t nbins = (counts_len + BIN_SLOTS - 1) >> PA_KEY_BIN_SHIFT;
+    const uint32_t cus = num_cus > 0 ? (uint32_t)num_cus : 256u;
+    const size_t lds = (size_t)(counts_len < BIN_SLOTS ? counts_len : BIN_SLOTS) * 4;
+    const void* count_fn = reinterpret_cast<const void*>(&pa_keys_count_kernel);
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(count_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+#ifdef PA_DEBUG_KNOBS
+    if (knob_int("PA_COUNT_MODE", 0) == 1) {
+        static uint32_t* rep = nullptr;   // (experiment only: one table, never freed)
+        const uint64_t stride = (counts_len + 63) / 64 * 64;
+        if (!rep) { if (hipMalloc(&rep, 8 * stride * 4) != hipSuccess || hipMemset(rep, 0, 8 * stride * 4) != hipSuccess) return (int)hipErrorOutOfMemory; }
+        hipLaunchKernelGGL(pa_keys_count_l2_kernel, dim3(cus * 8), dim3(256), 0, stream, keys, keys_top, keys_cap, rep, stride);
+        hipLaunchKernelGGL(pa_keys_fold_kernel, dim3((uint32_t)((counts_len + 255) / 256)), dim3(256), 0, stream, rep, stride, counts, counts_len);
+        return (int)hipGetLastError();
+    }
+    if (knob_int("PA_COUNT_MODE", 0) == 2) {
+        hipLaunchKernelGGL(pa_keys_count_direct_kernel, dim3(cus * 8), dim3(256), 0, stream, keys, keys_top, keys_cap, counts);
+        return (int)hipGetLastError();
+    }
+#endif
+    if (nbins > MAX_BINS) {
+        hipLaunchKernelGGL(pa_keys_count_direct_kernel, dim3(cus * 8), dim3(256), 0, stream, keys, keys_top, keys_cap, counts);
+        return (int)hipGetLastError();
+    }
+    if (nbins == 1) {
+        hipLaunchKernelGGL(pa_keys_count_kernel, dim3(cus), dim3(CS_BLOCK), lds, stream, keys, keys_top, keys_cap, (const uint32_t*)nullptr, cus, counts,
+                           counts_len);
+        return (int)hipGetLastError();
+    }
+    // ctl: hist[MAX_BINS] | wg_hist[nbins * G] | wg_base[nbins * G]
+    const uint32_t G = std::min<uint32_t>(SC_MAX_GRID, cus * 8);
+    uint32_t* hist = ctl;
+    uint32_t* wg_hist = ctl + MAX_BINS;
+    uint32_t* wg_base = wg_hist + (size_t)nbins * G;
+    hipLaunchKernelGGL(pa_keys_hist_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, keys_cap, (uint32_t)nbins, wg_hist);
+    hipLaunchKernelGGL(pa_keys_scan_kernel, dim3((uint32_t)nbins), dim3(1024), 0, stream, (const uint32_t*)wg_hist, G, wg_base, hist);
+    hipLaunchKernelGGL(pa_keys_scatter_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, keys_cap, (uint32_t)nbins, (const uint32_t*)wg_base, sorted);
+    // one workgroup per CU at most (an LDS table of 128 KiB each) and ONE round of them: 270 workgroups on 256 CUs take as long as 512
+    uint32_t parts = std::max<uint32_t>(1u, (uint32_t)(cus / nbins));
+    parts = (uint32_t)knob_int("PA_COUNT_PARTS", (int)parts);
+    hipLaunchKernelGGL(pa_keys_count_kernel, dim3((uint32_t)nbins * parts), dim3(CS_BLOCK), lds, stream, sorted, keys_top, keys_cap, hist, parts, counts,
+                       counts_len);
+    return (int)hipGetLastError();
+}
+
+}  // namespace pa

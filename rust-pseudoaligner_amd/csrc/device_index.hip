@@ -53,11 +53,12 @@ uint64_t list_hash_host(const uint32_t* v, uint32_t n) {   // must equal list_ha
 
 struct LaunchCtx {
     std::mutex mu;
-    DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status, [12..15] tile counter, [16..] statistics, [448..455] novel results listed
-    DevBuf spill, trace, xcd_counts, novel;
+    DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status, [12..15] tile counter, [16..] statistics, [448..455] novel results listed, [456..463] count keys handed out
+    DevBuf spill, trace, novel;
+    DevBuf keys, keys_sorted, keys_ctl;   // class-count launches: the waves' key streams, the keys partitioned by range, 2 KiB of histogram / cursors (count_sort.hip)
     uint32_t last_grid = 0;
     uint64_t last_arena_cap = 0;
-    void release() { for (DevBuf* b : {&ctl, &spill, &trace, &xcd_counts, &novel}) b->release(); }
+    void release() { for (DevBuf* b : {&ctl, &spill, &trace, &novel, &keys, &keys_sorted, &keys_ctl}) b->release(); }
 };
 
 struct pa_index {
@@ -339,18 +340,13 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     p.tile_ctr = cx->ctl.as<uint32_t>() + 3;
     p.spill = cx->spill.as<uint32_t>();
     p.spill_cap = spill_cap;
-    p.counts = reinterpret_cast<unsigned long long*>(d_counts);
     const uint64_t counts_len = (uint64_t)idx->stats.num_classes + 3;
-    const uint32_t xcd_stride = (uint32_t)((counts_len + 63) / 64 * 64);
-    if (d_counts) {   // per-XCD replicas of the table, zero on entry (the fold kernel clears what it adds)
-        const size_t need = (size_t)PA_COUNT_REPLICAS * xcd_stride * 4;
-        if (cx->xcd_counts.bytes < need) {
-            rc = cx->xcd_counts.ensure(need);
-            if (rc != PA_OK) return rc;
-            HIP_TRY(hipMemsetAsync(cx->xcd_counts.p, 0, cx->xcd_counts.bytes, stream));
-        }
-        p.xcd_counts = cx->xcd_counts.as<uint32_t>();
-        p.xcd_stride = xcd_stride;
+    uint64_t keys_cap = 0;
+    if (d_counts) {   // the waves' key streams (4.3 bytes per read) and the same keys partitioned by range (4 bytes per read)
+        keys_cap = key_stream_capacity(n_reads, grid * (PA_MAP_BLOCK / 64));
+        if ((rc = cx->keys.ensure(keys_cap * 4)) || (rc = cx->keys_sorted.ensure((n_reads + 64) * 4)) || (rc = cx->keys_ctl.ensure(count_keys_ctl_bytes(counts_len)))) return rc;
+        p.keys = cx->keys.as<uint32_t>();
+        p.keys_top = cx->ctl.as<unsigned long long>() + 57;
     }
     p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
     p.class_table_size = idx->class_table_size;
@@ -377,8 +373,9 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     const int e = launch_map_pool(p, grid, lds, stream);
     if (e) return fail(PA_ERR_HIP, "map launch (grid %u, lds %zu): %s", grid, lds, hipGetErrorString((hipError_t)e));
     if (d_counts) {
-        const int e2 = launch_counts_fold(p.xcd_counts, p.xcd_stride, p.counts, counts_len, stream);
-        if (e2) return fail(PA_ERR_HIP, "count fold launch: %s", hipGetErrorString((hipError_t)e2));
+        const int e2 = launch_count_keys(p.keys, p.keys_top, keys_cap, cx->keys_sorted.as<uint32_t>(), cx->keys_ctl.as<uint32_t>(),
+                                         reinterpret_cast<unsigned long long*>(d_counts), counts_len, idx->num_cus, stream);
+        if (e2) return fail(PA_ERR_HIP, "count launch: %s", hipGetErrorString((hipError_t)e2));
         if (ovf) {
             rc = overflow_after_map(ovf, p.novel_list, p.novel_ctr, p.novel_cap, d_arena, stream);
             if (rc != PA_OK) return rc;

@@ -9,7 +9,8 @@ namespace pa {
 constexpr uint32_t PA_MAP_BLOCK = 256;          // 4 independent waves per workgroup, no barriers
 constexpr uint32_t PA_ARENA_CHUNK = 1024;       // u32 entries a wave reserves per global atomic
 constexpr uint32_t PA_LDS_READ_WORDS = 16;        // reads of up to 512 bases live in LDS while they are mapped, longer ones stay in their HBM tile
-constexpr uint32_t PA_COUNT_REPLICAS = 8;        // XCDs of an MI355X
+constexpr uint32_t PA_KEY_CHUNK = 1024;         // count keys a wave reserves per global atomic (map_pool.hip, count_sort.hip)
+constexpr uint32_t PA_KEY_BIN_SHIFT = 15;       // count_sort.hip: a bin = 32768 consecutive count slots = 128 KiB of LDS counters
 constexpr uint32_t PA_STATUS_ARENA_FULL = 1u;
 constexpr uint32_t PA_STATUS_SPILL_OVERFLOW = 2u;
 constexpr unsigned long long PA_NOVEL_LIST_FULL = 4ull;   // OVF_STATUS_LIST_FULL of collective.hip
@@ -31,13 +32,12 @@ struct MapParams {
     uint32_t* spill;
     uint32_t spill_cap;
     uint32_t pool_slots;       // read slots per wave (<= 256)
-    // optional fused class-count table (pa_counts_len entries) and the class-list hash table it needs for novel subsets
-    unsigned long long* counts;
-    // the fused counts go to one u32 replica of the table per XCD (PA_COUNT_REPLICAS x xcd_stride entries),
-    // which pa_counts_fold_kernel adds into `counts` afterwards: an atomic on a line that only one XCD touches stays in
-    // that XCD's L2, while one table shared by the eight L2s moves its lines between them at ~3 G atomics/s
-    uint32_t* xcd_counts;
-    uint32_t xcd_stride;
+    // optional class-count table (pa_map_count_batch_device): every finished read appends its KEY — the slot of the table it
+    // counts in — to its wave's stream in `keys` (chunks of PA_KEY_CHUNK entries handed out through *keys_top, unused tails
+    // padded with 0xFFFFFFFF); count_sort.hip turns the streams into the table after the launch. class_table: the class-list
+    // hash table the keys of novel subsets are looked up in.
+    uint32_t* keys;
+    unsigned long long* keys_top;      // entries handed out so far (zero at launch)
     const uint32_t* class_table;
     uint64_t class_table_size;
     // optional (with the fused count table): {arena offset, length} of every result that is NO index class goes on this list;
@@ -63,7 +63,12 @@ uint32_t pool_max_slots();              // slots a wave can schedule
 size_t pool_lds_bytes(uint32_t wpr, uint32_t slots);
 int launch_map_pool(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream);
 int pool_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu);
-int launch_counts_fold(uint32_t* xcd_counts, uint32_t xcd_stride, unsigned long long* counts, uint64_t len, hipStream_t stream);
+// count_sort.hip: the key streams of a launch -> counts[counts_len] += (keys partitioned by range, counted in LDS). `sorted` holds
+// n_reads u32 and `ctl` count_keys_ctl_bytes() of scratch; both may be reused once the stream has passed these kernels.
+uint64_t key_stream_capacity(uint64_t n_reads, uint32_t nwaves);
+size_t count_keys_ctl_bytes(uint64_t counts_len);                  // bytes of `ctl`   // u32 entries `keys` must hold for a launch of nwaves waves
+int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top, uint64_t keys_cap, uint32_t* sorted, uint32_t* ctl,
+                      unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream);
 int launch_encode(const uint8_t* ascii, const uint64_t* offsets, uint64_t n, uint32_t wpr, uint64_t* tiles, uint32_t* lens,
                   hipStream_t stream);
 int launch_simulate(const uint64_t* packed, const uint64_t* tx_start, const uint64_t* cum, uint32_t num_tx, uint64_t total,

@@ -13,7 +13,7 @@
 // Rare states simply wait until enough slots have gathered in them, so they are executed at full width too.
 // Nothing is shared between waves: no locks, no barriers, no atomics besides the arena chunk grab and the count table.
 //
-// LDS per wave (S slots, wpr words per read):   [960 B fixed: arena chunk, statistics, count cache, state bytes, pop list |
+// LDS per wave (S slots, wpr words per read):   [960 B fixed: arena chunk, key chunk, statistics, state bytes, pop list |
 //                                                 rd u64[wpr][S] | st {u32 x 8}[S] | win {u32 x 4}[S] | {class id, read id}[S]]
 // HBM per slot: a row of spill_cap u32 that holds the class lists of a read in list mode (lane_steps.hpp, ColRef) and,
 // in TRACE builds, a second row with the visited node ids.
@@ -67,9 +67,8 @@ __device__ __forceinline__ DevIndexView view_of(karg_ptr p) {   // member-wise: 
 constexpr uint32_t ST_NSTAT = ST_COUNT + 4;   // statistics entries: one per state, the dual (forward + probe) iterations, and the plain forward step
                                                // split into issue / wait / compute (PA_MAP_STATS only)
 constexpr uint32_t ST_DUAL = ST_COUNT;
-constexpr uint32_t POOL_FIXED = 960;   // per wave: arena chunk {cur, end} (16 B), statistics, count cache (64 x {class, count}), state bytes (128 B), pop list (64 B)
+constexpr uint32_t POOL_FIXED = 960;   // per wave: arena chunk {cur, end} (16 B), statistics, key chunk {cur, end} (8 B at +256), state bytes (128 B), pop list (64 B)
 constexpr uint32_t POOL_MAX_SLOTS = 128;   // every lane watches the state bytes of two slots (lane, lane + 64)
-constexpr uint32_t COUNT_CACHE_PERIOD = 128;   // output steps between two flushes of the count cache
 constexpr uint32_t LIST_ROW_HDR = 12;  // list mode row: refs[4], lens[4], cids[4], then (ref, len, class id, -) quads
 
 __device__ __forceinline__ uint32_t rank_in(uint64_t m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
@@ -114,31 +113,38 @@ __device__ __forceinline__ void trace_out(const Lane& s, bool mapped, uint32_t g
     for (uint32_t j = 0; j < nn; ++j) out[j] = tr[j];
 }
 
-// one more read for count slot `cslot`, through the wave's count cache in LDS: 64 direct-mapped {slot, count} pairs that absorb
-// the slots many reads of the wave hit (a highly expressed class; the "novel" / "empty" / "unmapped" slots at the table's end,
-// which EVERY such read hits: straight atomics on them are one hot word per XCD) and are flushed every COUNT_CACHE_PERIOD
-// output steps; a slot whose pair is taken goes straight to the replica table
-// the add into this XCD's replica. A/B build -DPA_COUNT_WG=1: workgroup scope — executed in this XCD's L2 instead of being forwarded
-// to the memory side (every wave that touches replica x runs on XCD x, and the fold kernel reads after the launch has ended)
-#ifndef PA_COUNT_WG
-#define PA_COUNT_WG 0
-#endif
-__device__ __forceinline__ void replica_add(glb_u32w p, uint32_t v) {
-    if (PA_COUNT_WG) __hip_atomic_fetch_add((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else atomicAdd((uint32_t*)p, v);
-}
-__device__ __forceinline__ void count_cached(lds_u32 ctag, lds_u32 ccnt, glb_u32w xcounts, uint32_t cslot) {
-    const uint32_t hs = (cslot * 0x9E3779B1u) >> 26;
-    const uint32_t old = atomicCAS((uint32_t*)(ctag + hs), NO_CLASS, cslot);
-    if (old == NO_CLASS || old == cslot) atomicAdd((uint32_t*)(ccnt + hs), 1u);
-    else replica_add(xcounts + cslot, 1u);
+// The class-count table is NOT updated here. Every finished read has one KEY — the slot of the table it counts in (class id,
+// or the novel / empty / unmapped slot at the table's end) — and the wave appends the keys of a step to a stream of its own in
+// HBM: private chunks of PA_KEY_CHUNK entries (one global atomic per chunk), the lanes of a step write consecutive entries
+// (one or two lines per step). count_sort.hip turns the streams into the table afterwards (partition by key range, count in
+// LDS). Round 2 added into per-XCD replicas of the table with one atomic per read: 100 M random 32-byte requests forwarded to
+// the memory side per 100 M reads — 3 GB of write traffic and 8-9 % of the kernel; the streams are 0.4 GB, fully coalesced.
+constexpr uint32_t NO_KEY = 0xFFFFFFFFu;   // padding of a chunk's unused tail (count_sort.hip skips it)
+__device__ __forceinline__ void append_keys(uint32_t key, uint32_t lane, karg_ptr p, lds_u32 kchunk) {
+    const uint64_t m = __ballot(key != NO_KEY);
+    if (m == 0) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    const glb_u32w keys = (glb_u32w)p->keys;
+    asm volatile("" ::: "memory");   // (LDS words one lane writes and all lanes read: see arena_alloc)
+    uint32_t cur = kchunk[0], end = kchunk[1];
+    if (cur + cnt > end) {   // fewer than 64 entries left: pad them, take the next chunk
+        if (cur + lane < end) keys[cur + lane] = NO_KEY;
+        uint32_t base = 0;
+        if (lane == 0) base = (uint32_t)atomicAdd(p->keys_top, (unsigned long long)PA_KEY_CHUNK);
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        end = cur + PA_KEY_CHUNK;
+        if (lane == 0) kchunk[1] = end;
+    }
+    if (key != NO_KEY) keys[cur + rank_in(m)] = key;
+    if (lane == 0) kchunk[0] = cur + cnt;
+    asm volatile("" ::: "memory");
 }
 
-// list mode: record + class-count update of one finished read; leaves the lane in ST_EMPTY, or in ST_F_NOVEL when the class
-// of a strict-subset result still has to be looked up by content before it can be counted
+// list mode: record of one finished read; returns its count key and leaves the lane in ST_EMPTY — or NO_KEY and ST_F_NOVEL when
+// the class of a strict-subset result still has to be looked up by content before it can be counted
 template <bool TRACE>
-__device__ __forceinline__ void emit_record(Lane& s, uint32_t cnt, uint32_t cnt_alloc, uint64_t my_off, uint32_t base_len,
-                                            uint32_t base_colour, uint32_t gslot, karg_ptr p, glb_u32w xcounts, lds_u32 ctag, lds_u32 ccnt) {
+__device__ __forceinline__ uint32_t emit_record(Lane& s, uint32_t cnt, uint32_t cnt_alloc, uint64_t my_off, uint32_t base_len,
+                                                uint32_t base_colour, uint32_t gslot, karg_ptr p) {
     uint32_t colour = NO_CLASS, class_off = (uint32_t)my_off;
     bool novel = false;
     if (my_off + cnt_alloc > p->arena_cap) atomicOr(p->status, PA_STATUS_ARENA_FULL);
@@ -150,18 +156,16 @@ __device__ __forceinline__ void emit_record(Lane& s, uint32_t cnt, uint32_t cnt_
     ((glb_v4w)p->results)[s.rid] = u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, class_off, cnt};
     trace_out<TRACE>(s, true, gslot, p);
     const glb_u32w colour_out = (glb_u32w)p->colour_out;
-    if (novel && (xcounts != nullptr || colour_out != nullptr) && my_off + cnt_alloc <= p->arena_cap) {   // content lookup: NOVEL state
+    if (novel && (p->keys != nullptr || colour_out != nullptr) && my_off + cnt_alloc <= p->arena_cap) {   // content lookup: NOVEL state
         s.h = (uint32_t)my_off;
         s.rr = cnt;
         l_set_st(s, ST_F_NOVEL);
-        return;
+        return NO_KEY;
     }
     if (colour_out) colour_out[s.rid] = colour;
-    if (xcounts) {   // fused class-count table: fire-and-forget atomic
-        const uint32_t num_classes = p->ix.num_classes;
-        count_cached(ctag, ccnt, xcounts, cnt == 0 ? num_classes + 1 : colour == NO_CLASS ? num_classes : colour);
-    }
     s.lk = 0;   // ST_EMPTY
+    const uint32_t num_classes = p->ix.num_classes;
+    return cnt == 0 ? num_classes + 1 : colour == NO_CLASS ? num_classes : colour;   // the read's count key
 }
 
 // which of the eight base ids b[] occur in the list of record `xref` (nch 16-byte chunks; the loop runs to the wave-uniform
@@ -252,10 +256,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
     const lds_u64w chunk = (lds_u64w)wbase;
     const lds_u32 dbg = (lds_u32)(wbase + 16);                            // [0..ST_NSTAT) iterations, [ST_NSTAT..2*ST_NSTAT) slots served; entry ST_COUNT = dual iterations
     const lds_u64w dbg_clk = (lds_u64w)(wbase + 16 + 8 * ST_NSTAT);        // wall ticks per state
-    // count cache: 64 direct-mapped {count slot, count} pairs. A class that many reads of this wave hit (a highly expressed
-    // gene) is counted in LDS and reaches the replica table once per flush; without it a handful of hot classes serialise
-    // the L2 atomics (7 classes: 0.5 ms -> 6.8 ms per 10 M reads)
-    const lds_u32 ctag = (lds_u32)(wbase + 256), ccnt = (lds_u32)(wbase + 512);
+    const lds_u32 kchunk = (lds_u32)(wbase + 256);   // {cur, end} of this wave's chunk of the key stream (both 0: none taken yet)
     const lds_u64 rd = (lds_u64)(wbase + POOL_FIXED);
     // the lane state as TWO arrays of one 16-byte vector per slot (not one array of 32-byte records: with a 32-byte stride the
     // vectors of 64 random slots fall into 4 bank groups, with 16 bytes into 8 — half of the LDS cycles were bank conflicts)
@@ -270,9 +271,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
     const lds_u8 sb = (lds_u8)(wbase + 768);
     const lds_u8 poplist = (lds_u8)(wbase + 896);
     if (lane < 64) ((lds_u32)wbase)[lane] = 0;
-    ctag[lane] = NO_CLASS;
-    ccnt[lane] = 0;
-    uint32_t out_steps = 0;
+    if (lane < 2) kchunk[lane] = 0;
     ((lds_u16)sb)[lane] = (uint16_t)((lane < S ? (uint32_t)ST_EMPTY : 0xFFu) | ((lane + 64 < S ? (uint32_t)ST_EMPTY : 0xFFu) << 8));
 
     // Work distribution: chunks of up to 16 tiles (1024 reads). Chunk w is wave w's first one; further chunks come from a
@@ -289,9 +288,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
     bool more = true;   // chunks may be left
     uint32_t seen = nwaves * chunk_tiles;   // tiles known to be handed out
 
-    // this XCD's replica of the count table (HW_REG_XCC_ID, bits 3:0)
-    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & (PA_COUNT_REPLICAS - 1);
-    const glb_u32w xcounts = p.counts ? (glb_u32w)p.xcd_counts + (uint64_t)xcc * p.xcd_stride : (glb_u32w) nullptr;
+    const bool counting = p.keys != nullptr;   // class-count keys are wanted (pa_map_count_batch_device)
 
 #define PA_CNT(t) ((uint32_t)__popcll(__ballot(st_lo == (t))) + (uint32_t)__popcll(__ballot(st_hi == (t))))
     // the first nn slots in state t, one per lane (lanes >= nn: slot 0)
@@ -458,6 +455,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         } else if (sel == ST_F_BITS) {
             // output of window-mode reads and of unmapped reads: no loads. A non-empty window that is a strict subset of
             // every class seen goes on to NOVEL (is it an index class all the same?) and is written there.
+            uint32_t ckey = NO_KEY;
             if (active && lane < n_own) {
                 const bool mapped = l_st(s) != ST_NONE;
                 const u32x4 w = win[slot];
@@ -473,10 +471,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     trace_out<TRACE>(s, mapped, gslot, kp);
                     const glb_u32w colour_out = (glb_u32w)p.colour_out;
                     if (colour_out) colour_out[s.rid] = is_ref ? cand : NO_CLASS;
-                    if (xcounts && !PA_ABLATE(2u)) {
-                        const uint32_t cslot = !mapped ? ix.num_classes + 2 : count == 0 ? ix.num_classes + 1 : cand;
-                        count_cached(ctag, ccnt, xcounts, cslot);
-                    }
+                    ckey = !mapped ? ix.num_classes + 2 : count == 0 ? ix.num_classes + 1 : cand;
                     s.lk = 0;   // ST_EMPTY
                 }
             }
@@ -491,12 +486,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     next += take;
                 }
             }
-            if (xcounts && (++out_steps % COUNT_CACHE_PERIOD) == 0) {   // flush: hot classes re-enter at once, squatters leave
-                const uint32_t t = ctag[lane], c = ccnt[lane];
-                if (t != NO_CLASS && c) replica_add(xcounts + t, c);
-                ctag[lane] = NO_CLASS;
-                ccnt[lane] = 0;
-            }
+            if (counting && !PA_ABLATE(2u)) append_keys(ckey, lane, kp, kchunk);
         } else if (sel == ST_F_NOVEL) {
             // the result is a strict subset of every class seen: does it equal some index class all the same?
             const bool lists = l_flags(s) & F_LISTS;
@@ -532,9 +522,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 }
                 const glb_u32w colour_out = (glb_u32w)p.colour_out;
                 if (colour_out) colour_out[s.rid] = colour;
-                if (xcounts) count_cached(ctag, ccnt, xcounts, colour == NO_CLASS ? ix.num_classes : colour);   // (the novel slot is one word for every such read)
                 s.lk = 0;   // ST_EMPTY
             }
+            if (counting) append_keys(active ? (colour == NO_CLASS ? ix.num_classes : colour) : NO_KEY, lane, kp, kchunk);
             if (p.novel_list) {   // a class no index class equals: remember where its ids are (one atomic per step)
                 const bool rec = active && colour == NO_CLASS && (lists || my_off + cnt_alloc <= p.arena_cap);
                 const uint64_t m = __ballot(rec);
@@ -644,6 +634,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             const uint32_t cnt = active ? (uint32_t)__popc(my_alive) : 0u;
             const uint32_t cnt_alloc = active && cnt != is.base_len ? cnt : 0u;   // a result that is an index class is returned by reference
             const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
+            uint32_t ckey = NO_KEY;
             if (active) {
                 if (cnt_alloc && my_off + cnt_alloc <= p.arena_cap) {
                     const glb_u32w dst = (glb_u32w)p.arena + my_off;
@@ -651,8 +642,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     uint32_t k = 0;
                     for (uint32_t t = my_alive; t; t &= t - 1) dst[k++] = bids[__ffs((int)t) - 1];
                 }
-                emit_record<TRACE>(s, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts, ctag, ccnt);
+                ckey = emit_record<TRACE>(s, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp);
             }
+            if (counting) append_keys(ckey, lane, kp, kchunk);
         } else if (sel == ST_F_COOP) {
             // the whole wave works on one read at a time (list mode, base list of more than 8 ids). Lane e owns base ids
             // e, e+64, ...; membership in every other list is a scan of 16-byte loads (short lists) or a binary search;
@@ -729,7 +721,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 }
                 if (lane == Lr) my_count = total;
             }
-            if (active) emit_record<TRACE>(s, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts, ctag, ccnt);
+            uint32_t ckey = NO_KEY;
+            if (active) ckey = emit_record<TRACE>(s, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp);
+            if (counting) append_keys(ckey, lane, kp, kchunk);
         } else {   // ST_F_LIGHT: list mode — pick a tier, intersect, write
             Isect is;
             is.count = 0;
@@ -751,6 +745,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             const uint32_t cntv2 = emit_now ? is.count : 0u;
             const uint32_t cnt_alloc = cntv2 == is.base_len ? 0u : cntv2;   // a result that is an index class is returned by reference
             const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
+            uint32_t ckey = NO_KEY;
             if (emit_now) {
                 if (cnt_alloc && my_off + cnt_alloc <= p.arena_cap) {
                     const glb_u32w dst = (glb_u32w)p.arena + my_off;
@@ -759,8 +754,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     for (int j = 0; j < 7; ++j)   // survivors straight from registers
                         if ((alive >> j) & 1u) dst[__popc(alive & ((1u << j) - 1))] = is.ids[j];
                 }
-                emit_record<TRACE>(s, cntv2, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, xcounts, ctag, ccnt);
+                ckey = emit_record<TRACE>(s, cntv2, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp);
             }
+            if (counting) append_keys(ckey, lane, kp, kchunk);
         }
 
         const unsigned long long t_step = PA_DBG ? __builtin_readcyclecounter() : 0ull;
@@ -781,9 +777,10 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             dbg_clk[ST_NONE] += t_end - t_step;
         }
     }
-    if (xcounts) {
-        const uint32_t t = ctag[lane], c = ccnt[lane];
-        if (t != NO_CLASS && c) replica_add(xcounts + t, c);
+    if (counting) {   // the unused tail of this wave's last chunk of the key stream is padding
+        asm volatile("" ::: "memory");
+        const uint32_t cur = kchunk[0], end = kchunk[1];
+        for (uint32_t i = cur + lane; i < end; i += 64) ((glb_u32w)p.keys)[i] = NO_KEY;
     }
     if (PA_DBG && lane < 2 * ST_NSTAT) atomicAdd(p.dbg + lane, (unsigned long long)dbg[lane]);
     if (PA_DBG && lane < ST_NSTAT) atomicAdd(p.dbg + 2 * ST_NSTAT + lane, dbg_clk[lane]);
@@ -792,26 +789,6 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
 #undef PA_DBG
 #undef PA_ABLATE
 #undef p
-}
-
-// counts[c] += sum of the per-XCD replicas, which are cleared for the next launch
-__global__ __launch_bounds__(256) void pa_counts_fold_kernel(uint32_t* __restrict__ rep, uint32_t stride, unsigned long long* __restrict__ counts,
-                                                             uint64_t len) {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= len) return;
-    unsigned long long sum = 0;
-#pragma unroll
-    for (uint32_t r = 0; r < PA_COUNT_REPLICAS; ++r) {
-        const uint32_t v = rep[(uint64_t)r * stride + c];
-        if (v) { sum += v; rep[(uint64_t)r * stride + c] = 0; }
-    }
-    if (sum) atomicAdd(counts + c, sum);   // (launches on two streams may fold into one table at the same time)
-}
-
-int launch_counts_fold(uint32_t* xcd_counts, uint32_t xcd_stride, unsigned long long* counts, uint64_t len, hipStream_t stream) {
-    if (len == 0) return 0;
-    hipLaunchKernelGGL(pa_counts_fold_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream, xcd_counts, xcd_stride, counts, len);
-    return (int)hipGetLastError();
 }
 
 size_t pool_slot_bytes(uint32_t wpr) { return 8 * (size_t)(wpr > PA_LDS_READ_WORDS ? 0 : wpr) + SLOT_FIXED_BYTES; }   // longer reads stay in HBM

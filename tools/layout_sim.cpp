@@ -221,7 +221,7 @@ int main(int argc, char** argv) {
     for (const Cand& c : cands) {
         uint64_t total = 0;
         const std::vector<uint64_t> at = place_blobs(f, *c.order, c.gran, c.keep, &total);
-        uint64_t per_step = 0, per_read = 0, lines64 = 0;
+        uint64_t per_step = 0, per_read = 0, lines64 = 0, clipped = 0;
         std::set<uint64_t> seen_read, seen_step, seen64;
         uint32_t cur_read = 0xFFFFFFFFu;
         for (const Touch& tc : touches) {
@@ -232,10 +232,17 @@ int main(int argc, char** argv) {
                 for (uint64_t b = (at[tc.node] + tc.r[j][0]); b < at[tc.node] + tc.r[j][1]; b += 16) { seen_step.insert(b / 128); seen_read.insert(b / 128); seen64.insert(b / 64); }
             per_step += seen_step.size();
             lines64 += seen64.size();
+            {   // the same step if loads past the node's last sequence word were not issued
+                std::set<uint64_t> sc;
+                const uint64_t bsz = BLOB_HDR_BYTES + 8ull * ((f.node_len[tc.node] + 31) / 32);
+                for (uint32_t j = 0; j < tc.nr; ++j)
+                    for (uint64_t b = (at[tc.node] + tc.r[j][0]); b < at[tc.node] + std::min<uint64_t>(tc.r[j][1], bsz); b += 8) sc.insert(b / 128);
+                clipped += sc.size();
+            }
         }
         per_read += seen_read.size();
-        printf("%-48s blobs %7.1f MB  blocks/step %.3f  blocks/read (steps summed) %.3f  distinct blocks/read %.3f  64B lines/read %.3f\n", c.name, total / 1e6,
-               (double)per_step / touches.size(), (double)per_step / n, (double)per_read / n, (double)lines64 / n);
+        printf("%-48s blobs %7.1f MB  blocks/step %.3f  blocks/read (steps summed) %.3f  distinct blocks/read %.3f  64B lines/read %.3f  clipped-to-node blocks/read %.3f\n", c.name, total / 1e6,
+               (double)per_step / touches.size(), (double)per_step / n, (double)per_read / n, (double)lines64 / n, (double)clipped / n);
     }
     return 0;
 }
