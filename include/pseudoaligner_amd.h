@@ -230,6 +230,11 @@ int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* a
  * it (after synchronising the stream): call it before destroying a stream you launched on; pa_index_destroy frees what
  * is left. A host that launches from a pool of N streams holds N contexts. */
 int pa_index_release_stream(pa_index* idx, void* stream);
+/* Measurement (bench.py's roofline leg): with timing on, every launch records HIP events around its mapping kernel on the launch
+ * stream; pa_map_kernel_ms returns the duration of the last launch's mapping kernel on `stream` (it waits for that kernel).
+ * The class-count kernels of pa_map_count_batch_device run after the second event. */
+int pa_index_set_timing(pa_index* idx, int on);
+int pa_map_kernel_ms(pa_index* idx, void* stream, float* ms);
 /* arena capacity (u32 entries) that suffices for typical batches of n_reads; the exact need is data dependent */
 uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads);
 

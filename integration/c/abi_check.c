@@ -163,11 +163,13 @@ int main(int argc, char** argv) {
         pa_overflow* ovf = NULL;
         EXPECT(pa_overflow_create(0, 1024, 1 << 16, &ovf) == PA_OK && pa_index_set_overflow(idx, ovf) == PA_OK);
         EXPECT(pa_event_record(ev0, NULL) == PA_OK);
+        EXPECT(pa_index_set_timing(idx, 1) == PA_OK);
         EXPECT(pa_map_count_batch_device(idx, (const uint64_t*)d_tiles, (const uint32_t*)d_lens, nsim, sim_wpr, 2, (pa_read_result*)d_res,
                                          (uint32_t*)d_arena, arena_cap, (uint64_t*)d_counts, NULL) == PA_OK);
         EXPECT(pa_event_record(ev1, NULL) == PA_OK);
         uint64_t used = 0, need = 0;
         EXPECT(pa_map_finish(idx, NULL, &used, &need) == PA_OK);
+        { float kms = -1.0f; EXPECT(pa_map_kernel_ms(idx, NULL, &kms) == PA_OK && kms > 0.0f); EXPECT(pa_index_set_timing(idx, 0) == PA_OK); }
         EXPECT(pa_index_release_stream(idx, NULL) == PA_OK);   /* the null stream's launch context goes; the next launch makes a new one */
         EXPECT(pa_event_elapsed_ms(ev0, ev1, &ms) == PA_OK && ms >= 0.0f);
         EXPECT(pa_map_batch_device(idx, (const uint64_t*)d_tiles, (const uint32_t*)d_lens, nsim, sim_wpr, 2, (pa_read_result*)d_res, (uint32_t*)d_arena,

@@ -68,6 +68,8 @@ extern "C" {
                                      d_arena: *mut u32, arena_cap: u64, d_counts: *mut u64, stream: *mut c_void) -> c_int;
     pub fn pa_map_finish(idx: *mut PaIndex, stream: *mut c_void, arena_used: *mut u64, arena_needed: *mut u64) -> c_int;
     pub fn pa_index_release_stream(idx: *mut PaIndex, stream: *mut c_void) -> c_int;
+    pub fn pa_index_set_timing(idx: *mut PaIndex, on: c_int) -> c_int;
+    pub fn pa_map_kernel_ms(idx: *mut PaIndex, stream: *mut c_void, ms: *mut f32) -> c_int;
     pub fn pa_map_arena_hint(idx: *const PaIndex, n_reads: u64) -> u64;
     pub fn pa_counts_len(idx: *const PaIndex) -> u64;
 

@@ -368,6 +368,18 @@ class Pseudoaligner:
         check(lib().pa_map_finish(self._h, stream or None, C.byref(used), C.byref(need)))
         return used.value, need.value
 
+    def set_timing(self, on: bool = True) -> None:
+        """HIP events around the mapping kernel of every launch (pa_map_kernel_ms)"""
+        check(lib().pa_index_set_timing(self._h, 1 if on else 0))
+
+    def map_kernel_ms(self, stream: int = 0) -> float:
+        ms = C.c_float()
+        check(lib().pa_map_kernel_ms(self._h, stream or None, C.byref(ms)))
+        return ms.value
+
+    def release_stream(self, stream: int = 0) -> None:
+        check(lib().pa_index_release_stream(self._h, stream or None))
+
     def arena_hint(self, n_reads: int) -> int:
         return lib().pa_map_arena_hint(self._h, n_reads)
 

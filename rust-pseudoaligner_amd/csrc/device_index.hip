@@ -58,7 +58,15 @@ struct LaunchCtx {
     DevBuf keys, keys_sorted, keys_ctl;   // class-count launches: the waves' key streams, the keys partitioned by range, 2 KiB of histogram / cursors (count_sort.hip)
     uint32_t last_grid = 0;
     uint64_t last_arena_cap = 0;
-    void release() { for (DevBuf* b : {&ctl, &spill, &trace, &novel, &keys, &keys_sorted, &keys_ctl}) b->release(); }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the map kernel of the last launch (pa_index_set_timing)
+    bool timed = false;
+    void release() {
+        for (DevBuf* b : {&ctl, &spill, &trace, &novel, &keys, &keys_sorted, &keys_ctl}) b->release();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        ev0 = ev1 = nullptr;
+        timed = false;
+    }
 };
 
 struct pa_index {
@@ -74,6 +82,7 @@ struct pa_index {
     std::mutex mu;                // guards `ctxs` and `ovf`
     std::map<hipStream_t, std::unique_ptr<LaunchCtx>> ctxs;
     pa_overflow* ovf = nullptr;   // attached overflow table of novel classes (collective.hip), not owned
+    bool timing = false;          // pa_index_set_timing: HIP events around the map kernel of every launch
     std::mutex hmu;               // the host-buffer convenience path (b_* below) is one batch at a time
     // host-buffer convenience path
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
@@ -369,9 +378,17 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     p.nodes_len = d_nodes_len;
     cx->last_grid = grid;
     cx->last_arena_cap = p.arena_cap;
+    cx->timed = false;
     if (n_reads == 0) return PA_OK;
+    bool timing = false;
+    { std::lock_guard<std::mutex> g(idx->mu); timing = idx->timing; }
+    if (timing) {
+        if (!cx->ev0) { HIP_TRY(hipEventCreate(&cx->ev0)); HIP_TRY(hipEventCreate(&cx->ev1)); }
+        HIP_TRY(hipEventRecord(cx->ev0, stream));
+    }
     const int e = launch_map_pool(p, grid, lds, stream);
     if (e) return fail(PA_ERR_HIP, "map launch (grid %u, lds %zu): %s", grid, lds, hipGetErrorString((hipError_t)e));
+    if (timing) { HIP_TRY(hipEventRecord(cx->ev1, stream)); cx->timed = true; }
     if (d_counts) {
         const int e2 = launch_count_keys(p.keys, p.keys_top, keys_cap, cx->keys_sorted.as<uint32_t>(), cx->keys_ctl.as<uint32_t>(),
                                          reinterpret_cast<unsigned long long*>(d_counts), counts_len, idx->num_cus, stream);
@@ -464,6 +481,25 @@ int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* a
     std::lock_guard<std::mutex> g(cx->mu);
     HIP_TRY(hipSetDevice(idx->device));
     return map_finish_locked(idx, cx, static_cast<hipStream_t>(stream), arena_used, arena_needed);
+}
+
+int pa_index_set_timing(pa_index* idx, int on) {
+    if (!idx) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> g(idx->mu);
+    idx->timing = on != 0;
+    return PA_OK;
+}
+
+int pa_map_kernel_ms(pa_index* idx, void* stream, float* ms) {
+    if (!idx || !ms) return fail(PA_ERR_INVALID_ARG, "null argument");
+    LaunchCtx* cx = nullptr;
+    const int rc0 = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
+    if (rc0 != PA_OK) return rc0;
+    std::lock_guard<std::mutex> g(cx->mu);
+    if (!cx->timed) return fail(PA_ERR_INVALID_ARG, "no timed launch on this stream (pa_index_set_timing before the launch)");
+    HIP_TRY(hipEventSynchronize(cx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, cx->ev0, cx->ev1));
+    return PA_OK;
 }
 
 uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads) {
