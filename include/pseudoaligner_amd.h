@@ -244,6 +244,19 @@ uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads);
 int pa_map_batch(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads,
                  uint32_t allowed_mismatches, pa_read_result* results, uint64_t* class_offsets,
                  const uint32_t** class_ids);
+/* The same for reads the caller already holds 2-bit packed — what `DnaString::from_dna_string` made of the record (:450) and
+ * what `map_read(&self, read_seq: &DnaString)` (:381) receives: no ASCII round trip. Read i = lens[i] bases in the words
+ * words[word_offsets[i] .. word_offsets[i+1]) (every read starts on a word boundary; bases beyond the length are ignored).
+ * layout 0: this library's words (base j in bits 2 (j % 32) of word j / 32); layout 1: MSB-first words (base j in bits
+ * 62 - 2 (j % 32)), the storage order of the debruijn crate's DnaString as far as it is known here. */
+#define PA_PACKED_LSB_FIRST 0
+#define PA_PACKED_MSB_FIRST 1
+int pa_map_batch_packed(pa_index* idx, const uint64_t* words, const uint64_t* word_offsets, const uint32_t* lens, uint64_t n_reads,
+                        int layout, uint32_t allowed_mismatches, pa_read_result* results, uint64_t* class_offsets,
+                        const uint32_t** class_ids);
+/* map_read_with_mismatch (:361) / map_read (:381) of one packed read: returns 1 = Some, 0 = None, <0 error. */
+int pa_map_read_packed(pa_index* idx, const uint64_t* words, uint32_t len, int layout, uint32_t allowed_mismatches,
+                       uint32_t* class_buf, uint32_t class_cap, uint32_t* class_len, uint32_t* coverage, uint32_t* mismatches);
 /* map_read (src/pseudoaligner.rs:381): returns 1 = Some, 0 = None, <0 error. */
 int pa_map_read(pa_index* idx, const uint8_t* ascii, uint32_t len, uint32_t* class_buf, uint32_t class_cap,
                 uint32_t* class_len, uint32_t* coverage);
@@ -275,6 +288,27 @@ int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offs
  * pa_index_destroy frees them. */
 int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads,
                      uint64_t* n_reads_out, uint64_t* n_flagged_out);
+
+/* process_reads for a caller that HOLDS the reader. The reference's signature consumes an open fastq::Reader
+ * (src/pseudoaligner.rs:420-425), so its drop-in replacement cannot ask for a path: the caller pushes the records it reads —
+ * ids as record.id() returns them (:456), sequences as record.seq() (:449), both concatenated with offsets[n+1] — and pulls the
+ * reference's Debug tuples (:490), one line per record, in PUSH order. Behind the two calls runs the batch pipeline of
+ * pa_process_reads: a full batch (batch_reads, 0 = 4 Mi reads) is packed by `num_threads` workers (0 = all usable CPUs) and
+ * launched on the stream's own HIP stream while the caller goes on reading; the batch before it is rendered meanwhile.
+ *   push   copies the records (the caller's buffers are free afterwards); may pack + launch a batch and render the previous one
+ *   pull   copies rendered text into buf, whole lines only, never waits for the GPU; *n_bytes = 0: nothing ready yet
+ *   flush  launches what is left, waits and renders: afterwards pull drains every record pushed so far
+ * One thread at a time per stream object; several objects may share an index. A failure is sticky: every later call on the
+ * object returns it. */
+typedef struct pa_record_stream pa_record_stream;
+int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads, pa_record_stream** out);
+int pa_records_push(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs,
+                    const uint64_t* seq_offsets, uint64_t n_records);
+int pa_records_pull(pa_record_stream* s, char* buf, size_t cap, size_t* n_bytes);
+int pa_records_flush(pa_record_stream* s);
+/* records rendered so far and how many of them carry the flag of :455 (coverage >= 32 and an empty class) */
+int pa_record_stream_stats(const pa_record_stream* s, uint64_t* n_reads, uint64_t* n_flagged);
+void pa_record_stream_destroy(pa_record_stream* s);
 
 /* The scan stage of pa_process_reads by itself, without a GPU: the number of records of a FASTQ file (plain, gzip'ed or with
  * wrapped lines: same acceptance rules and errors as above) and, for the first `capacity` of them, where the record starts,

@@ -141,6 +141,36 @@ int main(int argc, char** argv) {
         uint64_t coff[3];
         const uint32_t* cids = NULL;
         EXPECT(pa_map_batch(idx, ascii, offsets, 2, 2, res, coff, &cids) == PA_OK);
+        /* the same two reads as a DnaString would hold them: 2-bit words (LSB-first: the host encoder's tiles of reads 0 and 1) */
+        {
+            uint64_t pw[8];
+            uint32_t plen[2] = {lens[0], lens[1]};
+            uint64_t poff[3] = {0, wpr, 2ull * wpr};
+            for (uint32_t w = 0; w < wpr && w < 4; ++w) { pw[w] = tiles[(uint64_t)w * 64]; pw[wpr + w] = tiles[(uint64_t)w * 64 + 1]; }
+            pa_read_result pres[2];
+            uint64_t pcoff[3];
+            const uint32_t* pcids = NULL;
+            EXPECT(pa_map_batch_packed(idx, pw, poff, plen, 2, PA_PACKED_LSB_FIRST, 2, pres, pcoff, &pcids) == PA_OK);
+            EXPECT(pres[0].coverage == res[0].coverage && pres[1].coverage == res[1].coverage && pcoff[2] == coff[2]);
+            uint32_t pcls[64], pn = 0, pcov = 0, pmm = 0;
+            EXPECT(pa_map_read_packed(idx, pw, plen[0], PA_PACKED_LSB_FIRST, 2, pcls, 64, &pn, &pcov, &pmm) >= 0 && pcov == res[0].coverage);
+        }
+        /* process_reads for a caller that holds the reader: push records, pull the tuples */
+        {
+            pa_record_stream* rs = NULL;
+            EXPECT(pa_record_stream_create(idx, 2, 64, &rs) == PA_OK && rs);
+            const uint8_t ids2[] = "r0r1";
+            const uint64_t ioff[3] = {0, 2, 4};
+            EXPECT(pa_records_push(rs, ids2, ioff, ascii, offsets, 2) == PA_OK);
+            char text[512];
+            size_t nb = 1;
+            EXPECT(pa_records_pull(rs, text, sizeof text, &nb) == PA_OK && nb == 0);   /* nothing rendered yet: the batch is still being filled */
+            EXPECT(pa_records_flush(rs) == PA_OK);
+            EXPECT(pa_records_pull(rs, text, sizeof text, &nb) == PA_OK && nb > 0 && text[nb - 1] == '\n' && text[0] == '(');
+            uint64_t rn = 0, rf = 0;
+            EXPECT(pa_record_stream_stats(rs, &rn, &rf) == PA_OK && rn == 2);
+            pa_record_stream_destroy(rs);
+        }
         uint32_t nodes_flat[2 * 64], nodes_len[2];
         EXPECT(pa_map_batch_nodes(idx, ascii, offsets, 2, 2, res, nodes_flat, 64, nodes_len) == PA_OK);
         snprintf(path, sizeof path, "%s/abi_check_tuples.txt", dir);

@@ -3,25 +3,28 @@
 //! :30) is not exported: every hit is verified against the node sequence (:99-107), which makes it an exact dictionary that
 //! the library rebuilds. Not compiled in the image of this repository (no rustc): kept in step with
 //! include/pseudoaligner_amd.h by integration/c/abi_check.c, which exercises the same calls from C.
+use std::collections::HashMap;
 use std::ffi::{CStr, CString};
 use std::fmt::Debug;
 use std::fs::File;
-use std::io;
+use std::io::{self, Write};
 use std::path::Path;
+use std::sync::{Arc, Mutex, OnceLock};
 
+use anyhow::{anyhow, Error};                 // the crate's error type (src/pseudoaligner.rs:15)
 use bio::io::fastq;
+use debruijn::dna_string::DnaString;
 use debruijn::{Kmer, Mer, Vmer};
-use failure::{format_err, Error};
 use log::info;
 
 use crate::amd_ffi::*;
-use crate::config::READ_COVERAGE_THRESHOLD;
+use crate::config::DEFAULT_ALLOWED_MISMATCHES;
 use crate::pseudoaligner::Pseudoaligner;
 
 fn check(rc: i32) -> Result<i32, Error> {
     if rc >= 0 { return Ok(rc); }
     let msg = unsafe { CStr::from_ptr(pa_last_error()) }.to_string_lossy().into_owned();
-    Err(format_err!("pseudoaligner_amd error {}: {}", rc, msg))
+    Err(anyhow!("pseudoaligner_amd error {}: {}", rc, msg))
 }
 
 /// The arrays of the flat index (include/pseudoaligner_amd.h, pa_flat_index), owned on the Rust side for the duration of a call.
@@ -95,43 +98,105 @@ impl AmdIndex {
         Ok(AmdIndex { raw })
     }
 
-    /// map_read (src/pseudoaligner.rs:381): Some((eq_class, coverage)) | None
-    pub fn map_read(&self, read: &[u8]) -> Result<Option<(Vec<u32>, usize)>, Error> {
+    /// map_read_with_mismatch (src/pseudoaligner.rs:361) on the read as the caller holds it: the DnaString's bases go over as
+    /// 2-bit words (LSB-first, packed here through `Mer::get`, so nothing depends on the crate's storage order)
+    pub fn map_read_with_mismatch(&self, read_seq: &DnaString, allowed_mismatches: usize) -> Result<Option<(Vec<u32>, usize, usize)>, Error> {
+        let len = read_seq.len();
+        let mut words = vec![0u64; (len + 31) / 32 + 1];
+        for i in 0..len { words[i / 32] |= (read_seq.get(i) as u64) << (2 * (i % 32)); }
         let mut class = vec![0u32; 1 << 16];
-        let (mut n, mut cov) = (0u32, 0u32);
-        let rc = check(unsafe { pa_map_read(self.raw, read.as_ptr(), read.len() as u32, class.as_mut_ptr(),
-                                            class.len() as u32, &mut n, &mut cov) })?;
+        let (mut n, mut cov, mut mm) = (0u32, 0u32, 0u32);
+        let rc = check(unsafe { pa_map_read_packed(self.raw, words.as_ptr(), len as u32, PA_PACKED_LSB_FIRST, allowed_mismatches as u32,
+                                                   class.as_mut_ptr(), class.len() as u32, &mut n, &mut cov, &mut mm) })?;
         if rc == 0 { return Ok(None); }
         class.truncate(n as usize);
-        Ok(Some((class, cov as usize)))
+        Ok(Some((class, cov as usize, mm as usize)))
     }
 }
 impl Drop for AmdIndex { fn drop(&mut self) { unsafe { pa_index_destroy(self.raw) } } }
 
-/// process_reads (src/pseudoaligner.rs:420-425) with the same signature; the worker pool, the reader mutex
-/// (utils.rs:152-157) and the sync_channel (:430) become: fill a batch -> pa_map_batch -> print the tuples.
-pub fn process_reads<P: AsRef<Path> + Debug>(reader: fastq::Reader<io::BufReader<File>>, index: &AmdIndex, outdir: P,
-                                             _num_threads: usize) -> Result<(), Error> {
+// ---------------------------------------------------------------------------------------------------------------------------
+// Drop-in entry points with the reference's EXACT signatures. The GPU copy of an index is made on first use and cached by the
+// identity of the `Pseudoaligner` (address + node / class counts + k): callers keep passing `&Pseudoaligner<K>`.
+// ---------------------------------------------------------------------------------------------------------------------------
+type CacheKey = (usize, usize, usize, usize);
+fn cache() -> &'static Mutex<HashMap<CacheKey, Arc<AmdIndex>>> {
+    static CACHE: OnceLock<Mutex<HashMap<CacheKey, Arc<AmdIndex>>>> = OnceLock::new();
+    CACHE.get_or_init(|| Mutex::new(HashMap::new()))
+}
+fn key_of<K: Kmer>(index: &Pseudoaligner<K>) -> CacheKey {
+    (index as *const _ as usize, index.dbg.len(), index.eq_classes.len(), K::k())
+}
+fn device_of_env() -> i32 { std::env::var("PSEUDOALIGNER_AMD_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0) }
+
+/// the GPU copy of `index` (built once: 0.14 s for a 200 k-transcript index)
+pub fn gpu_index<K: Kmer>(index: &Pseudoaligner<K>) -> Result<Arc<AmdIndex>, Error> {
+    let key = key_of(index);
+    if let Some(hit) = cache().lock().unwrap().get(&key) { return Ok(hit.clone()); }
+    let made = Arc::new(AmdIndex::from_pseudoaligner(index, device_of_env())?);
+    Ok(cache().lock().unwrap().entry(key).or_insert(made).clone())
+}
+/// call before dropping a `Pseudoaligner` whose GPU copy should go too
+pub fn forget<K: Kmer>(index: &Pseudoaligner<K>) { cache().lock().unwrap().remove(&key_of(index)); }
+
+/// `Pseudoaligner::map_read` (src/pseudoaligner.rs:381), same arguments and result: replace its body by
+/// `crate::amd::map_read(self, read_seq)`. Panics where the reference panics (it has no error path, :307,446).
+pub fn map_read<K: Kmer + Sync + Send>(index: &Pseudoaligner<K>, read_seq: &DnaString) -> Option<(Vec<u32>, usize)> {
+    let gpu = gpu_index(index).expect("pseudoaligner_amd: GPU index");
+    gpu.map_read_with_mismatch(read_seq, DEFAULT_ALLOWED_MISMATCHES).expect("pseudoaligner_amd: map_read")
+        .map(|(eq_class, read_coverage, _mismatches)| (eq_class, read_coverage))
+}
+
+/// `process_reads` (src/pseudoaligner.rs:420-425) with the reference's signature. The worker pool, the reader mutex
+/// (utils.rs:152-157) and the sync_channel (:430) become: read a chunk of records -> pa_records_push (packs and launches full
+/// batches on the GPU while this thread goes on reading) -> pa_records_pull (the Debug tuples of :490, in input order) -> stdout.
+pub fn process_reads<K: Kmer + Sync + Send, P: AsRef<Path> + Debug>(
+    reader: fastq::Reader<io::BufReader<File>>,
+    index: &Pseudoaligner<K>,
+    outdir: P,
+    num_threads: usize,
+) -> Result<(), Error> {
+    info!("Done Reading index");
+    info!("Starting Multi-threaded Mapping");
     info!("Output directory: {:?}", outdir);
+    let gpu = gpu_index(index)?;
+    let mut stream = std::ptr::null_mut();
+    check(unsafe { pa_record_stream_create(gpu.raw, num_threads as i32, 0, &mut stream) })?;
+    struct Guard(*mut PaRecordStream);
+    impl Drop for Guard { fn drop(&mut self) { unsafe { pa_record_stream_destroy(self.0) } } }
+    let _guard = Guard(stream);
+
+    let stdout = io::stdout();
+    let mut out = io::BufWriter::with_capacity(1 << 22, stdout.lock());
+    let mut text = vec![0u8; 1 << 22];
+    let mut drain = |out: &mut dyn Write| -> Result<(), Error> {
+        loop {
+            let mut n = 0usize;
+            check(unsafe { pa_records_pull(stream, text.as_mut_ptr() as *mut _, text.len(), &mut n) })?;
+            if n == 0 { return Ok(()); }
+            out.write_all(&text[..n])?;
+        }
+    };
     let mut records = reader.records();
     loop {
-        let (mut ascii, mut offsets, mut ids) = (Vec::new(), vec![0u64], Vec::new());
-        for r in records.by_ref().take(1 << 20) {
-            let r = r?; ascii.extend_from_slice(r.seq()); offsets.push(ascii.len() as u64); ids.push(r.id().to_owned());
+        let (mut ids, mut id_off, mut seqs, mut seq_off) = (Vec::new(), vec![0u64], Vec::new(), vec![0u64]);
+        for r in records.by_ref().take(1 << 16) {
+            let r = r?;
+            ids.extend_from_slice(r.id().as_bytes()); id_off.push(ids.len() as u64);       // record.id() (:456)
+            seqs.extend_from_slice(r.seq()); seq_off.push(seqs.len() as u64);             // record.seq() (:449)
         }
-        if ids.is_empty() { break; }
-        let n = ids.len();
-        let mut res = vec![PaReadResult::default(); n];
-        let mut coff = vec![0u64; n + 1];
-        let mut cls: *const u32 = std::ptr::null();
-        check(unsafe { pa_map_batch(index.raw, ascii.as_ptr(), offsets.as_ptr(), n as u64, 2, res.as_mut_ptr(), coff.as_mut_ptr(), &mut cls) })?;
-        for i in 0..n {
-            let mapped = res[i].mismatches & PA_MAPPED_BIT != 0;
-            let class: Vec<u32> = unsafe { std::slice::from_raw_parts(cls.add(coff[i] as usize), res[i].class_len as usize) }.to_vec();
-            let cov = if mapped { res[i].coverage as usize } else { 0 };
-            let flag = mapped && cov >= READ_COVERAGE_THRESHOLD && class.is_empty();          // :455
-            println!("{:?}", (flag, ids[i].clone(), class, cov));                             // :490
-        }
+        let n = id_off.len() - 1;
+        if n == 0 { break; }
+        check(unsafe { pa_records_push(stream, ids.as_ptr(), id_off.as_ptr(), seqs.as_ptr(), seq_off.as_ptr(), n as u64) })?;
+        drain(&mut out)?;
     }
+    check(unsafe { pa_records_flush(stream) })?;
+    drain(&mut out)?;
+    out.flush()?;
+    let (mut n_reads, mut n_flagged) = (0u64, 0u64);
+    check(unsafe { pa_record_stream_stats(stream, &mut n_reads, &mut n_flagged) })?;
+    eprintln!();
+    info!("Done Mapping Reads");
+    info!("Mapped {} reads, {} flagged", n_reads, n_flagged);
     Ok(())
 }

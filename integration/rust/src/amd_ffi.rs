@@ -29,6 +29,10 @@ pub struct PaReadResult { pub coverage: u32, pub mismatches: u32, pub class_off:
 #[repr(C)] pub struct PaHostIndex { _private: [u8; 0] }
 #[repr(C)] pub struct PaOverflow { _private: [u8; 0] }
 #[repr(C)] pub struct PaComm { _private: [u8; 0] }
+#[repr(C)] pub struct PaRecordStream { _private: [u8; 0] }
+
+pub const PA_PACKED_LSB_FIRST: c_int = 0;   // base j in bits 2 (j % 32) of word j / 32
+pub const PA_PACKED_MSB_FIRST: c_int = 1;
 
 extern "C" {
     pub fn pa_abi_version() -> u32;
@@ -53,6 +57,18 @@ extern "C" {
                        class_len: *mut u32, coverage: *mut u32) -> c_int;
     pub fn pa_map_read_with_mismatch(idx: *mut PaIndex, ascii: *const u8, len: u32, allowed_mismatches: u32, class_buf: *mut u32,
                                      class_cap: u32, class_len: *mut u32, coverage: *mut u32, mismatches: *mut u32) -> c_int;
+    // reads the caller holds 2-bit packed (a DnaString): no ASCII round trip
+    pub fn pa_map_batch_packed(idx: *mut PaIndex, words: *const u64, word_offsets: *const u64, lens: *const u32, n_reads: u64, layout: c_int,
+                               allowed_mismatches: u32, results: *mut PaReadResult, class_offsets: *mut u64, class_ids: *mut *const u32) -> c_int;
+    pub fn pa_map_read_packed(idx: *mut PaIndex, words: *const u64, len: u32, layout: c_int, allowed_mismatches: u32, class_buf: *mut u32,
+                              class_cap: u32, class_len: *mut u32, coverage: *mut u32, mismatches: *mut u32) -> c_int;
+    // process_reads for a caller that holds the reader: push records, pull the Debug tuples (overlapped batch pipeline inside)
+    pub fn pa_record_stream_create(idx: *mut PaIndex, num_threads: c_int, batch_reads: u64, out: *mut *mut PaRecordStream) -> c_int;
+    pub fn pa_records_push(s: *mut PaRecordStream, ids: *const u8, id_offsets: *const u64, seqs: *const u8, seq_offsets: *const u64, n_records: u64) -> c_int;
+    pub fn pa_records_pull(s: *mut PaRecordStream, buf: *mut c_char, cap: usize, n_bytes: *mut usize) -> c_int;
+    pub fn pa_records_flush(s: *mut PaRecordStream) -> c_int;
+    pub fn pa_record_stream_stats(s: *const PaRecordStream, n_reads: *mut u64, n_flagged: *mut u64) -> c_int;
+    pub fn pa_record_stream_destroy(s: *mut PaRecordStream);
     pub fn pa_process_reads(idx: *mut PaIndex, fastq_path: *const c_char, out_path: *const c_char, num_threads: c_int,
                             n_reads: *mut u64, n_flagged: *mut u64) -> c_int;
     pub fn pa_fastq_scan_host(fastq_path: *const c_char, num_threads: c_int, n_records: *mut u64, starts: *mut u64, header_len: *mut u32,

@@ -339,6 +339,31 @@ class Pseudoaligner:
         class_ids = _np_view(ids.value, int(coff[-1]), np.uint32).copy()
         return results, coff, class_ids
 
+    def map_batch_packed(self, words: np.ndarray, word_offsets: np.ndarray, lens: np.ndarray, layout: int = 0,
+                         allowed_mismatches: int = PA_DEFAULT_ALLOWED_MISMATCHES):
+        """map_batch for reads held 2-bit packed (a DnaString, :450): read i = lens[i] bases in words[word_offsets[i]:word_offsets[i+1]];
+        layout 0 = LSB-first words, 1 = MSB-first words"""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        word_offsets = np.ascontiguousarray(word_offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        n = len(lens)
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        coff = np.zeros(n + 1, dtype=np.uint64)
+        ids = vp()
+        check(lib().pa_map_batch_packed(self._h, words.ctypes.data, word_offsets.ctypes.data, lens.ctypes.data, n, layout, allowed_mismatches,
+                                        results.ctypes.data, coff.ctypes.data, C.byref(ids)))
+        return results, coff, _np_view(ids.value, int(coff[-1]), np.uint32).copy()
+
+    def map_read_packed(self, words: np.ndarray, length: int, layout: int = 0, allowed_mismatches: int = PA_DEFAULT_ALLOWED_MISMATCHES, cap: int = 1 << 16):
+        """map_read_with_mismatch (:361) of one packed read -> (ids, coverage, mismatches) or None"""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        buf = np.zeros(cap, dtype=np.uint32)
+        clen, cov, mm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        rc = lib().pa_map_read_packed(self._h, words.ctypes.data, length, layout, allowed_mismatches, buf.ctypes.data, cap, C.byref(clen), C.byref(cov), C.byref(mm))
+        if rc < 0:
+            check(rc)
+        return (buf[: clen.value].tolist(), cov.value, mm.value) if rc == 1 else None
+
     def map_batch_nodes(self, reads: Sequence, allowed_mismatches: int = PA_DEFAULT_ALLOWED_MISMATCHES):
         data, offsets = reads if isinstance(reads, tuple) else concat_reads(reads)
         n = len(offsets) - 1
@@ -481,6 +506,54 @@ class Overflow:
             if self._h:
                 lib().pa_overflow_destroy(self._h)
                 self._h = vp()
+        except Exception:
+            pass
+
+
+class RecordStream:
+    """pa_record_stream: process_reads for a caller that holds the reader — push records, pull the reference's Debug tuples"""
+
+    def __init__(self, aligner: "Pseudoaligner", num_threads: int = 0, batch_reads: int = 0):
+        h = vp()
+        check(lib().pa_record_stream_create(aligner._h, num_threads, batch_reads, C.byref(h)))
+        self._h = h
+        self._aligner = aligner   # (the index must outlive the stream)
+
+    def push(self, ids: Sequence, seqs: Sequence) -> None:
+        i_data, i_off = concat_reads(ids)
+        s_data, s_off = concat_reads(seqs)
+        check(lib().pa_records_push(self._h, i_data.ctypes.data, i_off.ctypes.data, s_data.ctypes.data, s_off.ctypes.data, len(i_off) - 1))
+
+    def pull(self, cap: int = 1 << 20) -> bytes:
+        buf = C.create_string_buffer(cap)
+        n = C.c_size_t()
+        check(lib().pa_records_pull(self._h, buf, cap, C.byref(n)))
+        return buf.raw[: n.value]
+
+    def flush(self) -> None:
+        check(lib().pa_records_flush(self._h))
+
+    def drain(self, cap: int = 1 << 20) -> bytes:
+        out = []
+        while True:
+            b = self.pull(cap)
+            if not b:
+                return b"".join(out)
+            out.append(b)
+
+    def stats(self) -> Tuple[int, int]:
+        n, f = C.c_uint64(), C.c_uint64()
+        check(lib().pa_record_stream_stats(self._h, C.byref(n), C.byref(f)))
+        return n.value, f.value
+
+    def close(self) -> None:
+        if self._h:
+            lib().pa_record_stream_destroy(self._h)
+            self._h = vp()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

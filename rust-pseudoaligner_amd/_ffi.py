@@ -76,6 +76,14 @@ SIGNATURES = {
     "pa_map_count_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),
     "pa_map_finish": (C.c_int, [vp, vp, u64p, u64p]),
     "pa_index_release_stream": (C.c_int, [vp, vp]),
+    "pa_map_batch_packed": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_uint32, vp, vp, C.POINTER(vp)]),
+    "pa_map_read_packed": (C.c_int, [vp, vp, C.c_uint32, C.c_int, C.c_uint32, vp, C.c_uint32, u32p, u32p, u32p]),
+    "pa_record_stream_create": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "pa_records_push": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64]),
+    "pa_records_pull": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pa_records_flush": (C.c_int, [vp]),
+    "pa_record_stream_stats": (C.c_int, [vp, u64p, u64p]),
+    "pa_record_stream_destroy": (None, [vp]),
     "pa_index_set_timing": (C.c_int, [vp, C.c_int]),
     "pa_map_kernel_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     "pa_map_arena_hint": (C.c_uint64, [vp, C.c_uint64]),

@@ -509,10 +509,32 @@ uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads) {
 }
 
 // ---- host-buffer convenience: H2D, encode, map (retry on arena overflow), D2H, CSR in read order ----
-static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n, uint32_t allowed,
+// The reads of a host batch: ASCII (concatenated, offsets[n+1]) or already 2-bit packed (what a DnaString holds, :450: every
+// read starts on a word boundary of `words`, word_offsets[n+1] in words, lens[n] in bases; layout 0 = this library's
+// LSB-first words, 1 = MSB-first words: base j in bits 62 - 2 (j % 32)).
+struct HostReads {
+    const uint8_t* ascii = nullptr;
+    const uint64_t* offsets = nullptr;
+    const uint64_t* words = nullptr;
+    const uint64_t* word_offsets = nullptr;
+    const uint32_t* lens = nullptr;
+    int layout = 0;
+};
+
+static inline uint64_t msb_to_lsb_first(uint64_t w) {   // reverse the order of the 32 two-bit fields
+    w = ((w >> 2) & 0x3333333333333333ull) | ((w & 0x3333333333333333ull) << 2);
+    w = ((w >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((w & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(w);
+}
+
+static int map_batch_host(pa_index* idx, const HostReads& in, uint64_t n, uint32_t allowed,
                           pa_read_result* results, uint64_t* class_offsets, const uint32_t** class_ids, uint32_t* nodes_flat,
                           uint32_t nodes_stride_cap, uint32_t* nodes_len) {
-    if (!idx || !offsets || (n && !ascii) || !results) return fail(PA_ERR_INVALID_ARG, "null argument");
+    const bool packed = in.words != nullptr || in.word_offsets != nullptr;
+    if (!idx || !results) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (packed ? (!in.word_offsets || !in.lens || (n && !in.words && in.word_offsets[n] != in.word_offsets[0])) : (!in.offsets || (n && !in.ascii)))
+        return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (packed && in.layout != 0 && in.layout != 1) return fail(PA_ERR_INVALID_ARG, "packed layout %d (0 = LSB-first, 1 = MSB-first words)", in.layout);
     std::lock_guard<std::mutex> hg(idx->hmu);
     LaunchCtx* cx = nullptr;
     const int rc0 = ctx_of(idx, nullptr, &cx);
@@ -521,26 +543,51 @@ static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* o
     HIP_TRY(hipSetDevice(idx->device));
     uint64_t maxlen = 1;
     for (uint64_t i = 0; i < n; ++i) {
-        if (offsets[i + 1] < offsets[i]) return fail(PA_ERR_INVALID_ARG, "offsets not monotone at read %llu", (unsigned long long)i);
-        maxlen = std::max<uint64_t>(maxlen, offsets[i + 1] - offsets[i]);
+        if (packed) {
+            if (in.word_offsets[i + 1] < in.word_offsets[i] || (uint64_t)(in.lens[i] + 31) / 32 > in.word_offsets[i + 1] - in.word_offsets[i])
+                return fail(PA_ERR_INVALID_ARG, "read %llu: %u bases do not fit its words", (unsigned long long)i, in.lens[i]);
+            maxlen = std::max<uint64_t>(maxlen, in.lens[i]);
+        } else {
+            if (in.offsets[i + 1] < in.offsets[i]) return fail(PA_ERR_INVALID_ARG, "offsets not monotone at read %llu", (unsigned long long)i);
+            maxlen = std::max<uint64_t>(maxlen, in.offsets[i + 1] - in.offsets[i]);
+        }
     }
     if (maxlen > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
     const uint32_t wpr = pa_words_per_read((uint32_t)maxlen);
-    const uint64_t total_ascii = n ? offsets[n] - offsets[0] : 0;
     hipStream_t st = nullptr;
     int rc;
-    if ((rc = idx->b_ascii.ensure(total_ascii + 64)) || (rc = idx->b_offsets.ensure((n + 1) * 8)) ||
-        (rc = idx->b_tiles.ensure(pa_tiles_words(n, wpr) * 8 + 8)) || (rc = idx->b_lens.ensure((n + 64) * 4)) ||
+    if ((rc = idx->b_tiles.ensure(pa_tiles_words(n, wpr) * 8 + 8)) || (rc = idx->b_lens.ensure((n + 64) * 4)) ||
         (rc = idx->b_results.ensure((n + 1) * sizeof(pa_read_result))))
         return rc;
     if (n == 0) { if (class_offsets) class_offsets[0] = 0; if (class_ids) *class_ids = nullptr; return PA_OK; }
-    std::vector<uint64_t> rel(n + 1);
-    for (uint64_t i = 0; i <= n; ++i) rel[i] = offsets[i] - offsets[0];
-    HIP_TRY(hipMemcpyAsync(idx->b_ascii.p, ascii + offsets[0], total_ascii, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(idx->b_offsets.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
-    int e = launch_encode(idx->b_ascii.as<uint8_t>(), idx->b_offsets.as<uint64_t>(), n, wpr, idx->b_tiles.as<uint64_t>(),
-                          idx->b_lens.as<uint32_t>(), st);
-    if (e) return fail(PA_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
+    if (packed) {   // the words go into the tile layout on the host (bases beyond a read's length cleared, as the encoder leaves them)
+        std::vector<uint64_t> tiles(pa_tiles_words(n, wpr), 0);
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t* w = in.words + in.word_offsets[i];
+            const uint32_t len = in.lens[i], nw = (len + 31) / 32;
+            uint64_t* dst = tiles.data() + ((i >> 6) * wpr) * 64 + (i & 63);
+            for (uint32_t j = 0; j < nw; ++j) {
+                uint64_t v = in.layout == 1 ? msb_to_lsb_first(w[j]) : w[j];
+                const uint32_t rem = len - 32 * j;
+                if (rem < 32) v &= (1ull << (2 * rem)) - 1;
+                dst[(uint64_t)j * 64] = v;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(idx->b_tiles.p, tiles.data(), tiles.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(idx->b_lens.p, in.lens, n * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));   // (`tiles` is pageable and dies with this block)
+    } else {
+        const uint64_t total_ascii = in.offsets[n] - in.offsets[0];
+        if ((rc = idx->b_ascii.ensure(total_ascii + 64)) || (rc = idx->b_offsets.ensure((n + 1) * 8))) return rc;
+        std::vector<uint64_t> rel(n + 1);
+        for (uint64_t i = 0; i <= n; ++i) rel[i] = in.offsets[i] - in.offsets[0];
+        HIP_TRY(hipMemcpyAsync(idx->b_ascii.p, in.ascii + in.offsets[0], total_ascii, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(idx->b_offsets.p, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
+        int e = launch_encode(idx->b_ascii.as<uint8_t>(), idx->b_offsets.as<uint64_t>(), n, wpr, idx->b_tiles.as<uint64_t>(),
+                              idx->b_lens.as<uint32_t>(), st);
+        if (e) return fail(PA_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)e));
+        HIP_TRY(hipStreamSynchronize(st));   // (`rel` is pageable and dies with this block)
+    }
     const uint32_t spill_cap = spill_cap_of(wpr);
     uint32_t *d_nodes = nullptr, *d_nodes_len = nullptr;
     if (nodes_flat) {
@@ -596,7 +643,40 @@ static int map_batch_host(pa_index* idx, const uint8_t* ascii, const uint64_t* o
 
 int pa_map_batch(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads, uint32_t allowed_mismatches,
                  pa_read_result* results, uint64_t* class_offsets, const uint32_t** class_ids) {
-    return map_batch_host(idx, ascii, offsets, n_reads, allowed_mismatches, results, class_offsets, class_ids, nullptr, 0, nullptr);
+    HostReads in;
+    in.ascii = ascii;
+    in.offsets = offsets;
+    if (!offsets) return fail(PA_ERR_INVALID_ARG, "null argument");
+    return map_batch_host(idx, in, n_reads, allowed_mismatches, results, class_offsets, class_ids, nullptr, 0, nullptr);
+}
+
+int pa_map_batch_packed(pa_index* idx, const uint64_t* words, const uint64_t* word_offsets, const uint32_t* lens, uint64_t n_reads, int layout,
+                        uint32_t allowed_mismatches, pa_read_result* results, uint64_t* class_offsets, const uint32_t** class_ids) {
+    HostReads in;
+    in.words = words;
+    in.word_offsets = word_offsets;
+    in.lens = lens;
+    in.layout = layout;
+    if (!word_offsets || !lens) return fail(PA_ERR_INVALID_ARG, "null argument");
+    return map_batch_host(idx, in, n_reads, allowed_mismatches, results, class_offsets, class_ids, nullptr, 0, nullptr);
+}
+
+// map_read_with_mismatch on a read the caller holds 2-bit packed (a DnaString): no ASCII round trip
+int pa_map_read_packed(pa_index* idx, const uint64_t* words, uint32_t len, int layout, uint32_t allowed_mismatches, uint32_t* class_buf,
+                       uint32_t class_cap, uint32_t* class_len, uint32_t* coverage, uint32_t* mismatches) {
+    const uint64_t word_offsets[2] = {0, (len + 31) / 32};
+    pa_read_result r;
+    uint64_t co[2];
+    const uint32_t* ids = nullptr;
+    const int rc = pa_map_batch_packed(idx, words, word_offsets, &len, 1, layout, allowed_mismatches, &r, co, &ids);
+    if (rc != PA_OK) return rc;
+    if (class_len) *class_len = r.class_len;
+    if (coverage) *coverage = r.coverage;
+    if (mismatches) *mismatches = r.mismatches & ~PA_MAPPED_BIT;
+    if (!(r.mismatches & PA_MAPPED_BIT)) return 0;
+    if (r.class_len > class_cap) return fail(PA_ERR_INVALID_ARG, "class buffer too small: %u ids", r.class_len);
+    if (r.class_len && class_buf) memcpy(class_buf, ids, r.class_len * 4ull);
+    return 1;
 }
 
 int pa_map_read_with_mismatch(pa_index* idx, const uint8_t* ascii, uint32_t len, uint32_t allowed_mismatches, uint32_t* class_buf,
@@ -627,7 +707,10 @@ int pa_map_read_to_nodes(pa_index* idx, const uint8_t* ascii, uint32_t len, uint
     pa_read_result r;
     uint32_t nn = 0;
     std::vector<uint32_t> tmp(node_cap ? node_cap : 1);
-    const int rc = map_batch_host(idx, ascii, offsets, 1, allowed_mismatches, &r, nullptr, nullptr, tmp.data(), node_cap, &nn);
+    HostReads in;
+    in.ascii = ascii;
+    in.offsets = offsets;
+    const int rc = map_batch_host(idx, in, 1, allowed_mismatches, &r, nullptr, nullptr, tmp.data(), node_cap, &nn);
     if (rc != PA_OK) return rc;
     if (num_nodes) *num_nodes = nn;
     if (coverage) *coverage = r.coverage;
@@ -641,7 +724,11 @@ int pa_map_read_to_nodes(pa_index* idx, const uint8_t* ascii, uint32_t len, uint
 // batch variant of the node trace (test surface)
 int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offsets, uint64_t n_reads, uint32_t allowed_mismatches,
                        pa_read_result* results, uint32_t* nodes_flat, uint32_t nodes_stride, uint32_t* nodes_len) {
-    return map_batch_host(idx, ascii, offsets, n_reads, allowed_mismatches, results, nullptr, nullptr, nodes_flat, nodes_stride, nodes_len);
+    HostReads in;
+    in.ascii = ascii;
+    in.offsets = offsets;
+    if (!offsets) return fail(PA_ERR_INVALID_ARG, "null argument");
+    return map_batch_host(idx, in, n_reads, allowed_mismatches, results, nullptr, nullptr, nodes_flat, nodes_stride, nodes_len);
 }
 
 int pa_counts_by_barcode_device(pa_index* idx, const pa_read_result* d_results, const uint32_t* d_arena, const uint32_t* d_barcode, uint64_t n_reads,

@@ -1,0 +1,203 @@
+// process_reads (src/pseudoaligner.rs:420-514) for a caller that HOLDS the reader: the reference's signature consumes an open
+// fastq::Reader (:421), so a drop-in replacement cannot ask for a path. The caller pushes the records it reads — ids as
+// record.id() gives them (:456), sequences as record.seq() (:449) — and pulls the reference's Debug tuples (:490) in push order.
+// Behind the two calls runs the batch pipeline of fastq.cpp with its stages overlapped (ingest.hpp):
+//
+//   push     records are copied into the batch being filled; a full batch is 2-bit packed into pinned tiles by the worker
+//            pool and launched (H2D -> pa_map_batch_device -> D2H on the stream's own HIP stream), then the PREVIOUS batch —
+//            whose GPU leg ran while this one was being filled — is rendered into text by the pool
+//   pull     copies rendered text out, whole lines, never waits for the GPU
+//   flush    launches what is left, waits, renders: afterwards pull drains everything pushed so far
+//
+// The GPU leg of batch b therefore overlaps the caller's reading + the packing of batch b + 1 and the rendering of batch b - 1,
+// exactly as in pa_process_reads; output order is input order (the reference's is completion order, :490).
+#include <hip/hip_runtime.h>
+
+#include <deque>
+#include <memory>
+#include <new>
+
+#include "ingest.hpp"
+#include "pa_common.hpp"
+
+using namespace pa;
+using namespace pa::ingest;
+
+struct pa_record_stream {
+    pa_index* idx = nullptr;
+    std::unique_ptr<Pool> pool;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
+    uint64_t batch_reads = 4u << 20;
+    BatchCtx ctx[2];
+    std::vector<char> text[2];     // ids and sequences of the batch's records (Record offsets point into it)
+    uint32_t maxlen[2] = {0, 0};
+    bool inflight[2] = {false, false};
+    int cur = 0;                   // the batch being filled
+    std::deque<TextBuf> outq;      // rendered text in order; out_off = bytes of the front buffer already pulled
+    size_t out_off = 0;
+    uint64_t n_reads = 0, n_flagged = 0;
+    int rc = PA_OK;                // sticky: after a failure every call reports it
+    std::string why;
+};
+
+namespace {
+
+int fail_sticky(pa_record_stream* s, int rc) {
+    if (s->rc == PA_OK) { s->rc = rc; s->why = last_error_ref(); }
+    return rc;
+}
+
+void render(pa_record_stream* s, int k) {
+    BatchCtx& c = s->ctx[k];
+    const int P = s->pool->size() * 4;
+    std::vector<TextBuf> parts((size_t)P);
+    std::vector<uint64_t> flags((size_t)P, 0);
+    const char* text = s->text[k].data();
+    s->pool->run(P, [&](int t) {
+        TextBuf buf;
+        flags[(size_t)t] = format_records(c, c.n * (uint64_t)t / P, c.n * (uint64_t)(t + 1) / P, text, s->h_ec, s->h_class_ref, buf);
+        parts[(size_t)t] = std::move(buf);
+    });
+    for (uint64_t f : flags) s->n_flagged += f;
+    s->n_reads += c.n;
+    for (TextBuf& b : parts)
+        if (b.len) s->outq.push_back(std::move(b));
+    s->inflight[k] = false;
+    c.recs.clear();
+    c.n = 0;
+    s->text[k].clear();
+    s->maxlen[k] = 0;
+}
+
+// the batch being filled goes to the GPU; the one before it is waited for and rendered
+int submit(pa_record_stream* s) {
+    const int k = s->cur, o = k ^ 1;
+    BatchCtx& c = s->ctx[k];
+    c.n = c.recs.size();
+    if (c.n == 0) return PA_OK;
+    if (s->maxlen[k] > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
+    c.wpr = pa_words_per_read(s->maxlen[k] ? s->maxlen[k] : 1);
+    int rc = batch_ensure(s->idx, c, c.n, c.wpr, s->batch_reads);
+    if (rc != PA_OK) return rc;
+    batch_pack_tiles(*s->pool, c, s->text[k].data());
+    if (s->inflight[o] && (rc = batch_finish(s->idx, s->ctx[o], s->stream)) != PA_OK) return rc;
+    if ((rc = batch_launch(s->idx, c, s->stream)) != PA_OK) return rc;
+    s->inflight[k] = true;
+    if (s->inflight[o]) render(s, o);
+    s->cur = o;
+    return PA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads, pa_record_stream** out) {
+    if (!idx || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    pa_record_stream* s = new (std::nothrow) pa_record_stream();
+    if (!s) return fail(PA_ERR_OOM, "out of memory");
+    s->idx = idx;
+    index_host_classes(idx, &s->h_ec, &s->h_class_ref, &s->device);
+    if (batch_reads) s->batch_reads = std::max<uint64_t>(64, batch_reads / 64 * 64);
+    int T = num_threads > 0 ? num_threads : usable_threads();
+    if (T < 1) T = 1;
+    s->pool.reset(new Pool(T));
+    if (hipSetDevice(s->device) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess) {
+        s->stream = nullptr;
+        pa_record_stream_destroy(s);
+        return fail(PA_ERR_HIP, "hipStreamCreate failed");
+    }
+    *out = s;
+    return PA_OK;
+}
+
+void pa_record_stream_destroy(pa_record_stream* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) {
+        (void)pa_index_release_stream(s->idx, s->stream);   // (synchronises the stream; its launch context inside the index goes with it)
+        (void)hipStreamDestroy(s->stream);
+    }
+    for (BatchCtx& b : s->ctx) b.release();
+    delete s;
+}
+
+int pa_records_push(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs, const uint64_t* seq_offsets, uint64_t n) {
+    if (!s || (n && (!id_offsets || !seq_offsets))) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (s->rc != PA_OK) return fail(s->rc, "%s", s->why.c_str());
+    if (hipSetDevice(s->device) != hipSuccess) return fail_sticky(s, fail(PA_ERR_HIP, "hipSetDevice failed"));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (id_offsets[i + 1] < id_offsets[i] || seq_offsets[i + 1] < seq_offsets[i]) return fail(PA_ERR_INVALID_ARG, "offsets not monotone at record %llu", (unsigned long long)i);
+        const uint64_t il = id_offsets[i + 1] - id_offsets[i], sl = seq_offsets[i + 1] - seq_offsets[i];
+        if (il > 0xFFFFFFFFull || sl > 0xFFFFFFFFull || (il && !ids) || (sl && !seqs)) return fail(PA_ERR_INVALID_ARG, "record %llu: bad id or sequence", (unsigned long long)i);
+        const int k = s->cur;
+        std::vector<char>& t = s->text[k];
+        Record r;
+        r.id_off = t.size();
+        r.id_len = (uint32_t)il;
+        if (il) t.insert(t.end(), (const char*)ids + id_offsets[i], (const char*)ids + id_offsets[i + 1]);
+        r.seq_off = t.size();
+        r.seq_len = (uint32_t)sl;
+        if (sl) t.insert(t.end(), (const char*)seqs + seq_offsets[i], (const char*)seqs + seq_offsets[i + 1]);
+        s->ctx[k].recs.push_back(r);
+        s->maxlen[k] = std::max(s->maxlen[k], r.seq_len);
+        if (s->ctx[k].recs.size() >= s->batch_reads) {
+            const int rc = submit(s);
+            if (rc != PA_OK) return fail_sticky(s, rc);
+        }
+    }
+    return PA_OK;
+}
+
+int pa_records_flush(pa_record_stream* s) {
+    if (!s) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (s->rc != PA_OK) return fail(s->rc, "%s", s->why.c_str());
+    if (hipSetDevice(s->device) != hipSuccess) return fail_sticky(s, fail(PA_ERR_HIP, "hipSetDevice failed"));
+    int rc = submit(s);   // what is left of the batch being filled (renders the batch before it)
+    if (rc != PA_OK) return fail_sticky(s, rc);
+    for (int k = 0; k < 2; ++k) {
+        const int b = s->cur ^ 1 ^ k;   // the batch launched last is the one before `cur`
+        if (!s->inflight[b]) continue;
+        if ((rc = batch_finish(s->idx, s->ctx[b], s->stream)) != PA_OK) return fail_sticky(s, rc);
+        render(s, b);
+    }
+    return PA_OK;
+}
+
+int pa_records_pull(pa_record_stream* s, char* buf, size_t cap, size_t* n_bytes) {
+    if (!s || !n_bytes || (cap && !buf)) return fail(PA_ERR_INVALID_ARG, "null argument");
+    *n_bytes = 0;
+    if (s->rc != PA_OK) return fail(s->rc, "%s", s->why.c_str());
+    size_t got = 0;
+    while (!s->outq.empty() && got < cap) {
+        TextBuf& f = s->outq.front();
+        const size_t left = f.len - s->out_off, room = cap - got;
+        size_t take = left;
+        if (take > room) {   // whole lines only
+            const void* nl = memrchr(f.mem.data() + s->out_off, '\n', room);
+            take = nl ? (size_t)((const char*)nl - (f.mem.data() + s->out_off)) + 1 : 0;
+            if (take == 0) {
+                if (got == 0) return fail(PA_ERR_INVALID_ARG, "buffer of %zu bytes is smaller than one tuple", cap);
+                break;
+            }
+        }
+        memcpy(buf + got, f.mem.data() + s->out_off, take);
+        got += take;
+        s->out_off += take;
+        if (s->out_off == f.len) { s->outq.pop_front(); s->out_off = 0; }
+        else break;   // the buffer is full up to a line boundary
+    }
+    *n_bytes = got;
+    return PA_OK;
+}
+
+int pa_record_stream_stats(const pa_record_stream* s, uint64_t* n_reads, uint64_t* n_flagged) {
+    if (!s) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (n_reads) *n_reads = s->n_reads;
+    if (n_flagged) *n_flagged = s->n_flagged;
+    return PA_OK;
+}
+
+}  // extern "C"

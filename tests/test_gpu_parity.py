@@ -302,6 +302,89 @@ def _expected_lines(a, ids, seqs):
     return want
 
 
+def _pack_words(seqs, msb_first=False):
+    """reads as a DnaString holds them: 2-bit words, every read on a word boundary (checker-side packer: helpers.pack_read)"""
+    words, offs, lens = [], [0], []
+    for s in seqs:
+        w = helpers.pack_read(s)[: (len(s) + 31) // 32].copy()
+        if msb_first:   # base j in bits 62 - 2 (j % 32): the 32 two-bit fields of every word in the opposite order
+            out = np.zeros_like(w)
+            for j in range(32):
+                out |= ((w >> np.uint64(2 * j)) & np.uint64(3)) << np.uint64(62 - 2 * j)
+            w = out
+        words.append(w)
+        offs.append(offs[-1] + len(w))
+        lens.append(len(s))
+    return (np.concatenate(words) if words else np.zeros(0, np.uint64)), np.array(offs, np.uint64), np.array(lens, np.uint32)
+
+
+@pytest.mark.parametrize("k", [20, 64])
+def test_packed_reads_map_like_their_ascii(aligners, k):
+    """pa_map_batch_packed / pa_map_read_packed (map_read(&DnaString), src/pseudoaligner.rs:381): reads handed over as 2-bit
+    words, in both word orders, against the oracle; ragged lengths, empty and shorter-than-k reads, garbage beyond a read's length"""
+    a = aligners(k) if k == 20 else pa.Pseudoaligner(pa.build_index(str(helpers.FASTA), k, 8), 0)
+    _, seqs = helpers.read_fastq()
+    rng = np.random.default_rng(11)
+    reads = [s[: int(rng.integers(0, 61))] for s in seqs[:500]] + seqs[500:3000] + ["", "ACGT", seqs[0] * 3]
+    o_res, o_coff, o_ids, _ = helpers.Oracle(a.host).map_reads(reads, 2, 4)
+    for msb in (False, True):
+        words, offs, lens = _pack_words(reads, msb)
+        junk = words.copy()
+        for i, L in enumerate(lens):   # bits beyond the last base must not matter
+            if L % 32 and L:
+                last = int(offs[i]) + (int(L) - 1) // 32
+                keep = np.uint64((1 << (2 * (int(L) % 32))) - 1)
+                junk[last] |= ~(keep if not msb else ~np.uint64((1 << (64 - 2 * (int(L) % 32))) - 1))
+        res, coff, cids = a.map_batch_packed(junk, offs, lens, 1 if msb else 0, 2)
+        helpers.assert_same_as_oracle(res, coff, cids, o_res, o_coff, o_ids, "packed reads, msb_first=%s" % msb)
+    words, offs, lens = _pack_words(reads)
+    for i in (0, 600, 2999, len(reads) - 1, len(reads) - 3):
+        got = a.map_read_packed(words[int(offs[i]):int(offs[i + 1])], int(lens[i]))
+        want = (o_ids[int(o_coff[i]):int(o_coff[i + 1])].tolist(), int(o_res["coverage"][i]), int(o_res["mismatches"][i])) if o_res["mapped"][i] else None
+        assert got == want, i
+    with pytest.raises(pa.PaError):
+        a.map_batch_packed(words, offs, lens, 7)                       # unknown layout
+    with pytest.raises(pa.PaError):
+        a.map_batch_packed(words[:1], np.array([0, 1], np.uint64), np.array([40], np.uint32))   # 40 bases do not fit one word
+
+
+def test_record_stream_is_process_reads_for_a_caller_that_holds_the_reader(aligners):
+    """pa_record_stream_*: records pushed in uneven chunks through small batches (seams, words per read changing between batches),
+    tuples pulled in push order == the oracle's tuples; nothing is rendered before a batch is full or flushed"""
+    a = aligners(24)
+    ids, seqs = helpers.read_fastq()
+    rng = np.random.default_rng(9)
+    ids, seqs = list(ids[:5000]), list(seqs[:5000])
+    for i in range(0, 5000, 7):
+        seqs[i] = seqs[i][: int(rng.integers(0, 61))]
+    seqs[100] = seqs[101] * 4                                            # one long read: its batch needs more words per read
+    weird = 'we"ird\\id\ttab'                                            # a quote, a backslash, a tab: Rust's Debug escapes them
+    ids[5] = weird
+    seqs[6] = seqs[6].lower().replace("a", "n", 1)
+    want = [w.replace(weird, 'we\\"ird\\\\id\\ttab') for w in _expected_lines(a, ids, seqs)]
+    for batch, threads in ((640, 3), (64, 1), (0, 0)):
+        rs = pa.RecordStream(a, threads, batch)
+        got = b""
+        i = 0
+        while i < len(ids):
+            n = int(rng.integers(1, 900))
+            rs.push(ids[i:i + n], seqs[i:i + n])
+            got += rs.drain(1 << 12)                                     # small pulls: whole lines only
+            i += n
+        if batch == 0:
+            assert got == b""                                            # 5000 records never fill the default batch: nothing yet
+        rs.flush()
+        if batch == 0:
+            with pytest.raises(pa.PaError):
+                rs.pull(8)                                               # smaller than one tuple: refused, nothing lost
+        got += rs.drain()
+        assert rs.stats() == (len(ids), sum(1 for w in want if w.startswith("(true")))
+        assert got.decode().splitlines() == want, (batch, threads)
+        rs.flush()                                                       # nothing pending: a no-op
+        assert rs.drain() == b""
+        rs.close()
+
+
 def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
     """the ingest pipeline of process_reads: many small batches, every thread count, CRLF, no final newline, trailing
     blank lines, ragged read lengths (words per read change between batches), lower case and N, empty input"""
