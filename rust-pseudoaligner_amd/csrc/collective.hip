@@ -386,7 +386,9 @@ int pa_counts_allreduce(pa_index* idx, uint64_t* d_counts, pa_comm* comm, void* 
 
 int pa_overflow_allgather(pa_overflow* o, pa_comm* comm, void* stream, const uint32_t** words, uint64_t* n_words) {
     if (!o || !words || !n_words) return fail(PA_ERR_INVALID_ARG, "null argument");
-    if (!comm || comm->nranks == 1) return pa_overflow_fetch(o, stream, words, n_words);   // one GPU: the local table is the global one
+    // no communicator = one GPU: the local table is the global one. A communicator of ONE rank deliberately takes the collective
+    // path below (it costs a millisecond): it is the only way a one-GPU box — every test box — executes that code at all
+    if (!comm) return pa_overflow_fetch(o, stream, words, n_words);
     std::lock_guard<std::mutex> g(o->mu);
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint64_t nw = 0;
