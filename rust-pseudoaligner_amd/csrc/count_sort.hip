@@ -29,9 +29,21 @@ constexpr uint32_t MAX_BINS = 256;                       // tables of up to 8.4 
 constexpr uint32_t BIN_SLOTS = 1u << PA_KEY_BIN_SHIFT;
 constexpr uint32_t CS_BLOCK = 1024;
 
-__device__ __forceinline__ uint64_t stream_len(const unsigned long long* keys_top, uint64_t keys_cap) {
-    const unsigned long long t = *keys_top;
-    return t < keys_cap ? t : keys_cap;
+// The keys of a launch: what the waves of the map kernel appended (whole chunks of PA_KEY_CHUNK, *keys_top entries) and, right
+// behind them in the same buffer, one key per deferred read from pa_resolve_kernel (resolve.hip: as many as the stream of deferred
+// reads holds, a multiple of PA_DEFER_CHUNK; *extra_top, may be null). Both are multiples of four.
+struct KeyTops {
+    const unsigned long long* top;
+    uint64_t cap;
+    const unsigned long long* extra_top;
+    uint64_t extra_cap;
+};
+__device__ __forceinline__ uint64_t stream_len(const KeyTops k, uint64_t unused = 0) {
+    (void)unused;
+    unsigned long long t = *k.top, x = k.extra_top ? *k.extra_top : 0ull;
+    if (t > k.cap) t = k.cap;
+    if (x > k.extra_cap) x = k.extra_cap;
+    return t + x;
 }
 
 // Counting sort of the keys by bin without a single global atomic: the stream is cut into one slice per workgroup;
@@ -52,13 +64,12 @@ __device__ __forceinline__ void slice_of(uint64_t n, uint32_t g, uint32_t G, uin
     if (a > n) a = n;
 }
 
-__global__ __launch_bounds__(SC_BLOCK) void pa_keys_hist_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ keys_top,
-                                                                uint64_t keys_cap, uint32_t nbins, uint32_t* __restrict__ wg_hist) {
+__global__ __launch_bounds__(SC_BLOCK) void pa_keys_hist_kernel(const uint32_t* __restrict__ keys, const KeyTops keys_top, uint32_t nbins, uint32_t* __restrict__ wg_hist) {
     __shared__ uint32_t h[MAX_BINS];
     for (uint32_t i = threadIdx.x; i < nbins; i += SC_BLOCK) h[i] = 0;
     __syncthreads();
     uint64_t a, b;
-    slice_of(stream_len(keys_top, keys_cap), blockIdx.x, gridDim.x, a, b);
+    slice_of(stream_len(keys_top), blockIdx.x, gridDim.x, a, b);
     const uint4* k4 = reinterpret_cast<const uint4*>(keys);   // (chunks and tiles are multiples of 4 entries: 16-byte loads)
     for (uint64_t i = a / 4 + threadIdx.x; i < b / 4; i += SC_BLOCK) {
         const uint4 v = k4[i];
@@ -101,13 +112,12 @@ __global__ __launch_bounds__(1024) void pa_keys_scan_kernel(const uint32_t* __re
     if (t == 1023) hist[bin] = red[t];
 }
 
-__global__ __launch_bounds__(SC_BLOCK) void pa_keys_scatter_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ keys_top,
-                                                                   uint64_t keys_cap, uint32_t nbins, const uint32_t* __restrict__ wg_base,
+__global__ __launch_bounds__(SC_BLOCK) void pa_keys_scatter_kernel(const uint32_t* __restrict__ keys, const KeyTops keys_top, uint32_t nbins, const uint32_t* __restrict__ wg_base,
                                                                    uint32_t* __restrict__ sorted) {
     __shared__ uint32_t cnt[MAX_BINS], lbase[MAX_BINS], gbase[MAX_BINS], cursor[MAX_BINS], stage[SC_TILE], total;
     for (uint32_t b = threadIdx.x; b < nbins; b += SC_BLOCK) cursor[b] = wg_base[(uint64_t)b * gridDim.x + blockIdx.x];
     uint64_t sa, sb;
-    slice_of(stream_len(keys_top, keys_cap), blockIdx.x, gridDim.x, sa, sb);
+    slice_of(stream_len(keys_top), blockIdx.x, gridDim.x, sa, sb);
     for (uint64_t t0 = sa; t0 < sb; t0 += SC_TILE) {
         for (uint32_t b = threadIdx.x; b < nbins; b += SC_BLOCK) cnt[b] = 0;
         __syncthreads();
@@ -146,8 +156,7 @@ __global__ __launch_bounds__(SC_BLOCK) void pa_keys_scatter_kernel(const uint32_
 
 // counts[(bin << 15) + i] += occurrences of that key. Workgroup (bin, part) takes part `part` of `parts` of the bin's keys.
 // hist == nullptr: one bin, the raw streams (padding skipped).
-__global__ __launch_bounds__(CS_BLOCK) void pa_keys_count_kernel(const uint32_t* __restrict__ src, const unsigned long long* __restrict__ keys_top,
-                                                                 uint64_t keys_cap, const uint32_t* __restrict__ hist, uint32_t parts,
+__global__ __launch_bounds__(CS_BLOCK) void pa_keys_count_kernel(const uint32_t* __restrict__ src, const KeyTops keys_top, const uint32_t* __restrict__ hist, uint32_t parts,
                                                                  unsigned long long* __restrict__ counts, uint64_t counts_len) {
     extern __shared__ uint32_t tab[];   // BIN_SLOTS counters (or counts_len when that is less)
     const uint32_t bin = blockIdx.x / parts, part = blockIdx.x % parts;
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(CS_BLOCK) void pa_keys_count_kernel(const uint32_t*
     if (hist) {
         for (uint32_t j = 0; j < bin; ++j) lo += hist[j];
         n = hist[bin];
-    } else n = stream_len(keys_top, keys_cap);
+    } else n = stream_len(keys_top);
     const uint64_t a = lo + n * part / parts, b = lo + n * (part + 1) / parts;
     // 16-byte loads, four in flight per thread (one dependent round trip per iteration otherwise); the few keys before the
     // first and after the last aligned quad go one by one
@@ -195,45 +204,14 @@ __global__ __launch_bounds__(CS_BLOCK) void pa_keys_count_kernel(const uint32_t*
 }
 
 // tables beyond MAX_BINS bins: plain atomics per key
-__global__ __launch_bounds__(256) void pa_keys_count_direct_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ keys_top,
-                                                                   uint64_t keys_cap, unsigned long long* __restrict__ counts) {
-    const uint64_t n = stream_len(keys_top, keys_cap);
+__global__ __launch_bounds__(256) void pa_keys_count_direct_kernel(const uint32_t* __restrict__ keys, const KeyTops keys_top, unsigned long long* __restrict__ counts) {
+    const uint64_t n = stream_len(keys_top);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t k = keys[i];
         if (k != NO_KEY) atomicAdd(counts + k, 1ull);
     }
 }
 
-#ifdef PA_DEBUG_KNOBS
-// A/B experiment (PA_COUNT_MODE=1): no sort — every key is one workgroup-scope atomic into this XCD's replica of the table, executed
-// in that XCD's L2 (nothing but the key stream passes through the L2 in this kernel, so the replica stays resident), and a fold
-// kernel adds the eight replicas into the caller's table. Prices the L2's atomic rate against the three-kernel sort.
-__global__ __launch_bounds__(256) void pa_keys_count_l2_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ keys_top, uint64_t keys_cap,
-                                                               uint32_t* __restrict__ rep, uint64_t stride) {
-    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;   // HW_REG_XCC_ID
-    uint32_t* mine = rep + (uint64_t)xcc * stride;
-    const uint64_t n4 = stream_len(keys_top, keys_cap) / 4;
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const u32x4_t* k4 = reinterpret_cast<const u32x4_t*>(keys);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
-        const u32x4_t v = __builtin_nontemporal_load(k4 + i);
-        if (v.x != NO_KEY) __hip_atomic_fetch_add(mine + v.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (v.y != NO_KEY) __hip_atomic_fetch_add(mine + v.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (v.z != NO_KEY) __hip_atomic_fetch_add(mine + v.z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (v.w != NO_KEY) __hip_atomic_fetch_add(mine + v.w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-}
-__global__ __launch_bounds__(256) void pa_keys_fold_kernel(uint32_t* __restrict__ rep, uint64_t stride, unsigned long long* __restrict__ counts, uint64_t len) {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= len) return;
-    unsigned long long sum = 0;
-    for (uint32_t r = 0; r < 8; ++r) {
-        const uint32_t v = rep[r * stride + c];
-        if (v) { sum += v; rep[r * stride + c] = 0; }
-    }
-    if (sum) atomicAdd(counts + c, sum);
-}
-#endif
 
 }  // namespace
 
@@ -248,9 +226,10 @@ size_t count_keys_ctl_bytes(uint64_t counts_len) {
     return (MAX_BINS + 2 * (size_t)std::min<uint64_t>(nbins, MAX_BINS) * SC_MAX_GRID) * 4;
 }
 
-int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top, uint64_t keys_cap, uint32_t* sorted, uint32_t* ctl,
-                      unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream) {
+int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top_ptr, uint64_t keys_cap, const unsigned long long* extra_top, uint64_t extra_cap,
+                      uint32_t* sorted, uint32_t* ctl, unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream) {
     if (counts_len == 0) return 0;
+    const KeyTops keys_top{keys_top_ptr, keys_cap, extra_top, extra_cap};
     const uint64_t nbins = (counts_len + BIN_SLOTS - 1) >> PA_KEY_BIN_SHIFT;
     const uint32_t cus = num_cus > 0 ? (uint32_t)num_cus : 256u;
     const size_t lds = (size_t)(counts_len < BIN_SLOTS ? counts_len : BIN_SLOTS) * 4;
@@ -259,26 +238,12 @@ int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top, 
         const hipError_t e = hipFuncSetAttribute(count_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-#ifdef PA_DEBUG_KNOBS
-    if (knob_int("PA_COUNT_MODE", 0) == 1) {
-        static uint32_t* rep = nullptr;   // (experiment only: one table, never freed)
-        const uint64_t stride = (counts_len + 63) / 64 * 64;
-        if (!rep) { if (hipMalloc(&rep, 8 * stride * 4) != hipSuccess || hipMemset(rep, 0, 8 * stride * 4) != hipSuccess) return (int)hipErrorOutOfMemory; }
-        hipLaunchKernelGGL(pa_keys_count_l2_kernel, dim3(cus * 8), dim3(256), 0, stream, keys, keys_top, keys_cap, rep, stride);
-        hipLaunchKernelGGL(pa_keys_fold_kernel, dim3((uint32_t)((counts_len + 255) / 256)), dim3(256), 0, stream, rep, stride, counts, counts_len);
-        return (int)hipGetLastError();
-    }
-    if (knob_int("PA_COUNT_MODE", 0) == 2) {
-        hipLaunchKernelGGL(pa_keys_count_direct_kernel, dim3(cus * 8), dim3(256), 0, stream, keys, keys_top, keys_cap, counts);
-        return (int)hipGetLastError();
-    }
-#endif
     if (nbins > MAX_BINS) {
-        hipLaunchKernelGGL(pa_keys_count_direct_kernel, dim3(cus * 8), dim3(256), 0, stream, keys, keys_top, keys_cap, counts);
+        hipLaunchKernelGGL(pa_keys_count_direct_kernel, dim3(cus * 8), dim3(256), 0, stream, keys, keys_top, counts);
         return (int)hipGetLastError();
     }
     if (nbins == 1) {
-        hipLaunchKernelGGL(pa_keys_count_kernel, dim3(cus), dim3(CS_BLOCK), lds, stream, keys, keys_top, keys_cap, (const uint32_t*)nullptr, cus, counts,
+        hipLaunchKernelGGL(pa_keys_count_kernel, dim3(cus), dim3(CS_BLOCK), lds, stream, keys, keys_top, (const uint32_t*)nullptr, cus, counts,
                            counts_len);
         return (int)hipGetLastError();
     }
@@ -287,13 +252,13 @@ int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top, 
     uint32_t* hist = ctl;
     uint32_t* wg_hist = ctl + MAX_BINS;
     uint32_t* wg_base = wg_hist + (size_t)nbins * G;
-    hipLaunchKernelGGL(pa_keys_hist_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, keys_cap, (uint32_t)nbins, wg_hist);
+    hipLaunchKernelGGL(pa_keys_hist_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, (uint32_t)nbins, wg_hist);
     hipLaunchKernelGGL(pa_keys_scan_kernel, dim3((uint32_t)nbins), dim3(1024), 0, stream, (const uint32_t*)wg_hist, G, wg_base, hist);
-    hipLaunchKernelGGL(pa_keys_scatter_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, keys_cap, (uint32_t)nbins, (const uint32_t*)wg_base, sorted);
+    hipLaunchKernelGGL(pa_keys_scatter_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, (uint32_t)nbins, (const uint32_t*)wg_base, sorted);
     // one workgroup per CU at most (an LDS table of 128 KiB each) and ONE round of them: 270 workgroups on 256 CUs take as long as 512
     uint32_t parts = std::max<uint32_t>(1u, (uint32_t)(cus / nbins));
     parts = (uint32_t)knob_int("PA_COUNT_PARTS", (int)parts);
-    hipLaunchKernelGGL(pa_keys_count_kernel, dim3((uint32_t)nbins * parts), dim3(CS_BLOCK), lds, stream, sorted, keys_top, keys_cap, hist, parts, counts,
+    hipLaunchKernelGGL(pa_keys_count_kernel, dim3((uint32_t)nbins * parts), dim3(CS_BLOCK), lds, stream, sorted, keys_top, hist, parts, counts,
                        counts_len);
     return (int)hipGetLastError();
 }

@@ -55,13 +55,14 @@ struct LaunchCtx {
     std::mutex mu;
     DevBuf ctl;      // [0..7] arena_top (u64), [8..11] status, [12..15] tile counter, [16..] statistics, [448..455] novel results listed, [456..463] count keys handed out
     DevBuf spill, trace, novel;
-    DevBuf keys, keys_sorted, keys_ctl;   // class-count launches: the waves' key streams, the keys partitioned by range, 2 KiB of histogram / cursors (count_sort.hip)
+    DevBuf keys, keys_sorted, keys_ctl;   // class-count launches: the waves' key streams (+ one key per deferred read), the keys partitioned by range, histograms / cursors (count_sort.hip)
+    DevBuf defer;                          // reads whose class is looked up by content after the launch (resolve.hip): 32 bytes each, sized for every read
     uint32_t last_grid = 0;
     uint64_t last_arena_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the map kernel of the last launch (pa_index_set_timing)
     bool timed = false;
     void release() {
-        for (DevBuf* b : {&ctl, &spill, &trace, &novel, &keys, &keys_sorted, &keys_ctl}) b->release();
+        for (DevBuf* b : {&ctl, &spill, &trace, &novel, &keys, &keys_sorted, &keys_ctl, &defer}) b->release();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         ev0 = ev1 = nullptr;
@@ -350,12 +351,18 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     p.spill = cx->spill.as<uint32_t>();
     p.spill_cap = spill_cap;
     const uint64_t counts_len = (uint64_t)idx->stats.num_classes + 3;
+    // reads whose class has to be looked up by content are resolved after the launch (resolve.hip): 32 bytes per read in the worst case
+    const uint64_t defer_cap = defer_capacity(n_reads / (uint64_t)std::max(1, env_int("PA_DEFER_DIV", 1)), grid * (PA_MAP_BLOCK / 64));   // (A/B knob: a smaller buffer)
+    if ((rc = cx->defer.ensure(defer_cap * 32))) return rc;
+    p.defer = cx->defer.as<uint32_t>();
+    p.defer_top = cx->ctl.as<unsigned long long>() + 58;
     uint64_t keys_cap = 0;
-    if (d_counts) {   // the waves' key streams (4.3 bytes per read) and the same keys partitioned by range (4 bytes per read)
+    if (d_counts) {   // the waves' key streams (4.3 bytes per read), one key per deferred read behind them, and the keys partitioned by range (4 bytes per read)
         keys_cap = key_stream_capacity(n_reads, grid * (PA_MAP_BLOCK / 64));
-        if ((rc = cx->keys.ensure(keys_cap * 4)) || (rc = cx->keys_sorted.ensure((n_reads + 64) * 4)) || (rc = cx->keys_ctl.ensure(count_keys_ctl_bytes(counts_len)))) return rc;
+        if ((rc = cx->keys.ensure((keys_cap + defer_cap) * 4)) || (rc = cx->keys_sorted.ensure((n_reads + 64) * 4)) || (rc = cx->keys_ctl.ensure(count_keys_ctl_bytes(counts_len)))) return rc;
         p.keys = cx->keys.as<uint32_t>();
         p.keys_top = cx->ctl.as<unsigned long long>() + 57;
+        p.counts = reinterpret_cast<unsigned long long*>(d_counts);
     }
     p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
     p.class_table_size = idx->class_table_size;
@@ -389,8 +396,12 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     const int e = launch_map_pool(p, grid, lds, stream);
     if (e) return fail(PA_ERR_HIP, "map launch (grid %u, lds %zu): %s", grid, lds, hipGetErrorString((hipError_t)e));
     if (timing) { HIP_TRY(hipEventRecord(cx->ev1, stream)); cx->timed = true; }
+    {
+        const int e1 = launch_resolve(p, defer_cap, keys_cap, idx->num_cus, stream);
+        if (e1) return fail(PA_ERR_HIP, "resolve launch: %s", hipGetErrorString((hipError_t)e1));
+    }
     if (d_counts) {
-        const int e2 = launch_count_keys(p.keys, p.keys_top, keys_cap, cx->keys_sorted.as<uint32_t>(), cx->keys_ctl.as<uint32_t>(),
+        const int e2 = launch_count_keys(p.keys, p.keys_top, keys_cap, p.defer_top, defer_cap, cx->keys_sorted.as<uint32_t>(), cx->keys_ctl.as<uint32_t>(),
                                          reinterpret_cast<unsigned long long*>(d_counts), counts_len, idx->num_cus, stream);
         if (e2) return fail(PA_ERR_HIP, "count launch: %s", hipGetErrorString((hipError_t)e2));
         if (ovf) {
@@ -415,7 +426,9 @@ static int map_finish_locked(pa_index* idx, LaunchCtx* cx, hipStream_t stream, u
             if (d[i])
                 fprintf(stderr, " %s: %llu iters x %.1f lanes, %.0f ticks/iter;", names[i], d[i], (double)d[NS + i] / (double)d[i],
                         (double)d[2 * NS + i] / (double)d[i]);
-        fprintf(stderr, "\n");
+        unsigned long long tops[2];
+        HIP_TRY(hipMemcpy(tops, cx->ctl.as<unsigned long long>() + 57, sizeof tops, hipMemcpyDeviceToHost));
+        fprintf(stderr, " key stream %llu entries, deferred stream %llu entries\n", tops[0], tops[1]);
     }
     // the counter includes every wave's partly used chunk and may run past the caller's arena without any allocation having
     // crossed its end: what may be copied back is min(top, capacity); `needed` is the capacity that would have sufficed

@@ -10,6 +10,8 @@ constexpr uint32_t PA_MAP_BLOCK = 256;          // 4 independent waves per workg
 constexpr uint32_t PA_ARENA_CHUNK = 1024;       // u32 entries a wave reserves per global atomic
 constexpr uint32_t PA_LDS_READ_WORDS = 16;        // reads of up to 512 bases live in LDS while they are mapped, longer ones stay in their HBM tile
 constexpr uint32_t PA_KEY_CHUNK = 1024;         // count keys a wave reserves per global atomic (map_pool.hip, count_sort.hip)
+constexpr uint32_t PA_DEFER_CHUNK = 1024;       // deferred reads (32-byte entries) a wave reserves per global atomic (map_pool.hip, resolve.hip)
+constexpr uint32_t PA_DEFER_WINDOW = 0x80000000u, PA_DEFER_LIST = 0x40000000u;   // kind of a deferred entry (bits 31 / 30 of word 3, the id count below)
 constexpr uint32_t PA_KEY_BIN_SHIFT = 15;       // count_sort.hip: a bin = 32768 consecutive count slots = 128 KiB of LDS counters
 constexpr uint32_t PA_STATUS_ARENA_FULL = 1u;
 constexpr uint32_t PA_STATUS_SPILL_OVERFLOW = 2u;
@@ -38,6 +40,11 @@ struct MapParams {
     // hash table the keys of novel subsets are looked up in.
     uint32_t* keys;
     unsigned long long* keys_top;      // entries handed out so far (zero at launch)
+    unsigned long long* counts;        // the caller's table (resolve.hip adds the reads of the "novel" slot itself)
+    // finished reads whose class still has to be looked up by content (map_pool.hip append_deferred, resolve.hip): 32-byte entries
+    // in chunks of PA_DEFER_CHUNK handed out through *defer_top, unused tails padded with rid 0xFFFFFFFF; sized for every read
+    uint32_t* defer;
+    unsigned long long* defer_top;
     const uint32_t* class_table;
     uint64_t class_table_size;
     // optional (with the fused count table): {arena offset, length} of every result that is NO index class goes on this list;
@@ -67,8 +74,11 @@ int pool_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu);
 // n_reads u32 and `ctl` count_keys_ctl_bytes() of scratch; both may be reused once the stream has passed these kernels.
 uint64_t key_stream_capacity(uint64_t n_reads, uint32_t nwaves);
 size_t count_keys_ctl_bytes(uint64_t counts_len);                  // bytes of `ctl`   // u32 entries `keys` must hold for a launch of nwaves waves
-int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top, uint64_t keys_cap, uint32_t* sorted, uint32_t* ctl,
-                      unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream);
+int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top, uint64_t keys_cap, const unsigned long long* extra_top, uint64_t extra_cap,
+                      uint32_t* sorted, uint32_t* ctl, unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream);
+// resolve.hip: the deferred content lookups of a launch (records by reference / in the arena, count keys into keys_b, colours, novel list)
+uint64_t defer_capacity(uint64_t n_reads, uint32_t nwaves);   // 32-byte entries `defer` must hold
+int launch_resolve(const MapParams& p, uint64_t defer_cap, uint64_t keys_cap, int num_cus, hipStream_t stream);
 int launch_encode(const uint8_t* ascii, const uint64_t* offsets, uint64_t n, uint32_t wpr, uint64_t* tiles, uint32_t* lens,
                   hipStream_t stream);
 int launch_simulate(const uint64_t* packed, const uint64_t* tx_start, const uint64_t* cum, uint32_t num_tx, uint64_t total,

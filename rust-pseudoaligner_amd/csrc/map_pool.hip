@@ -140,11 +140,42 @@ __device__ __forceinline__ void append_keys(uint32_t key, uint32_t lane, karg_pt
     asm volatile("" ::: "memory");
 }
 
-// list mode: record of one finished read; returns its count key and leaves the lane in ST_EMPTY — or NO_KEY and ST_F_NOVEL when
-// the class of a strict-subset result still has to be looked up by content before it can be counted
+// A finished read whose class is not known to be an index class — a window result that is a strict subset of every class seen
+// (3 % of the config-3 reads), or a list-mode intersection that dropped ids — is NOT resolved here. The wave appends a 32-byte
+// entry to a stream of its own (chunks of PA_DEFER_CHUNK entries) and frees the slot at once; pa_resolve_kernel (resolve.hip)
+// looks the id set up by content afterwards, at full width, and writes the record / count key / colour. Round 2 resolved such
+// reads in a state of the pool (ST_F_NOVEL): steps of ~11 lanes and two dependent round trips each, 9 % of the wave time.
+//   window entry  {rid, coverage, mismatches, DEFER_WINDOW | count} {base1, mask1, base2, mask2}
+//   list entry    {rid, coverage, mismatches, DEFER_LIST | count}   {arena offset, 0, 0, 0}     (record and ids already written)
+__device__ __forceinline__ void append_deferred(bool has, u32x4 e0, u32x4 e1, uint32_t lane, karg_ptr p, lds_u32 dchunk) {
+    const uint64_t m = __ballot(has);
+    if (m == 0) return;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    const glb_v4w out = (glb_v4w)p->defer;
+    asm volatile("" ::: "memory");
+    uint32_t cur = dchunk[0], end = dchunk[1];
+    if (cur + cnt > end) {   // fewer than a step's entries left: pad them, take the next chunk
+        if (cur + lane < end) out[2ull * (cur + lane)] = u32x4{NO_KEY, 0u, 0u, 0u};
+        uint32_t base = 0;
+        if (lane == 0) base = (uint32_t)atomicAdd(p->defer_top, (unsigned long long)PA_DEFER_CHUNK);
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        end = cur + PA_DEFER_CHUNK;
+        if (lane == 0) dchunk[1] = end;
+    }
+    if (has) {
+        const uint64_t at = 2ull * (cur + rank_in(m));
+        out[at] = e0;
+        out[at + 1] = e1;
+    }
+    if (lane == 0) dchunk[0] = cur + cnt;
+    asm volatile("" ::: "memory");
+}
+
+// list mode: record of one finished read; returns its count key and leaves the lane in ST_EMPTY. `defer` is set (and NO_KEY
+// returned) when the class of a strict-subset result still has to be looked up by content before it can be counted
 template <bool TRACE>
 __device__ __forceinline__ uint32_t emit_record(Lane& s, uint32_t cnt, uint32_t cnt_alloc, uint64_t my_off, uint32_t base_len,
-                                                uint32_t base_colour, uint32_t gslot, karg_ptr p) {
+                                                uint32_t base_colour, uint32_t gslot, karg_ptr p, bool& defer) {
     uint32_t colour = NO_CLASS, class_off = (uint32_t)my_off;
     bool novel = false;
     if (my_off + cnt_alloc > p->arena_cap) atomicOr(p->status, PA_STATUS_ARENA_FULL);
@@ -156,10 +187,9 @@ __device__ __forceinline__ uint32_t emit_record(Lane& s, uint32_t cnt, uint32_t 
     ((glb_v4w)p->results)[s.rid] = u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, class_off, cnt};
     trace_out<TRACE>(s, true, gslot, p);
     const glb_u32w colour_out = (glb_u32w)p->colour_out;
-    if (novel && (p->keys != nullptr || colour_out != nullptr) && my_off + cnt_alloc <= p->arena_cap) {   // content lookup: NOVEL state
-        s.h = (uint32_t)my_off;
-        s.rr = cnt;
-        l_set_st(s, ST_F_NOVEL);
+    if (novel && (p->keys != nullptr || colour_out != nullptr) && my_off + cnt_alloc <= p->arena_cap) {   // content lookup: deferred (resolve.hip)
+        defer = true;
+        s.lk = 0;   // ST_EMPTY
         return NO_KEY;
     }
     if (colour_out) colour_out[s.rid] = colour;
@@ -257,6 +287,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
     const lds_u32 dbg = (lds_u32)(wbase + 16);                            // [0..ST_NSTAT) iterations, [ST_NSTAT..2*ST_NSTAT) slots served; entry ST_COUNT = dual iterations
     const lds_u64w dbg_clk = (lds_u64w)(wbase + 16 + 8 * ST_NSTAT);        // wall ticks per state
     const lds_u32 kchunk = (lds_u32)(wbase + 256);   // {cur, end} of this wave's chunk of the key stream (both 0: none taken yet)
+    const lds_u32 dchunk = (lds_u32)(wbase + 264);   // the same for the stream of deferred reads
     const lds_u64 rd = (lds_u64)(wbase + POOL_FIXED);
     // the lane state as TWO arrays of one 16-byte vector per slot (not one array of 32-byte records: with a 32-byte stride the
     // vectors of 64 random slots fall into 4 bank groups, with 16 bytes into 8 — half of the LDS cycles were bank conflicts)
@@ -271,7 +302,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
     const lds_u8 sb = (lds_u8)(wbase + 768);
     const lds_u8 poplist = (lds_u8)(wbase + 896);
     if (lane < 64) ((lds_u32)wbase)[lane] = 0;
-    if (lane < 2) kchunk[lane] = 0;
+    if (lane < 4) kchunk[lane] = 0;   // (kchunk and dchunk)
     ((lds_u16)sb)[lane] = (uint16_t)((lane < S ? (uint32_t)ST_EMPTY : 0xFFu) | ((lane + 64 < S ? (uint32_t)ST_EMPTY : 0xFFu) << 8));
 
     // Work distribution: chunks of up to 16 tiles (1024 reads). Chunk w is wave w's first one; further chunks come from a
@@ -343,10 +374,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
 #define PA_CONSIDER_RARE(t, c) PA_CONSIDER_RARE_MIN(t, c, PA_RARE_MIN)
         // the five rare states (left extension, the list-mode tiers, the content lookup) are only counted when some slot is in one
         // of them: one ballot instead of ten in most iterations (the order of consideration is the same either way)
-        constexpr uint32_t RARE = (1u << ST_LEFT) | (1u << ST_F_LIGHT) | (1u << ST_F_SCAN) | (1u << ST_F_COOP) | (1u << ST_F_NOVEL);
+        constexpr uint32_t RARE = (1u << ST_LEFT) | (1u << ST_F_LIGHT) | (1u << ST_F_SCAN) | (1u << ST_F_COOP);
         const bool any_rare = __ballot((((RARE >> (st_lo & 31u)) | (RARE >> (st_hi & 31u))) & 1u) != 0) != 0;   // (0xFF, no slot: bit 31, not rare)
         if (any_rare) {
-            PA_CONSIDER_RARE(ST_F_NOVEL, PA_CNT(ST_F_NOVEL))
             PA_CONSIDER_RARE_MIN(ST_F_COOP, PA_CNT(ST_F_COOP), PA_COOP_MIN)   // (the wave takes its reads one at a time: nothing to gain from gathering them)
             PA_CONSIDER_RARE(ST_F_SCAN, PA_CNT(ST_F_SCAN))
             PA_CONSIDER_RARE(ST_F_LIGHT, PA_CNT(ST_F_LIGHT))
@@ -456,13 +486,19 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             // output of window-mode reads and of unmapped reads: no loads. A non-empty window that is a strict subset of
             // every class seen goes on to NOVEL (is it an index class all the same?) and is written there.
             uint32_t ckey = NO_KEY;
+            bool dfr = false;
+            u32x4 d0{0u, 0u, 0u, 0u}, d1{0u, 0u, 0u, 0u};
             if (active && lane < n_own) {
                 const bool mapped = l_st(s) != ST_NONE;
                 const u32x4 w = win[slot];
                 const uint32_t cand = wc[2 * slot];
                 const uint32_t count = mapped ? (uint32_t)(__popc(w.y) + __popc(w.w)) : 0u;
-                if (mapped && count != 0 && cand == NO_CLASS) {
-                    l_set_st(s, ST_F_NOVEL);
+                if (mapped && count != 0 && cand == NO_CLASS) {   // a strict subset of every class seen: is it an index class all the same? resolve.hip finds out
+                    dfr = true;
+                    d0 = u32x4{s.rid, l_cov(s), l_mism(s), PA_DEFER_WINDOW | count};
+                    d1 = w;
+                    trace_out<TRACE>(s, true, gslot, kp);
+                    s.lk = 0;   // ST_EMPTY: the slot is free at once
                 } else {
                     const bool is_ref = mapped && count != 0;
                     if (!PA_ABLATE(1u))
@@ -487,62 +523,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 }
             }
             if (counting && !PA_ABLATE(2u)) append_keys(ckey, lane, kp, kchunk);
-        } else if (sel == ST_F_NOVEL) {
-            // the result is a strict subset of every class seen: does it equal some index class all the same?
-            const bool lists = l_flags(s) & F_LISTS;
-            uint32_t colour = NO_CLASS, count = 0;
-            u32x4 w{0u, 0u, 0u, 0u};
-            if (active && lists) {          // list mode: ids are in the arena, the record is written: look the list up by content
-                colour = class_of_list(p.arena + s.h, s.rr, ix, p.class_table, p.class_table_size);
-            } else if (active) {            // window mode: one fetch of the window table
-                w = win[slot];
-                count = (uint32_t)(__popc(w.y) + __popc(w.w));
-                uint32_t b1 = w.x, m1 = w.y, b2 = w.z, m2 = w.w;
-                window_canon(b1, m1, b2, m2);
-                colour = window_class(ix, b1, m1, b2, m2);
-            }
-            const bool fresh = active && !lists && colour == NO_CLASS;   // a new class: its ids go to the arena
-            const uint32_t cnt_alloc = fresh ? count : 0u;
-            const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
-            if (active) {
-                if (!lists) {
-                    uint32_t class_off = PA_CLASS_REF | colour;
-                    if (fresh) {
-                        class_off = (uint32_t)my_off;
-                        if (my_off + cnt_alloc > p.arena_cap) atomicOr(p.status, PA_STATUS_ARENA_FULL);
-                        else {
-                            const glb_u32w dst = (glb_u32w)p.arena + my_off;
-                            uint32_t k = 0;
-                            for (uint32_t t = w.y; t; t &= t - 1) dst[k++] = w.x + (uint32_t)(__ffs((int)t) - 1);
-                            for (uint32_t t = w.w; t; t &= t - 1) dst[k++] = w.z + (uint32_t)(__ffs((int)t) - 1);
-                        }
-                    }
-                    ((glb_v4w)p.results)[s.rid] = u32x4{l_cov(s), l_mism(s) | PA_MAPPED_BIT, class_off, count};
-                    trace_out<TRACE>(s, true, gslot, kp);
-                }
-                const glb_u32w colour_out = (glb_u32w)p.colour_out;
-                if (colour_out) colour_out[s.rid] = colour;
-                s.lk = 0;   // ST_EMPTY
-            }
-            if (counting) append_keys(active ? (colour == NO_CLASS ? ix.num_classes : colour) : NO_KEY, lane, kp, kchunk);
-            if (p.novel_list) {   // a class no index class equals: remember where its ids are (one atomic per step)
-                const bool rec = active && colour == NO_CLASS && (lists || my_off + cnt_alloc <= p.arena_cap);
-                const uint64_t m = __ballot(rec);
-                if (m) {
-                    const uint32_t first = (uint32_t)(__ffsll((unsigned long long)m) - 1);
-                    unsigned long long base = 0;
-                    if (lane == first) base = atomicAdd(p.novel_ctr, (unsigned long long)__popcll(m));
-                    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), (int)first) << 32) |
-                           (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
-                    if (rec) {
-                        const unsigned long long at = base + rank_in(m);
-                        if (at < p.novel_cap) {
-                            ((glb_u32w)p.novel_list)[2 * at] = lists ? s.h : (uint32_t)my_off;
-                            ((glb_u32w)p.novel_list)[2 * at + 1] = lists ? s.rr : count;
-                        } else atomicOr(p.novel_status, PA_NOVEL_LIST_FULL);
-                    }
-                }
-            }
+            append_deferred(dfr, d0, d1, lane, kp, dchunk);
         } else if (sel == ST_F_SCAN) {
             // List mode, base list of <= 8 ids, other lists of any number and length: ONE LIST PER LANE. The waiting reads
             // are packed into the wave, ncol lanes each; lane j of a read's segment loads the read's base ids, streams the
@@ -635,6 +616,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             const uint32_t cnt_alloc = active && cnt != is.base_len ? cnt : 0u;   // a result that is an index class is returned by reference
             const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
             uint32_t ckey = NO_KEY;
+            bool dfr = false;
+            u32x4 d0{0u, 0u, 0u, 0u}, d1{0u, 0u, 0u, 0u};
             if (active) {
                 if (cnt_alloc && my_off + cnt_alloc <= p.arena_cap) {
                     const glb_u32w dst = (glb_u32w)p.arena + my_off;
@@ -642,9 +625,13 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     uint32_t k = 0;
                     for (uint32_t t = my_alive; t; t &= t - 1) dst[k++] = bids[__ffs((int)t) - 1];
                 }
-                ckey = emit_record<TRACE>(s, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp);
+                const uint32_t cov_ = l_cov(s), mm_ = l_mism(s);
+                ckey = emit_record<TRACE>(s, cnt, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, dfr);
+                d0 = u32x4{s.rid, cov_, mm_, PA_DEFER_LIST | cnt};
+                d1 = u32x4{(uint32_t)my_off, 0u, 0u, 0u};
             }
             if (counting) append_keys(ckey, lane, kp, kchunk);
+            append_deferred(dfr, d0, d1, lane, kp, dchunk);
         } else if (sel == ST_F_COOP) {
             // the whole wave works on one read at a time (list mode, base list of more than 8 ids). Lane e owns base ids
             // e, e+64, ...; membership in every other list is a scan of 16-byte loads (short lists) or a binary search;
@@ -722,8 +709,16 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 if (lane == Lr) my_count = total;
             }
             uint32_t ckey = NO_KEY;
-            if (active) ckey = emit_record<TRACE>(s, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp);
+            bool dfr = false;
+            u32x4 d0{0u, 0u, 0u, 0u}, d1{0u, 0u, 0u, 0u};
+            if (active) {
+                const uint32_t cov_ = l_cov(s), mm_ = l_mism(s);
+                ckey = emit_record<TRACE>(s, my_count, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, dfr);
+                d0 = u32x4{s.rid, cov_, mm_, PA_DEFER_LIST | my_count};
+                d1 = u32x4{(uint32_t)my_off, 0u, 0u, 0u};
+            }
             if (counting) append_keys(ckey, lane, kp, kchunk);
+            append_deferred(dfr, d0, d1, lane, kp, dchunk);
         } else {   // ST_F_LIGHT: list mode — pick a tier, intersect, write
             Isect is;
             is.count = 0;
@@ -746,6 +741,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             const uint32_t cnt_alloc = cntv2 == is.base_len ? 0u : cntv2;   // a result that is an index class is returned by reference
             const uint64_t my_off = arena_alloc(cnt_alloc, lane, kp, chunk);
             uint32_t ckey = NO_KEY;
+            bool dfr = false;
+            u32x4 d0{0u, 0u, 0u, 0u}, d1{0u, 0u, 0u, 0u};
             if (emit_now) {
                 if (cnt_alloc && my_off + cnt_alloc <= p.arena_cap) {
                     const glb_u32w dst = (glb_u32w)p.arena + my_off;
@@ -754,9 +751,13 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     for (int j = 0; j < 7; ++j)   // survivors straight from registers
                         if ((alive >> j) & 1u) dst[__popc(alive & ((1u << j) - 1))] = is.ids[j];
                 }
-                ckey = emit_record<TRACE>(s, cntv2, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp);
+                const uint32_t cov_ = l_cov(s), mm_ = l_mism(s);
+                ckey = emit_record<TRACE>(s, cntv2, cnt_alloc, my_off, is.base_len, is.base_colour, gslot, kp, dfr);
+                d0 = u32x4{s.rid, cov_, mm_, PA_DEFER_LIST | cntv2};
+                d1 = u32x4{(uint32_t)my_off, 0u, 0u, 0u};
             }
             if (counting) append_keys(ckey, lane, kp, kchunk);
+            append_deferred(dfr, d0, d1, lane, kp, dchunk);
         }
 
         const unsigned long long t_step = PA_DBG ? __builtin_readcyclecounter() : 0ull;
@@ -776,6 +777,11 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             dbg[ST_NONE] += 1;
             dbg_clk[ST_NONE] += t_end - t_step;
         }
+    }
+    {   // the unused tail of this wave's last chunk of deferred reads is padding
+        asm volatile("" ::: "memory");
+        const uint32_t cur = dchunk[0], end = dchunk[1];
+        for (uint32_t i = cur + lane; i < end; i += 64) ((glb_v4w)p.defer)[2ull * i] = u32x4{NO_KEY, 0u, 0u, 0u};
     }
     if (counting) {   // the unused tail of this wave's last chunk of the key stream is padding
         asm volatile("" ::: "memory");

@@ -1,7 +1,7 @@
 # A/B runs of bench.py under tuning knobs, one host index build shared through --index-cache
 # usage: bash gpurun_ab.sh "ENV=.. [--bench-flag ..]" ...
 mkdir -p gpurun_out
-B="python bench.py --no-cpu-baseline --no-e2e --steps 6 --warmup 2"
+B="python bench.py --no-cpu-baseline --no-e2e --no-config5 --steps 6 --warmup 2"
 for cfg in "$@"; do
   envs=""; flags=""
   for tok in $cfg; do case "$tok" in --*) flags="$flags $tok";; *=*) envs="$envs $tok";; *) flags="$flags $tok";; esac; done
