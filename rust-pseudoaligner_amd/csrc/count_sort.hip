@@ -214,11 +214,9 @@ __global__ __launch_bounds__(256) void pa_keys_count_direct_kernel(const uint32_
 
 
 }  // namespace
-
-// a wave wastes at most 63 entries of every chunk it takes (append_keys pads when fewer than a step's keys are left) and
 // leaves one chunk partly used at its exit
-uint64_t key_stream_capacity(uint64_t n_reads, uint32_t nwaves) {
-    return (n_reads / (PA_KEY_CHUNK - 63) + nwaves + 1) * PA_KEY_CHUNK;
+uint64_t key_stream_capacity(uint64_t n_reads, uint32_t nwaves) {   // chunks are filled to the last entry; every wave leaves one partly used (padded)
+    return (n_reads / PA_KEY_CHUNK + nwaves + 2) * PA_KEY_CHUNK;
 }
 
 size_t count_keys_ctl_bytes(uint64_t counts_len) {

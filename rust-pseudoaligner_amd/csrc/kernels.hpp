@@ -10,7 +10,7 @@ constexpr uint32_t PA_MAP_BLOCK = 256;          // 4 independent waves per workg
 constexpr uint32_t PA_ARENA_CHUNK = 1024;       // u32 entries a wave reserves per global atomic
 constexpr uint32_t PA_LDS_READ_WORDS = 16;        // reads of up to 512 bases live in LDS while they are mapped, longer ones stay in their HBM tile
 constexpr uint32_t PA_KEY_CHUNK = 1024;         // count keys a wave reserves per global atomic (map_pool.hip, count_sort.hip)
-constexpr uint32_t PA_DEFER_CHUNK = 1024;       // deferred reads (32-byte entries) a wave reserves per global atomic (map_pool.hip, resolve.hip)
+constexpr uint32_t PA_DEFER_CHUNK = 128;        // deferred reads (32-byte entries) a wave reserves per global atomic (map_pool.hip, resolve.hip)
 constexpr uint32_t PA_DEFER_WINDOW = 0x80000000u, PA_DEFER_LIST = 0x40000000u;   // kind of a deferred entry (bits 31 / 30 of word 3, the id count below)
 constexpr uint32_t PA_KEY_BIN_SHIFT = 15;       // count_sort.hip: a bin = 32768 consecutive count slots = 128 KiB of LDS counters
 constexpr uint32_t PA_STATUS_ARENA_FULL = 1u;

@@ -126,17 +126,18 @@ __device__ __forceinline__ void append_keys(uint32_t key, uint32_t lane, karg_pt
     const uint32_t cnt = (uint32_t)__popcll(m);
     const glb_u32w keys = (glb_u32w)p->keys;
     asm volatile("" ::: "memory");   // (LDS words one lane writes and all lanes read: see arena_alloc)
-    uint32_t cur = kchunk[0], end = kchunk[1];
-    if (cur + cnt > end) {   // fewer than 64 entries left: pad them, take the next chunk
-        if (cur + lane < end) keys[cur + lane] = NO_KEY;
-        uint32_t base = 0;
-        if (lane == 0) base = (uint32_t)atomicAdd(p->keys_top, (unsigned long long)PA_KEY_CHUNK);
-        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        end = cur + PA_KEY_CHUNK;
-        if (lane == 0) kchunk[1] = end;
+    const uint32_t cur = kchunk[0], room = kchunk[1] - cur;
+    uint32_t nbase = 0;
+    if (cnt > room) {   // the step's keys straddle the chunk's end: the first `room` fill it up, the rest open the next chunk
+        if (lane == 0) nbase = (uint32_t)atomicAdd(p->keys_top, (unsigned long long)PA_KEY_CHUNK);
+        nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)nbase);
     }
-    if (key != NO_KEY) keys[cur + rank_in(m)] = key;
-    if (lane == 0) kchunk[0] = cur + cnt;
+    const uint32_t r = rank_in(m);
+    if (key != NO_KEY) keys[r < room ? cur + r : nbase + (r - room)] = key;
+    if (lane == 0) {
+        if (cnt > room) { kchunk[0] = nbase + (cnt - room); kchunk[1] = nbase + PA_KEY_CHUNK; }
+        else kchunk[0] = cur + cnt;
+    }
     asm volatile("" ::: "memory");
 }
 
@@ -153,21 +154,22 @@ __device__ __forceinline__ void append_deferred(bool has, u32x4 e0, u32x4 e1, ui
     const uint32_t cnt = (uint32_t)__popcll(m);
     const glb_v4w out = (glb_v4w)p->defer;
     asm volatile("" ::: "memory");
-    uint32_t cur = dchunk[0], end = dchunk[1];
-    if (cur + cnt > end) {   // fewer than a step's entries left: pad them, take the next chunk
-        if (cur + lane < end) out[2ull * (cur + lane)] = u32x4{NO_KEY, 0u, 0u, 0u};
-        uint32_t base = 0;
-        if (lane == 0) base = (uint32_t)atomicAdd(p->defer_top, (unsigned long long)PA_DEFER_CHUNK);
-        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        end = cur + PA_DEFER_CHUNK;
-        if (lane == 0) dchunk[1] = end;
+    const uint32_t cur = dchunk[0], room = dchunk[1] - cur;
+    uint32_t nbase = 0;
+    if (cnt > room) {   // (as append_keys: fill the chunk up, go on in the next one)
+        if (lane == 0) nbase = (uint32_t)atomicAdd(p->defer_top, (unsigned long long)PA_DEFER_CHUNK);
+        nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)nbase);
     }
     if (has) {
-        const uint64_t at = 2ull * (cur + rank_in(m));
+        const uint32_t r = rank_in(m);
+        const uint64_t at = 2ull * (r < room ? cur + r : nbase + (r - room));
         out[at] = e0;
         out[at + 1] = e1;
     }
-    if (lane == 0) dchunk[0] = cur + cnt;
+    if (lane == 0) {
+        if (cnt > room) { dchunk[0] = nbase + (cnt - room); dchunk[1] = nbase + PA_DEFER_CHUNK; }
+        else dchunk[0] = cur + cnt;
+    }
     asm volatile("" ::: "memory");
 }
 

@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void pa_resolve_kernel(const MapParams p, uint
 
 }  // namespace
 
-uint64_t defer_capacity(uint64_t n_reads, uint32_t nwaves) {   // entries: every read can be deferred; a wave wastes < 64 entries per chunk and leaves one chunk partly used
-    return (n_reads / (PA_DEFER_CHUNK - 63) + nwaves + 1) * PA_DEFER_CHUNK;
+uint64_t defer_capacity(uint64_t n_reads, uint32_t nwaves) {   // entries: every read can be deferred; chunks are filled to the last entry, a wave leaves one partly used
+    return (n_reads / PA_DEFER_CHUNK + nwaves + 2) * PA_DEFER_CHUNK;
 }
 
 int launch_resolve(const MapParams& p, uint64_t defer_cap, uint64_t keys_cap, int num_cus, hipStream_t stream) {
