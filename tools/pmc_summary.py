@@ -7,7 +7,7 @@ import glob
 import sys
 
 root = sys.argv[1]
-kernels = sys.argv[2:] or ["pa_map_pool", "pa_keys_hist", "pa_keys_scan", "pa_keys_scatter", "pa_keys_count"]
+kernels = sys.argv[2:] or ["pa_map_pool", "pa_resolve", "pa_keys_hist", "pa_keys_scan", "pa_keys_scatter", "pa_keys_count"]
 print("# rocprofv3 --pmc (one pass per directory) averages per launch, launches with the full batch only")
 for d in sorted(glob.glob(root + "/pmc_*")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):

@@ -32,7 +32,7 @@ def main():
     print("# rocprofv3 --kernel-trace --stats summary of: %s" % " ".join(sys.argv[2:]))
     print("%-60s %6s %12s %12s %12s %12s %6s %5s %5s %7s %9s %5s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "vgpr", "sgpr", "lds", "grid", "wg"))
     for r in rows:
-        name = r[0].split("(")[0][-60:]
+        name = r[0].replace("pa::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
         print("%-60s %6d %12.1f %12.1f %12.1f %12.1f %6.2f %5s %5s %7s %9s %5s" % (name, r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[2] / total, *r[6:11]))
 
 
