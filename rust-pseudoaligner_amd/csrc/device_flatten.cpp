@@ -264,7 +264,7 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
 
     // ---- blobs + edges ----
     const uint64_t granules = out.blobs.size() / BLOB_GRANULE;
-    out.ledge.assign(4ull * granules + 4, NO_HANDLE);
+    out.ledge.assign(8ull * granules + 8, NO_HANDLE);   // {handle, length}[4] per granule (lengths filled in below)
     out.nid_of_handle.assign(granules + 1, 0xFFFFFFFFu);
     std::atomic<uint32_t> dangling{NO_HANDLE};
     par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
@@ -314,12 +314,20 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
                     if (le == NO_HANDLE && (f.node_ledge || !device_dict)) dangling.store((uint32_t)i);
                 }
                 hd[4 + base] = re;
-                out.ledge[4ull * out.handle[i] + base] = le;
+                out.ledge[8ull * out.handle[i] + 2 * base] = le;
             }
         }
     });
     if (dangling.load() != NO_HANDLE)
         return fail(PA_ERR_FORMAT, "node %u has an extension bit without a terminal neighbour k-mer (missing link)", dangling.load());
+    // every left edge carries the length of the node it leads to (every header exists now)
+    par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
+        for (uint64_t i = a; i < b; ++i)
+            for (uint32_t base = 0; base < 4; ++base) {
+                uint32_t* e = out.ledge.data() + 8ull * out.handle[i] + 2 * base;
+                e[1] = e[0] == NO_HANDLE ? 0u : (*reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)e[0] * BLOB_GRANULE) & 0xFFFFFFu);
+            }
+    });
     // left-edge targets must be entered at their LAST k-mer (offset len-k): check now that every header exists
     if (!f.node_ledge && !device_dict) {
         par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {

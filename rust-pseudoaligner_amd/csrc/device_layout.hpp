@@ -26,7 +26,9 @@
 //               the colour's id list is addressable without an offsets table, and for window classes (transcripts of
 //               one gene are neighbours in the FASTA; a second window covers a paralog or an overlapping gene) the
 //               intersection of nodes_to_eq_class is an AND of masks that never touches the id lists.
-//   ledge       u32[4*granules] left-edge handles by blob handle (Node::l_edges), only touched by the left extension
+//   ledge       u32[8*granules] by blob handle: {handle, length}[4] of the nodes reached by left-extending with base b (Node::l_edges;
+//               handle 0xFFFFFFFF = none). Only the left extension touches it; the length lets a lane that hops left fetch the END
+//               of the neighbour's sequence together with its header (lane_steps.hpp, left_issue)
 //   nid_of_handle  u32[granules] node id by blob handle (only the node-trace test surface reads it)
 //   ec          class records, 16-byte aligned, at least 32 bytes, padded with 0xFFFFFFFF: record r = words [4r, ...) =
 //               {class id, id0, id1, ...} — the sorted transcript-id lists of eq_classes: Vec<Vec<u32>>
@@ -74,7 +76,7 @@ struct DevIndexView {
     const uint32_t* table;    // nbuckets * 16 words
     uint64_t nbuckets;
     const uint8_t* blobs;     // node blobs
-    const uint32_t* ledge;    // [4 * granules], by handle
+    const uint32_t* ledge;    // [8 * granules]: {handle, length}[4] by handle
     const uint32_t* nid_of_handle;   // [granules]
     const uint32_t* ec;       // class records (16-byte aligned records of u32)
     const uint32_t* class_ref;   // [num_classes]

@@ -174,15 +174,17 @@ __global__ __launch_bounds__(256) void pa_fill_edges_kernel(uint8_t* blobs, uint
             hd[4 + base] = re;
         }
         if (need_l) {   // find_link(first.extend_left(b), Dir::Left): the node whose LAST k-mer it is
-            uint32_t le = NO_HANDLE;
+            uint32_t le = NO_HANDLE, ll = 0;
             if (exts & (1u << (4 + base))) {
                 if (dict_find<KT>(table, nbuckets, ((first << 2) | (KT)base) & mask, fh, fo, probes)) {
                     le = fh;
                     const uint32_t tlen = *reinterpret_cast<const uint32_t*>(blobs + (uint64_t)fh * BLOB_GRANULE) & 0xFFFFFFu;   // (word 0 of a header is never written here)
+                    ll = tlen;
                     if (fo != tlen - k) atomicMin(flags + 3, i);
                 } else atomicMin(flags + 2, i);
             }
-            ledge[4ull * h + base] = le;
+            ledge[8ull * h + 2 * base] = le;       // {handle, length of that node}
+            ledge[8ull * h + 2 * base + 1] = ll;
         }
     }
 }

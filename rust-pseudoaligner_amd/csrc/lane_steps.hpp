@@ -598,12 +598,31 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
 }
 
 // ---------------------------------------------------------------------------------------------- LEFT
-// Left extension (:131-203): one call = enter/continue one node and compare up to 32 bases leftwards.
+// Left extension (:131-203): one call = enter/continue one node and compare up to 32 bases leftwards. The node header and the two
+// sequence words the compare can need are fetched together (left_issue), the rest is arithmetic (left_finish) — plus, when the
+// walk hops to a left neighbour, one dependent 8-byte load of the edge. What makes the first part ONE round trip: a lane that
+// hops takes the neighbour's LENGTH along with its handle (the left-edge table holds both), so the position of the words it will
+// compare there — the END of that node — is known before its header has been read. (Fetching the node's four edges up front as
+// well makes the hop free of a dependent load, but costs a request per step on a kernel that is bound by requests: config 5
+// +2.7 % time, measured.)
+struct LeftLoad {
+    U4 h0, h1, h2;   // header of the node
+    Q2 sq;           // the two sequence words around the bases to compare
+};
+// bases of the node still to the left of the compare position (:196 / :129 / continued)
+PA_HD uint32_t left_na(const Lane& s) { return s.rr & 0xFFFFFFu; }
+PA_HD void left_issue(const Lane& s, const DevIndexView& ix, LeftLoad& f) {
+    const U4* hp = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)s.ph * BLOB_GRANULE);   // dbg.get_node(prev_node_id) (:132)
+    f.h0 = hp[0]; f.h1 = hp[1]; f.h2 = hp[2];
+    const uint32_t na = left_na(s);
+    const uint32_t po = na ? na - 1 : 0, st = po >= 31 ? po - 31 : 0;                       // ref_pos of idx 0 (:152): 32 bases ending there
+    f.sq = *reinterpret_cast<const Q2*>(node_seq(ix, s.ph) + (st >> 5));
+}
 template <bool TRACE = false>
-PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
+PA_HD void left_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed, const LeftLoad& f) {
     const uint32_t K = ix.k;
-    const Hdr hd = load_hdr(ix, s.ph);                              // dbg.get_node(prev_node_id) (:132)
-    uint32_t na = s.rr & 0xFFFFFFu, snp = s.rr >> 24, rem = s.rm & 0xFFFFu, ra = s.rm >> 16, cov = l_cov(s), mism = l_mism(s);
+    const Hdr hd{f.h0.x & 0xFFFFFFu, f.h0.x >> 24, f.h0.y, f.h0.z, f.h0.w, f.h1.x, f.h1.y, f.h1.z, f.h1.w, f.h2.x, f.h2.y, f.h2.z, f.h2.w};
+    uint32_t na = left_na(s), snp = s.rr >> 24, rem = s.rm & 0xFFFFu, ra = s.rm >> 16, cov = l_cov(s), mism = l_mism(s);
     const uint32_t fl = l_flags(s);
     if (fl & F_FRESH) {
         if (!(fl & F_LEFT_SEED)) {
@@ -611,7 +630,7 @@ PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, u
                 restart_lists(s, K);
                 return;
             }
-            na = hd.len - K + 1;                                    // prev_kmer_offset = len - k (:196)
+            // na = len - k + 1: prev_kmer_offset = len - k (:196); the hop brought it along (== hd.len - K + 1)
         }
         rem = pa_min(ra, na);                                       // max_matchable_pos (:139-145)
         snp = 0;                                                    // :150
@@ -622,13 +641,12 @@ PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, u
     uint32_t matched = 0;
     if (n > 0) {
         const uint32_t po = na - 1, lp = ra - 1;                    // ref_pos / read_offset of idx 0 (:152-153)
-        const uint64_t* sq = node_seq(ix, s.ph);
         uint64_t sw;
         if (po >= 31) {
             const uint32_t st = po - 31;
-            sw = funnel(sq[st >> 5], sq[(st >> 5) + 1], (st & 31) * 2);
+            sw = funnel(f.sq.a, f.sq.b, (st & 31) * 2);
         } else {
-            sw = sq[0] << (2 * (31 - po));
+            sw = f.sq.a << (2 * (31 - po));
         }
         // base idx 0 sits in the top bits: fold each base's two XOR bits onto its odd bit, then bit-reverse so that
         // bit 2i = i-th base compared
@@ -648,13 +666,21 @@ PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, u
     if (!(ra == 0 || premature)) {                                  // :173-175
         const uint32_t b = read_base(rd, ra - 1);                   // next_base = read_seq.get(last_pos) (:182)
         if ((hd.exts >> (4 + b)) & 1u) {                            // has_ext(Dir::Left, b) (:183)
-            s.ph = ix.ledge[4ull * s.ph + b];                       // l_edges()[index].0 (:191-194)
+            const uint64_t e = *reinterpret_cast<const uint64_t*>(ix.ledge + 8ull * s.ph + 2 * b);   // l_edges()[index].0 (:191-194) and that node's length
+            s.ph = (uint32_t)e;
+            s.rr = ((uint32_t)(e >> 32) - K + 1) | (snp << 24);     // prev_kmer_offset + 1 = len - k + 1 (:196)
             l_or_flags(s, F_FRESH);
             return;
         }                                                           // else :200-202
     }
     l_set_st(s, ST_FWD);                                            // forward search from the seed (:208)
     l_or_flags(s, F_FRESH);
+}
+template <bool TRACE = false>
+PA_HD void left_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
+    LeftLoad f;
+    left_issue(s, ix, f);
+    left_finish<TRACE>(s, ix, rd, cols, allowed, f);
 }
 
 // ---------------------------------------------------------------------------------------------- ISECT
