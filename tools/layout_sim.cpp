@@ -77,6 +77,7 @@ int main(int argc, char** argv) {
     uint64_t n_fwd = 0, n_left = 0, n_seek = 0, hops_next = 0, hops = 0;
     std::vector<uint32_t> succ_count(f.num_nodes, 0);
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> edge_use;
+    std::map<uint32_t, uint64_t> ncol_hist;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t t = i >> 6, r = i & 63;
         for (uint32_t w = 0; w < wpr; ++w) rd[w] = tiles[(t * wpr + w) * 64 + r];
@@ -126,6 +127,15 @@ int main(int argc, char** argv) {
                 prev_node = 0xFFFFFFFFu;
             }
         }
+        if ((l_flags(s) & F_LISTS) && l_st(s) == ST_ISECT) ncol_hist[l_ncol(s)]++;
+    }
+    {
+        uint64_t tot = 0;
+        for (auto& kv : ncol_hist) tot += kv.second;
+        fprintf(stderr, "list-mode reads: %llu of %llu; distinct classes per such read:", (unsigned long long)tot, (unsigned long long)n);
+        uint64_t acc = 0;
+        for (auto& kv : ncol_hist) { acc += kv.second; if (kv.first <= 12 || kv.first % 8 == 0) fprintf(stderr, " <=%u:%.1f%%", kv.first, 100.0 * acc / (tot ? tot : 1)); }
+        fprintf(stderr, "\n");
     }
     fprintf(stderr, "reads %llu: seek %.3f fwd %.3f left %.3f steps/read, hops %.3f/read\n", (unsigned long long)n, (double)n_seek / n, (double)n_fwd / n,
             (double)n_left / n, (double)hops / n);
