@@ -206,7 +206,7 @@ int pa_encode_reads_host(const uint8_t* ascii, const uint64_t* offsets, uint64_t
  *              reached by the read, 0xFFFFFFFF otherwise (input of pa_counts_accumulate_device); may be NULL
  * Asynchronous on `stream`; completion status is fetched with pa_map_finish(idx, stream, ...) (which synchronises that
  * stream). The index is immutable and shareable: launches on DIFFERENT streams — from one host thread or several — run
- * concurrently (every stream gets its own control block, spill rows and count replicas inside the handle; two launches may
+ * concurrently (every stream gets its own control block, list-mode rows and result streams inside the handle; two launches may
  * accumulate into one d_counts). Launches on ONE stream are ordered by the stream and share a control block: call
  * pa_map_finish between them if you need each launch's own status / arena use. */
 int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads,
@@ -224,11 +224,13 @@ int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint
 /* Synchronise and report: PA_OK, or PA_ERR_ARENA_FULL with *arena_needed set (re-run with a larger arena).
  * *arena_used = entries of d_arena that may hold ids (never more than the arena_cap of the launch). */
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed);
-/* Per-stream scratch: the first launch on a stream creates that stream's launch context inside the handle (control block,
- * list-mode rows of CUs x 3 x 4 waves x 128 slots x (256 x words_per_read + 24) x 4 bytes — about 2 GB at 150 bp on a 256-CU
- * part —, count replicas, novel list) and keeps it for later launches on the same stream. pa_index_release_stream frees
- * it (after synchronising the stream): call it before destroying a stream you launched on; pa_index_destroy frees what
- * is left. A host that launches from a pool of N streams holds N contexts. */
+/* Per-stream scratch: the first launch on a stream creates that stream's launch context inside the handle and keeps it for
+ * later launches on the same stream: a control block; list-mode rows of CUs x 3 x 4 waves x 128 slots x (256 x words_per_read
+ * + 24) x 4 bytes (about 2 GB at 150 bp on a 256-CU part); the stream of reads whose class is looked up by content after the
+ * mapping kernel, sized for the worst case (32 bytes per read of the largest launch); and for class-count launches the key
+ * streams (about 13 bytes per read) and, with an overflow table attached, the novel list (8 bytes per read) — some 4.5 GB for
+ * 100 M-read launches. pa_index_release_stream frees it (after synchronising the stream): call it before destroying a stream
+ * you launched on; pa_index_destroy frees what is left. A host that launches from a pool of N streams holds N contexts. */
 int pa_index_release_stream(pa_index* idx, void* stream);
 /* Measurement (bench.py's roofline leg): with timing on, every launch records HIP events around its mapping kernel on the launch
  * stream; pa_map_kernel_ms returns the duration of the last launch's mapping kernel on `stream` (it waits for that kernel).

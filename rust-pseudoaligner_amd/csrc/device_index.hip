@@ -439,7 +439,7 @@ static int map_finish_locked(pa_index* idx, LaunchCtx* cx, hipStream_t stream, u
     return PA_OK;
 }
 
-// The launch context of `stream` (control block, list-mode rows, count replicas, novel list: about 2 GB at 150 bp on a 256-CU
+// The launch context of `stream` (control block, list-mode rows, key / deferred-read streams, novel list: 2 GB + 45 bytes per read at 150 bp on a 256-CU
 // part) is freed; the next launch on that stream creates a fresh one. Callers that create and destroy streams call this
 // before hipStreamDestroy — a context left behind would stay until pa_index_destroy and could be matched to a later stream
 // whose handle value the runtime reuses.

@@ -521,7 +521,7 @@ def test_random_transcriptomes(tmp_path, seed):
 
 
 def test_hot_classes_count_table(tmp_path):
-    """a handful of classes take every read (a highly expressed gene): the per-wave count cache and the per-XCD replicas
+    """a handful of classes take every read (a highly expressed gene): the counting sort of the key streams (count_sort.hip: LDS atomics on few addresses)
     must still add up to exactly the histogram of the per-read results, also across repeated launches into one table"""
     import torch
     _, seqs = helpers.read_fasta()

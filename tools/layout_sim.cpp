@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     uint64_t n_fwd = 0, n_left = 0, n_seek = 0, hops_next = 0, hops = 0;
     std::vector<uint32_t> succ_count(f.num_nodes, 0);
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> edge_use;
-    std::map<uint32_t, uint64_t> ncol_hist;
+    std::map<uint32_t, uint64_t> ncol_hist, maxlen_hist, base_hist;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t t = i >> 6, r = i & 63;
         for (uint32_t w = 0; w < wpr; ++w) rd[w] = tiles[(t * wpr + w) * 64 + r];
@@ -127,7 +127,13 @@ int main(int argc, char** argv) {
                 prev_node = 0xFFFFFFFFu;
             }
         }
-        if ((l_flags(s) & F_LISTS) && l_st(s) == ST_ISECT) ncol_hist[l_ncol(s)]++;
+        if ((l_flags(s) & F_LISTS) && l_st(s) == ST_ISECT) {
+            ncol_hist[l_ncol(s)]++;
+            uint32_t mx = 0, mn = 0xFFFFFFFFu;
+            for (uint32_t c = 0; c < l_ncol(s); ++c) { uint32_t ref, len; get_class(cr, c, ref, len); mx = std::max(mx, len); mn = std::min(mn, len); }
+            maxlen_hist[mx <= 8 ? 8 : mx <= 16 ? 16 : mx <= 32 ? 32 : mx <= 64 ? 64 : mx <= 128 ? 128 : mx <= 256 ? 256 : mx <= 1024 ? 1024 : 1u << 20]++;
+            base_hist[mn <= 8 ? 8 : mn <= 64 ? 64 : 1u << 20]++;
+        }
     }
     {
         uint64_t tot = 0;
@@ -135,6 +141,10 @@ int main(int argc, char** argv) {
         fprintf(stderr, "list-mode reads: %llu of %llu; distinct classes per such read:", (unsigned long long)tot, (unsigned long long)n);
         uint64_t acc = 0;
         for (auto& kv : ncol_hist) { acc += kv.second; if (kv.first <= 12 || kv.first % 8 == 0) fprintf(stderr, " <=%u:%.1f%%", kv.first, 100.0 * acc / (tot ? tot : 1)); }
+        fprintf(stderr, "\n   longest class list of such a read:");
+        for (auto& kv : maxlen_hist) fprintf(stderr, " <=%u:%.1f%%", kv.first, 100.0 * kv.second / (tot ? tot : 1));
+        fprintf(stderr, "\n   shortest (the base):");
+        for (auto& kv : base_hist) fprintf(stderr, " <=%u:%.1f%%", kv.first, 100.0 * kv.second / (tot ? tot : 1));
         fprintf(stderr, "\n");
     }
     fprintf(stderr, "reads %llu: seek %.3f fwd %.3f left %.3f steps/read, hops %.3f/read\n", (unsigned long long)n, (double)n_seek / n, (double)n_fwd / n,
@@ -214,6 +224,15 @@ int main(int argc, char** argv) {
         for (uint32_t i = 0; i < N; ++i) if (!placed[i]) tx_order.push_back(i);
     }
 
+    {   // a header copy in EVERY 128-byte block of a blob (48 B header + 80 B = 10 sequence words): a step touches the blocks of its words only
+        uint64_t blocks = 0;
+        for (const Touch& tc : touches) {
+            if (tc.nr < 2) { ++blocks; continue; }
+            const uint32_t w0 = (tc.r[1][0] - BLOB_HDR_BYTES) / 8, w1 = (tc.r[tc.nr - 1][1] - BLOB_HDR_BYTES) / 8 - 1;
+            blocks += w1 / 10 - w0 / 10 + 1;
+        }
+        printf("%-48s blocks/step %.3f  blocks/read %.3f\n", "header copy in every block (10 words per block)", (double)blocks / touches.size(), (double)blocks / n);
+    }
     struct Cand { const char* name; const std::vector<uint32_t>* order; uint32_t gran, keep; };
     const Cand cands[] = {
         {"index order, 128-aligned (now)", &index_order, 128, 0},

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""profiles/latest_pmc.json from the PMC summaries of tools/gpurun/profile_r03.sh: FETCH_SIZE + WRITE_SIZE per STEP (every kernel of
+a pa_map_count_batch_device call) and the sha256 of the kernel sources they were measured on (bench.py compares it with the built
+sources and reports no traffic figure on a mismatch). usage: make_latest_pmc.py config3=<pmc.txt> config5=<pmc.txt> [reads_per_launch]"""
+import importlib.util
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+spec = importlib.util.spec_from_file_location("bench", ROOT / "bench.py")
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+reads = 100_000_000
+out = {"note": "FETCH_SIZE / WRITE_SIZE (KB) per step = sum over the kernels of one pa_map_count_batch_device call (pa_map_pool_kernel, pa_resolve_kernel, "
+               "pa_keys_hist / scan / scatter / count_kernel), rocprofv3 --pmc, separate passes, per-launch averages over the full-batch launches. "
+               "Calibration of the counters on this chip: profiles/r02_pmc_calibration.txt (random 64-byte lines exact, coalesced streams at one half: "
+               "bench.py adds the other half of the read tiles back).",
+       "kernel_source_sha256": bench.kernel_source_sha256(), "workloads": {}}
+for arg in sys.argv[1:]:
+    if "=" not in arg:
+        reads = int(arg)
+        continue
+    name, path = arg.split("=", 1)
+    per_kernel = {}
+    for line in open(path):
+        f = line.split()
+        if len(f) >= 5 and f[2] in ("FETCH_SIZE", "WRITE_SIZE"):
+            per_kernel.setdefault(f[1], {})[f[2]] = float(f[4].split("=")[1])
+    out["workloads"][name] = {"reads_per_launch": reads, "kernels": per_kernel,
+                              "FETCH_SIZE_KB": sum(k.get("FETCH_SIZE", 0.0) for k in per_kernel.values()),
+                              "WRITE_SIZE_KB": sum(k.get("WRITE_SIZE", 0.0) for k in per_kernel.values()), "source": "profiles/r03_%s_pmc.txt" % name}
+json.dump(out, open(ROOT / "profiles" / "latest_pmc.json", "w"), indent=1)
+print(json.dumps({k: (v["FETCH_SIZE_KB"], v["WRITE_SIZE_KB"]) for k, v in out["workloads"].items()}))
