@@ -22,7 +22,7 @@ for d in sorted(glob.glob(root + "/pmc_*")):
                 if int(r["Grid_Size"]) == gmax:
                     acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             for k, v in sorted(acc.items()):
-                if kernel.startswith("pa_keys"):   # every launch of a batch has the same grid: keep the launches of the full batch (largest values)
+                if not kernel.startswith("pa_map_pool"):   # every launch of a batch has the same grid: keep the launches of the full batch (largest values)
                     top = max(v)
                     v = [x for x in v if x > 0.5 * top] if top > 0 else v
                 print("%-12s %-18s %-32s launches=%d avg_per_launch=%.6g" % (d.split("/")[-1], kernel, k, len(v), sum(v) / len(v)))
