@@ -222,8 +222,10 @@ def roofline_of(run, ctr, map_ms, step_ms):
     # hash of the kernel sources it was measured on: a kernel change without a new PMC pass reports no traffic instead of stale bytes.
     try:
         doc = json.load(open(ROOT / "profiles" / "latest_pmc.json"))
-        pmc = doc["workloads"][run.name]
-        if doc.get("kernel_source_sha256") != kernel_source_sha256():
+        pmc = doc["workloads"].get(run.name)
+        if pmc is None:
+            traffic_note = "no committed PMC pass for workload %s (profiles/latest_pmc.json holds %s)" % (run.name, ", ".join(sorted(doc["workloads"])))
+        elif doc.get("kernel_source_sha256") != kernel_source_sha256():
             traffic_note = "profiles/latest_pmc.json was measured on other kernel sources (sha256 %s..., built: %s...): no traffic figure" % (
                 str(doc.get("kernel_source_sha256"))[:12], kernel_source_sha256()[:12])
         elif pmc.get("reads_per_launch") != B:

@@ -25,7 +25,7 @@ def test_usable_cpus_is_sane():
 import pytest
 
 
-@pytest.mark.parametrize("name", ["r01_pool_bench.json", "r02_bench_config3.json", "r02_bench_config5.json"])
+@pytest.mark.parametrize("name", ["r01_pool_bench.json", "r02_bench_config3.json", "r02_bench_config5.json", "r03_bench_config3.json", "r03_bench_config5.json"])
 def test_committed_bench_line_has_the_contract_fields(name):
     line = json.loads((ROOT / "profiles" / name).read_text())
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
@@ -40,6 +40,13 @@ def test_committed_bench_line_has_the_contract_fields(name):
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["unit"] == line["unit"] and "sample" in c
     assert abs(line["value"] - line["config"]["reads_per_step_per_gpu"] * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
     assert r["kernel_ms"] <= line["ms_per_step"] * 1.001   # the dominant kernel fits inside the step it belongs to
+    if name.startswith("r03"):   # round 3: the map kernel is timed by the library, the step holds more kernels; config 5 rides in the default line
+        assert r["kernel"] == "pa_map_pool_kernel" and r["kernel_ms"] <= r["step_device_ms"] <= line["ms_per_step"] * 1.001 and "rccl_ranks" in line
+        assert c["cpus_visible"] >= c["cores"]
+        if "config3" in name:
+            c5 = line["config5"]
+            assert c5["value"] > 0 and c5["parity_sample"]["bit_exact_vs_oracle"] is True and 0 < c5["roofline"]["frac"] < 1
+            assert r["traffic"] is not None and line["e2e_reads_per_s"] > 0
     if name.startswith("r02"):   # round 2: the host-to-host leg (config 3 only) and the index set-up times ride along as extra keys
         assert "index_build_s" in line["config"] and "kernel_ms_steps" in r and len(r["kernel_ms_steps"]) == line["steps"]
         if "config3" in name:
