@@ -4,7 +4,7 @@
 //
 //   one bin  (table of <= 32768 slots, e.g. gencode_small)     pa_keys_count_kernel straight over the streams
 //   several  pa_keys_hist_kernel     keys per bin (bin = key >> 15: 32768 consecutive slots = 128 KiB of LDS counters)
-//            pa_keys_scatter_kernel  keys partitioned by bin into `sorted` (counting sort: a workgroup counts its tile's
+//            pa_keys_scatter_kernel  keys partitioned by bin into `sorted` — as 16-bit keys, the position names the bin — (counting sort: a workgroup counts its tile's
 //                                    keys per bin in LDS, reserves the runs with one global atomic per bin, writes every
 //                                    key to its run; the lines of a run fill up inside the L2 within one tile)
 //            pa_keys_count_kernel    one LDS table per workgroup and bin: LDS atomics over its share of the bin's keys,
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(1024) void pa_keys_scan_kernel(const uint32_t* __re
 }
 
 __global__ __launch_bounds__(SC_BLOCK) void pa_keys_scatter_kernel(const uint32_t* __restrict__ keys, const KeyTops keys_top, uint32_t nbins, const uint32_t* __restrict__ wg_base,
-                                                                   uint32_t* __restrict__ sorted) {
+                                                                   uint16_t* __restrict__ sorted) {
     __shared__ uint32_t cnt[MAX_BINS], lbase[MAX_BINS], gbase[MAX_BINS], cursor[MAX_BINS], stage[SC_TILE], total;
     for (uint32_t b = threadIdx.x; b < nbins; b += SC_BLOCK) cursor[b] = wg_base[(uint64_t)b * gridDim.x + blockIdx.x];
     uint64_t sa, sb;
@@ -148,58 +148,81 @@ __global__ __launch_bounds__(SC_BLOCK) void pa_keys_scatter_kernel(const uint32_
         const uint32_t tot = total;
         for (uint32_t i = threadIdx.x; i < tot; i += SC_BLOCK) {   // consecutive threads, consecutive words of a run; the key names its bin
             const uint32_t key = stage[i], b = key >> PA_KEY_BIN_SHIFT;
-            sorted[gbase[b] + (i - lbase[b])] = key;
+            sorted[gbase[b] + (i - lbase[b])] = (uint16_t)(key & (BIN_SLOTS - 1));   // the position names the bin: 15 bits of the key are left
         }
         __syncthreads();
     }
 }
 
-// counts[(bin << 15) + i] += occurrences of that key. Workgroup (bin, part) takes part `part` of `parts` of the bin's keys.
-// hist == nullptr: one bin, the raw streams (padding skipped).
-__global__ __launch_bounds__(CS_BLOCK) void pa_keys_count_kernel(const uint32_t* __restrict__ src, const KeyTops keys_top, const uint32_t* __restrict__ hist, uint32_t parts,
+// counts[(bin << 15) + i] += occurrences of key i in the bin's run of `sorted` (16-bit keys: what scatter left of them). Workgroup
+// (bin, part) takes part `part` of `parts` of the run.
+__global__ __launch_bounds__(CS_BLOCK) void pa_keys_count_kernel(const uint16_t* __restrict__ src, const uint32_t* __restrict__ hist, uint32_t parts,
                                                                  unsigned long long* __restrict__ counts, uint64_t counts_len) {
-    extern __shared__ uint32_t tab[];   // BIN_SLOTS counters (or counts_len when that is less)
+    extern __shared__ uint32_t tab[];   // BIN_SLOTS counters
     const uint32_t bin = blockIdx.x / parts, part = blockIdx.x % parts;
     const uint64_t slot0 = (uint64_t)bin << PA_KEY_BIN_SHIFT;
     const uint32_t nslots = (uint32_t)(counts_len - slot0 < BIN_SLOTS ? counts_len - slot0 : BIN_SLOTS);
     for (uint32_t i = threadIdx.x; i < nslots; i += CS_BLOCK) tab[i] = 0;
     __syncthreads();
-    uint64_t lo = 0, n;
-    if (hist) {
-        for (uint32_t j = 0; j < bin; ++j) lo += hist[j];
-        n = hist[bin];
-    } else n = stream_len(keys_top);
+    uint64_t lo = 0;
+    for (uint32_t j = 0; j < bin; ++j) lo += hist[j];
+    const uint64_t n = hist[bin];
     const uint64_t a = lo + n * part / parts, b = lo + n * (part + 1) / parts;
-    // 16-byte loads, four in flight per thread (one dependent round trip per iteration otherwise); the few keys before the
-    // first and after the last aligned quad go one by one
-    const uint64_t a4 = (a + 3) & ~3ull, b4 = b & ~3ull;
-    if (a4 >= b4) {
-        for (uint64_t i = a + threadIdx.x; i < b; i += CS_BLOCK) { const uint32_t k = src[i]; if (k != NO_KEY) atomicAdd(&tab[k & (BIN_SLOTS - 1)], 1u); }
+    // 16-byte loads (eight keys), four in flight per thread; the few keys before the first and after the last aligned octet one by one
+    const uint64_t a8 = (a + 7) & ~7ull, b8 = b & ~7ull;
+    if (a8 >= b8) {
+        for (uint64_t i = a + threadIdx.x; i < b; i += CS_BLOCK) atomicAdd(&tab[src[i]], 1u);
     } else {
-        if (a + threadIdx.x < a4) { const uint32_t k = src[a + threadIdx.x]; if (k != NO_KEY) atomicAdd(&tab[k & (BIN_SLOTS - 1)], 1u); }
-        if (b4 + threadIdx.x < b) { const uint32_t k = src[b4 + threadIdx.x]; if (k != NO_KEY) atomicAdd(&tab[k & (BIN_SLOTS - 1)], 1u); }
+        if (a + threadIdx.x < a8) atomicAdd(&tab[src[a + threadIdx.x]], 1u);
+        if (b8 + threadIdx.x < b) atomicAdd(&tab[src[b8 + threadIdx.x]], 1u);
         const uint4* q = reinterpret_cast<const uint4*>(src);
         constexpr uint32_t DEPTH = 4;
-        for (uint64_t i0 = a4 / 4; i0 < b4 / 4; i0 += (uint64_t)DEPTH * CS_BLOCK) {
+        for (uint64_t i0 = a8 / 8; i0 < b8 / 8; i0 += (uint64_t)DEPTH * CS_BLOCK) {
             uint4 v[DEPTH];
+            bool in[DEPTH];
 #pragma unroll
             for (uint32_t j = 0; j < DEPTH; ++j) {
                 const uint64_t i = i0 + (uint64_t)j * CS_BLOCK + threadIdx.x;
-                v[j] = i < b4 / 4 ? q[i] : uint4{NO_KEY, NO_KEY, NO_KEY, NO_KEY};
+                in[j] = i < b8 / 8;
+                v[j] = in[j] ? q[i] : uint4{0u, 0u, 0u, 0u};
             }
 #pragma unroll
-            for (uint32_t j = 0; j < DEPTH; ++j) {
-                if (v[j].x != NO_KEY) atomicAdd(&tab[v[j].x & (BIN_SLOTS - 1)], 1u);
-                if (v[j].y != NO_KEY) atomicAdd(&tab[v[j].y & (BIN_SLOTS - 1)], 1u);
-                if (v[j].z != NO_KEY) atomicAdd(&tab[v[j].z & (BIN_SLOTS - 1)], 1u);
-                if (v[j].w != NO_KEY) atomicAdd(&tab[v[j].w & (BIN_SLOTS - 1)], 1u);
-            }
+            for (uint32_t j = 0; j < DEPTH; ++j)
+                if (in[j]) {
+                    atomicAdd(&tab[v[j].x & 0xFFFFu], 1u); atomicAdd(&tab[v[j].x >> 16], 1u);
+                    atomicAdd(&tab[v[j].y & 0xFFFFu], 1u); atomicAdd(&tab[v[j].y >> 16], 1u);
+                    atomicAdd(&tab[v[j].z & 0xFFFFu], 1u); atomicAdd(&tab[v[j].z >> 16], 1u);
+                    atomicAdd(&tab[v[j].w & 0xFFFFu], 1u); atomicAdd(&tab[v[j].w >> 16], 1u);
+                }
         }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nslots; i += CS_BLOCK) {
         const uint32_t c = tab[i];
         if (c) atomicAdd(counts + slot0 + i, (unsigned long long)c);   // (launches on several streams may count into one table)
+    }
+}
+
+// a table of one bin: straight over the raw streams (32-bit keys, padding skipped); workgroup `blockIdx.x` of `gridDim.x` takes its share
+__global__ __launch_bounds__(CS_BLOCK) void pa_keys_count_raw_kernel(const uint32_t* __restrict__ src, const KeyTops keys_top, unsigned long long* __restrict__ counts,
+                                                                     uint64_t counts_len) {
+    extern __shared__ uint32_t tab[];   // counts_len counters
+    for (uint32_t i = threadIdx.x; i < counts_len; i += CS_BLOCK) tab[i] = 0;
+    __syncthreads();
+    const uint64_t n4 = stream_len(keys_top) / 4;
+    const uint64_t a = n4 * blockIdx.x / gridDim.x, b = n4 * (blockIdx.x + 1) / gridDim.x;
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    for (uint64_t i = a + threadIdx.x; i < b; i += CS_BLOCK) {
+        const uint4 v = q[i];
+        if (v.x != NO_KEY) atomicAdd(&tab[v.x], 1u);
+        if (v.y != NO_KEY) atomicAdd(&tab[v.y], 1u);
+        if (v.z != NO_KEY) atomicAdd(&tab[v.z], 1u);
+        if (v.w != NO_KEY) atomicAdd(&tab[v.w], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < counts_len; i += CS_BLOCK) {
+        const uint32_t c = tab[i];
+        if (c) atomicAdd(counts + i, (unsigned long long)c);
     }
 }
 
@@ -231,9 +254,9 @@ int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top_p
     const uint64_t nbins = (counts_len + BIN_SLOTS - 1) >> PA_KEY_BIN_SHIFT;
     const uint32_t cus = num_cus > 0 ? (uint32_t)num_cus : 256u;
     const size_t lds = (size_t)(counts_len < BIN_SLOTS ? counts_len : BIN_SLOTS) * 4;
-    const void* count_fn = reinterpret_cast<const void*>(&pa_keys_count_kernel);
     if (lds > 48 * 1024) {
-        const hipError_t e = hipFuncSetAttribute(count_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pa_keys_count_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pa_keys_count_raw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     if (nbins > MAX_BINS) {
@@ -241,8 +264,7 @@ int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top_p
         return (int)hipGetLastError();
     }
     if (nbins == 1) {
-        hipLaunchKernelGGL(pa_keys_count_kernel, dim3(cus), dim3(CS_BLOCK), lds, stream, keys, keys_top, (const uint32_t*)nullptr, cus, counts,
-                           counts_len);
+        hipLaunchKernelGGL(pa_keys_count_raw_kernel, dim3(cus), dim3(CS_BLOCK), lds, stream, keys, keys_top, counts, counts_len);
         return (int)hipGetLastError();
     }
     // ctl: hist[MAX_BINS] | wg_hist[nbins * G] | wg_base[nbins * G]
@@ -252,11 +274,11 @@ int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top_p
     uint32_t* wg_base = wg_hist + (size_t)nbins * G;
     hipLaunchKernelGGL(pa_keys_hist_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, (uint32_t)nbins, wg_hist);
     hipLaunchKernelGGL(pa_keys_scan_kernel, dim3((uint32_t)nbins), dim3(1024), 0, stream, (const uint32_t*)wg_hist, G, wg_base, hist);
-    hipLaunchKernelGGL(pa_keys_scatter_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, (uint32_t)nbins, (const uint32_t*)wg_base, sorted);
+    hipLaunchKernelGGL(pa_keys_scatter_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, (uint32_t)nbins, (const uint32_t*)wg_base, reinterpret_cast<uint16_t*>(sorted));
     // one workgroup per CU at most (an LDS table of 128 KiB each) and ONE round of them: 270 workgroups on 256 CUs take as long as 512
     uint32_t parts = std::max<uint32_t>(1u, (uint32_t)(cus / nbins));
     parts = (uint32_t)knob_int("PA_COUNT_PARTS", (int)parts);
-    hipLaunchKernelGGL(pa_keys_count_kernel, dim3((uint32_t)nbins * parts), dim3(CS_BLOCK), lds, stream, sorted, keys_top, hist, parts, counts,
+    hipLaunchKernelGGL(pa_keys_count_kernel, dim3((uint32_t)nbins * parts), dim3(CS_BLOCK), lds, stream, reinterpret_cast<const uint16_t*>(sorted), (const uint32_t*)hist, parts, counts,
                        counts_len);
     return (int)hipGetLastError();
 }

@@ -77,7 +77,8 @@ int main(int argc, char** argv) {
     uint64_t n_fwd = 0, n_left = 0, n_seek = 0, hops_next = 0, hops = 0;
     std::vector<uint32_t> succ_count(f.num_nodes, 0);
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> edge_use;
-    std::map<uint32_t, uint64_t> ncol_hist, maxlen_hist, base_hist;
+    std::map<uint32_t, uint64_t> ncol_hist, maxlen_hist, base_hist, bigmax_hist;
+    std::map<std::pair<uint32_t, uint32_t>, uint64_t> big_hist;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t t = i >> 6, r = i & 63;
         for (uint32_t w = 0; w < wpr; ++w) rd[w] = tiles[(t * wpr + w) * 64 + r];
@@ -133,6 +134,20 @@ int main(int argc, char** argv) {
             for (uint32_t c = 0; c < l_ncol(s); ++c) { uint32_t ref, len; get_class(cr, c, ref, len); mx = std::max(mx, len); mn = std::min(mn, len); }
             maxlen_hist[mx <= 8 ? 8 : mx <= 16 ? 16 : mx <= 32 ? 32 : mx <= 64 ? 64 : mx <= 128 ? 128 : mx <= 256 ? 256 : mx <= 1024 ? 1024 : 1u << 20]++;
             base_hist[mn <= 8 ? 8 : mn <= 64 ? 64 : 1u << 20]++;
+            // which of the classes do not fit two 32-id windows (the only reason the read is in list mode)?
+            uint32_t nbig = 0, bigmax = 0;
+            for (uint32_t c = 0; c < l_ncol(s); ++c) {
+                uint32_t ref, len; get_class(cr, c, ref, len);
+                const uint32_t* ids = fd.ec.data() + 4ull * ref + 1;
+                uint32_t j = 0;
+                while (j < len && ids[j] - ids[0] < 32) ++j;
+                bool fits = true;
+                if (j < len) { const uint32_t b2 = ids[j]; for (; j < len; ++j) if (ids[j] - b2 >= 32) fits = false; }
+                if (!fits) { ++nbig; bigmax = std::max(bigmax, len); }
+            }
+            const uint32_t nwin = l_ncol(s) - nbig;
+            big_hist[{nwin ? 1u : 0u, std::min(nbig, 5u)}]++;
+            bigmax_hist[bigmax <= 8 ? 8 : bigmax <= 16 ? 16 : bigmax <= 32 ? 32 : bigmax <= 64 ? 64 : bigmax <= 128 ? 128 : bigmax <= 256 ? 256 : bigmax <= 1024 ? 1024 : 1u << 20]++;
         }
     }
     {
@@ -143,6 +158,10 @@ int main(int argc, char** argv) {
         for (auto& kv : ncol_hist) { acc += kv.second; if (kv.first <= 12 || kv.first % 8 == 0) fprintf(stderr, " <=%u:%.1f%%", kv.first, 100.0 * acc / (tot ? tot : 1)); }
         fprintf(stderr, "\n   longest class list of such a read:");
         for (auto& kv : maxlen_hist) fprintf(stderr, " <=%u:%.1f%%", kv.first, 100.0 * kv.second / (tot ? tot : 1));
+        fprintf(stderr, "\n   (has window classes, classes without windows [5 = more]):");
+        for (auto& kv : big_hist) fprintf(stderr, " (%u,%u):%.1f%%", kv.first.first, kv.first.second, 100.0 * kv.second / (tot ? tot : 1));
+        fprintf(stderr, "\n   longest class without windows:");
+        for (auto& kv : bigmax_hist) fprintf(stderr, " <=%u:%.1f%%", kv.first, 100.0 * kv.second / (tot ? tot : 1));
         fprintf(stderr, "\n   shortest (the base):");
         for (auto& kv : base_hist) fprintf(stderr, " <=%u:%.1f%%", kv.first, 100.0 * kv.second / (tot ? tot : 1));
         fprintf(stderr, "\n");
