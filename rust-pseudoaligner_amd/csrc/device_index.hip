@@ -420,7 +420,7 @@ static int map_finish_locked(pa_index* idx, LaunchCtx* cx, hipStream_t stream, u
         constexpr uint32_t NS = ST_COUNT + 4;   // ST_NSTAT of map_pool.hip: one entry per state, the dual iterations, the forward step in three parts
         unsigned long long d[3 * NS];
         HIP_TRY(hipMemcpy(d, cx->ctl.as<unsigned long long>() + 2, sizeof d, hipMemcpyDeviceToHost));
-        static const char* names[NS] = {"refill", "seek", "fwd", "left", "pick+pop", "store+push", "fin_light", "fin_scan", "fin_coop", "fin_bits", "fin_novel", "fwd+seek", "fwd:issue", "fwd:wait", "fwd:wait+compute"};
+        static const char* names[NS] = {"refill", "seek", "fwd", "left", "pick+pop", "store+push", "fin_light", "fin_scan", "fin_coop", "fin_bits", "fin_mask", "fwd+seek", "fwd:issue", "fwd:wait", "fwd:wait+compute"};
         fprintf(stderr, "[pa map stats] grid=%u", cx->last_grid);
         for (uint32_t i = 0; i < NS; ++i)
             if (d[i])

@@ -21,7 +21,7 @@ namespace pa {
 
 // walk states, then the finishing states the kernel schedules separately (ST_ISECT = walk ended, tier not yet chosen)
 enum : uint32_t { ST_EMPTY = 0, ST_SEEK = 1, ST_FWD = 2, ST_LEFT = 3, ST_ISECT = 4, ST_NONE = 5,
-                  ST_F_LIGHT = 6, ST_F_SCAN = 7, ST_F_COOP = 8, ST_F_BITS = 9, ST_F_NOVEL = 10, ST_COUNT = 11 };
+                  ST_F_LIGHT = 6, ST_F_SCAN = 7, ST_F_COOP = 8, ST_F_BITS = 9, ST_F_MASK = 10, ST_COUNT = 11 };
 enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_CAREFUL = 16u, F_LISTS = 32u,
                   F_SMALL_BASE = 64u };   // list mode: the shortest class met has <= 8 ids
 constexpr uint32_t NO_CLASS = 0xFFFFFFFFu;
@@ -37,8 +37,9 @@ struct Lane {
     uint32_t rr;    // FWD: ref offset in the node, LEFT: node bases still to the left (0..23) | seen_snp (24..31)
     uint32_t rm;    // bases of max_matchable_pos not yet compared (0..15) | LEFT: read bases still to the left (16..31)
     uint32_t ph;    // LEFT: prev_node_id as a blob handle                                  (:128)
-    uint32_t nc;    // distinct classes collected (0..13) | dictionary probe index (14..17) | TRACE: nodes.len() (18..31)
-                    // (a read of L <= 16383 bases visits at most L nodes — every visit consumes a base — so 14 bits hold both counts)
+    uint32_t nc;    // classes collected (0..13) | dictionary probe index (14..17) | TRACE: nodes.len() (18..31)
+                    // (a read of L <= 16383 bases visits at most L nodes — every visit consumes a base — so 14 bits hold both counts).
+                    // Classes collected: list mode = the distinct classes; window mode = bit 0 "a window is held" | pending classes << 1
 };
 
 PA_HD uint32_t l_st(const Lane& s) { return s.lk >> 28; }
@@ -57,6 +58,8 @@ constexpr uint32_t NC_COL_MASK = 0x3FFFu, NC_PROBE_SHIFT = 14, NC_TRACE_SHIFT = 
 PA_HD uint32_t l_ncol(const Lane& s) { return s.nc & NC_COL_MASK; }
 PA_HD uint32_t l_probe(const Lane& s) { return (s.nc >> NC_PROBE_SHIFT) & 15u; }
 PA_HD uint32_t l_ntrace(const Lane& s) { return s.nc >> NC_TRACE_SHIFT; }
+PA_HD uint32_t l_npend(const Lane& s) { return l_ncol(s) >> 1; }   // window mode: classes without windows met so far
+constexpr uint32_t PEND_MAX = NC_COL_MASK >> 1;
 
 struct ReadRef {   // the lane's packed read: word w < wmax at p[w * stride]; words from wmax on read as zero
     const uint64_t* p;
@@ -68,14 +71,18 @@ struct ReadRef {   // the lane's packed read: word w < wmax at p[w * stride]; wo
 //   window mode (default)  win[0..3] = {base1, mask1, base2, mask2}: the running intersection of the classes of every
 //                          node pushed so far as two 32-id windows (bit i of mask w = transcript base w + i; base2 >=
 //                          base1 + 32) and wcand[0] = the class id when that intersection IS one of the classes seen,
-//                          else NO_CLASS. Nothing else is kept.
+//                          else NO_CLASS. A class that does NOT fit two windows (cmask == 0: few ids, far apart — a repeat
+//                          shared by distant genes) is only noted: (ref, len) appended to pend[], the same HBM row
+//                          list mode uses. Such a class cannot BE the result once a window is held (the result fits
+//                          the window, the class does not), it can only remove ids from it: mask_pending does that
+//                          after the walk, one pass over the class's ids per pending entry (state ST_F_MASK).
 //   list mode (F_LISTS)    the classes seen: the first LDS_CLASSES as refs[0..3] / lens[0..3] / cids[0..3] (each one
 //                          16-byte vector), the rest as (ref, len, class id, -) quads in `spill` — all of it in HBM and
 //                          only written during the walk. What the walk reads back is in LDS: win[0..2] = refs of the
 //                          first three classes (exact dedupe while there are <= 3, which the register tier needs),
 //                          win[3] / wcand[0] = ref / length of the shortest class so far (the base of the intersection).
-// A read starts in window mode; the first node whose class does not fit two windows (cmask == 0) restarts the read in
-// list mode.
+// A read starts in window mode. A read that ends its walk with pending classes and NO window (every class it met lacks
+// windows), or with more than PEND_MAX pending, is restarted in list mode.
 struct ColRef {
     uint32_t* win;    // window mode: one 16-byte vector
     uint32_t* wcand;  // window mode: one word
@@ -84,6 +91,7 @@ struct ColRef {
     uint32_t* cids;
     uint32_t* spill;
     uint32_t spill_cap;   // u32 words
+    uint32_t* pend;       // window mode: (ref, len) pairs of the classes without windows; capacity >= spill_cap words
     uint32_t* trace;      // TRACE builds only: node ids in visit order (map_read_to_nodes, :54-61), capacity spill_cap
 };
 
@@ -321,10 +329,17 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
     }
     const uint32_t n = l_ncol(s);
     if (!(l_flags(s) & F_LISTS)) {                                   // window mode: AND of masks
-        if (hd.cmask == 0) return true;
+        if (hd.cmask == 0) {                                         // no windows: noted, applied after the walk
+            const uint32_t np = n >> 1;
+            if (np >= PEND_MAX || 2 * np + 1 >= c.spill_cap) return true;
+            c.pend[2 * np] = hd.ec_ref;
+            c.pend[2 * np + 1] = hd.ec_len;
+            s.nc += 2;
+            return false;
+        }
         U4 w = *reinterpret_cast<const U4*>(c.win);                  // {base1, mask1, base2, mask2}
         uint32_t cand = hd.cid;
-        if (n == 0) {
+        if (!(n & 1u)) {
             w = U4{hd.cmin, hd.cmask, hd.cmin2, hd.cmask2};
         } else {
             // the class's windows re-based onto each running window (ids outside a running window cannot survive)
@@ -337,7 +352,7 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
         }
         *reinterpret_cast<U4*>(c.win) = w;
         c.wcand[0] = cand;
-        s.nc = (s.nc & ~NC_COL_MASK) | 1u;
+        s.nc |= 1u;
         return false;
     }
     // list mode: win = {ref of class 0, 1, 2, ref of the shortest class so far}, wcand = the shortest length (both in LDS:
@@ -376,10 +391,44 @@ PA_HD void lane_start(Lane& s, uint32_t rid, uint32_t L, uint32_t k) {
     s.h = s.rr = s.rm = s.ph = s.nc = 0;
     s.of = F_FIRST_SEEK << 24;
 }
-// a class without a window was met: map the read again from its first base, this time collecting class lists
+// only classes without windows were met (or too many of them): map the read again from its first base, this time collecting class lists
 PA_HD void restart_lists(Lane& s, uint32_t k) {
     lane_start(s, s.rid, l_L(s), k);
     l_or_flags(s, F_LISTS);
+}
+// window mode, the walk has ended (ST_ISECT): what is left to do before the result can be written?
+//   0 nothing (no pending classes)   1 mask_pending (ST_F_MASK)   2 restart in list mode (pending classes, no window to mask)
+PA_HD uint32_t window_todo(const Lane& s) {
+    const uint32_t n = l_ncol(s);
+    return (n >> 1) == 0 ? 0u : (n & 1u) ? 1u : 2u;
+}
+// ids of the sorted list (record `ref`, `len` ids) that fall into the windows [b1, b1 + 32) and [b2, b2 + 32), as masks.
+// (Host form: the kernel does the same with 16-byte chunks per lane and a binary search into long lists — map_pool.hip, ST_F_MASK.)
+PA_HD void list_window_mask(const DevIndexView& ix, uint32_t ref, uint32_t len, uint32_t b1, uint32_t b2, uint32_t& m1, uint32_t& m2) {
+    const uint32_t* ids = ix.ec + 4ull * ref + 1;
+    m1 = m2 = 0;
+    for (uint32_t j = 0; j < len; ++j) {
+        const uint32_t d1 = ids[j] - b1, d2 = ids[j] - b2;
+        if (d1 < CLASS_WINDOW) m1 |= 1u << d1;
+        if (d2 < CLASS_WINDOW) m2 |= 1u << d2;
+    }
+}
+// the pending classes of a window-mode read applied to its window; leaves the read as a plain window-mode result
+PA_HD void mask_pending(Lane& s, const DevIndexView& ix, ColRef c) {
+    U4 w = *reinterpret_cast<const U4*>(c.win);
+    const uint32_t np = l_npend(s);
+    uint32_t a1 = w.y, a2 = w.w;
+    for (uint32_t i = 0; i < np; ++i) {
+        uint32_t m1, m2;
+        list_window_mask(ix, c.pend[2 * i], c.pend[2 * i + 1], w.x, w.z, m1, m2);
+        a1 &= m1;
+        a2 &= m2;
+    }
+    if (a1 != w.y || a2 != w.w) c.wcand[0] = NO_CLASS;   // a strict subset of the window classes seen, and no class without windows fits a window
+    w.y = a1;
+    w.w = a2;
+    *reinterpret_cast<U4*>(c.win) = w;
+    s.nc = (s.nc & ~NC_COL_MASK) | 1u;
 }
 
 // ---------------------------------------------------------------------------------------------- SEEK

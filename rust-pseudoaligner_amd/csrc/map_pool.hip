@@ -219,12 +219,70 @@ __device__ __forceinline__ uint32_t list_hits(glb_u32 ec, uint32_t xref, uint32_
     return acc;
 }
 
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+    for (uint32_t o = 32; o; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, (int)o, 64));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// ids of the list of record `xref` (`len` ids) inside the windows [b1, b1 + 32) and [b2, b2 + 32), as masks (list_window_mask of
+// lane_steps.hpp, one list per lane). Lists of up to 64 ids are scanned whole, 16-byte chunks, four in flight; in a longer one the
+// first id >= b1 (>= b2) is found by binary search and the nine chunks from there are scanned (32 ids and the chunk they start
+// in). Every loop runs to the wave's longest range; lanes with act == false do nothing.
+__device__ __forceinline__ void window_hits(glb_u32 ec, uint32_t xref, uint32_t len, bool act, uint32_t b1, uint32_t b2, uint32_t& m1, uint32_t& m2) {
+    const glb_v4 rec = (glb_v4)(ec + 4ull * xref);
+    const uint32_t nch = act ? (len + 4) >> 2 : 0u;
+    uint32_t c[2] = {0u, 0u}, e[2] = {nch, 0u};
+    const bool lng = act && len > 64;
+    if (__ballot(lng)) {
+        if (lng) {
+            const glb_u32 ids = ec + 4ull * xref + 1;
+#pragma unroll
+            for (uint32_t r = 0; r < 2; ++r) {
+                const uint32_t b = r ? b2 : b1;
+                uint32_t lo = 0, hi = len;
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (ids[mid] < b) lo = mid + 1; else hi = mid;
+                }
+                c[r] = (1 + lo) >> 2;                                      // id j is word 1 + j of the record
+                e[r] = min(nch, ((1 + lo + CLASS_WINDOW - 1) >> 2) + 1);   // ids lo .. lo + 31 (sorted: no id of the window lies beyond)
+            }
+        }
+    }
+    m1 = m2 = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < 2; ++r) {
+        const uint32_t mx = wave_max(e[r] > c[r] ? e[r] - c[r] : 0u);
+        for (uint32_t c0 = 0; c0 < mx; c0 += 4) {
+            u32x4 w[4];
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) w[t] = rec[c[r] + c0 + t < e[r] ? c[r] + c0 + t : 0u];
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t)
+                if (c[r] + c0 + t < e[r]) {
+                    const uint32_t v[4] = {w[t].x, w[t].y, w[t].z, w[t].w};
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; ++i) {
+                        if (i == 0 && c[r] + c0 + t == 0) continue;   // word 0 of a record is its class id (0xFFFFFFFF padding never falls into a window)
+                        const uint32_t d1 = v[i] - b1, d2 = v[i] - b2;
+                        if (d1 < CLASS_WINDOW) m1 |= 1u << d1;
+                        if (d2 < CLASS_WINDOW) m2 |= 1u << d2;
+                    }
+                }
+        }
+    }
+}
+
 // the queue a slot goes to after a step
-__device__ __forceinline__ uint32_t queue_of(Lane& s) {
+__device__ __forceinline__ uint32_t queue_of(Lane& s, uint32_t K) {
     uint32_t st = l_st(s);
-    if (st == ST_ISECT) {   // the walk just ended: window mode has nothing left to intersect; list mode goes to its tier
+    if (st == ST_ISECT) {   // the walk just ended: window mode has nothing left to intersect (but for pending classes); list mode goes to its tier
         const uint32_t fl = l_flags(s);
-        st = !(fl & F_LISTS) ? ST_F_BITS : l_ncol(s) <= 3 ? ST_F_LIGHT : (fl & F_SMALL_BASE) ? ST_F_SCAN : ST_F_COOP;
+        if (!(fl & F_LISTS)) {
+            const uint32_t todo = window_todo(s);
+            if (todo == 2) { restart_lists(s, K); return ST_SEEK; }   // nothing but classes without windows: once more, collecting lists
+            st = todo ? ST_F_MASK : ST_F_BITS;
+        } else st = l_ncol(s) <= 3 ? ST_F_LIGHT : (fl & F_SMALL_BASE) ? ST_F_SCAN : ST_F_COOP;
         l_set_st(s, st);
     }
     return st == ST_NONE ? (uint32_t)ST_F_BITS : st;   // unmapped reads share the output queue
@@ -374,14 +432,15 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
 #define PA_CONSIDER_RARE_MIN(t, c, mn) { const uint32_t c_ = (c), w_ = (PA_RARE_MIN && c_ >= (mn)) ? 64u + c_ : c_; \
                                          if (best < 64 && w_ > best) { best = w_; bestn = c_; sel = (t); } }
 #define PA_CONSIDER_RARE(t, c) PA_CONSIDER_RARE_MIN(t, c, PA_RARE_MIN)
-        // the five rare states (left extension, the list-mode tiers, the content lookup) are only counted when some slot is in one
+        // the five rare states (left extension, the list-mode tiers, the pending classes of window mode) are only counted when some slot is in one
         // of them: one ballot instead of ten in most iterations (the order of consideration is the same either way)
-        constexpr uint32_t RARE = (1u << ST_LEFT) | (1u << ST_F_LIGHT) | (1u << ST_F_SCAN) | (1u << ST_F_COOP);
+        constexpr uint32_t RARE = (1u << ST_LEFT) | (1u << ST_F_LIGHT) | (1u << ST_F_SCAN) | (1u << ST_F_COOP) | (1u << ST_F_MASK);
         const bool any_rare = __ballot((((RARE >> (st_lo & 31u)) | (RARE >> (st_hi & 31u))) & 1u) != 0) != 0;   // (0xFF, no slot: bit 31, not rare)
         if (any_rare) {
             PA_CONSIDER_RARE_MIN(ST_F_COOP, PA_CNT(ST_F_COOP), PA_COOP_MIN)   // (the wave takes its reads one at a time: nothing to gain from gathering them)
             PA_CONSIDER_RARE(ST_F_SCAN, PA_CNT(ST_F_SCAN))
             PA_CONSIDER_RARE(ST_F_LIGHT, PA_CNT(ST_F_LIGHT))
+            PA_CONSIDER_RARE(ST_F_MASK, PA_CNT(ST_F_MASK))
         }
         PA_CONSIDER(ST_F_BITS, PA_CNT(ST_F_BITS))
         PA_CONSIDER(ST_FWD, PA_CNT(ST_FWD))
@@ -435,7 +494,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         const ReadRef rr = GREAD ? ReadRef{p.tiles + ((uint64_t)(s.rid >> 6) * wpr) * 64 + (s.rid & 63), 64u, wpr} : ReadRef{(const uint64_t*)(rd + slot), S, wpr};
         const glb_u32w row = (glb_u32w)p.spill + (uint64_t)gslot * spill_cap;
         const ColRef cols{(uint32_t*)&win[slot], (uint32_t*)(wc + 2 * slot), (uint32_t*)row, (uint32_t*)(row + 4), (uint32_t*)(row + 8),
-                          (uint32_t*)(row + LIST_ROW_HDR), spill_cap - LIST_ROW_HDR,
+                          (uint32_t*)(row + LIST_ROW_HDR), spill_cap - LIST_ROW_HDR, (uint32_t*)row,
                           TRACE ? (uint32_t*)((glb_u32w)p.trace + (uint64_t)gslot * spill_cap) : nullptr};
 
         uint32_t nq2 = 0xFFu;   // DUAL: the queue the second batch's slot goes to
@@ -478,9 +537,9 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             }
             if (active2) {
                 seek_complete(s2, K, pq, cand, ent);
+                nq2 = queue_of(s2, K);   // (may rewrite the state: before the store)
                 stA[slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
                 stB[slot2] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};
-                nq2 = queue_of(s2);
             }
         } else if (sel == ST_LEFT) {
             if (active) left_step<TRACE>(s, ix, rr, cols, allowed);
@@ -526,6 +585,71 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             }
             if (counting && !PA_ABLATE(2u)) append_keys(ckey, lane, kp, kchunk);
             append_deferred(dfr, d0, d1, lane, kp, dchunk);
+        } else if (sel == ST_F_MASK) {
+            // Window mode, classes without windows pending (lane_steps.hpp, mask_pending): ONE PENDING CLASS PER LANE. The
+            // waiting reads are packed into the wave, one lane per pending class; the lane streams that class's ids and
+            // notes which fall into the read's two windows; the masks of a read's lanes are ANDed (segmented reduction)
+            // and applied to its window. The read then is a plain window-mode result (ST_F_BITS). Three round trips per
+            // pass: the (ref, len) pair, the ids, and nothing else.
+            const u32x4 w = active ? win[slot] : u32x4{0u, 0u, 0u, 0u};
+            const uint32_t np_mine = active ? l_npend(s) : 0u;
+            uint32_t a1 = w.y, a2 = w.w;
+            for (uint64_t todo = __ballot(active && np_mine <= 64); todo;) {   // (as ST_F_SCAN: the longest prefix of the waiting reads that fits in 64 lanes)
+                const uint32_t want = ((todo >> lane) & 1ull) ? np_mine : 0u;
+                const uint32_t incl = wave_incl_scan(want);
+                const uint32_t start = incl - want;
+                const bool inpass = want != 0 && incl <= 64;   // the first waiting read always is
+                const uint64_t pass = __ballot(inpass);
+                todo &= ~pass;
+                uint32_t Lr = 64, jg = 0, seg_end = 0;   // the read this lane works for, which of its pending classes, where its lanes end
+                for (uint64_t m = pass; m; m &= m - 1) {   // uniform: hand the lanes out
+                    const uint32_t o = (uint32_t)(__ffsll((unsigned long long)m) - 1);
+                    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)start, (int)o);
+                    const uint32_t nc = (uint32_t)__builtin_amdgcn_readlane((int)np_mine, (int)o);
+                    if (lane - st < nc) { Lr = o; jg = lane - st; seg_end = st + nc; }
+                }
+                const bool gact = Lr < 64;
+                const int src = (int)(Lr & 63u);
+                const uint32_t b1 = (uint32_t)__shfl((int)w.x, src, 64), b2 = (uint32_t)__shfl((int)w.z, src, 64), slotL = (uint32_t)__shfl((int)slot, src, 64);
+                const glb_u32w rowL = (glb_u32w)p.spill + (uint64_t)(wave * S + slotL) * spill_cap;
+                uint32_t xref = 0, xlen = 0;
+                if (gact) { xref = rowL[2 * jg]; xlen = rowL[2 * jg + 1]; }
+                uint32_t m1, m2;
+                window_hits(ec, xref, xlen, gact, b1, b2, m1, m2);
+                for (uint32_t o = 1; o < 64; o <<= 1) {   // AND over the lanes of a read: lane `start` ends up with all of them
+                    const uint32_t t1 = (uint32_t)__shfl_down((int)m1, o, 64), t2 = (uint32_t)__shfl_down((int)m2, o, 64);
+                    if (gact && lane + o < seg_end) { m1 &= t1; m2 &= t2; }
+                }
+                const uint32_t r1 = (uint32_t)__shfl((int)m1, (int)(start & 63u), 64), r2 = (uint32_t)__shfl((int)m2, (int)(start & 63u), 64);
+                if (inpass) { a1 &= r1; a2 &= r2; }
+            }
+            for (uint64_t todo = __ballot(active && np_mine > 64); todo; todo &= todo - 1) {   // more pending classes: the whole wave per read
+                const uint32_t Lr = (uint32_t)(__ffsll((unsigned long long)todo) - 1);
+                const uint32_t b1 = (uint32_t)__shfl((int)w.x, (int)Lr, 64), b2 = (uint32_t)__shfl((int)w.z, (int)Lr, 64);
+                const uint32_t npL = (uint32_t)__shfl((int)np_mine, (int)Lr, 64), slotL = (uint32_t)__shfl((int)slot, (int)Lr, 64);
+                const glb_u32w rowL = (glb_u32w)p.spill + (uint64_t)(wave * S + slotL) * spill_cap;
+                uint32_t r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu;
+                for (uint32_t g = 0; g < npL; g += 64) {
+                    const uint32_t ci = g + lane;
+                    const bool gact = ci < npL;
+                    uint32_t xref = 0, xlen = 0;
+                    if (gact) { xref = rowL[2 * ci]; xlen = rowL[2 * ci + 1]; }
+                    uint32_t m1, m2;
+                    window_hits(ec, xref, xlen, gact, b1, b2, m1, m2);
+                    if (gact) { r1 &= m1; r2 &= m2; }
+                }
+                for (uint32_t o = 32; o; o >>= 1) {
+                    r1 &= (uint32_t)__shfl_xor((int)r1, (int)o, 64);
+                    r2 &= (uint32_t)__shfl_xor((int)r2, (int)o, 64);
+                }
+                if (lane == Lr) { a1 &= r1; a2 &= r2; }
+            }
+            if (active) {
+                if (a1 != w.y || a2 != w.w) wc[2 * slot] = NO_CLASS;   // a strict subset of the window classes seen (and no class without windows fits a window)
+                win[slot] = u32x4{w.x, a1, w.z, a2};
+                s.nc = (s.nc & ~NC_COL_MASK) | 1u;
+                l_set_st(s, ST_F_BITS);
+            }
         } else if (sel == ST_F_SCAN) {
             // List mode, base list of <= 8 ids, other lists of any number and length: ONE LIST PER LANE. The waiting reads
             // are packed into the wave, ncol lanes each; lane j of a read's segment loads the read's base ids, streams the
@@ -764,7 +888,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
 
         const unsigned long long t_step = PA_DBG ? __builtin_readcyclecounter() : 0ull;
         // ---- 4. store the lane state, push every slot onto the queue of its new state
-        const uint32_t nq = active ? queue_of(s) : 0xFFu;
+        const uint32_t nq = active ? queue_of(s, K) : 0xFFu;
         if (active) {
             stA[slot] = u32x4{s.lk, s.cm, s.h, s.of};
             stB[slot] = u32x4{s.rr, s.rm, s.ph, s.nc};

@@ -46,7 +46,7 @@ uint64_t emu_index_info(const emu_index* e, int what) {
     }
 }
 
-// results as pa_read_result; class ids as malloc'd CSR in read order; optional step counters [4] = seek, fwd, left steps, spills
+// results as pa_read_result; class ids as malloc'd CSR in read order; optional step counters [5] = seek, fwd, left steps, spills, reads whose pending classes were masked
 int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const uint32_t* lens, uint64_t n, uint32_t allowed,
                   uint32_t col_cap, pa_read_result* results, uint64_t* class_offsets, uint32_t** class_ids, uint32_t* colour_out,
                   uint64_t* steps, uint32_t* nodes_out, uint32_t nodes_stride, uint32_t* nodes_len) {
@@ -55,9 +55,9 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
     std::vector<uint64_t> rd(wpr + 2);
     alignas(16) uint32_t refs[4], lens4[4], cids4[4], win4[4];
     uint32_t wcand[2];
-    std::vector<uint32_t> spill, trace;
+    std::vector<uint32_t> spill, trace, pend;
     (void)col_cap;
-    uint64_t st_seek = 0, st_fwd = 0, st_left = 0, st_spill = 0;
+    uint64_t st_seek = 0, st_fwd = 0, st_left = 0, st_spill = 0, st_mask = 0;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t t = i >> 6, r = i & 63;
         for (uint32_t w = 0; w < wpr; ++w) rd[w] = tiles[(t * wpr + w) * 64 + r];
@@ -65,17 +65,25 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
         const uint32_t L = lens[i];
         spill.assign(8 * (size_t)L + 8, 0);
         trace.assign(8 * (size_t)L + 8, 0);
+        pend.assign(8 * (size_t)L + 8, 0);
         Lane s;
         lane_start(s, (uint32_t)i, L, ix.k);
         const ReadRef rr{rd.data(), 1, wpr};
-        const ColRef cr{win4, wcand, refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), trace.data()};
-        while (l_st(s) == ST_SEEK || l_st(s) == ST_FWD || l_st(s) == ST_LEFT) {
-            if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
-            else if (l_st(s) == ST_FWD) { fwd_step<true>(s, ix, rr, cr, allowed); ++st_fwd; }
-            else { left_step<true>(s, ix, rr, cr, allowed); ++st_left; }
+        const ColRef cr{win4, wcand, refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), pend.data(), trace.data()};
+        for (;;) {
+            while (l_st(s) == ST_SEEK || l_st(s) == ST_FWD || l_st(s) == ST_LEFT) {
+                if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
+                else if (l_st(s) == ST_FWD) { fwd_step<true>(s, ix, rr, cr, allowed); ++st_fwd; }
+                else { left_step<true>(s, ix, rr, cr, allowed); ++st_left; }
+            }
+            if (l_st(s) != ST_ISECT || (l_flags(s) & F_LISTS)) break;
+            const uint32_t todo = window_todo(s);   // window mode: classes without windows still to apply?
+            if (todo == 2) { restart_lists(s, ix.k); continue; }
+            if (todo == 1) { mask_pending(s, ix, cr); ++st_mask; }
+            break;
         }
         if (l_flags(s) & F_SPILL_OVERFLOW) return PA_ERR_INTERNAL;
-        if (l_ncol(s) > LDS_CLASSES) ++st_spill;
+        if ((l_flags(s) & F_LISTS) && l_ncol(s) > LDS_CLASSES) ++st_spill;
         if (nodes_out) {
             nodes_len[i] = l_ntrace(s);
             for (uint32_t j = 0; j < l_ntrace(s) && j < nodes_stride; ++j) nodes_out[i * nodes_stride + j] = trace[j];
@@ -134,7 +142,7 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
     if (!p) return PA_ERR_OOM;
     memcpy(p, all.data(), all.size() * 4);
     *class_ids = p;
-    if (steps) { steps[0] = st_seek; steps[1] = st_fwd; steps[2] = st_left; steps[3] = st_spill; }
+    if (steps) { steps[0] = st_seek; steps[1] = st_fwd; steps[2] = st_left; steps[3] = st_spill; steps[4] = st_mask; }
     return PA_OK;
 }
 

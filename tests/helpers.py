@@ -228,7 +228,7 @@ class Emu:
         coff = np.zeros(n + 1, np.uint64)
         ids = C.c_void_p()
         colour = np.zeros(max(n, 1), np.uint32)
-        steps = np.zeros(4, np.uint64)
+        steps = np.zeros(5, np.uint64)
         lens = np.ascontiguousarray(lens, np.uint32)
         stride = 2 * int(lens.max() if n else 1) + 8
         nodes = np.zeros((n, stride), np.uint32) if want_nodes else None

@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> rd(wpr + 2);
     alignas(16) uint32_t refs[4], lens4[4], cids4[4], win4[4];
     uint32_t wcand[2];
-    std::vector<uint32_t> spill(8 * read_len + 64), trace(8 * read_len + 64);
+    std::vector<uint32_t> spill(8 * read_len + 64), trace(8 * read_len + 64), pend(8 * read_len + 64);
     uint64_t n_fwd = 0, n_left = 0, n_seek = 0, hops_next = 0, hops = 0;
     std::vector<uint32_t> succ_count(f.num_nodes, 0);
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> edge_use;
@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
         Lane s;
         lane_start(s, (uint32_t)i, lens[i], ix.k);
         const ReadRef rr{rd.data(), 1, wpr};
-        const ColRef cr{win4, wcand, refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), trace.data()};
+        const ColRef cr{win4, wcand, refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), pend.data(), trace.data()};
         uint32_t prev_node = 0xFFFFFFFFu;
         while (l_st(s) == ST_SEEK || l_st(s) == ST_FWD || l_st(s) == ST_LEFT) {
             if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++n_seek; prev_node = 0xFFFFFFFFu; }
