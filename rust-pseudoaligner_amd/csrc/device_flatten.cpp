@@ -9,6 +9,7 @@
 #include <atomic>
 #include <thread>
 
+#include "dict_slots.hpp"
 #include "lane_steps.hpp"
 #include "pa_common.hpp"
 
@@ -69,6 +70,7 @@ struct Dict<u128> {   // k > 32: two whole entries {key word 0..3, handle, off, 
             if (++b == nbuckets) b = 0;
         }
     }
+    void insert_rest_mt(u128, uint32_t, uint32_t) {}   // (one pass)
     bool find(u128 kmer, uint32_t& handle, uint32_t& off, uint32_t* probes_out = nullptr) const {
         uint64_t b = bucket_of(kmer);
         for (uint64_t probes = 0; probes < nbuckets; ++probes) {
@@ -91,49 +93,24 @@ struct Dict<u128> {   // k > 32: two whole entries {key word 0..3, handle, off, 
     }
 };
 
+struct HostAtomics {
+    static bool cas(uint32_t* p, uint32_t expect, uint32_t v) { return __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED); }
+    static void and_(uint32_t* p, uint32_t m) { __atomic_fetch_and(p, m, __ATOMIC_RELAXED); }
+};
+
 template <>
-struct Dict<uint64_t> {   // host-side builder/reader of the bucket lines described in device_layout.hpp
+struct Dict<uint64_t> {   // host-side builder/reader of the 16-byte slots described in device_layout.hpp (dict_slots.hpp)
     static constexpr double LOAD = 0.5;
     static constexpr uint32_t SLOTS = SLOTS_PER_BUCKET;
     uint32_t* words;
     uint64_t nbuckets;
-    uint64_t bucket_of(uint64_t kmer) const { return pa_bucket(kmer, (uint32_t)nbuckets); }   // same function as the kernel
-    void insert_mt(uint64_t kmer, uint32_t handle, uint32_t off) {
-        const uint32_t klo = (uint32_t)kmer, want = klo & 0x7FFFFFFFu;
-        uint64_t b = bucket_of(kmer);
-        for (;;) {
-            uint32_t* line = words + b * BUCKET_WORDS;
-            for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i) {
-                uint32_t expect = FP_EMPTY;
-                if (__atomic_compare_exchange_n(&line[i], &expect, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
-                    line[4 + 3 * i] = (uint32_t)(kmer >> 32);
-                    line[5 + 3 * i] = handle;
-                    line[6 + 3 * i] = off | (klo & 0x80000000u);
-                    return;
-                }
-            }
-            if (++b == nbuckets) b = 0;
-        }
-    }
+    void insert_mt(uint64_t kmer, uint32_t handle, uint32_t off) { dict_insert_home<HostAtomics>(words, (uint32_t)nbuckets, kmer, handle, off); }          // pass 1
+    void insert_rest_mt(uint64_t kmer, uint32_t handle, uint32_t off) { dict_insert_rest<HostAtomics>(words, (uint32_t)nbuckets, kmer, handle, off); }     // pass 2
     bool find(uint64_t kmer, uint32_t& handle, uint32_t& off, uint32_t* probes_out = nullptr) const {
-        const uint32_t klo = (uint32_t)kmer, want = klo & 0x7FFFFFFFu, khi = (uint32_t)(kmer >> 32);
-        uint64_t b = bucket_of(kmer);
-        for (uint64_t probes = 0; probes < nbuckets; ++probes) {
-            const uint32_t* line = words + b * BUCKET_WORDS;
-            bool full = true;
-            for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i) {
-                if (line[i] == FP_EMPTY) { full = false; continue; }
-                if (line[i] == want && line[4 + 3 * i] == khi && (line[6 + 3 * i] >> 31) == (klo >> 31)) {
-                    handle = line[5 + 3 * i];
-                    off = line[6 + 3 * i] & 0x7FFFFFFFu;
-                    if (probes_out) *probes_out = (uint32_t)probes;
-                    return true;
-                }
-            }
-            if (!full) return false;
-            if (++b == nbuckets) b = 0;
-        }
-        return false;
+        uint32_t probes = 0;
+        const bool found = dict_find64(words, (uint32_t)nbuckets, kmer, handle, off, probes);
+        if (probes_out) *probes_out = probes;
+        return found;
     }
 };
 
@@ -244,10 +221,13 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
     for (double load = Dict<KT>::LOAD; !device_dict; load *= 0.75) {
         out.nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (Dict<KT>::SLOTS * load)) + 1);
         if (out.nbuckets >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "dictionary exceeds 2^32 buckets");
-        out.table.assign(out.nbuckets * BUCKET_WORDS, FP_EMPTY);
+        out.table.assign(out.nbuckets * BUCKET_WORDS, 0xFFFFFFFFu);   // empty slots, no flags
         dict = Dict<KT>{out.table.data(), out.nbuckets};
         par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
             for (uint64_t i = a; i < b; ++i) node_kmers((uint32_t)i, [&](KT km, uint32_t o) { dict.insert_mt(km, out.handle[i], o); });
+        });
+        par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {   // k <= 32: keys that did not get their home slot (dict_slots.hpp)
+            for (uint64_t i = a; i < b; ++i) node_kmers((uint32_t)i, [&](KT km, uint32_t o) { dict.insert_rest_mt(km, out.handle[i], o); });
         });
         std::atomic<uint32_t> bad{NO_HANDLE}, far{0};
         par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
@@ -255,7 +235,7 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
                 node_kmers((uint32_t)i, [&](KT km, uint32_t o) {
                     uint32_t h, off, probes = 0;
                     if (!dict.find(km, h, off, &probes) || h != out.handle[i] || off != o) bad.store((uint32_t)i);
-                    if (probes > 15) far.store(1);
+                    if (probes > DICT_MAX_PROBES) far.store(1);
                 });
         });
         if (bad.load() != NO_HANDLE) return fail(PA_ERR_FORMAT, "a k-mer of node %u occurs twice in the graph", bad.load());

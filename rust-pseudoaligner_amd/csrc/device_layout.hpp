@@ -3,16 +3,21 @@
 //
 // HBM layout (all little-endian, all read-only after pa_index_create):
 //
-//   dictionary  bucketed open addressing, one 64-byte line per bucket of four k-mers:
-//                 +0   u32 fp[4]      low 31 bits of the k-mer (bit 31 clear); 0xFFFFFFFF = empty slot
-//                 +16  {u32 key_hi, u32 handle, u32 off | key bit 31 << 31}[4]
-//               bucket = mulhi64(fmix64(key), nbuckets), linear probing over buckets (a bucket with a free slot ends
-//               the probe sequence). A lookup is ONE 16-byte load of the fingerprints and, on a fingerprint match, one
-//               dependent 12-byte load from the same line that both returns (handle, off) and VERIFIES the remaining
-//               33 key bits — the dictionary stores whole keys, so unlike the reference's MPHF (src/pseudoaligner.rs:
-//               96-107) no node sequence has to be fetched to confirm a hit.
+//   dictionary  (k <= 32) open addressing over 16-byte SLOTS, four to a 64-byte bucket line:
+//                 slot = {u32 key_lo, u32 key_hi, u32 handle (0xFFFFFFFF = empty), u32 off (bits 0..23) | ~flags << 24}
+//               bucket = mulhi32(fmix64(key) >> 32, nbuckets); every key also has a HOME slot in its bucket, j = fmix64(key) & 3.
+//               A key sits in its home slot when that was free (78 % of the keys at load 0.5: the builders place all home
+//               keys first), else in another slot t of the bucket — then flag bit ((t - j - 1) & 3) of the HOME slot says so —
+//               else it overflows into the next bucket (flag bit 3 of the home slot) where the same rule applies. Flags are
+//               stored inverted (a set flag is a cleared bit) so that an all-ones fill is "empty, no flags". A lookup is ONE
+//               16-byte load — the home slot holds the whole key and the answer — and only when the home slot holds another
+//               key AND names other slots, one more load from the same line (21 % of the hits, 9 % of the misses). Round 2's
+//               line {fp[4], entries[4]} took two dependent loads for every hit, and on this chip the second load of a line that
+//               lives in HBM costs almost what the first did (tools/microbench/gather_multi.hip: 47 G lines/s with one load per
+//               lane, 33 G with a dependent second one). The dictionary stores whole keys, so unlike the reference's MPHF
+//               (src/pseudoaligner.rs:96-107) no node sequence has to be fetched to confirm a hit.
 //               k > 32 (two-word k-mers): a line holds two whole entries {key word 0..3, handle, off, -, -}, handle
-//               0xFFFFFFFF = empty, load <= 1/3.
+//               0xFFFFFFFF = empty, load <= 1/3, linear probing over lines (a line with a free entry ends the probe sequence).
 //   node blobs  one blob per unitig, 64-byte aligned (one HBM line), addressed by handle = byte offset / 64:
 //                 +0  u32 len (bits 0..23) | debruijn::Exts byte (bits 24..31)
 //                 +4  u32 class id         +8  u32 class record ref      +12 u32 class length (ids)
@@ -58,7 +63,11 @@ constexpr uint32_t BLOB_HDR_BYTES = 48;
 constexpr uint32_t CLASS_WINDOW = 32;   // ids per class window (one mask word)
 constexpr uint32_t SLOTS_PER_BUCKET = 4;
 constexpr uint32_t BUCKET_WORDS = 16;
-constexpr uint32_t FP_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t SLOT_WORDS = 4;                 // k <= 32: {key_lo, key_hi, handle, off | ~flags << 24}
+constexpr uint32_t SLOT_OFF_MASK = 0xFFFFFFu;      // node length < 2^24
+constexpr uint32_t SLOT_FLAG_SHIFT = 24;           // flags 0..2: slot (home + 1 + i) & 3 holds a key of this home; flag 3: one overflowed to the next bucket
+constexpr uint32_t SLOT_FLAG_OVERFLOW = 8u;
+constexpr uint32_t DICT_MAX_PROBES = 15;           // buckets a key may overflow through (the builders keep every chain shorter)
 
 struct alignas(16) U4 {
     uint32_t x, y, z, w;

@@ -3,9 +3,10 @@
 //
 // Replaces make_dbg_index (src/build_index.rs:182-221: boomphf MPHF + (node id, offset) scatter over every k-mer of every
 // node) and the edge resolution the debruijn crate does by hashing at every hop (Node::r_edges / l_edges):
-//   pa_fill_insert_kernel   one thread per k-mer of the graph: bucket of the k-mer, compare-and-swap on the first free
-//                           fingerprint (k <= 32) / handle word (k > 32) of the line, then the entry words — the same lines
-//                           the host flattener (device_flatten.cpp, kept for the CPU-only test tier) writes
+//   pa_fill_insert_kernel   one thread per k-mer of the graph. k <= 32: two passes (dict_slots.hpp) — compare-and-swap on the handle
+//                           word of the key's home slot; then the keys that did not get it take another slot of the bucket and
+//                           flag the home slot. k > 32: compare-and-swap on the handle word of the first free entry of the line.
+//                           The host flattener (device_flatten.cpp, kept for the CPU-only test tier) runs the same text
 //   pa_fill_verify_kernel   every k-mer is looked up again: it must come back as (its node, its offset) — a k-mer that
 //                           occurs twice in the graph does not — within the 15 overflow buckets the mapping kernel follows
 //   pa_fill_edges_kernel    one thread per node: the four right neighbours of its last k-mer must be FIRST k-mers (offset 0),
@@ -16,6 +17,7 @@
 #include <algorithm>
 
 #include "device_flatten.hpp"
+#include "dict_slots.hpp"
 #include "lane_steps.hpp"
 #include "pa_common.hpp"
 
@@ -35,33 +37,11 @@ template <> struct FillOps<uint64_t> {
     static constexpr double LOAD = 0.5;
     __host__ __device__ static uint64_t mask(uint32_t k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1); }
     __device__ static uint64_t get(const uint64_t* seq, uint32_t o, uint32_t k) { return win32(seq, o) & mask(k); }
-    __device__ static uint32_t bucket(uint64_t km, uint32_t nbuckets) { return pa_bucket(km, nbuckets); }
-    __device__ static bool try_insert(uint32_t* line, uint64_t km, uint32_t handle, uint32_t off) {
-        const uint32_t klo = (uint32_t)km, want = klo & 0x7FFFFFFFu;
-        for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i)
-            if (atomicCAS(line + i, FP_EMPTY, want) == FP_EMPTY) {
-                line[4 + 3 * i] = (uint32_t)(km >> 32);
-                line[5 + 3 * i] = handle;
-                line[6 + 3 * i] = off | (klo & 0x80000000u);
-                return true;
-            }
-        return false;
-    }
-    // 1 found, 0 absent (a line with a free slot ends the probe sequence), 2 keep probing
-    __device__ static int look(const uint32_t* line, uint64_t km, uint32_t& handle, uint32_t& off) {
-        const uint32_t klo = (uint32_t)km, want = klo & 0x7FFFFFFFu, khi = (uint32_t)(km >> 32);
-        bool full = true;
-        for (uint32_t i = 0; i < SLOTS_PER_BUCKET; ++i) {
-            const uint32_t fp = line[i];
-            if (fp == FP_EMPTY) { full = false; continue; }
-            if (fp == want && line[4 + 3 * i] == khi && (line[6 + 3 * i] >> 31) == (klo >> 31)) {
-                handle = line[5 + 3 * i];
-                off = line[6 + 3 * i] & 0x7FFFFFFFu;
-                return 1;
-            }
-        }
-        return full ? 2 : 0;
-    }
+    // (the k <= 32 dictionary is built and read by dict_slots.hpp: two insertion passes)
+};
+struct DeviceAtomics {
+    __device__ static bool cas(uint32_t* p, uint32_t expect, uint32_t v) { return atomicCAS(p, expect, v) == expect; }
+    __device__ static void and_(uint32_t* p, uint32_t m) { atomicAnd(p, m); }
 };
 template <> struct FillOps<u128> {
     static constexpr uint32_t SLOTS = 2;
@@ -97,10 +77,16 @@ template <> struct FillOps<u128> {
 };
 
 template <class KT>
-__device__ __forceinline__ bool dict_find(const uint32_t* table, uint32_t nbuckets, KT km, uint32_t& handle, uint32_t& off, uint32_t& probes) {
-    uint32_t b = FillOps<KT>::bucket(km, nbuckets);
+__device__ __forceinline__ bool dict_find(const uint32_t* table, uint32_t nbuckets, KT km, uint32_t& handle, uint32_t& off, uint32_t& probes);
+template <>
+__device__ __forceinline__ bool dict_find<uint64_t>(const uint32_t* table, uint32_t nbuckets, uint64_t km, uint32_t& handle, uint32_t& off, uint32_t& probes) {
+    return dict_find64(table, nbuckets, km, handle, off, probes);
+}
+template <>
+__device__ __forceinline__ bool dict_find<u128>(const uint32_t* table, uint32_t nbuckets, u128 km, uint32_t& handle, uint32_t& off, uint32_t& probes) {
+    uint32_t b = FillOps<u128>::bucket(km, nbuckets);
     for (probes = 0; probes < nbuckets; ++probes) {
-        const int r = FillOps<KT>::look(table + (uint64_t)b * BUCKET_WORDS, km, handle, off);
+        const int r = FillOps<u128>::look(table + (uint64_t)b * BUCKET_WORDS, km, handle, off);
         if (r != 2) return r == 1;
         if (++b == nbuckets) b = 0;
     }
@@ -123,15 +109,21 @@ __device__ __forceinline__ uint32_t node_of_kmer(const uint64_t* kcum, uint32_t 
 
 template <class KT>
 __global__ __launch_bounds__(256) void pa_fill_insert_kernel(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ handle, const uint64_t* __restrict__ kcum,
-                                                             uint32_t num_nodes, uint64_t nk, uint32_t k, uint32_t* table, uint32_t nbuckets) {
+                                                             uint32_t num_nodes, uint64_t nk, uint32_t k, uint32_t* table, uint32_t nbuckets, int pass) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nk) return;
     const uint32_t i = node_of_kmer(kcum, num_nodes, g), o = (uint32_t)(g - kcum[i]), h = handle[i];
     const KT km = FillOps<KT>::get(blob_seq(blobs, h), o, k);
-    uint32_t b = FillOps<KT>::bucket(km, nbuckets);
-    for (;;) {   // load <= 1/2 (1/3): a free slot exists
-        if (FillOps<KT>::try_insert(table + (uint64_t)b * BUCKET_WORDS, km, h, o)) return;
-        if (++b == nbuckets) b = 0;
+    if constexpr (sizeof(KT) == 8) {   // k <= 32: pass 0 = home slots, pass 1 = the keys that did not get theirs (dict_slots.hpp)
+        if (pass == 0) dict_insert_home<DeviceAtomics>(table, nbuckets, km, h, o);
+        else dict_insert_rest<DeviceAtomics>(table, nbuckets, km, h, o);
+    } else {
+        if (pass != 0) return;
+        uint32_t b = FillOps<KT>::bucket(km, nbuckets);
+        for (;;) {   // load <= 1/3: a free entry exists
+            if (FillOps<KT>::try_insert(table + (uint64_t)b * BUCKET_WORDS, km, h, o)) return;
+            if (++b == nbuckets) b = 0;
+        }
     }
 }
 
@@ -147,7 +139,7 @@ __global__ __launch_bounds__(256) void pa_fill_verify_kernel(const uint8_t* __re
     const KT km = FillOps<KT>::get(blob_seq(blobs, h), o, k);
     uint32_t fh = 0, fo = 0, probes = 0;
     if (!dict_find<KT>(table, nbuckets, km, fh, fo, probes) || fh != h || fo != o) atomicMin(flags, i);
-    if (probes > 15) flags[1] = 1;
+    if (probes > DICT_MAX_PROBES) flags[1] = 1;
 }
 
 // flags[2] = a node with an extension bit but no terminal neighbour k-mer, flags[3] = a node whose left neighbour k-mer is
@@ -216,14 +208,16 @@ int fill_t(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, u
         if (*d_table) { (void)hipFree(*d_table); *d_table = nullptr; }
         const hipError_t em = hipMalloc(d_table, nbuckets * BUCKET_WORDS * 4);
         if (em != hipSuccess) { *d_table = nullptr; return done(fail(PA_ERR_OOM, "hipMalloc(%llu) for the dictionary: %s", (unsigned long long)(nbuckets * BUCKET_WORDS * 4), hipGetErrorString(em))); }
-        FILL_TRY(hipMemsetAsync(*d_table, 0xFF, nbuckets * BUCKET_WORDS * 4, nullptr));   // FP_EMPTY / NO_HANDLE in every word
+        FILL_TRY(hipMemsetAsync(*d_table, 0xFF, nbuckets * BUCKET_WORDS * 4, nullptr));   // empty slots, no flags (NO_HANDLE in every word)
         const uint32_t init[4] = {NO_HANDLE, 0u, NO_HANDLE, NO_HANDLE};
         FILL_TRY(hipMemcpy(d_flags, init, 16, hipMemcpyHostToDevice));
         if (nk) {
             const dim3 grid((uint32_t)((nk + 255) / 256));
-            hipLaunchKernelGGL(pa_fill_insert_kernel<KT>, grid, dim3(256), 0, nullptr, static_cast<const uint8_t*>(d_blobs), static_cast<const uint32_t*>(d_handle),
-                               static_cast<const uint64_t*>(d_kcum), N, nk, k, static_cast<uint32_t*>(*d_table), (uint32_t)nbuckets);
-            FILL_TRY(hipGetLastError());
+            for (int pass = 0; pass < (sizeof(KT) == 8 ? 2 : 1); ++pass) {   // (stream order is the barrier between the passes)
+                hipLaunchKernelGGL(pa_fill_insert_kernel<KT>, grid, dim3(256), 0, nullptr, static_cast<const uint8_t*>(d_blobs), static_cast<const uint32_t*>(d_handle),
+                                   static_cast<const uint64_t*>(d_kcum), N, nk, k, static_cast<uint32_t*>(*d_table), (uint32_t)nbuckets, pass);
+                FILL_TRY(hipGetLastError());
+            }
             hipLaunchKernelGGL(pa_fill_verify_kernel<KT>, grid, dim3(256), 0, nullptr, static_cast<const uint8_t*>(d_blobs), static_cast<const uint32_t*>(d_handle),
                                static_cast<const uint64_t*>(d_kcum), N, nk, k, static_cast<const uint32_t*>(*d_table), (uint32_t)nbuckets,
                                static_cast<uint32_t*>(d_flags));

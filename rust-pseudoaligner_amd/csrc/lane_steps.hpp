@@ -109,16 +109,6 @@ PA_HD uint64_t pa_mix64(uint64_t x) {   // murmur3 fmix64
     return x;
 }
 
-// dictionary bucket of a k-mer: the high half of the mixed hash scaled to [0, nbuckets) — nbuckets < 2^32
-PA_HD uint32_t pa_bucket(uint64_t kmer, uint32_t nbuckets) {
-    const uint32_t hi = (uint32_t)(pa_mix64(kmer) >> 32);
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(hi, nbuckets);
-#else
-    return (uint32_t)(((uint64_t)hi * nbuckets) >> 32);
-#endif
-}
-
 PA_HD uint32_t pa_popc32(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__popc(x);
@@ -432,43 +422,55 @@ PA_HD void mask_pending(Lane& s, const DevIndexView& ix, ColRef c) {
 }
 
 // ---------------------------------------------------------------------------------------------- SEEK
-// One dictionary probe of find_kmer_match (:91-114), K <= 32, in the three pieces the kernel interleaves with other work:
-//   seek_issue     k-mer -> bucket, the 16-byte fingerprint load goes out
-//   seek_cands / seek_entry   fingerprints -> candidate slots, the dependent 12-byte entry load (same line) goes out
-//   seek_complete  verification of the other 33 key bits, further candidates (rare), the lane's next state
+// One dictionary probe of find_kmer_match (:91-114), K <= 32 (layout: device_layout.hpp), in the pieces the kernel interleaves
+// with other work:
+//   seek_issue     k-mer -> bucket and home slot, the 16-byte load of the home slot goes out
+//   seek_second    home slot holds another key and names other slots of the bucket: which one to load next (rare)
+//   seek_complete  the answer, further named slots (rarer), the lane's next state
 struct SeekProbe {
-    const uint32_t* linew;   // the bucket line
-    U4 fp;                   // its four fingerprints
+    const uint32_t* bucket;  // the bucket line
+    uint32_t home;           // home slot of the key in it
+    U4 v;                    // the home slot
     uint32_t klo, khi;       // the k-mer
 };
+// bucket and home slot of a k-mer (one hash)
+PA_HD uint32_t pa_bucket_home(uint64_t kmer, uint32_t nbuckets, uint32_t& home) {
+    const uint64_t m = pa_mix64(kmer);
+    home = (uint32_t)m & 3u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi((uint32_t)(m >> 32), nbuckets);
+#else
+    return (uint32_t)(((m >> 32) * nbuckets) >> 32);
+#endif
+}
 PA_HD void seek_issue(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekProbe& q) {
     const uint64_t kmer = read_window_in(rd, l_kp(s)) & ix.kmask;   // read_seq.get_kmer(kmer_pos) (:93); kmer_pos <= L - K
-    uint32_t b = pa_bucket(kmer, (uint32_t)ix.nbuckets) + l_probe(s);
+    uint32_t b = pa_bucket_home(kmer, (uint32_t)ix.nbuckets, q.home) + l_probe(s);
     if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
-    q.linew = ix.table + (uint64_t)b * BUCKET_WORDS;
-    q.fp = PA_LD(4, reinterpret_cast<const U4*>(q.linew));
+    q.bucket = ix.table + (uint64_t)b * BUCKET_WORDS;
+    q.v = PA_LD(4, reinterpret_cast<const U4*>(q.bucket + SLOT_WORDS * q.home));
     q.klo = (uint32_t)kmer;
     q.khi = (uint32_t)(kmer >> 32);
 }
-// entries {key_hi, handle, off | key bit 31 << 31} at words 4+3j: the slots whose fingerprint (low 31 key bits) matches.
-// Two keys of one bucket can share their low 31 bits (low-complexity sequence): every matching slot is tried.
-PA_HD uint32_t seek_cands(const SeekProbe& q) {
-    const uint32_t want = q.klo & 0x7FFFFFFFu;
-    return (q.fp.x == want ? 1u : 0u) | (q.fp.y == want ? 2u : 0u) | (q.fp.z == want ? 4u : 0u) | (q.fp.w == want ? 8u : 0u);
-}
-PA_HD U3 seek_entry(const SeekProbe& q, uint32_t cand) {            // entry of the first candidate (no candidate: entry 0, ignored)
-    return PA_LD(4, reinterpret_cast<const U3*>(q.linew + 4 + 3 * (cand ? pa_ctz32(cand) : 0u)));
+PA_HD bool slot_holds(const U4& v, uint32_t klo, uint32_t khi) { return v.z != NO_HANDLE && v.x == klo && v.y == khi; }
+PA_HD uint32_t slot_flags(const U4& v) { return (~v.w >> SLOT_FLAG_SHIFT) & 15u; }
+// the other slots of the bucket that hold keys of this home, as a mask over i = 0..2 (slot (home + 1 + i) & 3); 0 when the
+// home slot already answers (a hit there, or nothing named)
+PA_HD uint32_t seek_second(const SeekProbe& q) { return slot_holds(q.v, q.klo, q.khi) ? 0u : slot_flags(q.v) & 7u; }
+PA_HD const U4* seek_second_slot(const SeekProbe& q, uint32_t cand) {   // cand != 0: the first named slot
+    return reinterpret_cast<const U4*>(q.bucket + SLOT_WORDS * ((q.home + 1 + pa_ctz32(cand)) & 3u));
 }
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe);
-PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand, U3 e) {
-    const uint32_t top = q.klo >> 31;
+// `cand` = seek_second(q), `v2` = the first named slot (loaded by the caller when cand != 0)
+PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand, U4 v2) {
     uint32_t h = NO_HANDLE, off = 0;
-    while (cand) {                                                  // almost always exactly one candidate on a hit
+    if (slot_holds(q.v, q.klo, q.khi)) { h = q.v.z; off = q.v.w & SLOT_OFF_MASK; }
+    while (cand) {                                                  // almost always at most one named slot
+        if (slot_holds(v2, q.klo, q.khi)) { h = v2.z; off = v2.w & SLOT_OFF_MASK; break; }
         cand &= cand - 1;
-        if (e.x == q.khi && (e.z >> 31) == top) { h = e.y; off = e.z & 0x7FFFFFFFu; cand = 0; }
-        else if (cand) e = *reinterpret_cast<const U3*>(q.linew + 4 + 3 * pa_ctz32(cand));
+        if (cand) v2 = *seek_second_slot(q, cand);
     }
-    seek_finish(s, K, h, off, ((q.fp.x | q.fp.y | q.fp.z | q.fp.w) >> 31) == 0, l_probe(s));
+    seek_finish(s, K, h, off, (slot_flags(q.v) & SLOT_FLAG_OVERFLOW) != 0, l_probe(s));
 }
 
 // what a probe found -> the lane's next state (the tail of find_kmer_match and of :118-129)
@@ -491,7 +493,7 @@ PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full,
         }
         return;
     }
-    if (full && probe < 15) {                                       // no free slot: the key may live in the next bucket
+    if (full && probe < DICT_MAX_PROBES) {                          // a key of this home slot (K > 32: of this line) went on to the next bucket
         s.nc |= (probe + 1) << NC_PROBE_SHIFT;
         return;
     }
@@ -524,9 +526,10 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
     }
     SeekProbe q;
     seek_issue(s, ix, rd, q);
-    uint32_t cand = seek_cands(q);
-    const U3 e = seek_entry(q, cand);
-    seek_complete(s, K, q, cand, e);
+    const uint32_t cand = seek_second(q);
+    U4 v2{0u, 0u, NO_HANDLE, 0u};
+    if (cand) v2 = *seek_second_slot(q, cand);
+    seek_complete(s, K, q, cand, v2);
 }
 
 // ---------------------------------------------------------------------------------------------- FWD

@@ -453,7 +453,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         if (best == 0) break;
         // DUAL iteration: a forward step and a dictionary probe are each one dependent round trip and touch different parts
         // of the memory system (node blobs: MALL / L2; dictionary: HBM). When both queues hold work the wave pops BOTH, lets
-        // the probe's fingerprint load and the node fetch go out back to back, and does the probe's arithmetic while the
+        // the probe's slot load and the node fetch go out back to back, and does the probe's arithmetic while the
         // node lines are on their way: two round trips in flight per wave instead of one (K <= 32: the two-word dictionary
         // has no dependent second load to hide).
         const uint32_t n_seek_q = PA_CNT(ST_SEEK), n_fwd_q = PA_CNT(ST_FWD);
@@ -509,8 +509,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             // One text for the plain forward step and the DUAL iteration (n2 = 0: the probe half runs on all-zero states and is
             // thrown away). Straight-line issue: every lane executes every load (a lane without a slot carries an all-zero state:
             // blob 0, bucket of whatever slot 0 holds) and nothing branches between the loads and their first use, so that the
-            // number of loads in flight is a constant and the waits are exact: vmcnt(6) for the fingerprints, then the node, then
-            // the entry.
+            // waits stay exact: first the probe's slot, then the node, then the probe's second slot (the few lanes that need one).
             Lane s2;
             {
                 const u32x4 a = stA[slot2], b = stB[slot2];
@@ -523,11 +522,14 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             const ReadRef rr2 = GREAD ? ReadRef{p.tiles + ((uint64_t)(rid2 >> 6) * wpr) * 64 + (rid2 & 63), 64u, wpr} : ReadRef{(const uint64_t*)(rd + slot2), S, wpr};
             SeekProbe pq;
             FwdLoad fl;
-            seek_issue(s2, ix, rr2, pq);                               // fingerprints of the bucket (HBM)
+            seek_issue(s2, ix, rr2, pq);                               // home slot of the k-mer (HBM)
             fwd_issue(s, ix, fl);                                      // node header + sequence words (MALL / L2)
             __builtin_amdgcn_sched_barrier(0);                         // (left alone the scheduler finishes the probe first and only then issues the node loads)
-            const uint32_t cand = seek_cands(pq);
-            const U3 ent = seek_entry(pq, cand);                       // the probe's dependent load: same line, now in the L1 / L2
+            // the probe's second load, only for the lanes whose home slot holds another key and names other slots (same line,
+            // now in the L1 / L2)
+            const uint32_t cand = active2 ? seek_second(pq) : 0u;
+            U4 pv2{0u, 0u, NO_HANDLE, 0u};
+            if (cand) pv2 = *seek_second_slot(pq, cand);
             const unsigned long long t1 = PA_DBG ? __builtin_readcyclecounter() : 0ull;
             if (active) fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
             if (PA_DBG && lane == 0) {   // statistics only: issue | wait + compute of the forward half
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 dbg_clk[ST_COUNT + 1] += t1 - t_pop; dbg_clk[ST_COUNT + 3] += t3 - t1;
             }
             if (active2) {
-                seek_complete(s2, K, pq, cand, ent);
+                seek_complete(s2, K, pq, cand, pv2);
                 nq2 = queue_of(s2, K);   // (may rewrite the state: before the store)
                 stA[slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
                 stB[slot2] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../rust-pseudoaligner_amd/csrc/device_flatten.hpp"
+#include "../rust-pseudoaligner_amd/csrc/dict_slots.hpp"
 #include "../rust-pseudoaligner_amd/csrc/lane_steps.hpp"
 #include "../rust-pseudoaligner_amd/csrc/pa_common.hpp"
 
@@ -217,23 +218,8 @@ int main(int argc, char** argv) {
             while (p + k <= b) {
                 const uint64_t km = get_kmer(packed, p, k);
                 // find the node through the host dictionary of the flattened index
-                Lane s; lane_start(s, 0, 0, k);
-                uint32_t hh = NO_HANDLE, off = 0;
-                {
-                    uint32_t bkt = pa_bucket(km, (uint32_t)ix.nbuckets);
-                    for (uint32_t probe = 0; probe < 64 && hh == NO_HANDLE; ++probe) {
-                        const uint32_t* line = ix.table + (uint64_t)bkt * BUCKET_WORDS;
-                        bool full = true;
-                        for (uint32_t j = 0; j < 4; ++j) {
-                            if (line[j] == FP_EMPTY) { full = false; continue; }
-                            if (line[j] == ((uint32_t)km & 0x7FFFFFFFu) && line[4 + 3 * j] == (uint32_t)(km >> 32) && (line[6 + 3 * j] >> 31) == ((uint32_t)km >> 31)) {
-                                hh = line[5 + 3 * j]; off = line[6 + 3 * j] & 0x7FFFFFFFu;
-                            }
-                        }
-                        if (!full) { if (++bkt == ix.nbuckets) bkt = 0; } else break;
-                        if (!full && hh == NO_HANDLE) break;
-                    }
-                }
+                uint32_t hh = NO_HANDLE, off = 0, probes = 0;
+                if (!dict_find64(ix.table, (uint32_t)ix.nbuckets, km, hh, off, probes)) hh = NO_HANDLE;
                 if (hh == NO_HANDLE) { ++p; continue; }
                 const uint32_t node = fd.nid_of_handle[hh];
                 if (!placed[node]) { placed[node] = 1; tx_order.push_back(node); }
