@@ -187,8 +187,11 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
         if (f.node_len[i] >= (1u << 24)) return fail(PA_ERR_UNSUPPORTED, "node %u longer than 2^24 bases", i);
         if (f.node_colour[i] >= f.num_classes) return fail(PA_ERR_FORMAT, "node %u: colour out of range", i);
         const uint64_t size = (BLOB_HDR_BYTES + 8ull * ((f.node_len[i] + 31) / 32) + BLOB_ALIGN - 1) / BLOB_ALIGN * BLOB_ALIGN;
-        if (cursor / BLOB_GRANULE >= NO_HANDLE) return fail(PA_ERR_UNSUPPORTED, "graph exceeds the 256 GiB blob address space");
-        out.handle[i] = (uint32_t)(cursor / BLOB_GRANULE);
+        if (cursor / BLOB_GRANULE >= NO_HANDLE - 1) return fail(PA_ERR_UNSUPPORTED, "graph exceeds the 256 GiB blob address space");
+        // bit 0 (blobs start on 128-byte blocks: always clear in the address) = the header's third vector is needed: the class has a
+        // second window, or no windows at all
+        const U4 cwi = cwin[f.node_colour[i]];
+        out.handle[i] = (uint32_t)(cursor / BLOB_GRANULE) | ((cwi.y == 0 || cwi.w != 0) ? HANDLE_WIDE : 0u);
         cursor += size;
         nk += f.node_len[i] - k + 1;
     }
@@ -249,7 +252,7 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
     std::atomic<uint32_t> dangling{NO_HANDLE};
     par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
         for (uint64_t i = a; i < b; ++i) {
-            uint8_t* blob = out.blobs.data() + (uint64_t)out.handle[i] * BLOB_GRANULE;
+            uint8_t* blob = out.blobs.data() + (uint64_t)(out.handle[i] & ~HANDLE_WIDE) * BLOB_GRANULE;
             uint32_t* hd = reinterpret_cast<uint32_t*>(blob);
             uint64_t* sq = reinterpret_cast<uint64_t*>(blob + BLOB_HDR_BYTES);
             const uint32_t len = f.node_len[i];
@@ -257,10 +260,11 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
             hd[0] = len | ((uint32_t)f.node_exts[i] << 24);
             hd[1] = f.node_colour[i];
             out.nid_of_handle[out.handle[i]] = (uint32_t)i;
-            hd[2] = out.class_ref[f.node_colour[i]];
-            hd[3] = out.class_len[f.node_colour[i]];
             const U4 cw = cwin[f.node_colour[i]];
-            hd[8] = cw.x; hd[9] = cw.y; hd[10] = cw.z; hd[11] = cw.w;
+            hd[2] = cw.x; hd[3] = cw.y;
+            hd[8] = cw.z; hd[9] = cw.w;
+            hd[10] = out.class_ref[f.node_colour[i]];
+            hd[11] = out.class_len[f.node_colour[i]];
             for (uint32_t w = 0; w < (len + 31) / 32; ++w) {
                 uint64_t v = window32(node_seq, s + 32ull * w);
                 const uint32_t rem = len - 32 * w;
@@ -305,7 +309,7 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
         for (uint64_t i = a; i < b; ++i)
             for (uint32_t base = 0; base < 4; ++base) {
                 uint32_t* e = out.ledge.data() + 8ull * out.handle[i] + 2 * base;
-                e[1] = e[0] == NO_HANDLE ? 0u : (*reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)e[0] * BLOB_GRANULE) & 0xFFFFFFu);
+                e[1] = e[0] == NO_HANDLE ? 0u : (*reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)(e[0] & ~HANDLE_WIDE) * BLOB_GRANULE) & 0xFFFFFFu);
             }
     });
     // left-edge targets must be entered at their LAST k-mer (offset len-k): check now that every header exists
@@ -317,7 +321,7 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
                     if (!(f.node_exts[i] & (1u << (4 + base)))) continue;
                     uint32_t h = 0, off = 0;
                     dict.find(((first << 2) | base) & mask, h, off);
-                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)h * BLOB_GRANULE) & 0xFFFFFFu;
+                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)(h & ~HANDLE_WIDE) * BLOB_GRANULE) & 0xFFFFFFu;
                     if (off != tlen - k) dangling.store((uint32_t)i);
                 }
             }

@@ -18,13 +18,18 @@
 //               (src/pseudoaligner.rs:96-107) no node sequence has to be fetched to confirm a hit.
 //               k > 32 (two-word k-mers): a line holds two whole entries {key word 0..3, handle, off, -, -}, handle
 //               0xFFFFFFFF = empty, load <= 1/3, linear probing over lines (a line with a free entry ends the probe sequence).
-//   node blobs  one blob per unitig, 64-byte aligned (one HBM line), addressed by handle = byte offset / 64:
-//                 +0  u32 len (bits 0..23) | debruijn::Exts byte (bits 24..31)
-//                 +4  u32 class id         +8  u32 class record ref      +12 u32 class length (ids)
+//   node blobs  one blob per unitig, starting on a 128-byte block, addressed by handle = byte offset / 64 — so bit 0 of a blob's
+//               offset/64 is always clear, and every handle (dictionary slots, edges, lane state) carries there the WIDE flag
+//               of its node: the third 16-byte vector of the header is needed (second class window, or no windows at all).
+//               The blob address is (handle & ~1) * 64; nid_of_handle / ledge are indexed by the handle as it is.
+//                 +0  u32 len (bits 0..23) | debruijn::Exts byte (bits 24..31)     +4  u32 class id
+//                 +8  u32 cmin, cmask   the class as WINDOWS of 32 transcript ids: {cmin + i : bit i of cmask} ...
 //                 +16 u32 redge[4]      handle of the node reached by right-extending with base b (Node::r_edges)
-//                 +32 u32 cmin, cmask, cmin2, cmask2   the class as two WINDOWS of 32 transcript ids: {cmin + i : bit i of
-//                                           cmask} U {cmin2 + i : bit i of cmask2}, cmin2 >= cmin + 32 (cmask2 = 0: one window);
-//                                           cmask = 0 when the class does not fit (then only the id list describes it)
+//                 +32 u32 cmin2, cmask2 ... U {cmin2 + i : bit i of cmask2}, cmin2 >= cmin + 32 (cmask2 = 0: one window);
+//                                       cmask = 0 when the class does not fit (then only the id list describes it)
+//                 +40 u32 class record ref   +44 u32 class length (ids)
+//               A forward step loads +0 and +16 for every lane and +32 only for lanes whose handle has the WIDE flag or whose
+//               read collects class lists (list mode): one access of the vector L1 less for ~90 % of the node visits.
 //                 +48 u64 seq[ceil(len/32)]  2-bit packed, LSB-first
 //               so a node visit is ONE dependent fetch (header and the first 64 bases share a line), the hop to the
 //               next node needs no further lookup (the reference re-derives every edge by hashing: SURVEY.md §3.2),
@@ -58,6 +63,7 @@ namespace pa {
 
 constexpr uint32_t NO_HANDLE = 0xFFFFFFFFu;
 constexpr uint32_t BLOB_GRANULE = 64;
+constexpr uint32_t HANDLE_WIDE = 1u;   // bit 0 of a handle: the node's header vector at +32 is needed (device_layout.hpp, node blobs)
 constexpr uint32_t BLOB_ALIGN = 128;   // the memory system moves 128-byte blocks: two adjacent 64-byte lines of ONE block cost what one line costs, lines of two blocks cost double (tools/microbench/gather_pair.hip); header + first 320 bases = one block
 constexpr uint32_t BLOB_HDR_BYTES = 48;
 constexpr uint32_t CLASS_WINDOW = 32;   // ids per class window (one mask word)

@@ -94,7 +94,7 @@ __device__ __forceinline__ bool dict_find<u128>(const uint32_t* table, uint32_t 
 }
 
 __device__ __forceinline__ const uint64_t* blob_seq(const uint8_t* blobs, uint32_t handle) {
-    return reinterpret_cast<const uint64_t*>(blobs + (uint64_t)handle * BLOB_GRANULE + BLOB_HDR_BYTES);
+    return reinterpret_cast<const uint64_t*>(blobs + (uint64_t)(handle & ~HANDLE_WIDE) * BLOB_GRANULE + BLOB_HDR_BYTES);   // (bit 0 of a handle is its WIDE flag)
 }
 
 // node of the g-th k-mer of the graph: the last i with kcum[i] <= g
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void pa_fill_edges_kernel(uint8_t* blobs, uint
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_nodes) return;
     const uint32_t h = handle[i];
-    uint32_t* hd = reinterpret_cast<uint32_t*>(blobs + (uint64_t)h * BLOB_GRANULE);
+    uint32_t* hd = reinterpret_cast<uint32_t*>(blobs + (uint64_t)(h & ~HANDLE_WIDE) * BLOB_GRANULE);
     const uint32_t len = hd[0] & 0xFFFFFFu, exts = hd[0] >> 24, topshift = 2 * (k - 1);
     const uint64_t* seq = blob_seq(blobs, h);
     const KT first = FillOps<KT>::get(seq, 0, k), last = FillOps<KT>::get(seq, len - k, k), mask = FillOps<KT>::mask(k);
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void pa_fill_edges_kernel(uint8_t* blobs, uint
             if (exts & (1u << (4 + base))) {
                 if (dict_find<KT>(table, nbuckets, ((first << 2) | (KT)base) & mask, fh, fo, probes)) {
                     le = fh;
-                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(blobs + (uint64_t)fh * BLOB_GRANULE) & 0xFFFFFFu;   // (word 0 of a header is never written here)
+                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(blobs + (uint64_t)(fh & ~HANDLE_WIDE) * BLOB_GRANULE) & 0xFFFFFFu;   // (word 0 of a header is never written here)
                     ll = tlen;
                     if (fo != tlen - k) atomicMin(flags + 3, i);
                 } else atomicMin(flags + 2, i);

@@ -210,14 +210,18 @@ PA_HD uint64_t ld_nt(const uint64_t* p) { return *p; }
 #endif
 #define PA_LD(bit, ptr) ((PA_NT & (bit)) ? ld_nt(ptr) : *(ptr))
 
+// first byte of the blob of the node with handle `h` (bit 0 of a handle is the WIDE flag, not part of the address)
+PA_HD const uint8_t* node_blob(const DevIndexView& ix, uint32_t h) { return ix.blobs + (uint64_t)(h & ~HANDLE_WIDE) * BLOB_GRANULE; }
+// header vectors {len|exts, cid, cmin, cmask} {e0..e3} {cmin2, cmask2, ec_ref, ec_len} -> fields
+PA_HD Hdr make_hdr(const U4& a, const U4& b, const U4& c) {
+    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, c.z, c.w, b.x, b.y, b.z, b.w, a.z, a.w, c.x, c.y};
+}
 PA_HD Hdr load_hdr(const DevIndexView& ix, uint32_t h) {
-    const U4* p = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)h * BLOB_GRANULE);
+    const U4* p = reinterpret_cast<const U4*>(node_blob(ix, h));
     const U4 a = PA_LD(8, p), b = PA_LD(8, p + 1), c = PA_LD(8, p + 2);
-    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    return make_hdr(a, b, c);
 }
-PA_HD const uint64_t* node_seq(const DevIndexView& ix, uint32_t h) {
-    return reinterpret_cast<const uint64_t*>(ix.blobs + (uint64_t)h * BLOB_GRANULE + BLOB_HDR_BYTES);
-}
+PA_HD const uint64_t* node_seq(const DevIndexView& ix, uint32_t h) { return reinterpret_cast<const uint64_t*>(node_blob(ix, h) + BLOB_HDR_BYTES); }
 
 // mismatch mask of a 32-base XOR restricted to its first n bases (1 <= n <= 32): bit 2i set <=> base i differs.
 // (the 32-bit halves can be shifted separately: the bit that would cross lands on an odd position and is masked away)
@@ -541,13 +545,20 @@ struct FwdLoad {     // what fwd_issue leaves in flight: the node header and the
     U4 h0, h1, h2;
     Q2 s01, s23, s45;
 };
+PA_HD bool fwd_wide(const Lane& s) { return ((s.h & HANDLE_WIDE) | (l_flags(s) & F_LISTS)) != 0; }
 PA_HD void fwd_issue(const Lane& s, const DevIndexView& ix, FwdLoad& f) {
     const uint32_t K = ix.k, L = l_L(s);
     const bool fresh = l_flags(s) & F_FRESH;
     const uint32_t ro0 = fresh ? l_off(s) + K : (s.rr & 0xFFFFFFu);   // ref_offset (:227)
     const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
-    const U4* hp = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)s.h * BLOB_GRANULE);   // dbg.get_node (:210)
-    f.h0 = PA_LD(8, hp); f.h1 = PA_LD(8, hp + 1); f.h2 = PA_LD(8, hp + 2);
+    const U4* hp = reinterpret_cast<const U4*>(node_blob(ix, s.h));   // dbg.get_node (:210)
+    f.h0 = PA_LD(8, hp); f.h1 = PA_LD(8, hp + 1);
+    // the third header vector (second window, class record) only for nodes that have one to show — their handles say so — and for
+    // reads that collect class lists
+    // (not a branch around the load — its result would be merged with a constant behind a vmcnt(0) — but a load every lane
+    // issues: the lanes that do not need the vector all read the first line of the blob array, which costs the L1 one access per
+    // group of lanes instead of one per lane; fwd_finish ignores what they got)
+    f.h2 = PA_LD(8, fwd_wide(s) ? hp + 2 : reinterpret_cast<const U4*>(ix.blobs));
     const Q2* sq2 = reinterpret_cast<const Q2*>(node_seq(ix, s.h) + (ro0 >> 5));
     // sequence words this step can need, known before the header arrives: the node visit compares at most the rest of the
     // read (fresh) / of the visit (continued), 128 bases per step; words beyond are not fetched (each may be another line)
@@ -567,7 +578,7 @@ PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, 
     const bool fresh = fl & F_FRESH, careful = fl & F_CAREFUL;
     const uint32_t ro0 = fresh ? l_off(s) + K : (s.rr & 0xFFFFFFu);   // ref_offset (:227)
     const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
-    const Hdr hd{f.h0.x & 0xFFFFFFu, f.h0.x >> 24, f.h0.y, f.h0.z, f.h0.w, f.h1.x, f.h1.y, f.h1.z, f.h1.w, f.h2.x, f.h2.y, f.h2.z, f.h2.w};
+    const Hdr hd = make_hdr(f.h0, f.h1, fwd_wide(s) ? f.h2 : U4{0u, 0u, 0u, 0u});
     uint32_t rem = s.rm & 0xFFFFu, snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
     const uint32_t most = pa_min(fresh ? L - kp0 : rem, 128u), nwords = ((ro0 & 31) + most + 31) >> 5;   // as in fwd_issue
     const uint64_t a[5] = {f.s01.a, f.s01.b, nwords > 2 ? f.s23.a : 0ull, nwords > 2 ? f.s23.b : 0ull, nwords > 4 ? f.s45.a : 0ull};
@@ -665,7 +676,7 @@ struct LeftLoad {
 // bases of the node still to the left of the compare position (:196 / :129 / continued)
 PA_HD uint32_t left_na(const Lane& s) { return s.rr & 0xFFFFFFu; }
 PA_HD void left_issue(const Lane& s, const DevIndexView& ix, LeftLoad& f) {
-    const U4* hp = reinterpret_cast<const U4*>(ix.blobs + (uint64_t)s.ph * BLOB_GRANULE);   // dbg.get_node(prev_node_id) (:132)
+    const U4* hp = reinterpret_cast<const U4*>(node_blob(ix, s.ph));   // dbg.get_node(prev_node_id) (:132)
     f.h0 = hp[0]; f.h1 = hp[1]; f.h2 = hp[2];
     const uint32_t na = left_na(s);
     const uint32_t po = na ? na - 1 : 0, st = po >= 31 ? po - 31 : 0;                       // ref_pos of idx 0 (:152): 32 bases ending there
@@ -674,7 +685,7 @@ PA_HD void left_issue(const Lane& s, const DevIndexView& ix, LeftLoad& f) {
 template <bool TRACE = false>
 PA_HD void left_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed, const LeftLoad& f) {
     const uint32_t K = ix.k;
-    const Hdr hd{f.h0.x & 0xFFFFFFu, f.h0.x >> 24, f.h0.y, f.h0.z, f.h0.w, f.h1.x, f.h1.y, f.h1.z, f.h1.w, f.h2.x, f.h2.y, f.h2.z, f.h2.w};
+    const Hdr hd = make_hdr(f.h0, f.h1, f.h2);
     uint32_t na = left_na(s), snp = s.rr >> 24, rem = s.rm & 0xFFFFu, ra = s.rm >> 16, cov = l_cov(s), mism = l_mism(s);
     const uint32_t fl = l_flags(s);
     if (fl & F_FRESH) {
