@@ -240,6 +240,12 @@ def roofline_of(run, ctr, map_ms, step_ms):
             step_avg = sum(step_ms) / max(len(step_ms), 1)
             requests = {"per_read": per_launch / B, "per_s": per_launch / (step_avg * 1e-3), "gather_hbm_per_s": 49e9, "gather_mall_per_s": 57e9,
                         "frac_of_gather_hbm": per_launch / (step_avg * 1e-3) / 49e9,
+                        # L2 misses of the map kernel (TCC_MISS of the same PMC passes) over this run's map-kernel time, against the rate at
+                        # which the chip serves lanes that each fetch from a random 128-byte block of a table beyond the L2
+                        # (tools/microbench/gather_multi.hip, profiles/r03_gather_multi.txt: 55-57 G blocks/s, MALL-sized table)
+                        "map_kernel_l2_misses_per_read": (pmc["map_kernel_l2_misses"] / B) if pmc.get("map_kernel_l2_misses") else None,
+                        "map_kernel_l2_misses_per_s": (pmc["map_kernel_l2_misses"] / (kernel_avg_ms * 1e-3)) if pmc.get("map_kernel_l2_misses") else None,
+                        "random_block_ceiling_per_s": 55e9,
                         "what": "(FETCH_SIZE + WRITE_SIZE) / 64 B of the committed PMC passes (all kernels of a step) over this run's step time; ceilings: "
                                 "tools/microbench/gather.hip, every lane a different random line, HBM- and MALL-resident tables"}
     except (OSError, ValueError, KeyError) as e:
