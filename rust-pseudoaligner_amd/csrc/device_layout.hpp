@@ -78,9 +78,6 @@ constexpr uint32_t DICT_MAX_PROBES = 15;           // buckets a key may overflow
 struct alignas(16) U4 {
     uint32_t x, y, z, w;
 };
-struct U3 {   // 12-byte, 4-byte aligned (global_load_dwordx3)
-    uint32_t x, y, z;
-};
 struct alignas(8) Q2 {   // two sequence words, 8-byte aligned (global_load_dwordx4)
     uint64_t a, b;
 };

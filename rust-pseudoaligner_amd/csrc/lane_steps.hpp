@@ -95,7 +95,7 @@ struct ColRef {
     uint32_t* trace;      // TRACE builds only: node ids in visit order (map_read_to_nodes, :54-61), capacity spill_cap
 };
 
-struct Hdr {   // the 32-byte header of a node blob
+struct Hdr {   // the fields of the 48-byte header of a node blob (device_layout.hpp; make_hdr)
     uint32_t len, exts, cid, ec_ref, ec_len, e0, e1, e2, e3, cmin, cmask, cmin2, cmask2;
 };
 
@@ -197,14 +197,8 @@ PA_HD Q2 ld_nt(const Q2* p) {
     const pa_nt_u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const pa_nt_u64x2*>(p));
     return Q2{v.x, v.y};
 }
-typedef uint32_t pa_nt_u32x3 __attribute__((ext_vector_type(3), aligned(4)));
-PA_HD U3 ld_nt(const U3* p) {
-    const pa_nt_u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const pa_nt_u32x3*>(p));
-    return U3{v.x, v.y, v.z};
-}
 #else
 PA_HD Q2 ld_nt(const Q2* p) { return *p; }
-PA_HD U3 ld_nt(const U3* p) { return *p; }
 PA_HD U4 ld_nt(const U4* p) { return *p; }
 PA_HD uint64_t ld_nt(const uint64_t* p) { return *p; }
 #endif
