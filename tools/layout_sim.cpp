@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
     alignas(16) uint32_t refs[4], lens4[4], cids4[4], win4[4];
     uint32_t wcand[2];
     std::vector<uint32_t> spill(8 * read_len + 64), trace(8 * read_len + 64), pend(8 * read_len + 64);
-    uint64_t n_fwd = 0, n_left = 0, n_seek = 0, hops_next = 0, hops = 0;
+    uint64_t n_fwd = 0, n_left = 0, n_seek = 0, hops_next = 0, hops = 0, hop_small = 0, hop_small_fits = 0, hop_mid = 0;
     std::vector<uint32_t> succ_count(f.num_nodes, 0);
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> edge_use;
     std::map<uint32_t, uint64_t> ncol_hist, maxlen_hist, base_hist, bigmax_hist;
@@ -108,7 +108,14 @@ int main(int argc, char** argv) {
                 if (nwords > 2) { tc.r[tc.nr][0] = sb + 16; tc.r[tc.nr][1] = sb + 32; ++tc.nr; }
                 if (nwords > 4) { tc.r[tc.nr][0] = sb + 32; tc.r[tc.nr][1] = sb + 48; ++tc.nr; }
                 touches.push_back(tc);
-                if (fresh && l_off(s) == 0 && prev_node != 0xFFFFFFFFu) { ++hops; edge_use[{prev_node, tc.node}]++; }
+                if (fresh && l_off(s) == 0 && prev_node != 0xFFFFFFFFu) {
+                    ++hops; edge_use[{prev_node, tc.node}]++;
+                    // tuning question: how often is the node hopped into a small blob (<= 64 B), and does the predecessor's last block have room for it?
+                    const uint32_t bsz = BLOB_HDR_BYTES + 8 * ((f.node_len[tc.node] + 31) / 32), psz = BLOB_HDR_BYTES + 8 * ((f.node_len[prev_node] + 31) / 32);
+                    hop_small += bsz <= 64;
+                    hop_small_fits += bsz <= 64 && ((psz + 127) / 128 * 128 - psz) >= 64;
+                    hop_mid += bsz > 64 && bsz <= 128;
+                }
                 prev_node = tc.node;
                 fwd_step<true>(s, ix, rr, cr, 2);
                 ++n_fwd;
@@ -167,6 +174,8 @@ int main(int argc, char** argv) {
         for (auto& kv : base_hist) fprintf(stderr, " <=%u:%.1f%%", kv.first, 100.0 * kv.second / (tot ? tot : 1));
         fprintf(stderr, "\n");
     }
+    fprintf(stderr, "hops into blobs <= 64 B: %.3f/read (%.3f/read where the predecessor's last block has 64 B free), into blobs of 65..128 B: %.3f/read\n", (double)hop_small / n,
+            (double)hop_small_fits / n, (double)hop_mid / n);
     fprintf(stderr, "reads %llu: seek %.3f fwd %.3f left %.3f steps/read, hops %.3f/read\n", (unsigned long long)n, (double)n_seek / n, (double)n_fwd / n,
             (double)n_left / n, (double)hops / n);
 
