@@ -21,7 +21,8 @@ DevIndexView FlatDevice::host_view() const {
     v.nbuckets = nbuckets;
     v.blobs = blobs.data();
     v.ledge = ledge.data();
-    v.nid_of_handle = nid_of_handle.data();
+    v.seg_g = seg_g.data();
+    v.seg_nid = seg_nid.data();
     v.ec = ec.data();
     v.class_ref = class_ref.data();
     v.class_len = class_len.data();
@@ -32,6 +33,7 @@ DevIndexView FlatDevice::host_view() const {
     v.k = k;
     v.num_nodes = num_nodes;
     v.num_classes = num_classes;
+    v.num_segs = (uint32_t)seg_g.size();
     return v;
 }
 
@@ -116,6 +118,33 @@ struct Dict<uint64_t> {   // host-side builder/reader of the 16-byte slots descr
 
 }  // namespace
 
+// first / last k-mer of a node -> node id (open addressing, built once by one thread, read by many)
+template <class KT>
+struct KmerMap {
+    std::vector<KT> keys;
+    std::vector<uint32_t> vals;
+    uint64_t mask;
+    explicit KmerMap(uint32_t n) {
+        uint64_t cap = 16;
+        while (cap < 2ull * n + 2) cap <<= 1;
+        keys.assign(cap, 0);
+        vals.assign(cap, NO_HANDLE);
+        mask = cap - 1;
+    }
+    void insert(KT km, uint32_t v) {
+        for (uint64_t j = KmerOps<KT>::hash(km) & mask;; j = (j + 1) & mask) {
+            if (vals[j] == NO_HANDLE) { keys[j] = km; vals[j] = v; return; }
+            if (keys[j] == km) return;   // (a k-mer that occurs twice is reported by the dictionary's self-check)
+        }
+    }
+    uint32_t find(KT km) const {
+        for (uint64_t j = KmerOps<KT>::hash(km) & mask;; j = (j + 1) & mask) {
+            if (vals[j] == NO_HANDLE) return NO_HANDLE;
+            if (keys[j] == km) return vals[j];
+        }
+    }
+};
+
 template <class KT>
 static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool device_dict) {
     if (threads < 1) threads = 1;
@@ -179,47 +208,291 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
         }
     }
 
-    // ---- blob placement: every blob starts on a 128-byte block (handles stay in 64-byte units) ----
-    out.handle.resize(N);
-    uint64_t cursor = 0, nk = 0;
+    // ---- neighbours: the node whose FIRST k-mer is last(i).extend_right(b) / whose LAST k-mer is first(i).extend_left(b)
+    // (Node::r_edges / l_edges of the debruijn crate resolve them by hashing at every hop; taken from the flat
+    // index when it supplies them) ----
+    std::vector<uint64_t> seq_pad(f.node_seq, f.node_seq + (f.seq_bases + 31) / 32);   // read up to three words past the end: a padded copy
+    seq_pad.resize(seq_pad.size() + 3, 0);
+    const uint64_t* node_seq = seq_pad.data();
+    uint64_t nk = 0;
     for (uint32_t i = 0; i < N; ++i) {
         if (f.node_len[i] < k) return fail(PA_ERR_FORMAT, "node %u shorter than k", i);
         if (f.node_len[i] >= (1u << 24)) return fail(PA_ERR_UNSUPPORTED, "node %u longer than 2^24 bases", i);
         if (f.node_colour[i] >= f.num_classes) return fail(PA_ERR_FORMAT, "node %u: colour out of range", i);
-        const uint64_t size = (BLOB_HDR_BYTES + 8ull * ((f.node_len[i] + 31) / 32) + BLOB_ALIGN - 1) / BLOB_ALIGN * BLOB_ALIGN;
-        if (cursor / BLOB_GRANULE >= NO_HANDLE - 1) return fail(PA_ERR_UNSUPPORTED, "graph exceeds the 256 GiB blob address space");
-        // bit 0 (blobs start on 128-byte blocks: always clear in the address) = the header's third vector is needed: the class has a
-        // second window, or no windows at all
-        const U4 cwi = cwin[f.node_colour[i]];
-        out.handle[i] = (uint32_t)(cursor / BLOB_GRANULE) | ((cwi.y == 0 || cwi.w != 0) ? HANDLE_WIDE : 0u);
-        cursor += size;
         nk += f.node_len[i] - k + 1;
     }
     out.num_kmers = nk;
-    out.blobs.assign(cursor + 64, 0);   // tail pad: fwd_step reads up to 5 words past a node's last word
+    std::vector<uint32_t> redge(4ull * N, NO_HANDLE), ledge_n(4ull * N, NO_HANDLE);   // node ids
+    {
+        KmerMap<KT> first_of(N), last_of(N);
+        if (!f.node_redge || !f.node_ledge)
+            for (uint32_t i = 0; i < N; ++i) {
+                first_of.insert(KmerOps<KT>::get(node_seq, f.node_start[i], k), i);
+                last_of.insert(KmerOps<KT>::get(node_seq, f.node_start[i] + f.node_len[i] - k, k), i);
+            }
+        std::atomic<uint32_t> dangling{NO_HANDLE};
+        par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
+            for (uint64_t i = a; i < b; ++i) {
+                const uint64_t s = f.node_start[i];
+                const KT first = KmerOps<KT>::get(node_seq, s, k), last = KmerOps<KT>::get(node_seq, s + f.node_len[i] - k, k);
+                for (uint32_t base = 0; base < 4; ++base) {
+                    if (f.node_exts[i] & (1u << base)) {
+                        const uint32_t t = f.node_redge ? f.node_redge[4 * i + base] : first_of.find((last >> 2) | ((KT)base << topshift));
+                        if (t >= N) dangling.store((uint32_t)i);
+                        else redge[4 * i + base] = t;
+                    }
+                    if (f.node_exts[i] & (1u << (4 + base))) {
+                        const uint32_t t = f.node_ledge ? f.node_ledge[4 * i + base] : last_of.find(((first << 2) | (KT)base) & mask);
+                        if (t >= N) dangling.store((uint32_t)i);
+                        else ledge_n[4 * i + base] = t;
+                    }
+                }
+            }
+        });
+        if (dangling.load() != NO_HANDLE)
+            return fail(PA_ERR_FORMAT, "node %u has an extension bit without a terminal neighbour k-mer (missing link)", dangling.load());
+    }
 
-    // ---- dictionary: every k-mer of every node -> (handle, offset); the kernel follows at most 15 overflow buckets, so
+    // ---- chains (device_layout.hpp): B follows A in a chain when A's only right extension leads to B, B's only left extension
+    // to A, and every block the pair shares still fits its four slots ----
+    auto is_wide = [&](uint32_t i) { const U4 cw = cwin[f.node_colour[i]]; return cw.y == 0 || cw.w != 0; };
+    auto has_redge = [&](uint32_t i) { return (f.node_exts[i] & 15u) != 0; };
+    std::vector<uint32_t> succ(N, NO_HANDLE);
+    std::vector<uint8_t> has_pred(N, 0);
+    for (uint32_t a = 0; a < N; ++a) {
+        const uint32_t re = f.node_exts[a] & 15u;
+        if (re == 0 || (re & (re - 1))) continue;
+        const uint32_t bnode = redge[4 * a + (uint32_t)__builtin_ctz(re)];
+        const uint32_t le = (f.node_exts[bnode] >> 4) & 15u;
+        if (bnode == a || le == 0 || (le & (le - 1)) || ledge_n[4 * bnode + (uint32_t)__builtin_ctz(le)] != a) continue;
+        succ[a] = bnode;
+        has_pred[bnode] = 1;
+    }
+    struct SegI {
+        uint32_t node, s, e;   // e: where the node ends in the chain — or, link set, where the chain's copy of it ends
+        bool link;             // a tail copy cut short: the walk goes on in the node's own chain
+    };
+    std::vector<SegI> segs;             // every node, chain after chain
+    segs.reserve(N);
+    std::vector<uint32_t> chain_first;  // index into segs of every chain's first node (+ end sentinel)
+    // slots block j of the chain v[c0..) needs (v's last entry is the chain's last record)
+    auto block_slots = [&](const std::vector<SegI>& v, size_t c0, uint32_t j) {
+        const uint64_t base = (uint64_t)j << CH_STRIDE_LOG2;
+        uint32_t cnt = 0;
+        for (size_t t = v.size(); t-- > c0;) {
+            const SegI& g = v[t];
+            if (g.e <= base) break;
+            if (g.s >= base + CH_WINDOW) continue;
+            cnt += 1 + (is_wide(g.node) ? 1u : 0u);
+            if (t + 1 == v.size() && (g.link || has_redge(g.node)) && g.e - base < CH_WINDOW) ++cnt;   // the edge / link slot, where a step can reach the chain's end
+        }
+        return cnt;
+    };
+    // may `g` be appended to the chain v[c0..)? (every block its bases lie in, or the record before it can be seen from, must fit)
+    auto fits_after = [&](std::vector<SegI>& v, size_t c0, const SegI& g) {
+        const uint32_t prev_e = v.back().e;
+        v.push_back(g);
+        const uint32_t jlo = g.s < CH_WINDOW ? 0u : ((g.s - CH_WINDOW) >> CH_STRIDE_LOG2) + 1;
+        const uint32_t jhi = std::min<uint32_t>((g.e - 1) >> CH_STRIDE_LOG2, (prev_e >> CH_STRIDE_LOG2) + 1);
+        bool ok = true;
+        for (uint32_t j = jlo; j <= jhi && ok; ++j) ok = block_slots(v, c0, j) <= CH_SLOTS;
+        if (!ok) v.pop_back();
+        return ok;
+    };
+    out.handle.assign(N, 0);
+    out.node_s.assign(N, 0);
+    std::vector<uint8_t> visited(N, 0);
+    auto run = [&](uint32_t start) {
+        uint32_t i = start;
+        size_t c0 = segs.size();
+        chain_first.push_back((uint32_t)c0);
+        segs.push_back(SegI{i, 0u, f.node_len[i], false});
+        for (;;) {
+            visited[i] = 1;
+            const uint32_t bn = succ[i];
+            if (bn == NO_HANDLE || visited[bn]) break;
+            const uint64_t sb = (uint64_t)segs.back().e - (k - 1), eb = sb + f.node_len[bn];
+            if (!(eb < (1ull << 31) && fits_after(segs, c0, SegI{bn, (uint32_t)sb, (uint32_t)eb, false}))) {   // bn starts a chain of its own
+                c0 = segs.size();
+                chain_first.push_back((uint32_t)c0);
+                segs.push_back(SegI{bn, 0u, f.node_len[bn], false});
+            }
+            i = bn;
+        }
+    };
+    for (uint32_t i = 0; i < N; ++i)
+        if (!has_pred[i] && !visited[i]) run(i);
+    for (uint32_t i = 0; i < N; ++i)
+        if (!visited[i]) run(i);   // closed loops of nodes cut only by colour
+    const uint32_t nchains = (uint32_t)chain_first.size();
+    chain_first.push_back((uint32_t)segs.size());
+    out.num_chains = nchains;
+    for (uint32_t c = 0; c < nchains; ++c)
+        for (uint32_t t = chain_first[c]; t < chain_first[c + 1]; ++t) {
+            out.handle[segs[t].node] = c;   // (the chain's number for now)
+            out.node_s[segs[t].node] = segs[t].s;
+        }
+
+    // ---- tails (device_layout.hpp): after a chain's last node Z, COPIES of the nodes a read can only go on to — Z's one
+    // right extension, that node's one right extension, ... — for up to CH_TAIL bases, so that the step that runs over Z's end
+    // finds them in the block it already holds. A copy that is cut short ends in a link to the same base of the node's own chain
+    {
+        std::vector<SegI> fin;
+        std::vector<uint32_t> fin_first;
+        fin.reserve(segs.size() + nchains);
+        for (uint32_t c = 0; c < nchains; ++c) {
+            const size_t c0 = fin.size();
+            fin_first.push_back((uint32_t)c0);
+            fin.insert(fin.end(), segs.begin() + chain_first[c], segs.begin() + chain_first[c + 1]);
+            const uint64_t limit = (uint64_t)fin.back().e + CH_TAIL;
+            for (uint32_t cur = fin.back().node; limit < (1ull << 31);) {
+                const uint32_t re = f.node_exts[cur] & 15u;
+                if (re == 0 || (re & (re - 1))) break;
+                const uint32_t bn = redge[4 * cur + (uint32_t)__builtin_ctz(re)];
+                const uint64_t sb = (uint64_t)fin.back().e - (k - 1), full = sb + f.node_len[bn];
+                if ((uint64_t)fin.back().e + 1 >= limit) break;          // no room for a base beyond the one the extension test looks at
+                const bool cut = full > limit;
+                if (!fits_after(fin, c0, SegI{bn, (uint32_t)sb, (uint32_t)(cut ? limit : full), cut})) break;
+                if (cut) break;
+                cur = bn;
+            }
+            // a copy the tail ends with WHOLE hands the walk to its right edges, and those enter a node at its chain's first
+            // k-mer: fine for a node with several right extensions (none of them was merged with it), not for a node whose one
+            // successor follows it inside its own chain. Such a copy gives up its last base to a link — or, too short for that, goes
+            for (const size_t c1 = c0 + (chain_first[c + 1] - chain_first[c]); fin.size() > c1 && !fin.back().link;) {
+                const uint32_t re = f.node_exts[fin.back().node] & 15u;
+                if (re == 0 || (re & (re - 1)) || out.node_s[redge[4 * fin.back().node + (uint32_t)__builtin_ctz(re)]] == 0) break;
+                bool done = false;
+                if (fin.back().e >= fin[fin.size() - 2].e + 2) {
+                    SegI g = fin.back();
+                    g.e -= 1;
+                    g.link = true;
+                    fin.pop_back();
+                    done = fits_after(fin, c0, g);                   // (one base shorter: its end may now be in reach of one more block)
+                    if (!done) { g.e += 1; g.link = false; fin.push_back(g); }
+                }
+                if (!done) fin.pop_back();
+            }
+        }
+        fin_first.push_back((uint32_t)fin.size());
+        segs.swap(fin);
+        chain_first.swap(fin_first);
+    }
+    const size_t nsegs = segs.size();
+
+    // ---- placement: chain handle = 128-byte blocks before it ----
+    std::vector<uint32_t> chain_handle(nchains);
+    out.seg_g.resize(nsegs);
+    out.seg_nid.resize(nsegs);
+    uint64_t cursor = 0;
+    for (uint32_t c = 0; c < nchains; ++c) {
+        if (cursor >= NO_HANDLE - 8) return fail(PA_ERR_UNSUPPORTED, "graph exceeds the 512 GiB chain address space");
+        chain_handle[c] = (uint32_t)cursor;
+        for (uint32_t t = chain_first[c]; t < chain_first[c + 1]; ++t) {
+            out.seg_g[t] = ((uint64_t)cursor << CH_STRIDE_LOG2) + segs[t].s;
+            out.seg_nid[t] = segs[t].node;
+        }
+        cursor += (segs[chain_first[c + 1] - 1].e + CH_STRIDE - 1) >> CH_STRIDE_LOG2;
+    }
+    for (uint32_t i = 0; i < N; ++i) out.handle[i] = chain_handle[out.handle[i]];   // chain number -> chain handle
+    const uint64_t nblocks = cursor;
+    out.blobs.assign(nblocks * CH_BLOCK + 64, 0);   // tail pad: a step's last sequence load may reach one word past its block
+
+    // ---- blocks ----
+    std::atomic<uint32_t> bad_edge{NO_HANDLE}, bad_slots{NO_HANDLE};
+    par_ranges(threads, nchains, [&](uint64_t ca, uint64_t cb, int) {
+        std::vector<uint64_t> cs;   // the chain's sequence
+        for (uint64_t c = ca; c < cb; ++c) {
+            const uint32_t t0 = chain_first[c], t1 = chain_first[c + 1], clen = segs[t1 - 1].e;
+            cs.assign((clen + 31) / 32 + 9, 0);
+            for (uint32_t t = t0; t < t1; ++t) {
+                const SegI& g = segs[t];
+                const uint64_t src = f.node_start[g.node];
+                for (uint32_t o = t == t0 ? 0 : k - 1; g.s + o < g.e; ++o) set_base(cs.data(), g.s + o, get_base(node_seq, src + o));
+            }
+            const uint32_t nblk = (clen + CH_STRIDE - 1) >> CH_STRIDE_LOG2;
+            uint32_t tlo = t0;   // first node that can still overlap the current block
+            for (uint32_t j = 0; j < nblk; ++j) {
+                const uint32_t base = j << CH_STRIDE_LOG2;
+                uint8_t* blk = out.blobs.data() + ((uint64_t)chain_handle[c] + j) * CH_BLOCK;
+                uint32_t* sl = reinterpret_cast<uint32_t*>(blk);
+                uint64_t* sq = reinterpret_cast<uint64_t*>(blk + CH_SEQ_BYTES);
+                while (tlo < t1 && segs[tlo].e <= base) ++tlo;
+                uint32_t slot = 0, recmask = 0;
+                for (uint32_t t = tlo; t < t1 && segs[t].s < base + CH_WINDOW; ++t) {
+                    const SegI& g = segs[t];
+                    const U4 cw = cwin[f.node_colour[g.node]];
+                    const bool wide = is_wide(g.node), last = t + 1 == t1, reach = g.e - base < CH_WINDOW, edges = last && !g.link && has_redge(g.node) && reach,
+                               link = last && g.link && reach;
+                    if (slot + 1 + (wide ? 1 : 0) + (edges || link ? 1 : 0) > CH_SLOTS) { bad_slots.store(g.node); break; }   // (the merge rule keeps every block within its slots)
+                    recmask |= 1u << slot;
+                    uint32_t* r = sl + 4 * slot++;
+                    r[0] = std::min<uint32_t>(g.e - base, SEG_E_FAR) | (wide ? SEG_WIDE : 0u) | (last ? SEG_LAST : 0u) | (edges ? SEG_EDGES : 0u) | (link ? SEG_LINK : 0u);
+                    r[1] = f.node_colour[g.node]; r[2] = cw.x; r[3] = cw.y;
+                    if (wide) {
+                        uint32_t* x = sl + 4 * slot++;
+                        x[0] = cw.z; x[1] = cw.w; x[2] = out.class_ref[f.node_colour[g.node]]; x[3] = out.class_len[f.node_colour[g.node]];
+                    }
+                    if (edges) {
+                        uint32_t* x = sl + 4 * slot++;
+                        for (uint32_t b = 0; b < 4; ++b) {
+                            const uint32_t tn = redge[4 * g.node + b];
+                            if (tn != NO_HANDLE && out.node_s[tn] != 0) bad_edge.store(g.node);   // a right edge enters a node at its first k-mer, which starts its chain
+                            x[b] = tn == NO_HANDLE ? NO_HANDLE : out.handle[tn];
+                        }
+                    }
+                    if (link) {   // the base after the copy's last one, in the node's own chain, as a continuing step addresses it (fwd_finish)
+                        uint32_t* x = sl + 4 * slot++;
+                        const uint32_t xt = out.node_s[g.node] + (g.e - g.s), adv = (xt - 1) >> CH_STRIDE_LOG2;
+                        x[0] = out.handle[g.node] + adv;
+                        x[1] = xt - (adv << CH_STRIDE_LOG2);
+                        x[2] = x[3] = 0;
+                    }
+                }
+                sl[0] |= (std::min(j, CH_BACK_MAX) << SEG_BACK_SHIFT) | (recmask << SEG_RECMASK_SHIFT);
+                for (uint32_t w = 0; w < CH_WINDOW / 32; ++w) sq[w] = window32(cs.data(), base + 32ull * w);   // (cs is zero beyond the chain)
+            }
+        }
+    });
+    if (bad_slots.load() != NO_HANDLE) return fail(PA_ERR_INTERNAL, "node %u: a chain block needs more than its four slots", bad_slots.load());
+    if (bad_edge.load() != NO_HANDLE) return fail(PA_ERR_FORMAT, "node %u: a right edge does not lead to the first k-mer of a chain", bad_edge.load());
+
+    // ---- left edges by chain handle: where the extension goes on — the neighbour's last k-mer, in the block with the most
+    // room to the left of it ----
+    out.ledge.assign(8ull * nblocks + 8, NO_HANDLE);
+    for (uint32_t c = 0; c < nchains; ++c) {
+        const uint32_t a = segs[chain_first[c]].node;
+        for (uint32_t b = 0; b < 4; ++b) {
+            const uint32_t tn = ledge_n[4 * a + b];
+            uint32_t* e = out.ledge.data() + 8ull * chain_handle[c] + 2 * b;
+            e[1] = 0;
+            if (tn == NO_HANDLE) continue;
+            const uint32_t y = out.node_s[tn] + f.node_len[tn] - k;   // its last k-mer (prev_kmer_offset = len - k, :196)
+            const uint32_t jy = y >> CH_STRIDE_LOG2, j = jy > CH_BACK_MAX ? jy - CH_BACK_MAX : 0;
+            e[0] = out.handle[tn] + j;
+            e[1] = y - (j << CH_STRIDE_LOG2) + 1;
+        }
+    }
+    // (a left edge must enter its node at the node's LAST k-mer, which ends its chain: the neighbour tables above were built
+    // from last k-mers, so a left extension that leads anywhere else was reported as a missing link)
+
+    // ---- dictionary: every k-mer of every node -> (block, position); the kernel follows at most 15 overflow buckets, so
     // the table is rebuilt larger in the (practically impossible) case that some key sits further from its home ----
-    // the node sequence is read up to two words past its end: work on a padded copy
-    std::vector<uint64_t> seq_pad(f.node_seq, f.node_seq + (f.seq_bases + 31) / 32);
-    seq_pad.resize(seq_pad.size() + 3, 0);
-    const uint64_t* node_seq = seq_pad.data();
     auto node_kmers = [&](uint32_t i, auto&& fn) {
         const uint64_t s = f.node_start[i];
         const uint32_t n = f.node_len[i] - k + 1;
         KT km = KmerOps<KT>::get(node_seq, s, k);
         for (uint32_t o = 0; o < n; ++o) {
             if (o) km = (km >> 2) | ((KT)get_base(node_seq, s + o + k - 1) << topshift);
-            fn(km, o);
+            const uint32_t c = out.node_s[i] + o;
+            fn(km, out.handle[i] + (c >> CH_STRIDE_LOG2), dict_entry_off(c, o == 0));
         }
     };
     Dict<KT> dict{nullptr, 0};
-    if (device_dict) {   // the GPU fills the dictionary and derives the edges (index_fill.hip)
+    if (device_dict) {   // the GPU fills the dictionary from the uploaded blocks (index_fill.hip)
         out.node_kcum.resize((size_t)N + 1);
         out.node_kcum[0] = 0;
         for (uint32_t i = 0; i < N; ++i) out.node_kcum[i + 1] = out.node_kcum[i] + (f.node_len[i] - k + 1);
-        out.have_redge = f.node_redge != nullptr;
-        out.have_ledge = f.node_ledge != nullptr;
     }
     for (double load = Dict<KT>::LOAD; !device_dict; load *= 0.75) {
         out.nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (Dict<KT>::SLOTS * load)) + 1);
@@ -227,107 +500,22 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
         out.table.assign(out.nbuckets * BUCKET_WORDS, 0xFFFFFFFFu);   // empty slots, no flags
         dict = Dict<KT>{out.table.data(), out.nbuckets};
         par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
-            for (uint64_t i = a; i < b; ++i) node_kmers((uint32_t)i, [&](KT km, uint32_t o) { dict.insert_mt(km, out.handle[i], o); });
+            for (uint64_t i = a; i < b; ++i) node_kmers((uint32_t)i, [&](KT km, uint32_t h, uint32_t o) { dict.insert_mt(km, h, o); });
         });
         par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {   // k <= 32: keys that did not get their home slot (dict_slots.hpp)
-            for (uint64_t i = a; i < b; ++i) node_kmers((uint32_t)i, [&](KT km, uint32_t o) { dict.insert_rest_mt(km, out.handle[i], o); });
+            for (uint64_t i = a; i < b; ++i) node_kmers((uint32_t)i, [&](KT km, uint32_t h, uint32_t o) { dict.insert_rest_mt(km, h, o); });
         });
         std::atomic<uint32_t> bad{NO_HANDLE}, far{0};
         par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
             for (uint64_t i = a; i < b; ++i)
-                node_kmers((uint32_t)i, [&](KT km, uint32_t o) {
-                    uint32_t h, off, probes = 0;
-                    if (!dict.find(km, h, off, &probes) || h != out.handle[i] || off != o) bad.store((uint32_t)i);
+                node_kmers((uint32_t)i, [&](KT km, uint32_t h, uint32_t o) {
+                    uint32_t fh, fo, probes = 0;
+                    if (!dict.find(km, fh, fo, &probes) || fh != h || fo != o) bad.store((uint32_t)i);
                     if (probes > DICT_MAX_PROBES) far.store(1);
                 });
         });
         if (bad.load() != NO_HANDLE) return fail(PA_ERR_FORMAT, "a k-mer of node %u occurs twice in the graph", bad.load());
         if (!far.load()) break;
-    }
-
-    // ---- blobs + edges ----
-    const uint64_t granules = out.blobs.size() / BLOB_GRANULE;
-    out.ledge.assign(8ull * granules + 8, NO_HANDLE);   // {handle, length}[4] per granule (lengths filled in below)
-    out.nid_of_handle.assign(granules + 1, 0xFFFFFFFFu);
-    std::atomic<uint32_t> dangling{NO_HANDLE};
-    par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
-        for (uint64_t i = a; i < b; ++i) {
-            uint8_t* blob = out.blobs.data() + (uint64_t)(out.handle[i] & ~HANDLE_WIDE) * BLOB_GRANULE;
-            uint32_t* hd = reinterpret_cast<uint32_t*>(blob);
-            uint64_t* sq = reinterpret_cast<uint64_t*>(blob + BLOB_HDR_BYTES);
-            const uint32_t len = f.node_len[i];
-            const uint64_t s = f.node_start[i];
-            hd[0] = len | ((uint32_t)f.node_exts[i] << 24);
-            hd[1] = f.node_colour[i];
-            out.nid_of_handle[out.handle[i]] = (uint32_t)i;
-            const U4 cw = cwin[f.node_colour[i]];
-            hd[2] = cw.x; hd[3] = cw.y;
-            hd[8] = cw.z; hd[9] = cw.w;
-            hd[10] = out.class_ref[f.node_colour[i]];
-            hd[11] = out.class_len[f.node_colour[i]];
-            for (uint32_t w = 0; w < (len + 31) / 32; ++w) {
-                uint64_t v = window32(node_seq, s + 32ull * w);
-                const uint32_t rem = len - 32 * w;
-                if (rem < 32) v &= (1ull << (2 * rem)) - 1;
-                sq[w] = v;
-            }
-            const KT first = KmerOps<KT>::get(node_seq, s, k), last = KmerOps<KT>::get(node_seq, s + len - k, k);
-            for (uint32_t base = 0; base < 4; ++base) {
-                uint32_t re = NO_HANDLE, le = NO_HANDLE;
-                if (f.node_exts[i] & (1u << base)) {
-                    if (f.node_redge) {
-                        const uint32_t t = f.node_redge[4 * i + base];
-                        if (t < N) re = out.handle[t];
-                    } else if (!device_dict) {
-                        // find_link(last.extend_right(b), Dir::Right): node whose FIRST k-mer it is (offset 0)
-                        uint32_t h, off;
-                        if (dict.find((last >> 2) | ((KT)base << topshift), h, off) && off == 0) re = h;
-                    }
-                    if (re == NO_HANDLE && (f.node_redge || !device_dict)) dangling.store((uint32_t)i);
-                }
-                if (f.node_exts[i] & (1u << (4 + base))) {
-                    if (f.node_ledge) {
-                        const uint32_t t = f.node_ledge[4 * i + base];
-                        if (t < N) le = out.handle[t];
-                    } else if (!device_dict) {
-                        // find_link(first.extend_left(b), Dir::Left): node whose LAST k-mer it is
-                        // (that it IS the last k-mer is verified below, once every header has been written)
-                        uint32_t h, off;
-                        if (dict.find(((first << 2) | base) & mask, h, off)) le = h;
-                    }
-                    if (le == NO_HANDLE && (f.node_ledge || !device_dict)) dangling.store((uint32_t)i);
-                }
-                hd[4 + base] = re;
-                out.ledge[8ull * out.handle[i] + 2 * base] = le;
-            }
-        }
-    });
-    if (dangling.load() != NO_HANDLE)
-        return fail(PA_ERR_FORMAT, "node %u has an extension bit without a terminal neighbour k-mer (missing link)", dangling.load());
-    // every left edge carries the length of the node it leads to (every header exists now)
-    par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
-        for (uint64_t i = a; i < b; ++i)
-            for (uint32_t base = 0; base < 4; ++base) {
-                uint32_t* e = out.ledge.data() + 8ull * out.handle[i] + 2 * base;
-                e[1] = e[0] == NO_HANDLE ? 0u : (*reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)(e[0] & ~HANDLE_WIDE) * BLOB_GRANULE) & 0xFFFFFFu);
-            }
-    });
-    // left-edge targets must be entered at their LAST k-mer (offset len-k): check now that every header exists
-    if (!f.node_ledge && !device_dict) {
-        par_ranges(threads, N, [&](uint64_t a, uint64_t b, int) {
-            for (uint64_t i = a; i < b; ++i) {
-                const KT first = KmerOps<KT>::get(node_seq, f.node_start[i], k);
-                for (uint32_t base = 0; base < 4; ++base) {
-                    if (!(f.node_exts[i] & (1u << (4 + base)))) continue;
-                    uint32_t h = 0, off = 0;
-                    dict.find(((first << 2) | base) & mask, h, off);
-                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(out.blobs.data() + (uint64_t)(h & ~HANDLE_WIDE) * BLOB_GRANULE) & 0xFFFFFFu;
-                    if (off != tlen - k) dangling.store((uint32_t)i);
-                }
-            }
-        });
-        if (dangling.load() != NO_HANDLE)
-            return fail(PA_ERR_FORMAT, "node %u: left neighbour k-mer is not the last k-mer of its node", dangling.load());
     }
     return PA_OK;
 }

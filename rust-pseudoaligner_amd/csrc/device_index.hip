@@ -74,7 +74,7 @@ struct pa_index {
     int device = 0;
     int num_cus = 0;
     DevIndexView dv{};
-    void *d_table = nullptr, *d_blobs = nullptr, *d_ledge = nullptr, *d_nid = nullptr, *d_ec = nullptr, *d_class_ref = nullptr, *d_class_len = nullptr,
+    void *d_table = nullptr, *d_blobs = nullptr, *d_ledge = nullptr, *d_seg_g = nullptr, *d_seg_nid = nullptr, *d_ec = nullptr, *d_class_ref = nullptr, *d_class_len = nullptr,
          *d_class_table = nullptr, *d_wtable = nullptr;
     uint64_t class_table_size = 0;
     pa_index_stats stats{};
@@ -149,7 +149,7 @@ void index_put_ingest_cache(pa_index* idx, void* cache, void (*free_fn)(void*)) 
 void pa_index_destroy(pa_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
-    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table, idx->d_wtable})
+    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_seg_g, idx->d_seg_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table, idx->d_wtable})
         if (p) (void)hipFree(p);
     if (idx->ingest_cache && idx->ingest_cache_free) { idx->ingest_cache_free(idx->ingest_cache); idx->ingest_cache = nullptr; }   // (releases its stream's context)
     for (auto& kv : idx->ctxs) kv.second->release();
@@ -166,8 +166,8 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     FlatDevice fd;
     int threads = usable_threads();
     if (threads < 1) threads = 1;
-    // classes, window table, blob layout on the host; the dictionary (3.3 GB at config 3) and the edges are built on the GPU
-    // from the uploaded blobs (index_fill.hip) — nothing of the table exists on the host or crosses PCIe
+    // classes, window table, edges, chains and their blocks on the host; the dictionary (3.3 GB at config 3) is built on the GPU
+    // from the uploaded blocks (index_fill.hip) — nothing of the table exists on the host or crosses PCIe
     rc = flatten_for_device(*flat, threads, fd, /*device_dict=*/true);
     if (rc != PA_OK) return rc;
 
@@ -188,8 +188,9 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     if (idx->num_cus <= 0) idx->num_cus = 256;
     rc = upload(fd.blobs.data(), fd.blobs.size(), &idx->d_blobs);
     if (rc == PA_OK) rc = upload(fd.ledge.data(), fd.ledge.size() * 4, &idx->d_ledge);
-    if (rc == PA_OK) rc = device_fill_index(fd, idx->d_blobs, idx->d_ledge, &idx->d_table, &fd.nbuckets);
-    if (rc == PA_OK) rc = upload(fd.nid_of_handle.data(), fd.nid_of_handle.size() * 4, &idx->d_nid);
+    if (rc == PA_OK) rc = device_fill_index(fd, idx->d_blobs, &idx->d_table, &fd.nbuckets);
+    if (rc == PA_OK) rc = upload(fd.seg_g.data(), fd.seg_g.size() * 8, &idx->d_seg_g);
+    if (rc == PA_OK) rc = upload(fd.seg_nid.data(), fd.seg_nid.size() * 4, &idx->d_seg_nid);
     if (rc == PA_OK) rc = upload(fd.ec.data(), fd.ec.size() * 4, &idx->d_ec);
     if (rc == PA_OK) rc = upload(fd.class_ref.data(), fd.class_ref.size() * 4, &idx->d_class_ref);
     if (rc == PA_OK) rc = upload(fd.class_len.data(), fd.class_len.size() * 4, &idx->d_class_len);
@@ -201,7 +202,8 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     idx->dv.table = static_cast<const uint32_t*>(idx->d_table);
     idx->dv.blobs = static_cast<const uint8_t*>(idx->d_blobs);
     idx->dv.ledge = static_cast<const uint32_t*>(idx->d_ledge);
-    idx->dv.nid_of_handle = static_cast<const uint32_t*>(idx->d_nid);
+    idx->dv.seg_g = static_cast<const uint64_t*>(idx->d_seg_g);
+    idx->dv.seg_nid = static_cast<const uint32_t*>(idx->d_seg_nid);
     idx->h_ec = fd.ec;   // host copy of the class table: pa_map_batch resolves by-reference classes from it
     idx->h_class_ref = fd.class_ref;
     idx->dv.ec = static_cast<const uint32_t*>(idx->d_ec);
@@ -212,7 +214,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     s.num_kmers = fd.num_kmers;
     s.table_slots = fd.nbuckets * SLOTS_PER_BUCKET;
     s.bytes_table = fd.nbuckets * BUCKET_WORDS * 4;
-    s.bytes_graph = fd.blobs.size() + fd.ledge.size() * 4 + fd.nid_of_handle.size() * 4;
+    s.bytes_graph = fd.blobs.size() + fd.ledge.size() * 4 + fd.seg_g.size() * 12;
     s.bytes_classes = (fd.ec.size() + fd.class_ref.size() + fd.class_len.size() + ctab.size() + fd.wtable.size()) * 4;
     s.bytes_total = s.bytes_table + s.bytes_graph + s.bytes_classes;
     s.num_nodes = fd.num_nodes;

@@ -11,39 +11,59 @@
 //               else it overflows into the next bucket (flag bit 3 of the home slot) where the same rule applies. Flags are
 //               stored inverted (a set flag is a cleared bit) so that an all-ones fill is "empty, no flags". A lookup is ONE
 //               16-byte load — the home slot holds the whole key and the answer — and only when the home slot holds another
-//               key AND names other slots, one more load from the same line (21 % of the hits, 9 % of the misses). Round 2's
-//               line {fp[4], entries[4]} took two dependent loads for every hit, and on this chip the second load of a line that
-//               lives in HBM costs almost what the first did (tools/microbench/gather_multi.hip: 47 G lines/s with one load per
-//               lane, 33 G with a dependent second one). The dictionary stores whole keys, so unlike the reference's MPHF
-//               (src/pseudoaligner.rs:96-107) no node sequence has to be fetched to confirm a hit.
+//               key AND names other slots, one more load from the same line (21 % of the hits, 9 % of the misses). The
+//               dictionary stores whole keys, so unlike the reference's MPHF (src/pseudoaligner.rs:96-107) no node sequence
+//               has to be fetched to confirm a hit.
 //               k > 32 (two-word k-mers): a line holds two whole entries {key word 0..3, handle, off, -, -}, handle
 //               0xFFFFFFFF = empty, load <= 1/3, linear probing over lines (a line with a free entry ends the probe sequence).
-//   node blobs  one blob per unitig, starting on a 128-byte block, addressed by handle = byte offset / 64 — so bit 0 of a blob's
-//               offset/64 is always clear, and every handle (dictionary slots, edges, lane state) carries there the WIDE flag
-//               of its node: the third 16-byte vector of the header is needed (second class window, or no windows at all).
-//               The blob address is (handle & ~1) * 64; nid_of_handle / ledge are indexed by the handle as it is.
-//                 +0  u32 len (bits 0..23) | debruijn::Exts byte (bits 24..31)     +4  u32 class id
-//                 +8  u32 cmin, cmask   the class as WINDOWS of 32 transcript ids: {cmin + i : bit i of cmask} ...
-//                 +16 u32 redge[4]      handle of the node reached by right-extending with base b (Node::r_edges)
-//                 +32 u32 cmin2, cmask2 ... U {cmin2 + i : bit i of cmask2}, cmin2 >= cmin + 32 (cmask2 = 0: one window);
-//                                       cmask = 0 when the class does not fit (then only the id list describes it)
-//                 +40 u32 class record ref   +44 u32 class length (ids)
-//               A forward step loads +0 and +16 for every lane and +32 only for lanes whose handle has the WIDE flag or whose
-//               read collects class lists (list mode): one access of the vector L1 less for ~90 % of the node visits.
-//                 +48 u64 seq[ceil(len/32)]  2-bit packed, LSB-first
-//               so a node visit is ONE dependent fetch (header and the first 64 bases share a line), the hop to the
-//               next node needs no further lookup (the reference re-derives every edge by hashing: SURVEY.md §3.2),
-//               the colour's id list is addressable without an offsets table, and for window classes (transcripts of
-//               one gene are neighbours in the FASTA; a second window covers a paralog or an overlapping gene) the
-//               intersection of nodes_to_eq_class is an AND of masks that never touches the id lists.
-//   ledge       u32[8*granules] by blob handle: {handle, length}[4] of the nodes reached by left-extending with base b (Node::l_edges;
-//               handle 0xFFFFFFFF = none). Only the left extension touches it; the length lets a lane that hops left fetch the END
-//               of the neighbour's sequence together with its header (lane_steps.hpp, left_issue)
-//   nid_of_handle  u32[granules] node id by blob handle (only the node-trace test surface reads it)
+//               What an entry says (both forms): handle = the chain BLOCK the k-mer starts in (below), off = where:
+//                 bits 0..5  p      position of the k-mer's first base in that block's window (0..63)
+//                 bit  6     the k-mer is the FIRST k-mer of its node (kmer_offset == 0: the quirk of :129 needs to know)
+//                 bits 7..8  min(block index within the chain, 3): how many blocks a left extension may step back at once
+//
+//   chain blocks  Unitigs that the reference's graph cuts ONLY because the colour changes (A has one right extension, it
+//               leads to B, B has one left extension: 64-69 % of the nodes of a transcriptome) are laid out as ONE sequence,
+//               a CHAIN: node i+1 starts K-1 bases before node i ends, so the chain is A's sequence followed by the bases B
+//               adds, and node i covers chain positions [s_i, e_i), s_{i+1} = e_i - (K-1). A read that walks A -> B in the
+//               reference (has_ext + r_edges + get_node, :267-283) here just goes on comparing: position e_i is the base the
+//               extension test looks at, the positions between two such bases are one node's compare loop (:236-255).
+//               A chain is stored as OVERLAPPING 128-byte blocks: block j holds the 256 bases [64 j, 64 j + 256) and the
+//               records of every node that overlaps them, so whatever a 150-base read needs of a chain — sequence, node
+//               boundaries, classes, edges at the chain's end — arrives with ONE 128-byte request (the unit the memory
+//               system moves; the kernel is bound by the rate of such requests: DESIGN.md §4) and is consumed by ONE step.
+//               The price is replication (every base is stored four times: 2 bytes per base, 0.2 GB at config 3).
+//               handle = byte offset / 128; the block of chain position c is handle(chain) + c / 64.
+//                 +0   four 16-byte SLOTS
+//                 +64  u64 seq[8]   bases [64 j, 64 j + 256) of the chain, 2-bit packed, LSB-first, zero beyond the chain's end
+//               Slots, in order: one RECORD per node with e > 64 j and s < 64 j + 256 (ascending), each followed by its
+//               extension slot if WIDE, the chain's last record also by the edge slot if it has one:
+//                 record     {w0, class id, cmin, cmask}   the class as a WINDOW of 32 transcript ids {cmin + i : bit i of cmask}
+//                            w0 bits 0..15  e - 64 j, the node's end relative to the block (0xFFFF: further than that)
+//                               bit 16 WIDE     the next slot is this record's extension
+//                               bit 17 LAST     last node of the chain
+//                               bit 18 EDGES    (LAST) the slot after this record (and its extension) holds the right edges
+//                               bit 19 LINK     (LAST) a copy cut short: that slot holds {block, position} of the next base in the node's own chain
+//                               slot 0 only: bits 20..21 min(j, 3); bits 28..31 which of the four slots are records
+//                 extension  {cmin2, cmask2, class record ref, class length}: a second window (cmin2 >= cmin + 32), or — cmask
+//                            == 0 — a class that does not fit two windows and is only described by its id list
+//                 edges      {handle of the chain reached by right-extending the chain's last node with base b}[4]
+//                            (Node::r_edges; 0xFFFFFFFF = has_ext(Right, b) is false)
+//               The flattener only merges B onto a chain when every block still fits its four slots; a node on its own
+//               always does (record + extension + edges).
+//               TAILS. Most nodes with ONE right extension lead to a node that others lead to as well (a join): that node
+//               starts a chain of its own, and the walk would leave the block. So after a chain's last node Z the flattener
+//               appends COPIES of what can only follow — Z's one successor, that node's one successor, ... — for up to 128
+//               bases (what a 150-base read can still need), records and sequence like any other node of the chain. A copy
+//               that does not fit whole ends in a LINK: at that position the walk goes on, mid-node, in the node's own chain.
+//               The dictionary, the left edges and the right edges only ever point at a node's own place, never at a copy.
+//   ledge       u32[8 * blocks] by CHAIN handle: {block handle, y + 1}[4] — where a left extension that leaves the chain's
+//               first node with base b goes on (Node::l_edges): the last k-mer of the neighbour chain's last node, as position
+//               y of a block that has (up to) 192 bases to the left of it. Handle 0xFFFFFFFF = has_ext(Left, b) is false.
+//   seg_g / seg_nid  (node-trace test surface only) u64 64 * handle(chain) + s_i of every node, ascending, and its node id
 //   ec          class records, 16-byte aligned, at least 32 bytes, padded with 0xFFFFFFFF: record r = words [4r, ...) =
 //               {class id, id0, id1, ...} — the sorted transcript-id lists of eq_classes: Vec<Vec<u32>>
 //               (src/pseudoaligner.rs:29); a class of <= 7 ids is two 16-byte loads and needs no length checks.
-//   class_ref/class_len  u32[num_classes] record ref and length by class id (only the count table's content lookup)
+//   class_ref/class_len  u32[num_classes] record ref and length by class id (list mode: the record of a one-window class)
 //   wtable      window classes by content: open addressing over 64-byte lines of three {cmin, cmask, cmin2, cmask2, class
 //               id} entries (class id 0xFFFFFFFF = empty), line = mulhi32(hash(windows), wbuckets), linear probing —
 //               tells in ONE fetch whether a window result that is a strict subset of every class seen is itself a class
@@ -62,15 +82,28 @@
 namespace pa {
 
 constexpr uint32_t NO_HANDLE = 0xFFFFFFFFu;
-constexpr uint32_t BLOB_GRANULE = 64;
-constexpr uint32_t HANDLE_WIDE = 1u;   // bit 0 of a handle: the node's header vector at +32 is needed (device_layout.hpp, node blobs)
-constexpr uint32_t BLOB_ALIGN = 128;   // the memory system moves 128-byte blocks: two adjacent 64-byte lines of ONE block cost what one line costs, lines of two blocks cost double (tools/microbench/gather_pair.hip); header + first 320 bases = one block
-constexpr uint32_t BLOB_HDR_BYTES = 48;
+constexpr uint32_t CH_BLOCK = 128;          // bytes per chain block = the unit the memory system moves (tools/microbench/gather_pair.hip)
+constexpr uint32_t CH_STRIDE_LOG2 = 6;
+constexpr uint32_t CH_STRIDE = 1u << CH_STRIDE_LOG2;   // chain positions between consecutive blocks
+constexpr uint32_t CH_WINDOW = 256;         // bases a block holds
+constexpr uint32_t CH_SLOTS = 4;            // 16-byte slots per block
+constexpr uint32_t CH_SEQ_BYTES = 64;       // offset of the sequence words in a block
+constexpr uint32_t CH_BACK_MAX = 3;         // blocks a left extension steps back at once (window / stride - 1)
+constexpr uint32_t SEG_E_MASK = 0xFFFFu, SEG_E_FAR = 0xFFFFu;
+constexpr uint32_t SEG_WIDE = 1u << 16, SEG_LAST = 1u << 17, SEG_EDGES = 1u << 18, SEG_LINK = 1u << 19;
+constexpr uint32_t CH_TAIL = 128;           // bases of copied successor nodes after a chain's last node
+constexpr uint32_t SEG_BACK_SHIFT = 20, SEG_RECMASK_SHIFT = 28;
+constexpr uint32_t ENT_P_MASK = 63u, ENT_NODE_START = 64u, ENT_BACK_SHIFT = 7;   // dictionary entry, word `off`
+// second word of the dictionary entry of the k-mer that starts at chain position c (node_start: it is its node's first k-mer)
+PA_HD uint32_t dict_entry_off(uint32_t c, bool node_start) {
+    const uint32_t j = c >> CH_STRIDE_LOG2;
+    return (c & ENT_P_MASK) | (node_start ? ENT_NODE_START : 0u) | ((j < CH_BACK_MAX ? j : CH_BACK_MAX) << ENT_BACK_SHIFT);
+}
 constexpr uint32_t CLASS_WINDOW = 32;   // ids per class window (one mask word)
 constexpr uint32_t SLOTS_PER_BUCKET = 4;
 constexpr uint32_t BUCKET_WORDS = 16;
 constexpr uint32_t SLOT_WORDS = 4;                 // k <= 32: {key_lo, key_hi, handle, off | ~flags << 24}
-constexpr uint32_t SLOT_OFF_MASK = 0xFFFFFFu;      // node length < 2^24
+constexpr uint32_t SLOT_OFF_MASK = 0xFFFFFFu;
 constexpr uint32_t SLOT_FLAG_SHIFT = 24;           // flags 0..2: slot (home + 1 + i) & 3 holds a key of this home; flag 3: one overflowed to the next bucket
 constexpr uint32_t SLOT_FLAG_OVERFLOW = 8u;
 constexpr uint32_t DICT_MAX_PROBES = 15;           // buckets a key may overflow through (the builders keep every chain shorter)
@@ -87,9 +120,10 @@ constexpr uint32_t WT_ENTRIES = 3;   // window-table entries per 64-byte line, 5
 struct DevIndexView {
     const uint32_t* table;    // nbuckets * 16 words
     uint64_t nbuckets;
-    const uint8_t* blobs;     // node blobs
-    const uint32_t* ledge;    // [8 * granules]: {handle, length}[4] by handle
-    const uint32_t* nid_of_handle;   // [granules]
+    const uint8_t* blobs;     // chain blocks
+    const uint32_t* ledge;    // [8 * blocks]: {block handle, y + 1}[4] by chain handle
+    const uint64_t* seg_g;    // [num_nodes] 64 * chain handle + node start, ascending (node traces only)
+    const uint32_t* seg_nid;  // [num_nodes] node id of seg_g[i]
     const uint32_t* ec;       // class records (16-byte aligned records of u32)
     const uint32_t* class_ref;   // [num_classes]
     const uint32_t* class_len;   // [num_classes]
@@ -99,6 +133,7 @@ struct DevIndexView {
     uint64_t kmask_hi;        // k > 32: mask of the second k-mer word (bases 32..k-1)
     uint32_t k;
     uint32_t num_nodes, num_classes;
+    uint32_t num_segs;        // entries of seg_g / seg_nid (nodes and their copies in tails)
 };
 
 }  // namespace pa

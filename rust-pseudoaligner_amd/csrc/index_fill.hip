@@ -1,16 +1,15 @@
-// pa_index_create's device side: the k-mer dictionary is filled, verified and used to derive the node edges ON the GPU, from
-// the node blobs already resident in HBM — nothing of the 3.3 GB table (config 3) is built on the host or crosses PCIe.
+// pa_index_create's device side: the k-mer dictionary is filled and verified ON the GPU, from the chain blocks already
+// resident in HBM — nothing of the 3.3 GB table (config 3) is built on the host or crosses PCIe.
 //
 // Replaces make_dbg_index (src/build_index.rs:182-221: boomphf MPHF + (node id, offset) scatter over every k-mer of every
-// node) and the edge resolution the debruijn crate does by hashing at every hop (Node::r_edges / l_edges):
+// node):
 //   pa_fill_insert_kernel   one thread per k-mer of the graph. k <= 32: two passes (dict_slots.hpp) — compare-and-swap on the handle
 //                           word of the key's home slot; then the keys that did not get it take another slot of the bucket and
 //                           flag the home slot. k > 32: compare-and-swap on the handle word of the first free entry of the line.
 //                           The host flattener (device_flatten.cpp, kept for the CPU-only test tier) runs the same text
-//   pa_fill_verify_kernel   every k-mer is looked up again: it must come back as (its node, its offset) — a k-mer that
+//   pa_fill_verify_kernel   every k-mer is looked up again: it must come back as (its block, its position) — a k-mer that
 //                           occurs twice in the graph does not — within the 15 overflow buckets the mapping kernel follows
-//   pa_fill_edges_kernel    one thread per node: the four right neighbours of its last k-mer must be FIRST k-mers (offset 0),
-//                           the four left neighbours of its first k-mer LAST k-mers (offset len - k) of their nodes
+// (The edges — Node::r_edges / l_edges — are derived by the flattener, which needs them to merge nodes into chains.)
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 
@@ -93,9 +92,13 @@ __device__ __forceinline__ bool dict_find<u128>(const uint32_t* table, uint32_t 
     return false;
 }
 
-__device__ __forceinline__ const uint64_t* blob_seq(const uint8_t* blobs, uint32_t handle) {
-    return reinterpret_cast<const uint64_t*>(blobs + (uint64_t)(handle & ~HANDLE_WIDE) * BLOB_GRANULE + BLOB_HDR_BYTES);   // (bit 0 of a handle is its WIDE flag)
-}
+// the g-th k-mer of the graph: its node i (kcum), offset o in it, chain position c = node_s[i] + o; the block it starts in
+// holds all of it (k <= 64 bases from a window position < 64)
+struct KmerAt {
+    uint32_t node, block, off;   // block handle, second word of the dictionary entry (device_layout.hpp)
+    const uint64_t* seq;         // the block's sequence words
+    uint32_t rel;                // position of the k-mer's first base in them
+};
 
 // node of the g-th k-mer of the graph: the last i with kcum[i] <= g
 __device__ __forceinline__ uint32_t node_of_kmer(const uint64_t* kcum, uint32_t num_nodes, uint64_t g) {
@@ -107,21 +110,33 @@ __device__ __forceinline__ uint32_t node_of_kmer(const uint64_t* kcum, uint32_t 
     return lo;
 }
 
+__device__ __forceinline__ KmerAt kmer_at(const uint8_t* blobs, const uint32_t* handle, const uint32_t* node_s, const uint64_t* kcum, uint32_t num_nodes, uint64_t g) {
+    KmerAt a;
+    a.node = node_of_kmer(kcum, num_nodes, g);
+    const uint32_t o = (uint32_t)(g - kcum[a.node]), c = node_s[a.node] + o;
+    a.block = handle[a.node] + (c >> CH_STRIDE_LOG2);
+    a.off = dict_entry_off(c, o == 0);
+    a.seq = reinterpret_cast<const uint64_t*>(blobs + (uint64_t)a.block * CH_BLOCK + CH_SEQ_BYTES);
+    a.rel = c & (CH_STRIDE - 1);
+    return a;
+}
+
 template <class KT>
-__global__ __launch_bounds__(256) void pa_fill_insert_kernel(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ handle, const uint64_t* __restrict__ kcum,
-                                                             uint32_t num_nodes, uint64_t nk, uint32_t k, uint32_t* table, uint32_t nbuckets, int pass) {
+__global__ __launch_bounds__(256) void pa_fill_insert_kernel(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ handle, const uint32_t* __restrict__ node_s,
+                                                             const uint64_t* __restrict__ kcum, uint32_t num_nodes, uint64_t nk, uint32_t k, uint32_t* table,
+                                                             uint32_t nbuckets, int pass) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nk) return;
-    const uint32_t i = node_of_kmer(kcum, num_nodes, g), o = (uint32_t)(g - kcum[i]), h = handle[i];
-    const KT km = FillOps<KT>::get(blob_seq(blobs, h), o, k);
+    const KmerAt a = kmer_at(blobs, handle, node_s, kcum, num_nodes, g);
+    const KT km = FillOps<KT>::get(a.seq, a.rel, k);
     if constexpr (sizeof(KT) == 8) {   // k <= 32: pass 0 = home slots, pass 1 = the keys that did not get theirs (dict_slots.hpp)
-        if (pass == 0) dict_insert_home<DeviceAtomics>(table, nbuckets, km, h, o);
-        else dict_insert_rest<DeviceAtomics>(table, nbuckets, km, h, o);
+        if (pass == 0) dict_insert_home<DeviceAtomics>(table, nbuckets, km, a.block, a.off);
+        else dict_insert_rest<DeviceAtomics>(table, nbuckets, km, a.block, a.off);
     } else {
         if (pass != 0) return;
         uint32_t b = FillOps<KT>::bucket(km, nbuckets);
         for (;;) {   // load <= 1/3: a free entry exists
-            if (FillOps<KT>::try_insert(table + (uint64_t)b * BUCKET_WORDS, km, h, o)) return;
+            if (FillOps<KT>::try_insert(table + (uint64_t)b * BUCKET_WORDS, km, a.block, a.off)) return;
             if (++b == nbuckets) b = 0;
         }
     }
@@ -130,74 +145,37 @@ __global__ __launch_bounds__(256) void pa_fill_insert_kernel(const uint8_t* __re
 // flags[0] = a node one of whose k-mers does not come back as itself (a k-mer that occurs twice in the graph), else NO_HANDLE;
 // flags[1] = 1 when some k-mer sits more than 15 buckets from home
 template <class KT>
-__global__ __launch_bounds__(256) void pa_fill_verify_kernel(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ handle, const uint64_t* __restrict__ kcum,
-                                                             uint32_t num_nodes, uint64_t nk, uint32_t k, const uint32_t* __restrict__ table, uint32_t nbuckets,
-                                                             uint32_t* __restrict__ flags) {
+__global__ __launch_bounds__(256) void pa_fill_verify_kernel(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ handle, const uint32_t* __restrict__ node_s,
+                                                             const uint64_t* __restrict__ kcum, uint32_t num_nodes, uint64_t nk, uint32_t k,
+                                                             const uint32_t* __restrict__ table, uint32_t nbuckets, uint32_t* __restrict__ flags) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nk) return;
-    const uint32_t i = node_of_kmer(kcum, num_nodes, g), o = (uint32_t)(g - kcum[i]), h = handle[i];
-    const KT km = FillOps<KT>::get(blob_seq(blobs, h), o, k);
+    const KmerAt a = kmer_at(blobs, handle, node_s, kcum, num_nodes, g);
+    const KT km = FillOps<KT>::get(a.seq, a.rel, k);
     uint32_t fh = 0, fo = 0, probes = 0;
-    if (!dict_find<KT>(table, nbuckets, km, fh, fo, probes) || fh != h || fo != o) atomicMin(flags, i);
+    if (!dict_find<KT>(table, nbuckets, km, fh, fo, probes) || fh != a.block || fo != a.off) atomicMin(flags, a.node);
     if (probes > DICT_MAX_PROBES) flags[1] = 1;
 }
 
-// flags[2] = a node with an extension bit but no terminal neighbour k-mer, flags[3] = a node whose left neighbour k-mer is
-// not the last k-mer of its node (both NO_HANDLE when fine)
 template <class KT>
-__global__ __launch_bounds__(256) void pa_fill_edges_kernel(uint8_t* blobs, uint32_t* __restrict__ ledge, const uint32_t* __restrict__ handle, uint32_t num_nodes,
-                                                            uint32_t k, const uint32_t* __restrict__ table, uint32_t nbuckets, bool need_r, bool need_l,
-                                                            uint32_t* __restrict__ flags) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= num_nodes) return;
-    const uint32_t h = handle[i];
-    uint32_t* hd = reinterpret_cast<uint32_t*>(blobs + (uint64_t)(h & ~HANDLE_WIDE) * BLOB_GRANULE);
-    const uint32_t len = hd[0] & 0xFFFFFFu, exts = hd[0] >> 24, topshift = 2 * (k - 1);
-    const uint64_t* seq = blob_seq(blobs, h);
-    const KT first = FillOps<KT>::get(seq, 0, k), last = FillOps<KT>::get(seq, len - k, k), mask = FillOps<KT>::mask(k);
-    for (uint32_t base = 0; base < 4; ++base) {
-        uint32_t fh = 0, fo = 0, probes = 0;
-        if (need_r) {   // find_link(last.extend_right(b), Dir::Right): the node whose FIRST k-mer it is
-            uint32_t re = NO_HANDLE;
-            if (exts & (1u << base)) {
-                if (dict_find<KT>(table, nbuckets, (last >> 2) | ((KT)base << topshift), fh, fo, probes) && fo == 0) re = fh;
-                else atomicMin(flags + 2, i);
-            }
-            hd[4 + base] = re;
-        }
-        if (need_l) {   // find_link(first.extend_left(b), Dir::Left): the node whose LAST k-mer it is
-            uint32_t le = NO_HANDLE, ll = 0;
-            if (exts & (1u << (4 + base))) {
-                if (dict_find<KT>(table, nbuckets, ((first << 2) | (KT)base) & mask, fh, fo, probes)) {
-                    le = fh;
-                    const uint32_t tlen = *reinterpret_cast<const uint32_t*>(blobs + (uint64_t)(fh & ~HANDLE_WIDE) * BLOB_GRANULE) & 0xFFFFFFu;   // (word 0 of a header is never written here)
-                    ll = tlen;
-                    if (fo != tlen - k) atomicMin(flags + 3, i);
-                } else atomicMin(flags + 2, i);
-            }
-            ledge[8ull * h + 2 * base] = le;       // {handle, length of that node}
-            ledge[8ull * h + 2 * base + 1] = ll;
-        }
-    }
-}
-
-template <class KT>
-int fill_t(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, uint64_t* nbuckets_out) {
+int fill_t(const FlatDevice& fd, void* d_blobs, void** d_table, uint64_t* nbuckets_out) {
     const uint32_t N = fd.num_nodes, k = fd.k;
     const uint64_t nk = fd.num_kmers;
     *d_table = nullptr;
-    void *d_handle = nullptr, *d_kcum = nullptr, *d_flags = nullptr;
+    void *d_handle = nullptr, *d_node_s = nullptr, *d_kcum = nullptr, *d_flags = nullptr;
     auto done = [&](int rc) {
-        for (void* p : {d_handle, d_kcum, d_flags})
+        for (void* p : {d_handle, d_node_s, d_kcum, d_flags})
             if (p) (void)hipFree(p);
         if (rc != PA_OK && *d_table) { (void)hipFree(*d_table); *d_table = nullptr; }
         return rc;
     };
 #define FILL_TRY(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) return done(fail(PA_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_))); } while (0)
     FILL_TRY(hipMalloc(&d_handle, (size_t)(N ? N : 1) * 4));
+    FILL_TRY(hipMalloc(&d_node_s, (size_t)(N ? N : 1) * 4));
     FILL_TRY(hipMalloc(&d_kcum, ((size_t)N + 1) * 8));
     FILL_TRY(hipMalloc(&d_flags, 16));
     if (N) FILL_TRY(hipMemcpy(d_handle, fd.handle.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    if (N) FILL_TRY(hipMemcpy(d_node_s, fd.node_s.data(), (size_t)N * 4, hipMemcpyHostToDevice));
     FILL_TRY(hipMemcpy(d_kcum, fd.node_kcum.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
     uint64_t nbuckets = 0;
     double load0 = FillOps<KT>::LOAD;
@@ -215,11 +193,11 @@ int fill_t(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, u
             const dim3 grid((uint32_t)((nk + 255) / 256));
             for (int pass = 0; pass < (sizeof(KT) == 8 ? 2 : 1); ++pass) {   // (stream order is the barrier between the passes)
                 hipLaunchKernelGGL(pa_fill_insert_kernel<KT>, grid, dim3(256), 0, nullptr, static_cast<const uint8_t*>(d_blobs), static_cast<const uint32_t*>(d_handle),
-                                   static_cast<const uint64_t*>(d_kcum), N, nk, k, static_cast<uint32_t*>(*d_table), (uint32_t)nbuckets, pass);
+                                   static_cast<const uint32_t*>(d_node_s), static_cast<const uint64_t*>(d_kcum), N, nk, k, static_cast<uint32_t*>(*d_table), (uint32_t)nbuckets, pass);
                 FILL_TRY(hipGetLastError());
             }
             hipLaunchKernelGGL(pa_fill_verify_kernel<KT>, grid, dim3(256), 0, nullptr, static_cast<const uint8_t*>(d_blobs), static_cast<const uint32_t*>(d_handle),
-                               static_cast<const uint64_t*>(d_kcum), N, nk, k, static_cast<const uint32_t*>(*d_table), (uint32_t)nbuckets,
+                               static_cast<const uint32_t*>(d_node_s), static_cast<const uint64_t*>(d_kcum), N, nk, k, static_cast<const uint32_t*>(*d_table), (uint32_t)nbuckets,
                                static_cast<uint32_t*>(d_flags));
             FILL_TRY(hipGetLastError());
         }
@@ -228,17 +206,6 @@ int fill_t(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, u
         if (flags[0] != NO_HANDLE) return done(fail(PA_ERR_FORMAT, "a k-mer of node %u occurs twice in the graph", flags[0]));
         if (!flags[1]) break;   // else: some key sits further from home than the kernel follows; a larger table
     }
-    if (N && !(fd.have_redge && fd.have_ledge)) {
-        hipLaunchKernelGGL(pa_fill_edges_kernel<KT>, dim3((N + 255) / 256), dim3(256), 0, nullptr, static_cast<uint8_t*>(d_blobs), static_cast<uint32_t*>(d_ledge),
-                           static_cast<const uint32_t*>(d_handle), N, k, static_cast<const uint32_t*>(*d_table), (uint32_t)nbuckets, !fd.have_redge, !fd.have_ledge,
-                           static_cast<uint32_t*>(d_flags));
-        FILL_TRY(hipGetLastError());
-        uint32_t flags[4];
-        FILL_TRY(hipMemcpy(flags, d_flags, 16, hipMemcpyDeviceToHost));
-        if (flags[2] != NO_HANDLE)
-            return done(fail(PA_ERR_FORMAT, "node %u has an extension bit without a terminal neighbour k-mer (missing link)", flags[2]));
-        if (flags[3] != NO_HANDLE) return done(fail(PA_ERR_FORMAT, "node %u: left neighbour k-mer is not the last k-mer of its node", flags[3]));
-    }
 #undef FILL_TRY
     *nbuckets_out = nbuckets;
     return done(PA_OK);
@@ -246,8 +213,8 @@ int fill_t(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, u
 
 }  // namespace
 
-int device_fill_index(const FlatDevice& fd, void* d_blobs, void* d_ledge, void** d_table, uint64_t* nbuckets) {
-    return fd.k <= 32 ? fill_t<uint64_t>(fd, d_blobs, d_ledge, d_table, nbuckets) : fill_t<u128>(fd, d_blobs, d_ledge, d_table, nbuckets);
+int device_fill_index(const FlatDevice& fd, void* d_blobs, void** d_table, uint64_t* nbuckets) {
+    return fd.k <= 32 ? fill_t<uint64_t>(fd, d_blobs, d_table, nbuckets) : fill_t<u128>(fd, d_blobs, d_table, nbuckets);
 }
 
 }  // namespace pa

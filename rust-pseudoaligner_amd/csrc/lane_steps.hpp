@@ -32,11 +32,11 @@ struct Lane {
     uint32_t rid;
     uint32_t lk;    // L (bits 0..13) | kmer_pos (14..27) | state (28..31)                  (:70, :79)
     uint32_t cm;    // read_coverage (0..15) | mismatch_count (16..31)                      (:71-72)
-    uint32_t h;     // node_id of the forward search as a blob handle                       (:118-121)
-    uint32_t of;    // kmer_offset (0..23) | flags (24..31)
-    uint32_t rr;    // FWD: ref offset in the node, LEFT: node bases still to the left (0..23) | seen_snp (24..31)
-    uint32_t rm;    // bases of max_matchable_pos not yet compared (0..15) | LEFT: read bases still to the left (16..31)
-    uint32_t ph;    // LEFT: prev_node_id as a blob handle                                  (:128)
+    uint32_t h;     // forward search: the chain block it is in (node_id + kmer_offset of :118-121 as a place in a chain)
+    uint32_t of;    // position in that block's window (0..23): of the k-mer's first base (F_FRESH), else of the next base to compare | flags (24..31)
+    uint32_t rr;    // LEFT: position + 1 in the block's window of the next base to compare (0..23) | seen_snp (24..31)
+    uint32_t rm;    // LEFT: read bases still to the left (16..31)
+    uint32_t ph;    // LEFT: the chain block the extension is in                            (:128)
     uint32_t nc;    // classes collected (0..13) | dictionary probe index (14..17) | TRACE: nodes.len() (18..31)
                     // (a read of L <= 16383 bases visits at most L nodes — every visit consumes a base — so 14 bits hold both counts).
                     // Classes collected: list mode = the distinct classes; window mode = bit 0 "a window is held" | pending classes << 1
@@ -95,8 +95,11 @@ struct ColRef {
     uint32_t* trace;      // TRACE builds only: node ids in visit order (map_read_to_nodes, :54-61), capacity spill_cap
 };
 
-struct Hdr {   // the fields of the 48-byte header of a node blob (device_layout.hpp; make_hdr)
-    uint32_t len, exts, cid, ec_ref, ec_len, e0, e1, e2, e3, cmin, cmask, cmin2, cmask2;
+struct Seg {   // one node record of a chain block (device_layout.hpp), decoded
+    uint32_t e;        // the node's end relative to the block (SEG_E_FAR: beyond the window)
+    uint32_t flags;    // SEG_WIDE / SEG_LAST / SEG_EDGES (word 0 of the record as it is)
+    uint32_t cid, cmin, cmask, cmin2, cmask2;
+    uint32_t ec_ref, ec_len;   // ec_ref only when SEG_WIDE (a one-window class has its record looked up when list mode asks for it)
 };
 
 // ---------------------------------------------------------------------------------------------- helpers
@@ -204,18 +207,58 @@ PA_HD uint64_t ld_nt(const uint64_t* p) { return *p; }
 #endif
 #define PA_LD(bit, ptr) ((PA_NT & (bit)) ? ld_nt(ptr) : *(ptr))
 
-// first byte of the blob of the node with handle `h` (bit 0 of a handle is the WIDE flag, not part of the address)
-PA_HD const uint8_t* node_blob(const DevIndexView& ix, uint32_t h) { return ix.blobs + (uint64_t)(h & ~HANDLE_WIDE) * BLOB_GRANULE; }
-// header vectors {len|exts, cid, cmin, cmask} {e0..e3} {cmin2, cmask2, ec_ref, ec_len} -> fields
-PA_HD Hdr make_hdr(const U4& a, const U4& b, const U4& c) {
-    return Hdr{a.x & 0xFFFFFFu, a.x >> 24, a.y, c.z, c.w, b.x, b.y, b.z, b.w, a.z, a.w, c.x, c.y};
+// first byte of chain block `h`
+PA_HD const uint8_t* chain_block(const DevIndexView& ix, uint32_t h) { return ix.blobs + (uint64_t)h * CH_BLOCK; }
+// the four slots of a block as separate values (never an array: a per-lane index into one would be served from scratch memory)
+struct Slots {
+    U4 a, b, c, d;
+};
+// a / b / c / d by i = 0..3 as a tree of two-way selects on the bits of i (a chain `i == 0 ? a : i == 1 ? ...` is turned into a
+// switch by the compiler, and that into nested divergent branches)
+PA_HD uint32_t sel4(uint32_t i, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const bool b0 = i & 1u, b1 = i & 2u;
+    const uint32_t lo = b0 ? b : a, hi = b0 ? d : c;
+    return b1 ? hi : lo;
 }
-PA_HD Hdr load_hdr(const DevIndexView& ix, uint32_t h) {
-    const U4* p = reinterpret_cast<const U4*>(node_blob(ix, h));
-    const U4 a = PA_LD(8, p), b = PA_LD(8, p + 1), c = PA_LD(8, p + 2);
-    return make_hdr(a, b, c);
+PA_HD uint64_t sel4q(uint32_t i, uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+    const bool b0 = i & 1u, b1 = i & 2u;
+    const uint64_t lo = b0 ? b : a, hi = b0 ? d : c;
+    return b1 ? hi : lo;
 }
-PA_HD const uint64_t* node_seq(const DevIndexView& ix, uint32_t h) { return reinterpret_cast<const uint64_t*>(node_blob(ix, h) + BLOB_HDR_BYTES); }
+PA_HD U4 slot_at(const Slots& sl, uint32_t i) {
+    return U4{sel4(i, sl.a.x, sl.b.x, sl.c.x, sl.d.x), sel4(i, sl.a.y, sl.b.y, sl.c.y, sl.d.y), sel4(i, sl.a.z, sl.b.z, sl.c.z, sl.d.z),
+              sel4(i, sl.a.w, sl.b.w, sl.c.w, sl.d.w)};
+}
+// record in slot i (and its extension in slot i + 1)
+PA_HD Seg seg_at(const Slots& sl, uint32_t i) {
+    const U4 r = slot_at(sl, i), x = slot_at(sl, (i + 1) & 3u);
+    const bool wide = (r.x & SEG_WIDE) != 0;
+    Seg g;
+    g.e = r.x & SEG_E_MASK;
+    g.flags = r.x;
+    g.cid = r.y; g.cmin = r.z; g.cmask = r.w;
+    g.cmin2 = wide ? x.x : 0u;
+    g.cmask2 = wide ? x.y : 0u;
+    g.ec_ref = wide ? x.z : NO_HANDLE;
+    g.ec_len = wide ? x.w : 0u;
+    return g;
+}
+// the first record whose node ends beyond window position y (the node that owns the k-mer ending at y, or the base y + 1)
+PA_HD uint32_t seg_find(const Slots& sl, uint32_t y) {
+    const uint32_t gt = (uint32_t)((sl.a.x & SEG_E_MASK) > y) | ((uint32_t)((sl.b.x & SEG_E_MASK) > y) << 1) |
+                        ((uint32_t)((sl.c.x & SEG_E_MASK) > y) << 2) | ((uint32_t)((sl.d.x & SEG_E_MASK) > y) << 3);
+    const uint32_t m = gt & (sl.a.x >> SEG_RECMASK_SHIFT);
+    return pa_ctz32(m | 8u);
+}
+// node id of the node whose k-mers start at global position g = 64 * block handle + position in its window (node traces only)
+PA_HD uint32_t trace_nid(const DevIndexView& ix, uint64_t g) {
+    uint32_t lo = 0, hi = ix.num_segs - 1;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1) / 2;
+        if (ix.seg_g[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    return ix.seg_nid[lo];
+}
 
 // mismatch mask of a 32-base XOR restricted to its first n bases (1 <= n <= 32): bit 2i set <=> base i differs.
 // (the 32-bit halves can be shifted separately: the bit that would cross lands on an odd position and is masked away)
@@ -306,13 +349,14 @@ PA_HD uint32_t window_at(uint32_t b, uint32_t c, uint32_t n) {
     return d - 1u < 63u ? r : 0u;
 }
 
-// nodes.push(node_id) (:199, :219): fold the node's class into the lane's record. Returns true when the read has to
-// restart in list mode (the caller resets the lane with restart_lists).
+// nodes.push(node_id) (:199, :219): fold the node's class into the lane's record. `gpos` = global position of one of the node's
+// k-mers (trace_nid; TRACE builds only). Returns true when the read has to restart in list mode (the caller resets the lane
+// with restart_lists).
 template <bool TRACE>
-PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, uint32_t handle) {
+PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Seg& hd, uint64_t gpos) {
     if (TRACE) {
         const uint32_t nt = l_ntrace(s);
-        if (nt < c.spill_cap) c.trace[nt] = ix.nid_of_handle[handle];
+        if (nt < c.spill_cap) c.trace[nt] = trace_nid(ix, gpos);
         s.nc += 1u << NC_TRACE_SHIFT;
     }
     const uint32_t n = l_ncol(s);
@@ -344,28 +388,31 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Hdr& hd, u
         return false;
     }
     // list mode: win = {ref of class 0, 1, 2, ref of the shortest class so far}, wcand = the shortest length (both in LDS:
-    // the row in HBM is only written during the walk, never read)
+    // the row in HBM is only written during the walk, never read). A one-window class does not carry its record ref in the
+    // block: looked up here (a dependent load that only list-mode reads pay)
+    const bool wide = (hd.flags & SEG_WIDE) != 0;
+    const uint32_t ec_ref = wide ? hd.ec_ref : ix.class_ref[hd.cid], ec_len = wide ? hd.ec_len : pa_popc32(hd.cmask);
     U4 r = *reinterpret_cast<const U4*>(c.win);
-    const bool dup = (n > 0 && r.x == hd.ec_ref) | (n > 1 && r.y == hd.ec_ref) | (n > 2 && r.z == hd.ec_ref) | (n > 0 && r.w == hd.ec_ref);
+    const bool dup = (n > 0 && r.x == ec_ref) | (n > 1 && r.y == ec_ref) | (n > 2 && r.z == ec_ref) | (n > 0 && r.w == ec_ref);
     if (dup) return false;
-    if (n == 0) r.x = hd.ec_ref;
-    if (n == 1) r.y = hd.ec_ref;
-    if (n == 2) r.z = hd.ec_ref;
-    if (n == 0 || hd.ec_len < c.wcand[0]) {   // strict: the first of the shortest classes is the base
-        r.w = hd.ec_ref;
-        c.wcand[0] = hd.ec_len;
-        if (hd.ec_len <= 8) l_or_flags(s, F_SMALL_BASE);
+    if (n == 0) r.x = ec_ref;
+    if (n == 1) r.y = ec_ref;
+    if (n == 2) r.z = ec_ref;
+    if (n == 0 || ec_len < c.wcand[0]) {   // strict: the first of the shortest classes is the base
+        r.w = ec_ref;
+        c.wcand[0] = ec_len;
+        if (ec_len <= 8) l_or_flags(s, F_SMALL_BASE);
     }
     *reinterpret_cast<U4*>(c.win) = r;
     if (n < LDS_CLASSES) {
-        c.refs[n] = hd.ec_ref;
-        c.lens[n] = hd.ec_len;
+        c.refs[n] = ec_ref;
+        c.lens[n] = ec_len;
         c.cids[n] = hd.cid;
     } else {
         const uint32_t o = 4 * (n - LDS_CLASSES);
         if (o + 3 >= c.spill_cap || n >= NC_COL_MASK) { l_or_flags(s, F_SPILL_OVERFLOW); return false; }   // (unreachable: the row holds 2 L + 3 classes, the counter L)
-        c.spill[o] = hd.ec_ref;
-        c.spill[o + 1] = hd.ec_len;
+        c.spill[o] = ec_ref;
+        c.spill[o + 1] = ec_len;
         c.spill[o + 2] = hd.cid;
     }
     s.nc += 1;
@@ -471,22 +518,27 @@ PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand,
     seek_finish(s, K, h, off, (slot_flags(q.v) & SLOT_FLAG_OVERFLOW) != 0, l_probe(s));
 }
 
-// what a probe found -> the lane's next state (the tail of find_kmer_match and of :118-129)
+// what a probe found -> the lane's next state (the tail of find_kmer_match and of :118-129). `h` = the chain block the k-mer
+// starts in, `off` = the entry's second word (device_layout.hpp: position in the block, first-k-mer-of-its-node flag, blocks
+// before this one in the chain)
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe) {
     const uint32_t L = l_L(s), kp = l_kp(s);
     s.nc &= ~(15u << NC_PROBE_SHIFT);                               // probe index back to 0
     if (h != NO_HANDLE) {                                           // Some((nid, offset)) (:106)
         s.h = h;
-        const uint32_t fl = l_flags(s);
+        const uint32_t fl = l_flags(s), p = off & ENT_P_MASK;
         const uint32_t thr = L / 5;                                 // (0.2 * L as f64) as usize (:77) == L/5 for L < 2^31
         if ((fl & F_FIRST_SEEK) && kp >= thr) {                     // :124-126
+            const uint32_t back = (off >> ENT_BACK_SHIFT) & CH_BACK_MAX;
             s.rm = (s.rm & 0xFFFFu) | (kp << 16);                   // last_pos + 1 (:127)
-            s.ph = h;                                               // :128
-            s.rr = (off > 0 ? off - 1 : 0) + 1;                     // prev_kmer_offset + 1 (:129, quirk Q1 kept); snp = 0
-            s.of = off | (((fl & ~F_FIRST_SEEK) | F_FRESH | F_LEFT_SEED) << 24);
+            s.ph = h - back;                                        // :128 — the block with the most room to the left
+            // prev_kmer_offset (:129): one base to the left of the k-mer — or, quirk Q1 kept, the k-mer's own first base when
+            // it is the first k-mer of its node (kmer_offset == 0). Stored + 1; snp = 0
+            s.rr = p + CH_STRIDE * back + ((off & ENT_NODE_START) ? 1u : 0u);
+            s.of = p | (((fl & ~F_FIRST_SEEK) | F_FRESH | F_LEFT_SEED) << 24);
             l_set_st(s, ST_LEFT);
         } else {
-            s.of = off | (((fl & ~F_FIRST_SEEK) | F_FRESH) << 24);
+            s.of = p | (((fl & ~F_FIRST_SEEK) | F_FRESH) << 24);
             l_set_st(s, ST_FWD);
         }
         return;
@@ -531,123 +583,302 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
 }
 
 // ---------------------------------------------------------------------------------------------- FWD
-// Forward search (:209-301): one call = enter/continue one node (one dependent fetch of the node header + sequence
-// words, issued together). Fast mode compares up to 128 bases by counting mismatches only; when a node visit would
-// exceed its mismatch budget nothing is consumed and the lane switches to careful mode, which walks the same node 32
-// bases per call and locates the breaking base exactly as the reference's loop does (:236-255).
-struct FwdLoad {     // what fwd_issue leaves in flight: the node header and the sequence words this step can need
-    U4 h0, h1, h2;
+// Forward search (:209-301): one call = one chain block = one dependent fetch (the block's four slots and the sequence words
+// this step can need, issued together). A step compares up to 128 bases and walks through as many NODES of the chain as lie
+// in them: inside a node it counts mismatches (the compare loop :236-255 without a per-base loop); at a node's end e the
+// chain's base at e is the one right extension the node has, so `has_ext(Right, read[kmer_pos])` (:267) is "that base equals
+// the read's" and the hop (:275-283: kmer_pos and coverage move on by ONE base net, nodes.push, seen_snp = 0) needs no fetch.
+// At the chain's end the edge slot names the next chain. When a node would exceed its mismatch budget nothing of it is
+// consumed and the lane switches to careful mode, which walks it 32 bases per call and locates the breaking base exactly as
+// the reference's loop does.
+struct FwdLoad {     // what fwd_issue leaves in flight
+    U4 s0, s1, s2, s3;
     Q2 s01, s23, s45;
 };
-PA_HD bool fwd_wide(const Lane& s) { return ((s.h & HANDLE_WIDE) | (l_flags(s) & F_LISTS)) != 0; }
 PA_HD void fwd_issue(const Lane& s, const DevIndexView& ix, FwdLoad& f) {
     const uint32_t K = ix.k, L = l_L(s);
     const bool fresh = l_flags(s) & F_FRESH;
-    const uint32_t ro0 = fresh ? l_off(s) + K : (s.rr & 0xFFFFFFu);   // ref_offset (:227)
-    const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
-    const U4* hp = reinterpret_cast<const U4*>(node_blob(ix, s.h));   // dbg.get_node (:210)
-    f.h0 = PA_LD(8, hp); f.h1 = PA_LD(8, hp + 1);
-    // the third header vector (second window, class record) only for nodes that have one to show — their handles say so — and for
-    // reads that collect class lists
-    // (not a branch around the load — its result would be merged with a constant behind a vmcnt(0) — but a load every lane
-    // issues: the lanes that do not need the vector all read the first line of the blob array, which costs the L1 one access per
-    // group of lanes instead of one per lane; fwd_finish ignores what they got)
-    f.h2 = PA_LD(8, fwd_wide(s) ? hp + 2 : reinterpret_cast<const U4*>(ix.blobs));
-    const Q2* sq2 = reinterpret_cast<const Q2*>(node_seq(ix, s.h) + (ro0 >> 5));
-    // sequence words this step can need, known before the header arrives: the node visit compares at most the rest of the
-    // read (fresh) / of the visit (continued), 128 bases per step; words beyond are not fetched (each may be another line)
-    const uint32_t most = pa_min(fresh ? L - kp0 : (s.rm & 0xFFFFu), 128u), nwords = ((ro0 & 31) + most + 31) >> 5;
-    // the second and third 16-byte load only go out for the lanes that can need them (a lane that re-read its first pair
-    // instead, to keep the number of loads fixed, still cost the vector L1 an access each: -2.4 % time without them)
+    const uint32_t xs = l_off(s) + (fresh ? K : 0u);                  // first position to compare: ref_offset (:227) as a window position
+    const uint32_t kp0 = l_kp(s) + (fresh ? K : 0u);                  // kmer_pos += kmer_length (:215)
+    const uint8_t* blk = chain_block(ix, s.h);                        // dbg.get_node (:210)
+    const U4* sp = reinterpret_cast<const U4*>(blk);
+    f.s0 = PA_LD(8, sp); f.s1 = PA_LD(8, sp + 1); f.s2 = PA_LD(8, sp + 2); f.s3 = PA_LD(8, sp + 3);
+    // sequence words this step can need, known before the block arrives: at most the rest of the read, 128 bases per step
+    // (the second and third 16-byte load only go out for the lanes that can need them: every load is an access of the vector L1)
+    const uint32_t most = pa_min(L - kp0, 128u), nwords = ((xs & 31) + most + 31) >> 5;
+    const Q2* sq2 = reinterpret_cast<const Q2*>(blk + CH_SEQ_BYTES + 8u * (xs >> 5));
     f.s01 = PA_LD(8, sq2);
     f.s23 = f.s45 = Q2{0ull, 0ull};
     if (nwords > 2) f.s23 = PA_LD(8, sq2 + 1);
     if (nwords > 4) f.s45 = PA_LD(8, sq2 + 2);
 }
 
+// mismatches among the first z bases (0..128) of a step's compare masks m (bit 2i of word w = base 32 w + i differs), pc = their
+// running popcounts
+struct DiffMasks {   // (separate values, not arrays: see Slots)
+    uint64_t m0, m1, m2, m3;
+    uint32_t p0, p1, p2, p3;
+};
+PA_HD uint64_t diff_word(const DiffMasks& d, uint32_t w) { return sel4q(w, d.m0, d.m1, d.m2, d.m3); }
+PA_HD uint32_t mism_prefix(const DiffMasks& d, uint32_t z) {
+    const uint32_t w = z >> 5, r = z & 31u;
+    const uint32_t b03 = sel4(w, 0u, d.p0, d.p1, d.p2), base = (w & 4u) ? d.p3 : b03;
+    return base + pa_popc64(diff_word(d, w) & ((1ull << (2 * r)) - 1));          // (z == 128: r == 0, nothing of a fifth word)
+}
+
+// The general form of the step: any number of nodes per step (a loop), careful mode, list mode, node traces. The kernel runs
+// it for the lanes that need one of these (fwd_finish below); the host emulator also runs it for every read of a traced batch.
 template <bool TRACE = false>
-PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed, const FwdLoad& f) {
+PA_HD void fwd_finish_general(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed, const FwdLoad& f) {
     const uint32_t K = ix.k, L = l_L(s);
     const uint32_t fl = l_flags(s);
     const bool fresh = fl & F_FRESH, careful = fl & F_CAREFUL;
-    const uint32_t ro0 = fresh ? l_off(s) + K : (s.rr & 0xFFFFFFu);   // ref_offset (:227)
-    const uint32_t kp0 = fresh ? l_kp(s) + K : l_kp(s);               // kmer_pos += kmer_length (:215)
-    const Hdr hd = make_hdr(f.h0, f.h1, fwd_wide(s) ? f.h2 : U4{0u, 0u, 0u, 0u});
-    uint32_t rem = s.rm & 0xFFFFu, snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
-    const uint32_t most = pa_min(fresh ? L - kp0 : rem, 128u), nwords = ((ro0 & 31) + most + 31) >> 5;   // as in fwd_issue
+    uint32_t x = l_off(s) + (fresh ? K : 0u);                         // ref_offset (:227)
+    uint32_t kp = l_kp(s) + (fresh ? K : 0u);                         // kmer_pos += kmer_length (:215)
+    const uint32_t xs = x, kp0 = kp;
+    uint32_t snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
+    const uint32_t most = pa_min(L - kp0, 128u), nwords = ((xs & 31) + most + 31) >> 5;   // as in fwd_issue
     const uint64_t a[5] = {f.s01.a, f.s01.b, nwords > 2 ? f.s23.a : 0ull, nwords > 2 ? f.s23.b : 0ull, nwords > 4 ? f.s45.a : 0ull};
+    const Slots sl{f.s0, f.s1, f.s2, f.s3};
+    uint32_t cur = seg_find(sl, x - 1);                               // the node of the k-mer ending at x - 1 / of the base x
+    Seg g = seg_at(sl, cur);
     if (fresh) {
         cov += K;                                                     // :216
-        if (push_node<TRACE>(s, cols, ix, hd, s.h)) {                 // nodes.push (:219)
+        if (push_node<TRACE>(s, cols, ix, g, 64ull * s.h + l_off(s))) {   // nodes.push (:219)
             restart_lists(s, K);
             return;
         }
-        rem = pa_min(L - kp0, hd.len - ro0);                          // max_matchable_pos (:222-231)
         snp = 0;                                                      // :235
     }
-    const uint32_t sh_a = (ro0 & 31) * 2, sh_r = (kp0 & 31) * 2, rw = kp0 >> 5;
     // five read words, all LDS reads in flight together. Words beyond the read's last are NOT zeroed here (they re-read the last
-    // word): every compare below is masked to bases inside the read (n <= L - kp0), so what lies beyond is never looked at;
-    // one multiply for the first word, the others are an add and a clamp
+    // word): every compare below is limited to bases inside the read (n <= L - kp), so what lies beyond is never looked at
     uint64_t r[5];
     {
-        const uint32_t i0 = rw * rd.stride, ilast = (rd.wmax - 1) * rd.stride;
+        const uint32_t i0 = (kp0 >> 5) * rd.stride, ilast = (rd.wmax - 1) * rd.stride;
 #pragma unroll
         for (uint32_t i = 0; i < 5; ++i) r[i] = rd.p[pa_min(i0 + i * rd.stride, ilast)];
     }
-    bool premature = false;
-    uint32_t matched, nfl = (fl & ~F_FRESH) | (l_flags(s) & (F_SMALL_BASE | F_SPILL_OVERFLOW));   // (what push_node may just have set)
-    if (!careful) {
-        const uint32_t n = pa_min(rem, 128u);
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t done = 32u * c;
-            if (n > done) cnt += pa_popc64(diff_mask_nz(funnel(r[c], r[c + 1], sh_r) ^ funnel(a[c], a[c + 1], sh_a), pa_min(n - done, 32u)));
-        }
-        if (snp + cnt <= allowed) {
-            matched = n;
+    const uint32_t sh_a = (xs & 31) * 2, sh_r = (kp0 & 31) * 2;
+    DiffMasks dm;
+    dm.m0 = diff_mask(funnel(r[0], r[1], sh_r) ^ funnel(a[0], a[1], sh_a), 32u);
+    dm.m1 = most > 32u ? diff_mask(funnel(r[1], r[2], sh_r) ^ funnel(a[1], a[2], sh_a), 32u) : 0ull;
+    dm.m2 = most > 64u ? diff_mask(funnel(r[2], r[3], sh_r) ^ funnel(a[2], a[3], sh_a), 32u) : 0ull;
+    dm.m3 = most > 96u ? diff_mask(funnel(r[3], r[4], sh_r) ^ funnel(a[3], a[4], sh_a), 32u) : 0ull;
+    dm.p0 = pa_popc64(dm.m0); dm.p1 = dm.p0 + pa_popc64(dm.m1); dm.p2 = dm.p1 + pa_popc64(dm.m2); dm.p3 = dm.p2 + pa_popc64(dm.m3);
+    const uint32_t lim = careful ? 32u : 128u;
+    uint32_t consumed = 0, st = ST_FWD, h = s.h, nfl = fl & ~F_FRESH;
+    bool premature = false, hopped = false;
+    for (;;) {
+        const uint32_t n = pa_min(pa_min(g.e - x, L - kp), lim - consumed);   // max_matchable_pos (:222-231), as far as this step goes
+        uint32_t matched;
+        if (!careful) {
+            const uint32_t cnt = mism_prefix(dm, consumed + n) - mism_prefix(dm, consumed);
+            if (snp + cnt > allowed) { nfl |= F_CAREFUL; break; }    // over budget somewhere in these bases: redo this node carefully
             snp += cnt;
             mism += cnt;
-        } else {                                                      // over budget somewhere in these bases: redo carefully
-            matched = 0;
-            nfl |= F_CAREFUL;
+            matched = n;
+        } else {                                                      // (careful steps start at consumed == 0 and do one piece)
+            matched = compare_chunk(n ? dm.m0 & (~0ull >> (64u - 2u * n)) : 0ull, n, allowed, snp, mism, premature);
         }
-    } else {
-        const uint32_t n = pa_min(rem, 32u);
-        matched = compare_chunk(diff_mask(funnel(r[0], r[1], sh_r) ^ funnel(a[0], a[1], sh_a), n), n, allowed, snp, mism, premature);
-    }
-    const uint32_t kp = kp0 + matched;                                // :257
-    cov += matched;                                                   // :254
-    rem -= matched;
-    uint32_t st = ST_FWD, h = s.h, off = l_off(s), kp_out = kp;
-    if (!(nfl & F_CAREFUL) || careful) {
-        if (premature || rem == 0) {                                  // node visit finished
-            nfl &= ~F_CAREFUL;
-            if (kp >= L) st = ST_ISECT;                               // :259-261
-            else {
+        x += matched; kp += matched; cov += matched; consumed += matched;   // :254, :257
+        if (premature) { nfl &= ~F_CAREFUL; st = kp > L - K ? ST_ISECT : ST_SEEK; break; }   // :287-293 (a breaking base is left: kp < L)
+        if (kp >= L) { nfl &= ~F_CAREFUL; st = ST_ISECT; break; }     // :259-261
+        if (x < g.e) break;                                           // more of this node in the next step
+        if (g.flags & SEG_LINK) {                                     // the chain's copy of this node ends here: on in the node's own chain
+            const U4 lk = slot_at(sl, cur + 1 + ((g.flags & SEG_WIDE) ? 1u : 0u));
+            h = lk.x;
+            x = lk.y;
+            hopped = true;
+            break;
+        }
+        nfl &= ~F_CAREFUL;                                            // node visit finished
+        if (g.flags & SEG_LAST) {                                     // the chain's last node: its right edges (:265-283)
+            uint32_t nh = NO_HANDLE;
+            if (g.flags & SEG_EDGES) {
+                const U4 ed = slot_at(sl, cur + 1 + ((g.flags & SEG_WIDE) ? 1u : 0u));
                 const uint32_t b = read_base(rd, kp);                 // :265
-                if (!premature && ((hd.exts >> b) & 1u)) {            // :267
-                    h = b == 0 ? hd.e0 : b == 1 ? hd.e1 : b == 2 ? hd.e2 : hd.e3;   // r_edges()[index].0 (:275-278)
-                    off = 0;                                          // :279
-                    kp_out = kp - (K - 1);                            // :282
-                    cov -= K - 1;                                     // :283
-                    nfl |= F_FRESH;
-                } else if (kp > L - K) st = ST_ISECT;                 // :287-290
-                else st = ST_SEEK;                                    // find_kmer_match(&mut kmer_pos) (:293)
+                nh = sel4(b, ed.x, ed.y, ed.z, ed.w);                 // r_edges()[index].0 (:275-278); NO_HANDLE: !has_ext (:267)
+            }
+            if (nh != NO_HANDLE) {
+                h = nh;
+                x = 0;                                                // :279
+                kp -= K - 1;                                          // :282
+                cov -= K - 1;                                         // :283
+                nfl |= F_FRESH;
+                hopped = true;
+            } else st = kp > L - K ? ST_ISECT : ST_SEEK;              // :287-293
+            break;
+        }
+        if (consumed >= 128u) break;                                  // the base of the extension test is not in this step's masks
+        {
+            if ((diff_word(dm, consumed >> 5) >> (2 * (consumed & 31u))) & 1ull) {              // the node's one right extension is another base: !has_ext (:267)
+                st = kp > L - K ? ST_ISECT : ST_SEEK;
+                break;
             }
         }
+        // the next node of the chain (:267-283 and the top of the loop :215-219): one base net, nothing of the K-1 overlap re-verified
+        x += 1; kp += 1; cov += 1; consumed += 1;
+        cur += 1 + ((g.flags & SEG_WIDE) ? 1u : 0u);
+        g = seg_at(sl, cur);
+        if (push_node<TRACE>(s, cols, ix, g, 64ull * s.h + x - K)) {  // nodes.push (:219); the node's first k-mer starts at x - K
+            restart_lists(s, K);
+            return;
+        }
+        snp = 0;                                                      // :235
+        if (careful) break;
+    }
+    nfl |= l_flags(s) & (F_SMALL_BASE | F_SPILL_OVERFLOW);           // (what push_node may have set)
+    if (st == ST_FWD && !hopped) {                                    // goes on in this chain: the block whose window starts at most 64 bases before x
+        const uint32_t adv = (x - 1) >> CH_STRIDE_LOG2;               // (x >= 1; a position that is a multiple of 64 stays the 64th of the block before:
+        h += adv;                                                     //  a node that ends exactly there is still on that block's list)
+        x -= adv << CH_STRIDE_LOG2;
     }
     s.h = h;
-    s.lk = l_pack_lk(L, kp_out, st);
+    s.lk = l_pack_lk(L, kp, st);
     s.cm = cov | (mism << 16);
-    s.rr = (ro0 + matched) | (snp << 24);
-    s.rm = (s.rm & 0xFFFF0000u) | rem;
-    s.of = off | (nfl << 24);
+    s.rr = snp << 24;
+    s.of = x | (nfl << 24);
 }
 
-// Forward search (:209-301): one call = enter/continue one node (one dependent fetch of the node header + sequence
-// words, issued together)
+// nodes.push in window mode on values held in registers (push_node's window branch without its memory traffic): w / cand /
+// have = the running windows, the class id the running intersection is known to be, whether a window is held yet
+PA_HD void push_window(bool on, U4& w, uint32_t& cand, bool& have, uint32_t cid, uint32_t cmin, uint32_t cmask, uint32_t cmin2, uint32_t cmask2) {
+    const uint32_t m1 = w.y & (window_at(w.x, cmin, cmask) | window_at(w.x, cmin2, cmask2));
+    const uint32_t m2 = w.w & (window_at(w.z, cmin, cmask) | window_at(w.z, cmin2, cmask2));
+    const bool full = pa_popc32(m1) + pa_popc32(m2) == pa_popc32(cmask) + pa_popc32(cmask2);   // this class is a subset of all before: it IS the result
+    const bool same = m1 == w.y && m2 == w.w;                                                   // nothing removed
+    const uint32_t cand_h = full ? cid : same ? cand : NO_CLASS;
+    const bool first = on && !have, later = on && have;
+    w.x = first ? cmin : w.x;
+    w.y = first ? cmask : later ? m1 : w.y;
+    w.z = first ? cmin2 : w.z;
+    w.w = first ? cmask2 : later ? m2 : w.w;
+    cand = first ? cid : later ? cand_h : cand;
+    have = have || on;
+}
+
+// The step as the kernel's common lanes take it — window mode, not careful, no node trace — in straight-line code: the node the
+// step starts in (A) and, when the read runs over A's end into the chain's next node (B), B as well; a third node of the same
+// block is left to the next step, which finds the lane standing at B's end. Every decision is a select, the class windows are
+// read from and written to LDS once. Lanes in careful or list mode (and traced batches) take fwd_finish_general.
+template <bool TRACE = false>
+PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed, const FwdLoad& f) {
+    const uint32_t fl = l_flags(s);
+#ifndef PA_PROBE_FAST_ONLY   // (tools: instruction count of the straight-line part alone)
+    if (TRACE || (fl & (F_LISTS | F_CAREFUL))) {
+        fwd_finish_general<TRACE>(s, ix, rd, cols, allowed, f);
+        return;
+    }
+#endif
+    const uint32_t K = ix.k, L = l_L(s);
+    const bool fresh = fl & F_FRESH;
+    const uint32_t kadd = fresh ? K : 0u;
+    const uint32_t x0 = l_off(s) + kadd, kp0 = l_kp(s) + kadd;       // ref_offset (:227), kmer_pos += kmer_length (:215)
+    const uint32_t snp0 = fresh ? 0u : s.rr >> 24;                    // :235
+    const uint32_t most = pa_min(L - kp0, 128u), nwords = ((x0 & 31) + most + 31) >> 5;   // as in fwd_issue
+    const uint64_t a0 = f.s01.a, a1 = f.s01.b, a2 = nwords > 2 ? f.s23.a : 0ull, a3 = nwords > 2 ? f.s23.b : 0ull, a4 = nwords > 4 ? f.s45.a : 0ull;
+    // the block's slots rotated so that t0 is the record of the node this step starts in (the first one that ends beyond x0 - 1)
+    const Slots sl{f.s0, f.s1, f.s2, f.s3};
+    const uint32_t cur = seg_find(sl, x0 - 1);
+    const bool c1 = cur & 1u, c2 = cur & 2u;
+#define PA_ROT1(fld) const uint32_t u0##fld = c1 ? f.s1.fld : f.s0.fld, u1##fld = c1 ? f.s2.fld : f.s1.fld, u2##fld = c1 ? f.s3.fld : f.s2.fld, u3##fld = c1 ? f.s0.fld : f.s3.fld;
+    PA_ROT1(x) PA_ROT1(y) PA_ROT1(z) PA_ROT1(w)
+#undef PA_ROT1
+    const U4 t0{c2 ? u2x : u0x, c2 ? u2y : u0y, c2 ? u2z : u0z, c2 ? u2w : u0w}, t1{c2 ? u3x : u1x, c2 ? u3y : u1y, c2 ? u3z : u1z, c2 ? u3w : u1w},
+             t2{c2 ? u0x : u2x, c2 ? u0y : u2y, c2 ? u0z : u2z, c2 ? u0w : u2w}, t3{c2 ? u1x : u3x, c2 ? u1y : u3y, c2 ? u1z : u3z, c2 ? u1w : u3w};
+    const bool wideA = t0.x & SEG_WIDE, lastA = t0.x & SEG_LAST;
+    const U4 nx{wideA ? t2.x : t1.x, wideA ? t2.y : t1.y, wideA ? t2.z : t1.z, wideA ? t2.w : t1.w};   // B's record — or A's right edges
+    const U4 xb{wideA ? t3.x : t2.x, wideA ? t3.y : t2.y, wideA ? t3.z : t2.z, wideA ? t3.w : t2.w};   // B's extension slot
+    const bool wideB = nx.x & SEG_WIDE;
+    // five read words, all LDS reads in flight together (words beyond the read's last re-read the last one: never looked at)
+    uint64_t r0, r1, r2, r3, r4;
+    {
+        const uint32_t i0 = (kp0 >> 5) * rd.stride, ilast = (rd.wmax - 1) * rd.stride;
+        r0 = rd.p[pa_min(i0, ilast)]; r1 = rd.p[pa_min(i0 + rd.stride, ilast)]; r2 = rd.p[pa_min(i0 + 2 * rd.stride, ilast)];
+        r3 = rd.p[pa_min(i0 + 3 * rd.stride, ilast)]; r4 = rd.p[pa_min(i0 + 4 * rd.stride, ilast)];
+    }
+    const uint32_t sh_a = (x0 & 31) * 2, sh_r = (kp0 & 31) * 2;
+    DiffMasks dm;   // (bases beyond the read's end are never counted: every n below is limited to L - kp)
+    dm.m0 = diff_mask(funnel(r0, r1, sh_r) ^ funnel(a0, a1, sh_a), 32u);
+    dm.m1 = diff_mask(funnel(r1, r2, sh_r) ^ funnel(a1, a2, sh_a), 32u);
+    dm.m2 = diff_mask(funnel(r2, r3, sh_r) ^ funnel(a2, a3, sh_a), 32u);
+    dm.m3 = diff_mask(funnel(r3, r4, sh_r) ^ funnel(a3, a4, sh_a), 32u);
+    dm.p0 = pa_popc64(dm.m0); dm.p1 = dm.p0 + pa_popc64(dm.m1); dm.p2 = dm.p1 + pa_popc64(dm.m2); dm.p3 = dm.p2 + pa_popc64(dm.m3);
+    // ---- node A: the compare loop (:236-255) as a count
+    const uint32_t eA = t0.x & SEG_E_MASK;
+    const uint32_t nA = pa_min(pa_min(eA - x0, L - kp0), 128u);       // max_matchable_pos (:222-231), as far as this step goes
+    const uint32_t pA = mism_prefix(dm, nA), cntA = pA;
+    const bool okA = snp0 + cntA <= allowed;                          // else: over budget somewhere in these bases, redo this node carefully
+    const uint32_t kpA = kp0 + nA, xA = x0 + nA;                      // :257
+    const bool endA = okA && xA == eA && kpA < L;                     // node visit finished, read not (:259-261)
+    // ---- A's end: the chain's next node, or the chain's right edges
+    const bool bitA = (diff_word(dm, nA >> 5) >> (2 * (nA & 31u))) & 1ull;   // the chain's next base differs from the read's (nA < 128)
+    const uint32_t bA = read_base(rd, pa_min(kpA, L - 1));            // :265
+    const bool linkA = t0.x & SEG_LINK;                               // a copy cut short: the same node goes on in its own chain
+    const uint32_t edge = (t0.x & SEG_EDGES) ? sel4(bA, nx.x, nx.y, nx.z, nx.w) : linkA ? nx.x : NO_HANDLE;   // r_edges()[index].0 (:275-278)
+    const bool hop_chain = endA && lastA && edge != NO_HANDLE, hop_edge = hop_chain && !linkA;
+    const bool in_masks = nA < 128u;
+    const bool hopB = endA && !lastA && in_masks && !bitA;            // has_ext(Right, b) (:267): the chain's next node
+    const bool dead = endA && (lastA ? edge == NO_HANDLE : (in_masks && bitA));   // :287-293
+    // ---- node B
+    const uint32_t c1n = nA + 1, x1 = xA + 1, kp1 = kpA + 1;          // the hop: one base net (:282-283, :215-216)
+    const uint32_t eB = nx.x & SEG_E_MASK;
+    const uint32_t nB = hopB ? pa_min(pa_min(eB - x1, L - kp1), 128u - c1n) : 0u;
+    const uint32_t cntB = mism_prefix(dm, c1n + nB) - pA;            // (bit nA is clear when B is entered)
+    const bool okB = cntB <= allowed;
+    const bool useB = hopB && okB;
+    const uint32_t kpB = kp1 + nB, xB = x1 + nB;
+    // ---- classes: nodes.push (:219) of A (a fresh entry) and of B, on the windows held in LDS
+    const uint32_t ncol = l_ncol(s);
+    U4 w = *reinterpret_cast<const U4*>(cols.win);
+    uint32_t cand = cols.wcand[0];
+    bool have = ncol & 1u;
+    const bool pushA = fresh, pendA = pushA && t0.w == 0, pendB = hopB && nx.w == 0;
+    push_window(pushA && !pendA, w, cand, have, t0.y, t0.z, t0.w, wideA ? t1.x : 0u, wideA ? t1.y : 0u);
+    push_window(hopB && !pendB, w, cand, have, nx.y, nx.z, nx.w, wideB ? xb.x : 0u, wideB ? xb.y : 0u);
+    uint32_t np = ncol >> 1;
+    bool restart = false;
+    if (pendA | pendB) {                                              // classes without windows: noted, applied after the walk (push_node)
+        if (pendA) {
+            if (np >= PEND_MAX || 2 * np + 1 >= cols.spill_cap) restart = true;
+            else { cols.pend[2 * np] = t1.z; cols.pend[2 * np + 1] = t1.w; ++np; }
+        }
+        if (pendB && !restart) {
+            if (np >= PEND_MAX || 2 * np + 1 >= cols.spill_cap) restart = true;
+            else { cols.pend[2 * np] = xb.z; cols.pend[2 * np + 1] = xb.w; ++np; }
+        }
+    }
+    if (restart) { restart_lists(s, K); return; }
+    if (pushA | hopB) {
+        *reinterpret_cast<U4*>(cols.win) = w;
+        cols.wcand[0] = cand;
+    }
+    s.nc = (s.nc & ~NC_COL_MASK) | (np << 1) | (have ? 1u : 0u);
+    // ---- the lane's next state
+    const bool ended = useB ? kpB >= L : (okA && kpA >= L);           // :259-261
+    const uint32_t kp_dead = kpA;
+    uint32_t st = (ended || (dead && kp_dead > L - K)) ? (uint32_t)ST_ISECT : dead ? (uint32_t)ST_SEEK : (uint32_t)ST_FWD;
+    uint32_t kp = !okA ? kp0 : hop_edge ? kpA - (K - 1) : hopB ? (okB ? kpB : kp1) : kpA;
+    uint32_t x = !okA ? x0 : hop_chain ? (linkA ? nx.y : 0u) : hopB ? (okB ? xB : x1) : xA;
+    const uint32_t cov = l_cov(s) + kadd + (okA ? nA : 0u) + (hopB ? 1u : 0u) + (useB ? nB : 0u) - (hop_edge ? K - 1 : 0u);   // :216, :254, :283
+    const uint32_t mism = l_mism(s) + (okA ? cntA : 0u) + (useB ? cntB : 0u);
+    const uint32_t snp = !okA ? snp0 : hopB ? (okB ? cntB : 0u) : snp0 + cntA;
+    const bool careful = !okA || (hopB && !okB);
+    const uint32_t nfl = (fl & ~(F_FRESH | F_CAREFUL)) | (careful ? F_CAREFUL : 0u) | (hop_edge ? F_FRESH : 0u);
+    uint32_t h = hop_chain ? edge : s.h;
+    if (st == ST_FWD && !hop_chain) {                                 // goes on in this chain (fwd_finish_general)
+        const uint32_t adv = (x - 1) >> CH_STRIDE_LOG2;
+        h += adv;
+        x -= adv << CH_STRIDE_LOG2;
+    }
+    s.h = h;
+    s.lk = l_pack_lk(L, kp, st);
+    s.cm = cov | (mism << 16);
+    s.rr = snp << 24;
+    s.of = x | (nfl << 24);
+}
+
+// Forward search (:209-301): one call = one chain block
 template <bool TRACE = false>
 PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed) {
     FwdLoad f;
@@ -656,80 +887,98 @@ PA_HD void fwd_step(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, ui
 }
 
 // ---------------------------------------------------------------------------------------------- LEFT
-// Left extension (:131-203): one call = enter/continue one node and compare up to 32 bases leftwards. The node header and the two
-// sequence words the compare can need are fetched together (left_issue), the rest is arithmetic (left_finish) — plus, when the
-// walk hops to a left neighbour, one dependent 8-byte load of the edge. What makes the first part ONE round trip: a lane that
-// hops takes the neighbour's LENGTH along with its handle (the left-edge table holds both), so the position of the words it will
-// compare there — the END of that node — is known before its header has been read. (Fetching the node's four edges up front as
-// well makes the hop free of a dependent load, but costs a request per step on a kernel that is bound by requests: config 5
-// +2.7 % time, measured.)
+// Left extension (:131-203): one call = one chain block (its slots and the two sequence words around the bases to compare, one
+// round trip), up to 32 bases leftwards. In chain coordinates the reference's hop to a left neighbour (:183-199: has_ext(Left,
+// read[last_pos]), l_edges, prev_kmer_offset = len - k) is: the base just left of the node's first base must equal the read's,
+// and the compare goes on AT that base with a fresh mismatch budget. At the chain's first base the left-edge table (by chain
+// handle) names the block and position to go on in.
 struct LeftLoad {
-    U4 h0, h1, h2;   // header of the node
+    U4 s0, s1, s2, s3;
     Q2 sq;           // the two sequence words around the bases to compare
 };
-// bases of the node still to the left of the compare position (:196 / :129 / continued)
-PA_HD uint32_t left_na(const Lane& s) { return s.rr & 0xFFFFFFu; }
+PA_HD uint32_t left_y1(const Lane& s) { return s.rr & 0xFFFFFFu; }   // window position + 1 of the next base to compare
 PA_HD void left_issue(const Lane& s, const DevIndexView& ix, LeftLoad& f) {
-    const U4* hp = reinterpret_cast<const U4*>(node_blob(ix, s.ph));   // dbg.get_node(prev_node_id) (:132)
-    f.h0 = hp[0]; f.h1 = hp[1]; f.h2 = hp[2];
-    const uint32_t na = left_na(s);
-    const uint32_t po = na ? na - 1 : 0, st = po >= 31 ? po - 31 : 0;                       // ref_pos of idx 0 (:152): 32 bases ending there
-    f.sq = *reinterpret_cast<const Q2*>(node_seq(ix, s.ph) + (st >> 5));
+    const uint8_t* blk = chain_block(ix, s.ph);                      // dbg.get_node(prev_node_id) (:132)
+    const U4* sp = reinterpret_cast<const U4*>(blk);
+    f.s0 = sp[0]; f.s1 = sp[1]; f.s2 = sp[2]; f.s3 = sp[3];
+    const uint32_t y1 = left_y1(s), st = y1 > 32 ? y1 - 33 : 0;      // 33 bases ending at y = y1 - 1: the compare and the extension test
+    f.sq = *reinterpret_cast<const Q2*>(blk + CH_SEQ_BYTES + 8u * (st >> 5));
 }
 template <bool TRACE = false>
 PA_HD void left_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, uint32_t allowed, const LeftLoad& f) {
     const uint32_t K = ix.k;
-    const Hdr hd = make_hdr(f.h0, f.h1, f.h2);
-    uint32_t na = left_na(s), snp = s.rr >> 24, rem = s.rm & 0xFFFFu, ra = s.rm >> 16, cov = l_cov(s), mism = l_mism(s);
-    const uint32_t fl = l_flags(s);
+    const Slots sl{f.s0, f.s1, f.s2, f.s3};
+    uint32_t y1 = left_y1(s), snp = s.rr >> 24, ra = s.rm >> 16, cov = l_cov(s), mism = l_mism(s);
+    const uint32_t y = y1 - 1;                                       // ref_pos of idx 0 (:152) as a window position
+    const uint32_t ws = (y1 > 32 ? y1 - 33 : 0) >> 5;                // first sequence word loaded
+    const uint32_t fl = l_flags(s), recmask = f.s0.x >> SEG_RECMASK_SHIFT, back = (f.s0.x >> SEG_BACK_SHIFT) & CH_BACK_MAX;
+    const uint32_t cur = seg_find(sl, y + K - 1);                    // prev_node_id: the node whose k-mer starts at y
+    const uint32_t below = recmask & ((1u << cur) - 1);              // records before it in this block
+    const uint32_t prev = (below & 4u) ? 2u : (below >> 1) & 1u;
+    // window position of the node's first base: the node before ends K - 1 bases later (device_layout.hpp); -1: left of the window
+    int32_t s_lo = below ? (int32_t)(slot_at(sl, prev).x & SEG_E_MASK) - (int32_t)(K - 1) : (back == 0 ? 0 : -1);
+    if (s_lo < 0) s_lo = -1;
+    const uint32_t lo = s_lo < 0 ? 0u : (uint32_t)s_lo;
     if (fl & F_FRESH) {
         if (!(fl & F_LEFT_SEED)) {
-            if (push_node<TRACE>(s, cols, ix, hd, s.ph)) {          // nodes.push(prev_node.node_id) (:199)
+            if (push_node<TRACE>(s, cols, ix, seg_at(sl, cur), 64ull * s.ph + y)) {   // nodes.push(prev_node.node_id) (:199)
                 restart_lists(s, K);
                 return;
             }
-            // na = len - k + 1: prev_kmer_offset = len - k (:196); the hop brought it along (== hd.len - K + 1)
         }
-        rem = pa_min(ra, na);                                       // max_matchable_pos (:139-145)
         snp = 0;                                                    // :150
         l_clr_flags(s, F_FRESH | F_LEFT_SEED);
     }
     bool premature = false;
-    const uint32_t n = pa_min(rem, 32u);
+    const uint32_t n = pa_min(pa_min(ra, y1 - lo), 32u);            // max_matchable_pos (:139-145), 32 bases per step
     uint32_t matched = 0;
     if (n > 0) {
-        const uint32_t po = na - 1, lp = ra - 1;                    // ref_pos / read_offset of idx 0 (:152-153)
-        uint64_t sw;
-        if (po >= 31) {
-            const uint32_t st = po - 31;
-            sw = funnel(f.sq.a, f.sq.b, (st & 31) * 2);
-        } else {
-            sw = f.sq.a << (2 * (31 - po));
-        }
+        const uint32_t lp = ra - 1, pin = y - 32u * ws;              // read_offset of idx 0 (:153); y within the two words
+        const uint64_t sw = pin >= 63 ? f.sq.b : pin >= 31 ? funnel(f.sq.a, f.sq.b, (pin - 31) * 2) : f.sq.a << (2 * (31 - pin));   // 32 bases ending at y
         // base idx 0 sits in the top bits: fold each base's two XOR bits onto its odd bit, then bit-reverse so that
         // bit 2i = i-th base compared
-        const uint64_t x = read_window_end(rd, lp) ^ sw;
-        const uint64_t m = pa_brev64((x | (x << 1)) & 0xAAAAAAAAAAAAAAAAull);
+        const uint64_t xr = read_window_end(rd, lp) ^ sw;
+        const uint64_t mm = pa_brev64((xr | (xr << 1)) & 0xAAAAAAAAAAAAAAAAull);
         const uint64_t keep = n >= 32 ? ~0ull : ((1ull << (2 * n)) - 1);
-        matched = compare_chunk(m & keep, n, allowed, snp, mism, premature);
+        matched = compare_chunk(mm & keep, n, allowed, snp, mism, premature);
     }
     ra -= matched;                                                  // last_pos -= matched_bases (:178)
-    na -= matched;
-    rem -= matched;
+    y1 -= matched;
     cov += matched;                                                 // :169
     s.cm = cov | (mism << 16);
-    s.rr = na | (snp << 24);
-    s.rm = rem | (ra << 16);
-    if (!premature && rem > 0) return;
+    s.rr = y1 | (snp << 24);
+    s.rm = (s.rm & 0xFFFFu) | (ra << 16);
     if (!(ra == 0 || premature)) {                                  // :173-175
-        const uint32_t b = read_base(rd, ra - 1);                   // next_base = read_seq.get(last_pos) (:182)
-        if ((hd.exts >> (4 + b)) & 1u) {                            // has_ext(Dir::Left, b) (:183)
-            const uint64_t e = *reinterpret_cast<const uint64_t*>(ix.ledge + 8ull * s.ph + 2 * b);   // l_edges()[index].0 (:191-194) and that node's length
-            s.ph = (uint32_t)e;
-            s.rr = ((uint32_t)(e >> 32) - K + 1) | (snp << 24);     // prev_kmer_offset + 1 = len - k + 1 (:196)
-            l_or_flags(s, F_FRESH);
-            return;
-        }                                                           // else :200-202
+        if (y1 > lo) return;                                        // more of this node in this block
+        if (s_lo < 0) {                                             // the node goes on to the left of the window: an earlier block
+            if (back) {
+                s.ph -= back;
+                s.rr = (y1 + CH_STRIDE * back) | (snp << 24);
+                return;
+            }
+        } else {
+            const uint32_t b = read_base(rd, ra - 1);               // next_base = read_seq.get(last_pos) (:182)
+            if (s_lo > 0) {                                         // inside the chain: the node's one left extension is the base before it
+                const uint32_t q = (uint32_t)s_lo - 1 - 32u * ws;
+                const uint32_t cb = (uint32_t)((q < 32 ? f.sq.a : f.sq.b) >> (2 * (q & 31u))) & 3u;
+                if (cb == b) {                                      // has_ext(Dir::Left, b) (:183): on into that node at its last k-mer (:196)
+                    if (push_node<TRACE>(s, cols, ix, seg_at(sl, prev), 64ull * s.ph + (uint32_t)s_lo - 1)) {   // :199
+                        restart_lists(s, K);
+                        return;
+                    }
+                    s.rr = y1;                                      // snp = 0 (:150)
+                    return;
+                }
+            } else {                                                // the chain's first base: l_edges()[index].0 (:191-194) by chain handle
+                const uint64_t e = *reinterpret_cast<const uint64_t*>(ix.ledge + 8ull * s.ph + 2 * b);
+                if ((uint32_t)e != NO_HANDLE) {
+                    s.ph = (uint32_t)e;
+                    s.rr = (uint32_t)(e >> 32);                     // the neighbour's last k-mer (:196)
+                    l_or_flags(s, F_FRESH);
+                    return;
+                }
+            }                                                       // else :200-202
+        }
     }
     l_set_st(s, ST_FWD);                                            // forward search from the seed (:208)
     l_or_flags(s, F_FRESH);

@@ -33,6 +33,14 @@
 #define PA_RARE_MIN 10u
 #endif
 
+// -DPA_ISA_MARKS: comments in the ISA listing that tools/isa_sections.py counts instructions between (static cost of the
+// sections of an iteration); never defined in a build that runs
+#ifdef PA_ISA_MARKS
+#define PA_MARK(name) asm volatile("; PA_MARK " name ::: "memory")
+#else
+#define PA_MARK(name)
+#endif
+
 namespace pa {
 namespace {
 
@@ -59,8 +67,8 @@ typedef __attribute__((address_space(4))) const MapParams* karg_ptr;   // the ke
 __device__ __forceinline__ DevIndexView view_of(karg_ptr p) {   // member-wise: only the fields a step uses are actually loaded
     DevIndexView v;
     v.table = p->ix.table; v.nbuckets = p->ix.nbuckets; v.blobs = p->ix.blobs; v.ledge = p->ix.ledge;
-    v.nid_of_handle = p->ix.nid_of_handle; v.ec = p->ix.ec; v.class_ref = p->ix.class_ref; v.class_len = p->ix.class_len;
-    v.wtable = p->ix.wtable; v.wbuckets = p->ix.wbuckets; v.kmask = p->ix.kmask; v.kmask_hi = p->ix.kmask_hi; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes;
+    v.seg_g = p->ix.seg_g; v.seg_nid = p->ix.seg_nid; v.ec = p->ix.ec; v.class_ref = p->ix.class_ref; v.class_len = p->ix.class_len;
+    v.wtable = p->ix.wtable; v.wbuckets = p->ix.wbuckets; v.kmask = p->ix.kmask; v.kmask_hi = p->ix.kmask_hi; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes; v.num_segs = p->ix.num_segs;
     return v;
 }
 
@@ -395,6 +403,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
     }
 
     for (;;) {
+        PA_MARK("loop_top");
         asm volatile("" : "+s"(kp) : : "memory");   // also: slots and queues in LDS change hands between lanes every iteration
         const DevIndexView ix = view_of(kp);
         const glb_u32 ec = (glb_u32)ix.ec;
@@ -472,6 +481,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         const unsigned long long t_sec = PA_DBG ? __builtin_readcyclecounter() : 0ull;
 
         // ---- 2. pop n slots (and n2 slots of the SEEK queue)
+        PA_MARK("picked");
         const bool active = lane < n;
         uint32_t slot, slot2 = 0;
         PA_POP(sel, n_own, slot)
@@ -498,6 +508,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                           TRACE ? (uint32_t*)((glb_u32w)p.trace + (uint64_t)gslot * spill_cap) : nullptr};
 
         uint32_t nq2 = 0xFFu;   // DUAL: the queue the second batch's slot goes to
+        PA_MARK("popped");
         const unsigned long long t_pop = PA_DBG ? __builtin_readcyclecounter() : 0ull;
         // ---- 3. the step
         if (sel == ST_EMPTY) {   // REFILL: free slots take the next reads of this wave's range (coalesced: lane = consecutive read)
@@ -522,16 +533,20 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             const ReadRef rr2 = GREAD ? ReadRef{p.tiles + ((uint64_t)(rid2 >> 6) * wpr) * 64 + (rid2 & 63), 64u, wpr} : ReadRef{(const uint64_t*)(rd + slot2), S, wpr};
             SeekProbe pq;
             FwdLoad fl;
+            PA_MARK("dual_state2");
             seek_issue(s2, ix, rr2, pq);                               // home slot of the k-mer (HBM)
             fwd_issue(s, ix, fl);                                      // node header + sequence words (MALL / L2)
             __builtin_amdgcn_sched_barrier(0);                         // (left alone the scheduler finishes the probe first and only then issues the node loads)
+            PA_MARK("dual_issued");
             // the probe's second load, only for the lanes whose home slot holds another key and names other slots (same line,
             // now in the L1 / L2)
             const uint32_t cand = active2 ? seek_second(pq) : 0u;
             U4 pv2{0u, 0u, NO_HANDLE, 0u};
             if (cand) pv2 = *seek_second_slot(pq, cand);
             const unsigned long long t1 = PA_DBG ? __builtin_readcyclecounter() : 0ull;
+            PA_MARK("dual_second");
             if (active) fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
+            PA_MARK("dual_fwd_done");
             if (PA_DBG && lane == 0) {   // statistics only: issue | wait + compute of the forward half
                 const unsigned long long t3 = __builtin_readcyclecounter();
                 dbg[ST_COUNT + 1] += 1; dbg[ST_COUNT + 3] += 1;
@@ -543,9 +558,11 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 stA[slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
                 stB[slot2] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};
             }
+            PA_MARK("dual_seek_done");
         } else if (sel == ST_LEFT) {
             if (active) left_step<TRACE>(s, ix, rr, cols, allowed);
         } else if (sel == ST_F_BITS) {
+            PA_MARK("bits_begin");
             // output of window-mode reads and of unmapped reads: no loads. A non-empty window that is a strict subset of
             // every class seen goes on to NOVEL (is it an index class all the same?) and is written there.
             uint32_t ckey = NO_KEY;
@@ -587,6 +604,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             }
             if (counting && !PA_ABLATE(2u)) append_keys(ckey, lane, kp, kchunk);
             append_deferred(dfr, d0, d1, lane, kp, dchunk);
+            PA_MARK("bits_end");
         } else if (sel == ST_F_MASK) {
             // Window mode, classes without windows pending (lane_steps.hpp, mask_pending): ONE PENDING CLASS PER LANE. The
             // waiting reads are packed into the wave, one lane per pending class; the lane streams that class's ids and
@@ -889,6 +907,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         }
 
         const unsigned long long t_step = PA_DBG ? __builtin_readcyclecounter() : 0ull;
+        PA_MARK("step_done");
         // ---- 4. store the lane state, push every slot onto the queue of its new state
         const uint32_t nq = active ? queue_of(s, K) : 0xFFu;
         if (active) {
@@ -905,6 +924,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             dbg[ST_NONE] += 1;
             dbg_clk[ST_NONE] += t_end - t_step;
         }
+        PA_MARK("stored");
     }
     {   // the unused tail of this wave's last chunk of deferred reads is padding
         asm volatile("" ::: "memory");

@@ -41,6 +41,7 @@ uint64_t emu_index_info(const emu_index* e, int what) {
         case 0: return e->fd.num_kmers;
         case 1: return e->fd.nbuckets;
         case 2: return e->fd.blobs.size();
+        case 4: return e->fd.num_chains;
         case 3: return e->fd.max_class_len;
         default: return 0;
     }
@@ -73,8 +74,13 @@ int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const
         for (;;) {
             while (l_st(s) == ST_SEEK || l_st(s) == ST_FWD || l_st(s) == ST_LEFT) {
                 if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
-                else if (l_st(s) == ST_FWD) { fwd_step<true>(s, ix, rr, cr, allowed); ++st_fwd; }
-                else { left_step<true>(s, ix, rr, cr, allowed); ++st_left; }
+                else if (l_st(s) == ST_FWD) {   // a traced batch takes the general form of the step, any other the kernel's common text
+                    if (nodes_out) fwd_step<true>(s, ix, rr, cr, allowed); else fwd_step<false>(s, ix, rr, cr, allowed);
+                    ++st_fwd;
+                } else {
+                    if (nodes_out) left_step<true>(s, ix, rr, cr, allowed); else left_step<false>(s, ix, rr, cr, allowed);
+                    ++st_left;
+                }
             }
             if (l_st(s) != ST_ISECT || (l_flags(s) & F_LISTS)) break;
             const uint32_t todo = window_todo(s);   // window mode: classes without windows still to apply?
