@@ -42,7 +42,8 @@ WORKLOADS = {
 }
 
 # the device sources whose text decides what the PMC counters of profiles/latest_pmc.json were measured on
-KERNEL_SOURCES = ["map_pool.hip", "lane_steps.hpp", "device_layout.hpp", "count_sort.hip", "kernels.hpp"]
+KERNEL_SOURCES = ["map_pool.hip", "lane_steps.hpp", "device_layout.hpp", "count_sort.hip", "kernels.hpp", "dict_slots.hpp", "resolve.hip", "kernel_utils.hpp",
+                  "device_index.hip", "device_flatten.cpp", "index_fill.hip"]
 
 
 def kernel_source_sha256() -> str:
@@ -133,7 +134,7 @@ class Run:
         torch.cuda.synchronize()
 
     def step(self, i, separate_count=False):
-        """returns (device ms of the whole step's launches, ms of the mapping kernel alone)"""
+        """returns (device ms of the whole step's launches, (ms of the mapping kernel, of the resolve kernel, of the count kernels))"""
         pa, a = self.env["pa"], self.aligner
         b = i % self.n_batches
         import ctypes as C
@@ -154,7 +155,7 @@ class Run:
             raise SystemExit("arena too small for this workload: %s" % e)
         ms = C.c_float()
         pa.check(pa.lib().pa_event_elapsed_ms(self.ev[0], self.ev[1], C.byref(ms)))
-        return ms.value, a.map_kernel_ms(self.stream)
+        return ms.value, a.map_stage_ms(self.stream)
 
     def timed(self, K, W, reduce_fn=None, barrier=lambda: None, separate_count=False):
         """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns (elapsed s, [step device ms], [map kernel ms])"""
@@ -211,12 +212,18 @@ class Run:
         return oracle, ctr, first
 
 
-def roofline_of(run, ctr, map_ms, step_ms):
+def roofline_of(run, ctr, stage_ms, step_ms):
+    """stage_ms: per timed step (mapping kernel, resolve kernel, count kernels) ms. The roofline is priced over the MAPPING STAGE =
+    pa_map_pool_kernel + pa_resolve_kernel: the second writes the records of the reads whose class is looked up by content (about 3 %
+    of them), so the batch is not mapped before it has run."""
     wl, B = run.wl, run.B
     bytes_per_read = algorithmic_bytes_per_read(ctr, wl["read_len"], wl["k"])
-    kernel_avg_ms = sum(map_ms) / max(len(map_ms), 1)
+    n = max(len(stage_ms), 1)
+    map_ms = [m[0] + m[1] for m in stage_ms]
+    pool_avg_ms, resolve_avg_ms, count_avg_ms = (sum(m[i] for m in stage_ms) / n for i in range(3))
+    kernel_avg_ms = sum(map_ms) / n
     achieved = bytes_per_read * B / (kernel_avg_ms * 1e-3) / 1e9
-    requests = raw_traffic = traffic = None
+    requests = raw_traffic = traffic = miss_block_bytes = None
     traffic_note = None
     # HBM bytes per step from committed rocprofv3 PMC passes of this same workload (bench.py cannot run PMC itself). The file names the
     # hash of the kernel sources it was measured on: a kernel change without a new PMC pass reports no traffic instead of stale bytes.
@@ -236,6 +243,7 @@ def roofline_of(run, ctr, map_ms, step_ms):
             # lines, stores and atomics are exact): the other half of the streamed input (read tiles + lengths) is added back
             traffic = raw + 0.5 * (8.0 * run.wpr + 4.0) * B
             raw_traffic = raw
+            miss_block_bytes = 128.0 * pmc["map_kernel_l2_misses"] / B if pmc.get("map_kernel_l2_misses") else None
             per_launch = raw / 64.0
             step_avg = sum(step_ms) / max(len(step_ms), 1)
             requests = {"per_read": per_launch / B, "per_s": per_launch / (step_avg * 1e-3), "gather_hbm_per_s": 49e9, "gather_mall_per_s": 57e9,
@@ -252,12 +260,18 @@ def roofline_of(run, ctr, map_ms, step_ms):
         traffic_note = "profiles/latest_pmc.json unusable: %r" % (e,)
     step_avg = sum(step_ms) / max(len(step_ms), 1)
     return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-            "traffic": traffic, "traffic_raw_counters": raw_traffic, "traffic_note": traffic_note, "kernel": "pa_map_pool_kernel", "kernel_ms": kernel_avg_ms,
+            "traffic": traffic, "traffic_raw_counters": raw_traffic, "traffic_note": traffic_note,
+            # rocprof HBM GB/s against the chip's peak (north_star): the counters' bytes of a step over its device time
+            "traffic_gbps": (traffic / (step_avg * 1e-3) / 1e9) if traffic else None,
+            "traffic_frac_of_peak": (traffic / (step_avg * 1e-3) / 1e9 / 8000.0) if traffic else None,
+            "l2_miss_block_bytes_per_read": miss_block_bytes,
+            "kernel": "pa_map_pool_kernel + pa_resolve_kernel", "kernel_ms": kernel_avg_ms, "map_pool_kernel_ms": pool_avg_ms, "resolve_kernel_ms": resolve_avg_ms,
             "kernel_ms_min": min(map_ms) if map_ms else None, "kernel_ms_max": max(map_ms) if map_ms else None,
             "kernel_ms_steps": [round(x, 3) for x in map_ms],
-            "step_device_ms": step_avg, "count_kernels_ms": step_avg - kernel_avg_ms,
-            "timing": "HIP events on the launch stream: kernel_ms brackets pa_map_pool_kernel alone (recorded by the library), step_device_ms the whole "
-                      "pa_map_count_batch_device call (mapping kernel + the pa_keys_* class-count kernels)",
+            "step_device_ms": step_avg, "count_kernels_ms": count_avg_ms,
+            "timing": "HIP events on the launch stream, recorded by the library between the kernels of a launch (pa_map_stage_ms): kernel_ms = "
+                      "pa_map_pool_kernel + pa_resolve_kernel (the mapping stage), count_kernels_ms = the pa_keys_* class-count kernels, "
+                      "step_device_ms the whole pa_map_count_batch_device call",
             "algorithmic_bytes_per_read": bytes_per_read, "reads_per_launch": B, "requests": requests}
 
 

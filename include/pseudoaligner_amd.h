@@ -237,6 +237,10 @@ int pa_index_release_stream(pa_index* idx, void* stream);
  * The class-count kernels of pa_map_count_batch_device run after the second event. */
 int pa_index_set_timing(pa_index* idx, int on);
 int pa_map_kernel_ms(pa_index* idx, void* stream, float* ms);
+/* The three stages of the last timed launch on `stream`, in ms: ms[0] the mapping kernel, ms[1] the kernel that resolves the
+ * deferred content lookups (it writes the records of the reads whose class is looked up by content: part of mapping the
+ * batch), ms[2] the class-count kernels (zero-length for launches without a count table). Waits for the launch. */
+int pa_map_stage_ms(pa_index* idx, void* stream, float ms[3]);
 /* arena capacity (u32 entries) that suffices for typical batches of n_reads; the exact need is data dependent */
 uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads);
 

@@ -199,7 +199,8 @@ int main(int argc, char** argv) {
         EXPECT(pa_event_record(ev1, NULL) == PA_OK);
         uint64_t used = 0, need = 0;
         EXPECT(pa_map_finish(idx, NULL, &used, &need) == PA_OK);
-        { float kms = -1.0f; EXPECT(pa_map_kernel_ms(idx, NULL, &kms) == PA_OK && kms > 0.0f); EXPECT(pa_index_set_timing(idx, 0) == PA_OK); }
+        { float kms = -1.0f, st[3] = {-1.0f, -1.0f, -1.0f}; EXPECT(pa_map_kernel_ms(idx, NULL, &kms) == PA_OK && kms > 0.0f);
+          EXPECT(pa_map_stage_ms(idx, NULL, st) == PA_OK && st[0] > 0.0f && st[1] >= 0.0f && st[2] >= 0.0f); EXPECT(pa_index_set_timing(idx, 0) == PA_OK); }
         EXPECT(pa_index_release_stream(idx, NULL) == PA_OK);   /* the null stream's launch context goes; the next launch makes a new one */
         EXPECT(pa_event_elapsed_ms(ev0, ev1, &ms) == PA_OK && ms >= 0.0f);
         EXPECT(pa_map_batch_device(idx, (const uint64_t*)d_tiles, (const uint32_t*)d_lens, nsim, sim_wpr, 2, (pa_read_result*)d_res, (uint32_t*)d_arena,

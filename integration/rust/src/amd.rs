@@ -86,7 +86,7 @@ impl FlatArrays {
     }
 }
 
-pub struct AmdIndex { raw: *mut PaIndex }
+pub struct AmdIndex { raw: *mut PaIndex, max_class_len: usize }
 unsafe impl Send for AmdIndex {}
 unsafe impl Sync for AmdIndex {}
 
@@ -95,7 +95,9 @@ impl AmdIndex {
         let flat = FlatArrays::from_pseudoaligner(al);
         let mut raw = std::ptr::null_mut();
         check(unsafe { pa_index_create(&flat.view(), device, &mut raw) })?;   // arrays are only borrowed during the call
-        Ok(AmdIndex { raw })
+        let mut stats = PaIndexStats::default();
+        if let Err(e) = check(unsafe { pa_index_get_stats(raw, &mut stats) }) { unsafe { pa_index_destroy(raw) }; return Err(e); }
+        Ok(AmdIndex { raw, max_class_len: stats.max_class_len as usize })
     }
 
     /// map_read_with_mismatch (src/pseudoaligner.rs:361) on the read as the caller holds it: the DnaString's bases go over as
@@ -104,7 +106,8 @@ impl AmdIndex {
         let len = read_seq.len();
         let mut words = vec![0u64; (len + 31) / 32 + 1];
         for i in 0..len { words[i / 32] |= (read_seq.get(i) as u64) << (2 * (i % 32)); }
-        let mut class = vec![0u32; 1 << 16];
+        // a read's class is an intersection of index classes: never longer than the longest of them
+        let mut class = vec![0u32; self.max_class_len.max(1)];
         let (mut n, mut cov, mut mm) = (0u32, 0u32, 0u32);
         let rc = check(unsafe { pa_map_read_packed(self.raw, words.as_ptr(), len as u32, PA_PACKED_LSB_FIRST, allowed_mismatches as u32,
                                                    class.as_mut_ptr(), class.len() as u32, &mut n, &mut cov, &mut mm) })?;
@@ -117,16 +120,30 @@ impl Drop for AmdIndex { fn drop(&mut self) { unsafe { pa_index_destroy(self.raw
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Drop-in entry points with the reference's EXACT signatures. The GPU copy of an index is made on first use and cached by the
-// identity of the `Pseudoaligner` (address + node / class counts + k): callers keep passing `&Pseudoaligner<K>`.
+// CONTENT of the `Pseudoaligner` (k, node / class / transcript counts and a fingerprint of the class table and the node
+// lengths), not by its address: an index that was dropped and another one allocated in its place never meets a stale GPU copy,
+// a moved or cloned one finds its copy again. Callers keep passing `&Pseudoaligner<K>`.
 // ---------------------------------------------------------------------------------------------------------------------------
-type CacheKey = (usize, usize, usize, usize);
+type CacheKey = (usize, usize, usize, usize, u64);
+fn fingerprint<K: Kmer>(index: &Pseudoaligner<K>) -> u64 {
+    let mut h = 0xcbf2_9ce4_8422_2325u64;                                  // FNV-1a over 64-bit words
+    let mut mix = |v: u64| { h ^= v; h = h.wrapping_mul(0x0000_0100_0000_01b3); };
+    for c in &index.eq_classes {                                           // every class: its length, first and last id
+        mix(c.len() as u64);
+        if let (Some(a), Some(b)) = (c.first(), c.last()) { mix(((*a as u64) << 32) | *b as u64); }
+    }
+    for node in index.dbg.iter_nodes() { mix(((node.sequence().len() as u64) << 32) | *node.data() as u64); }   // node lengths and colours
+    h
+}
 fn cache() -> &'static Mutex<HashMap<CacheKey, Arc<AmdIndex>>> {
     static CACHE: OnceLock<Mutex<HashMap<CacheKey, Arc<AmdIndex>>>> = OnceLock::new();
     CACHE.get_or_init(|| Mutex::new(HashMap::new()))
 }
 fn key_of<K: Kmer>(index: &Pseudoaligner<K>) -> CacheKey {
-    (index as *const _ as usize, index.dbg.len(), index.eq_classes.len(), K::k())
+    (index.dbg.len(), index.eq_classes.len(), index.tx_names.len(), K::k(), fingerprint(index))
 }
+// (the fingerprint walks the graph once per call — a few ms at 200 k transcripts; `process_reads` looks its index up once per
+// run, a host that calls `map_read` per read keeps the `Arc<AmdIndex>` of `gpu_index` instead)
 fn device_of_env() -> i32 { std::env::var("PSEUDOALIGNER_AMD_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0) }
 
 /// the GPU copy of `index` (built once: 0.14 s for a 200 k-transcript index)
@@ -169,13 +186,30 @@ pub fn process_reads<K: Kmer + Sync + Send, P: AsRef<Path> + Debug>(
     let stdout = io::stdout();
     let mut out = io::BufWriter::with_capacity(1 << 22, stdout.lock());
     let mut text = vec![0u8; 1 << 22];
+    let mut millions_reported = 0u64;
     let mut drain = |out: &mut dyn Write| -> Result<(), Error> {
         loop {
             let mut n = 0usize;
-            check(unsafe { pa_records_pull(stream, text.as_mut_ptr() as *mut _, text.len(), &mut n) })?;
-            if n == 0 { return Ok(()); }
+            let rc = unsafe { pa_records_pull(stream, text.as_mut_ptr() as *mut _, text.len(), &mut n) };
+            if rc < 0 && n == 0 && text.len() < (1usize << 31) {
+                // one tuple longer than the buffer (a class of hundreds of thousands of ids): grow and ask again
+                let msg = unsafe { CStr::from_ptr(pa_last_error()) }.to_string_lossy().into_owned();
+                if msg.contains("smaller than one tuple") { text.resize(text.len() * 4, 0); continue; }
+            }
+            check(rc)?;
+            if n == 0 { break; }
             out.write_all(&text[..n])?;
         }
+        // the reference's progress line (src/pseudoaligner.rs:497-503), whenever another million reads have been printed
+        // (batch granular: the counts are those of the batches rendered so far)
+        let (mut n_reads, mut n_flagged) = (0u64, 0u64);
+        check(unsafe { pa_record_stream_stats(stream, &mut n_reads, &mut n_flagged) })?;
+        if n_reads / 1_000_000 > millions_reported {
+            millions_reported = n_reads / 1_000_000;
+            eprint!("\rDone Mapping {} reads w/ Rate: {}", n_reads, n_flagged as f32 * 100.0 / n_reads as f32);
+            io::stderr().flush().expect("Could not flush stdout");
+        }
+        Ok(())
     };
     let mut records = reader.records();
     loop {

@@ -25,6 +25,14 @@ pub struct PaFlatIndex {            // pa_flat_index
 #[derive(Clone, Copy, Default, Debug)]
 pub struct PaReadResult { pub coverage: u32, pub mismatches: u32, pub class_off: u32, pub class_len: u32 }
 
+#[repr(C)]
+#[derive(Clone, Copy, Default, Debug)]
+pub struct PaIndexStats {           // pa_index_stats
+    pub num_kmers: u64, pub table_slots: u64,
+    pub bytes_table: u64, pub bytes_graph: u64, pub bytes_classes: u64, pub bytes_total: u64,
+    pub num_nodes: u32, pub num_classes: u32, pub k: u32, pub max_class_len: u32,
+}
+
 #[repr(C)] pub struct PaIndex { _private: [u8; 0] }
 #[repr(C)] pub struct PaHostIndex { _private: [u8; 0] }
 #[repr(C)] pub struct PaOverflow { _private: [u8; 0] }
@@ -42,6 +50,7 @@ extern "C" {
     // index: flat form of `pub struct Pseudoaligner<K>` (src/pseudoaligner.rs:26-33) -> GPU
     pub fn pa_index_create(flat: *const PaFlatIndex, device: c_int, out: *mut *mut PaIndex) -> c_int;
     pub fn pa_index_create_multi(flat: *const PaFlatIndex, devices: *const c_int, ndev: c_int, out: *mut *mut PaIndex) -> c_int;
+    pub fn pa_index_get_stats(idx: *const PaIndex, stats: *mut PaIndexStats) -> c_int;
     pub fn pa_index_destroy(idx: *mut PaIndex);
     pub fn pa_host_index_from_flat(flat: *const PaFlatIndex, out: *mut *mut PaHostIndex) -> c_int;
     pub fn pa_host_index_build_fasta(fasta_path: *const c_char, k: u32, num_threads: c_int, out: *mut *mut PaHostIndex) -> c_int;
@@ -86,6 +95,7 @@ extern "C" {
     pub fn pa_index_release_stream(idx: *mut PaIndex, stream: *mut c_void) -> c_int;
     pub fn pa_index_set_timing(idx: *mut PaIndex, on: c_int) -> c_int;
     pub fn pa_map_kernel_ms(idx: *mut PaIndex, stream: *mut c_void, ms: *mut f32) -> c_int;
+    pub fn pa_map_stage_ms(idx: *mut PaIndex, stream: *mut c_void, ms: *mut f32) -> c_int;        // float ms[3]
     pub fn pa_map_arena_hint(idx: *const PaIndex, n_reads: u64) -> u64;
     pub fn pa_counts_len(idx: *const PaIndex) -> u64;
 

@@ -402,6 +402,12 @@ class Pseudoaligner:
         check(lib().pa_map_kernel_ms(self._h, stream or None, C.byref(ms)))
         return ms.value
 
+    def map_stage_ms(self, stream: int = 0):
+        """(mapping kernel, resolve kernel, count kernels) of the last timed launch, ms"""
+        ms = (C.c_float * 3)()
+        check(lib().pa_map_stage_ms(self._h, stream or None, ms))
+        return ms[0], ms[1], ms[2]
+
     def release_stream(self, stream: int = 0) -> None:
         check(lib().pa_index_release_stream(self._h, stream or None))
 

@@ -396,27 +396,48 @@ int pa_overflow_allgather(pa_overflow* o, pa_comm* comm, void* stream, const uin
     // the collectives the other ranks are about to enter — they would wait for it forever. Every rank always takes part in
     // the exchange of {words, status}; after it all of them know the largest table and whether ANY rank failed, and all
     // return the same error.
-    const int rc_local = export_locked(o, st, &nw);
-    const std::string why_local = rc_local != PA_OK ? last_error_ref() : std::string();
+    int rc_local = export_locked(o, st, &nw);
+    std::string why_local = rc_local != PA_OK ? last_error_ref() : std::string();
+    // {words, status} -> the maximum over the ranks. A HIP call of THIS rank that fails on the way is folded into the status
+    // this rank reports (and into rc_local), never returned before the all-reduce: the other ranks are about to enter it
+    auto exchange = [&](unsigned long long (&mine)[2], unsigned long long (&most)[2]) {
+        auto note = [&](hipError_t e, const char* what) {
+            if (e == hipSuccess || rc_local != PA_OK) return;
+            rc_local = PA_ERR_HIP;
+            why_local = std::string(what) + ": " + hipGetErrorString(e);
+            mine[0] = 0;
+            mine[1] = (unsigned long long)(-PA_ERR_HIP);
+        };
+        note(hipSetDevice(comm->device), "hipSetDevice");
+        note(hipMemcpyAsync(comm->d_scalar, mine, 16, hipMemcpyHostToDevice, st), "hipMemcpyAsync(status)");
+        if (rc_local == PA_ERR_HIP) (void)hipMemcpyAsync(comm->d_scalar, mine, 16, hipMemcpyHostToDevice, st);   // (the status, if the device still takes it)
+        const ncclResult_t r = rccl().AllReduce(comm->d_scalar, comm->d_scalar, 2, ncclUint64, ncclMax, comm->comm, st);
+        if (r != 0 && rc_local == PA_OK) { rc_local = PA_ERR_HIP; why_local = std::string("ncclAllReduce: ") + rccl().GetErrorString(r); }
+        note(hipMemcpyAsync(most, comm->d_scalar, 16, hipMemcpyDeviceToHost, st), "hipMemcpyAsync(result)");
+        note(hipStreamSynchronize(st), "hipStreamSynchronize");
+    };
     unsigned long long mine[2] = {rc_local == PA_OK ? nw : 0ull, (unsigned long long)(rc_local == PA_OK ? 0 : -rc_local)}, most[2] = {0, 0};
-    HIP_TRY(hipSetDevice(comm->device));
-    HIP_TRY(hipMemcpyAsync(comm->d_scalar, mine, 16, hipMemcpyHostToDevice, st));
-    NCCL_TRY(rccl().AllReduce(comm->d_scalar, comm->d_scalar, 2, ncclUint64, ncclMax, comm->comm, st));
-    HIP_TRY(hipMemcpyAsync(most, comm->d_scalar, 16, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (most[1] != 0) {   // some rank failed: everybody reports it (this rank's own reason when it has one)
-        if (rc_local != PA_OK) return fail(rc_local, "%s", why_local.c_str());
+    exchange(mine, most);
+    if (rc_local != PA_OK) return fail(rc_local, "%s", why_local.c_str());   // this rank's own reason
+    if (most[1] != 0)      // some other rank failed: everybody reports it
         return fail(-(int)most[1], "overflow gather: another rank could not export its table (status %d there); no rank merged anything", -(int)most[1]);
-    }
     const uint64_t len = most[0];
-    // send buffer of the common length (the largest table), zero padded: independent of this rank's own export capacity
+    // send buffer of the common length (the largest table), zero padded: independent of this rank's own export capacity. A rank that
+    // cannot allocate it says so in a second exchange, so that no rank enters the gather alone
     uint32_t *d_send = nullptr, *d_all = nullptr;
     hipError_t e = hipMalloc(&d_send, (size_t)len * 4);
     if (e == hipSuccess) e = hipMalloc(&d_all, (size_t)len * 4 * comm->nranks);
     if (e == hipSuccess) e = hipMemcpyAsync(d_send, o->d_export, (size_t)nw * 4, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && len > nw) e = hipMemsetAsync(d_send + nw, 0, (size_t)(len - nw) * 4, st);
-    // (a failed allocation here is fatal for the job: the other ranks are already in the gather)
-    if (e != hipSuccess) { (void)hipFree(d_send); (void)hipFree(d_all); return fail(PA_ERR_OOM, "overflow gather buffers (%llu words x %d ranks): %s", (unsigned long long)len, comm->nranks, hipGetErrorString(e)); }
+    if (e != hipSuccess) { rc_local = PA_ERR_OOM; why_local = std::string("overflow gather buffers: ") + hipGetErrorString(e); }
+    unsigned long long mine2[2] = {0ull, (unsigned long long)(rc_local == PA_OK ? 0 : -rc_local)}, most2[2] = {0, 0};
+    exchange(mine2, most2);
+    if (rc_local != PA_OK || most2[1] != 0) {
+        (void)hipFree(d_send);
+        (void)hipFree(d_all);
+        if (rc_local != PA_OK) return fail(rc_local, "%s (%llu words x %d ranks)", why_local.c_str(), (unsigned long long)len, comm->nranks);
+        return fail(-(int)most2[1], "overflow gather: another rank could not allocate its gather buffers (status %d there); no rank merged anything", -(int)most2[1]);
+    }
     ncclResult_t r = rccl().AllGather(d_send, d_all, (size_t)len, ncclUint32, comm->comm, st);
     if (r != 0) { (void)hipFree(d_send); (void)hipFree(d_all); return fail(PA_ERR_HIP, "ncclAllGather: %s", rccl().GetErrorString(r)); }
     std::vector<uint32_t> all((size_t)len * comm->nranks);

@@ -277,7 +277,7 @@ int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top_p
     hipLaunchKernelGGL(pa_keys_scatter_kernel, dim3(G), dim3(SC_BLOCK), 0, stream, keys, keys_top, (uint32_t)nbins, (const uint32_t*)wg_base, reinterpret_cast<uint16_t*>(sorted));
     // one workgroup per CU at most (an LDS table of 128 KiB each) and ONE round of them: 270 workgroups on 256 CUs take as long as 512
     uint32_t parts = std::max<uint32_t>(1u, (uint32_t)(cus / nbins));
-    parts = (uint32_t)knob_int("PA_COUNT_PARTS", (int)parts);
+    parts = std::max<uint32_t>(1u, (uint32_t)knob_int("PA_COUNT_PARTS", (int)parts));   // (A/B knob; never zero: the count kernel divides by it)
     hipLaunchKernelGGL(pa_keys_count_kernel, dim3((uint32_t)nbins * parts), dim3(CS_BLOCK), lds, stream, reinterpret_cast<const uint16_t*>(sorted), (const uint32_t*)hist, parts, counts,
                        counts_len);
     return (int)hipGetLastError();

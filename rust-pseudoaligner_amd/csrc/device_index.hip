@@ -59,13 +59,13 @@ struct LaunchCtx {
     DevBuf defer;                          // reads whose class is looked up by content after the launch (resolve.hip): 32 bytes each, sized for every read
     uint32_t last_grid = 0;
     uint64_t last_arena_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the map kernel of the last launch (pa_index_set_timing)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;   // before the map kernel / after it / after the resolve kernel / after the count kernels of the last launch (pa_index_set_timing)
     bool timed = false;
     void release() {
         for (DevBuf* b : {&ctl, &spill, &trace, &novel, &keys, &keys_sorted, &keys_ctl, &defer}) b->release();
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        ev0 = ev1 = nullptr;
+        for (hipEvent_t e : {ev0, ev1, ev2, ev3})
+            if (e) (void)hipEventDestroy(e);
+        ev0 = ev1 = ev2 = ev3 = nullptr;
         timed = false;
     }
 };
@@ -81,7 +81,7 @@ struct pa_index {
     // per-launch scratch: one context per stream the caller launches on, so that launches on different streams (from one or
     // several host threads) run concurrently; launches on ONE stream share a context and are ordered by the stream
     std::mutex mu;                // guards `ctxs` and `ovf`
-    std::map<hipStream_t, std::unique_ptr<LaunchCtx>> ctxs;
+    std::map<hipStream_t, std::shared_ptr<LaunchCtx>> ctxs;   // shared: a launch that looked its context up keeps it alive across pa_index_release_stream
     pa_overflow* ovf = nullptr;   // attached overflow table of novel classes (collective.hip), not owned
     bool timing = false;          // pa_index_set_timing: HIP events around the map kernel of every launch
     std::mutex hmu;               // the host-buffer convenience path (b_* below) is one batch at a time
@@ -300,17 +300,17 @@ static int pool_geometry(pa_index* idx, uint64_t n_reads, uint32_t wpr, uint32_t
 }
 
 // the launch context of a stream (created on first use)
-static int ctx_of(pa_index* idx, hipStream_t stream, LaunchCtx** out) {
+static int ctx_of(pa_index* idx, hipStream_t stream, std::shared_ptr<LaunchCtx>* out) {
     std::lock_guard<std::mutex> g(idx->mu);
     auto it = idx->ctxs.find(stream);
     if (it == idx->ctxs.end()) {
-        std::unique_ptr<LaunchCtx> c(new (std::nothrow) LaunchCtx());
+        std::shared_ptr<LaunchCtx> c(new (std::nothrow) LaunchCtx());
         if (!c) return fail(PA_ERR_OOM, "out of memory");
         const int rc = c->ctl.ensure(1024);
         if (rc != PA_OK) return rc;
         it = idx->ctxs.emplace(stream, std::move(c)).first;
     }
-    *out = it->second.get();
+    *out = it->second;
     return PA_OK;
 }
 
@@ -354,16 +354,19 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     p.spill_cap = spill_cap;
     const uint64_t counts_len = (uint64_t)idx->stats.num_classes + 3;
     // reads whose class has to be looked up by content are resolved after the launch (resolve.hip): 32 bytes per read in the worst case
-    const uint64_t defer_cap = defer_capacity(n_reads / (uint64_t)std::max(1, env_int("PA_DEFER_DIV", 1)), grid * (PA_MAP_BLOCK / 64));   // (A/B knob: a smaller buffer)
+    const uint64_t defer_cap = defer_capacity(n_reads, grid * (PA_MAP_BLOCK / 64));
     if ((rc = cx->defer.ensure(defer_cap * 32))) return rc;
     p.defer = cx->defer.as<uint32_t>();
     p.defer_top = cx->ctl.as<unsigned long long>() + 58;
+    p.defer_cap = defer_cap;
+    p.keys_cap = 0;
     uint64_t keys_cap = 0;
     if (d_counts) {   // the waves' key streams (4.3 bytes per read), one key per deferred read behind them, and the keys partitioned by range (4 bytes per read)
         keys_cap = key_stream_capacity(n_reads, grid * (PA_MAP_BLOCK / 64));
         if ((rc = cx->keys.ensure((keys_cap + defer_cap) * 4)) || (rc = cx->keys_sorted.ensure((n_reads + 64) * 4)) || (rc = cx->keys_ctl.ensure(count_keys_ctl_bytes(counts_len)))) return rc;
         p.keys = cx->keys.as<uint32_t>();
         p.keys_top = cx->ctl.as<unsigned long long>() + 57;
+        p.keys_cap = keys_cap;
         p.counts = reinterpret_cast<unsigned long long*>(d_counts);
     }
     p.class_table = static_cast<const uint32_t*>(idx->d_class_table);
@@ -392,7 +395,7 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     bool timing = false;
     { std::lock_guard<std::mutex> g(idx->mu); timing = idx->timing; }
     if (timing) {
-        if (!cx->ev0) { HIP_TRY(hipEventCreate(&cx->ev0)); HIP_TRY(hipEventCreate(&cx->ev1)); }
+        if (!cx->ev0) { HIP_TRY(hipEventCreate(&cx->ev0)); HIP_TRY(hipEventCreate(&cx->ev1)); HIP_TRY(hipEventCreate(&cx->ev2)); HIP_TRY(hipEventCreate(&cx->ev3)); }
         HIP_TRY(hipEventRecord(cx->ev0, stream));
     }
     const int e = launch_map_pool(p, grid, lds, stream);
@@ -402,6 +405,7 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
         const int e1 = launch_resolve(p, defer_cap, keys_cap, idx->num_cus, stream);
         if (e1) return fail(PA_ERR_HIP, "resolve launch: %s", hipGetErrorString((hipError_t)e1));
     }
+    if (timing) HIP_TRY(hipEventRecord(cx->ev2, stream));
     if (d_counts) {
         const int e2 = launch_count_keys(p.keys, p.keys_top, keys_cap, p.defer_top, defer_cap, cx->keys_sorted.as<uint32_t>(), cx->keys_ctl.as<uint32_t>(),
                                          reinterpret_cast<unsigned long long*>(d_counts), counts_len, idx->num_cus, stream);
@@ -411,6 +415,7 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
             if (rc != PA_OK) return rc;
         }
     }
+    if (timing) HIP_TRY(hipEventRecord(cx->ev3, stream));
     return PA_OK;
 }
 
@@ -436,7 +441,7 @@ static int map_finish_locked(pa_index* idx, LaunchCtx* cx, hipStream_t stream, u
     // crossed its end: what may be copied back is min(top, capacity); `needed` is the capacity that would have sufficed
     if (arena_used) *arena_used = ctl.top < cx->last_arena_cap ? ctl.top : cx->last_arena_cap;
     if (arena_needed) *arena_needed = ctl.top;
-    if (ctl.status & PA_STATUS_SPILL_OVERFLOW) return fail(PA_ERR_INTERNAL, "colour spill buffer overflow (should be impossible)");
+    if (ctl.status & PA_STATUS_SPILL_OVERFLOW) return fail(PA_ERR_INTERNAL, "a per-launch stream (class rows, count keys or deferred reads) overflowed its buffer (should be impossible)");
     if (ctl.status & PA_STATUS_ARENA_FULL) return fail(PA_ERR_ARENA_FULL, "class arena too small: %llu entries needed", ctl.top);
     return PA_OK;
 }
@@ -447,7 +452,7 @@ static int map_finish_locked(pa_index* idx, LaunchCtx* cx, hipStream_t stream, u
 // whose handle value the runtime reuses.
 int pa_index_release_stream(pa_index* idx, void* stream) {
     if (!idx) return fail(PA_ERR_INVALID_ARG, "null argument");
-    std::unique_ptr<LaunchCtx> cx;
+    std::shared_ptr<LaunchCtx> cx;
     {
         std::lock_guard<std::mutex> g(idx->mu);
         auto it = idx->ctxs.find(static_cast<hipStream_t>(stream));
@@ -455,10 +460,11 @@ int pa_index_release_stream(pa_index* idx, void* stream) {
         cx = std::move(it->second);
         idx->ctxs.erase(it);
     }
-    std::lock_guard<std::mutex> g(cx->mu);   // (a launch in progress on another thread finishes first)
-    HIP_TRY(hipSetDevice(idx->device));
-    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    cx->release();
+    std::lock_guard<std::mutex> g(cx->mu);   // (a launch in progress on another thread finishes first; one that only holds the pointer yet finds empty buffers and re-creates them)
+    hipError_t e = hipSetDevice(idx->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    cx->release();                           // also on the error path: the context is no longer reachable from the index
+    if (e != hipSuccess) return fail(PA_ERR_HIP, "pa_index_release_stream: %s", hipGetErrorString(e));
     return PA_OK;
 }
 
@@ -466,12 +472,12 @@ int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* 
                         uint32_t allowed_mismatches, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap,
                         uint32_t* d_colour, void* stream) {
     if (!idx || (n_reads && (!d_tiles || !d_lens || !d_results || !d_arena))) return fail(PA_ERR_INVALID_ARG, "null argument");
-    LaunchCtx* cx = nullptr;
+    std::shared_ptr<LaunchCtx> cx;
     const int rc0 = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
     if (rc0 != PA_OK) return rc0;
     std::lock_guard<std::mutex> g(cx->mu);
     HIP_TRY(hipSetDevice(idx->device));
-    return map_launch_locked(idx, cx, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, d_colour,
+    return map_launch_locked(idx, cx.get(), d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, d_colour,
                              nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
@@ -479,23 +485,23 @@ int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint
                               uint32_t allowed_mismatches, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap,
                               uint64_t* d_counts, void* stream) {
     if (!idx || !d_counts || (n_reads && (!d_tiles || !d_lens || !d_results || !d_arena))) return fail(PA_ERR_INVALID_ARG, "null argument");
-    LaunchCtx* cx = nullptr;
+    std::shared_ptr<LaunchCtx> cx;
     const int rc0 = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
     if (rc0 != PA_OK) return rc0;
     std::lock_guard<std::mutex> g(cx->mu);
     HIP_TRY(hipSetDevice(idx->device));
-    return map_launch_locked(idx, cx, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, nullptr,
+    return map_launch_locked(idx, cx.get(), d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, nullptr,
                              d_counts, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed) {
     if (!idx) return fail(PA_ERR_INVALID_ARG, "null argument");
-    LaunchCtx* cx = nullptr;
+    std::shared_ptr<LaunchCtx> cx;
     const int rc0 = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
     if (rc0 != PA_OK) return rc0;
     std::lock_guard<std::mutex> g(cx->mu);
     HIP_TRY(hipSetDevice(idx->device));
-    return map_finish_locked(idx, cx, static_cast<hipStream_t>(stream), arena_used, arena_needed);
+    return map_finish_locked(idx, cx.get(), static_cast<hipStream_t>(stream), arena_used, arena_needed);
 }
 
 int pa_index_set_timing(pa_index* idx, int on) {
@@ -507,13 +513,27 @@ int pa_index_set_timing(pa_index* idx, int on) {
 
 int pa_map_kernel_ms(pa_index* idx, void* stream, float* ms) {
     if (!idx || !ms) return fail(PA_ERR_INVALID_ARG, "null argument");
-    LaunchCtx* cx = nullptr;
+    std::shared_ptr<LaunchCtx> cx;
     const int rc0 = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
     if (rc0 != PA_OK) return rc0;
     std::lock_guard<std::mutex> g(cx->mu);
     if (!cx->timed) return fail(PA_ERR_INVALID_ARG, "no timed launch on this stream (pa_index_set_timing before the launch)");
     HIP_TRY(hipEventSynchronize(cx->ev1));
     HIP_TRY(hipEventElapsedTime(ms, cx->ev0, cx->ev1));
+    return PA_OK;
+}
+
+int pa_map_stage_ms(pa_index* idx, void* stream, float ms[3]) {
+    if (!idx || !ms) return fail(PA_ERR_INVALID_ARG, "null argument");
+    std::shared_ptr<LaunchCtx> cx;
+    const int rc0 = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
+    if (rc0 != PA_OK) return rc0;
+    std::lock_guard<std::mutex> g(cx->mu);
+    if (!cx->timed) return fail(PA_ERR_INVALID_ARG, "no timed launch on this stream (pa_index_set_timing before the launch)");
+    HIP_TRY(hipEventSynchronize(cx->ev3));
+    HIP_TRY(hipEventElapsedTime(&ms[0], cx->ev0, cx->ev1));
+    HIP_TRY(hipEventElapsedTime(&ms[1], cx->ev1, cx->ev2));
+    HIP_TRY(hipEventElapsedTime(&ms[2], cx->ev2, cx->ev3));
     return PA_OK;
 }
 
@@ -551,7 +571,7 @@ static int map_batch_host(pa_index* idx, const HostReads& in, uint64_t n, uint32
         return fail(PA_ERR_INVALID_ARG, "null argument");
     if (packed && in.layout != 0 && in.layout != 1) return fail(PA_ERR_INVALID_ARG, "packed layout %d (0 = LSB-first, 1 = MSB-first words)", in.layout);
     std::lock_guard<std::mutex> hg(idx->hmu);
-    LaunchCtx* cx = nullptr;
+    std::shared_ptr<LaunchCtx> cx;
     const int rc0 = ctx_of(idx, nullptr, &cx);
     if (rc0 != PA_OK) return rc0;
     std::lock_guard<std::mutex> g(cx->mu);
@@ -613,10 +633,10 @@ static int map_batch_host(pa_index* idx, const HostReads& in, uint64_t n, uint32
     uint64_t cap = pa_map_arena_hint(idx, n), used = 0, need = 0;
     for (int attempt = 0;; ++attempt) {
         if ((rc = idx->b_arena.ensure(cap * 4))) return rc;
-        rc = map_launch_locked(idx, cx, idx->b_tiles.as<uint64_t>(), idx->b_lens.as<uint32_t>(), n, wpr, allowed,
+        rc = map_launch_locked(idx, cx.get(), idx->b_tiles.as<uint64_t>(), idx->b_lens.as<uint32_t>(), n, wpr, allowed,
                                idx->b_results.as<pa_read_result>(), idx->b_arena.as<uint32_t>(), cap, nullptr, nullptr, d_nodes, d_nodes_len, st);
         if (rc != PA_OK) return rc;
-        rc = map_finish_locked(idx, cx, st, &used, &need);
+        rc = map_finish_locked(idx, cx.get(), st, &used, &need);
         if (rc == PA_ERR_ARENA_FULL && attempt < 3) { cap = need + need / 8 + 4096; continue; }
         if (rc != PA_OK) return rc;
         break;

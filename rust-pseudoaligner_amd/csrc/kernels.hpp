@@ -45,6 +45,7 @@ struct MapParams {
     // in chunks of PA_DEFER_CHUNK handed out through *defer_top, unused tails padded with rid 0xFFFFFFFF; sized for every read
     uint32_t* defer;
     unsigned long long* defer_top;
+    uint64_t keys_cap, defer_cap;      // entries `keys` / `defer` hold: a chunk that would end beyond them is not written (PA_STATUS_SPILL_OVERFLOW)
     const uint32_t* class_table;
     uint64_t class_table_size;
     // optional (with the fused count table): {arena offset, length} of every result that is NO index class goes on this list;

@@ -137,7 +137,10 @@ __device__ __forceinline__ void append_keys(uint32_t key, uint32_t lane, karg_pt
     const uint32_t cur = kchunk[0], room = kchunk[1] - cur;
     uint32_t nbase = 0;
     if (cnt > room) {   // the step's keys straddle the chunk's end: the first `room` fill it up, the rest open the next chunk
-        if (lane == 0) nbase = (uint32_t)atomicAdd(p->keys_top, (unsigned long long)PA_KEY_CHUNK);
+        if (lane == 0) {
+            nbase = (uint32_t)atomicAdd(p->keys_top, (unsigned long long)PA_KEY_CHUNK);
+            if ((uint64_t)nbase + PA_KEY_CHUNK > p->keys_cap) { atomicOr(p->status, PA_STATUS_SPILL_OVERFLOW); nbase = 0; }   // (the host sizes the stream for every read: never taken; the launch then fails instead of writing out of bounds)
+        }
         nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)nbase);
     }
     const uint32_t r = rank_in(m);
@@ -165,7 +168,10 @@ __device__ __forceinline__ void append_deferred(bool has, u32x4 e0, u32x4 e1, ui
     const uint32_t cur = dchunk[0], room = dchunk[1] - cur;
     uint32_t nbase = 0;
     if (cnt > room) {   // (as append_keys: fill the chunk up, go on in the next one)
-        if (lane == 0) nbase = (uint32_t)atomicAdd(p->defer_top, (unsigned long long)PA_DEFER_CHUNK);
+        if (lane == 0) {
+            nbase = (uint32_t)atomicAdd(p->defer_top, (unsigned long long)PA_DEFER_CHUNK);
+            if ((uint64_t)nbase + PA_DEFER_CHUNK > p->defer_cap) { atomicOr(p->status, PA_STATUS_SPILL_OVERFLOW); nbase = 0; }   // (as append_keys)
+        }
         nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)nbase);
     }
     if (has) {

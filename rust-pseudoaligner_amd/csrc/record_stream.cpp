@@ -71,7 +71,9 @@ void render(pa_record_stream* s, int k) {
     s->maxlen[k] = 0;
 }
 
-// the batch being filled goes to the GPU; the one before it is waited for and rendered
+// the batch being filled goes to the GPU; the one before it is waited for and rendered. (Both batches share the stream and
+// with it ONE launch context inside the index — its control block says how much of the arena a launch used — so the previous
+// batch is finished before the next is launched; the GPU then works on batch k while the host renders batch k - 1 and packs k + 1.)
 int submit(pa_record_stream* s) {
     const int k = s->cur, o = k ^ 1;
     BatchCtx& c = s->ctx[k];
@@ -128,10 +130,15 @@ int pa_records_push(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_
     if (!s || (n && (!id_offsets || !seq_offsets))) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (s->rc != PA_OK) return fail(s->rc, "%s", s->why.c_str());
     if (hipSetDevice(s->device) != hipSuccess) return fail_sticky(s, fail(PA_ERR_HIP, "hipSetDevice failed"));
+    // every record of the call is checked before the first one is taken: a call that fails has appended (and submitted) nothing,
+    // so the caller may correct it and push the same records again
     for (uint64_t i = 0; i < n; ++i) {
         if (id_offsets[i + 1] < id_offsets[i] || seq_offsets[i + 1] < seq_offsets[i]) return fail(PA_ERR_INVALID_ARG, "offsets not monotone at record %llu", (unsigned long long)i);
         const uint64_t il = id_offsets[i + 1] - id_offsets[i], sl = seq_offsets[i + 1] - seq_offsets[i];
         if (il > 0xFFFFFFFFull || sl > 0xFFFFFFFFull || (il && !ids) || (sl && !seqs)) return fail(PA_ERR_INVALID_ARG, "record %llu: bad id or sequence", (unsigned long long)i);
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t il = id_offsets[i + 1] - id_offsets[i], sl = seq_offsets[i + 1] - seq_offsets[i];
         const int k = s->cur;
         std::vector<char>& t = s->text[k];
         Record r;
