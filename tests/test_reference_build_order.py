@@ -162,8 +162,7 @@ def reference_order_nodes(seqs, k, perm_mode, min_shard=2000):
         y = int(succ_global[p[-1]])                                                   # the node's last k-mer under the node-level test
         if y >= 0 and y in head_of:
             node_succ[i] = head_of[y]
-    final, cyc2 = chains(node_succ)
-    assert len(cyc2) == 0 or len(cyc1) >= 0
+    final, cyc2 = chains(node_succ)                                                   # (a loop that pass 1 cut at shard seams closes again here)
     bases = "ACGT"
     out = set()
     for chain in final:
@@ -172,7 +171,7 @@ def reference_order_nodes(seqs, k, perm_mode, min_shard=2000):
         seq = "".join(bases[(first_km >> (2 * (k - 1 - t))) & 3] for t in range(k)) + "".join(bases[int(ukm[x]) & 3] for x in idx[1:])
         le, re = int(uext[idx[0]]) >> 4, int(uext[idx[-1]]) & 15
         out.add((seq, class_list[int(ucol[idx[0]])], "".join(bases[b] for b in range(4) if le >> b & 1), "".join(bases[b] for b in range(4) if re >> b & 1)))
-    cycle_kmers = len(cyc1) if len(cyc1) else 0
+    cycle_kmers = len(cyc1) + sum(len(nodes1[n]) for n in cyc2)                       # k-mers on pure cycles: in no node of `out`
     return out, n_shards, cycle_kmers, len(nodes1)
 
 
@@ -211,3 +210,59 @@ def test_shard_seams_do_cut_paths_in_the_first_pass():
     single, one, _, pass1_single = reference_order_nodes(seqs, 24, "identity", min_shard=10 ** 9)
     assert n_shards > 5 and one == 1 and full == single
     assert pass1 > len(full) and pass1_single == len(single)
+
+
+def _txome_strings(txome):
+    packed, tx_start = txome.arrays()
+    out = []
+    for t in range(len(tx_start) - 1):
+        pos = np.arange(int(tx_start[t]), int(tx_start[t + 1]), dtype=np.int64)
+        codes = ((packed[pos >> 5] >> ((pos & 31) * 2).astype(np.uint64)) & np.uint64(3)).astype(np.uint8)
+        out.append(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode())
+    return out
+
+
+@pytest.mark.parametrize("k", [24, 31])
+def test_two_pass_order_on_the_synthetic_transcriptome_of_the_bench(k):
+    """the index type bench.py times (csrc/synth.cpp: genes of exons, alternative transcripts, 5 % paralog copies), a 3000-gene
+    slice of it: the reference's two-pass sharded order and the product's builder give the same nodes"""
+    tx = pa.Txome.synthesize(3000, 10500, 7)
+    seqs = _txome_strings(tx)
+    assert len(seqs) >= 9000
+    want, n_shards, cyc, n_pass1 = reference_order_nodes(seqs, k, "identity")
+    got = product_nodes(pa.HostIndex.from_txome(tx, k, 4))
+    assert n_shards > 20 and n_pass1 > len(want)
+    assert cyc == 0
+    assert got == want, "%d nodes only in the product, %d only in the reference's order" % (len(got - want), len(want - got))
+
+
+def _rotations(s, k):
+    """k-mers of the closed walk whose sequence (period + k - 1 bases) is s"""
+    return {s[i:i + k] for i in range(len(s) - k + 1)}
+
+
+@pytest.mark.parametrize("k", [20, 31])
+def test_a_pure_kmer_cycle_is_cut_once_and_everything_else_agrees(tmp_path, k):
+    """A transcript that is a tandem repeat (three periods of a 57-base unit) makes a closed loop of 57 k-mers, every one with
+    exactly one left and one right extension and one colour: a PURE cycle. The reference cuts it where its walk happens to
+    start (A4), the product's builders where theirs do: the cut is the one listed exception. Asserted here: the
+    emulation sees the cycle (57 k-mers on it); the product has exactly ONE node for it, of period + k - 1 bases, whose k-mers are
+    the cycle's and whose single left / right extension closes the loop; every other node is identical."""
+    _, seqs = helpers.read_fasta()
+    seqs = [s.upper() for s in seqs[:200]]
+    rng = np.random.RandomState(5)
+    unit = "".join("ACGT"[i] for i in rng.randint(0, 4, 57))
+    seqs.insert(100, unit * 3)
+    fa = tmp_path / "cycle.fa"
+    fa.write_text("".join(">t%d\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+    want, _, cyc, _ = reference_order_nodes(seqs, k, "identity")
+    assert cyc == 57                                                                  # the listed exception, not cyc == 0
+    got = product_nodes(pa.build_index(str(fa), k, 2))
+    extra = got - want
+    assert want - got == set() and len(extra) == 1, (len(want - got), len(extra))
+    seq, cls, le, re = next(iter(extra))
+    assert len(seq) == 57 + k - 1 and cls == (100,) and len(le) == 1 and len(re) == 1
+    doubled = unit * 3
+    assert _rotations(seq, k) == {doubled[i:i + k] for i in range(57)}                # the node is the loop, cut somewhere
+    assert seq[:k - 1] == seq[57:57 + k - 1]                                          # it closes on itself: its last k-1 bases are its first
+    assert le == seq[56] and re == seq[k - 1]                                         # the extensions are the loop's own bases
