@@ -286,6 +286,8 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host leg (pinned tiles -> records on the host), an extra report at N=1")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the FASTQ-text leg (pa_process_reads / pa_record_stream_* on a bounded sample), an extra report at N=1")
+    ap.add_argument("--ingest-reads", type=int, default=8_000_000, help="reads of the FASTQ-text leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the extra config-5 measurement of the default N=1 run")
     ap.add_argument("--separate-count", action="store_true", help="class counts from the stored records (pa_counts_accumulate_device) instead of the key streams")
     ap.add_argument("--index-cache", default="", help="optional path to save/load the host index container")
@@ -389,6 +391,15 @@ def main() -> None:
             log("e2e leg failed: %r" % (e,))
             out["e2e_error"] = repr(e)
 
+    # ---- the drop-in entry points on this round's code, extra keys: FASTQ text -> Debug tuples through
+    # pa_process_reads (a path) and pa_record_stream_* (records pushed by the caller), with the host stages' seconds ----
+    if n_gpus == 1 and rank == 0 and not args.no_ingest and args.workload == "config3":
+        try:
+            out.update(ingest_leg(env, run, args.ingest_reads))
+        except Exception as e:   # an extra report: never lose the bench line over it
+            log("ingest leg failed: %r" % (e,))
+            out["ingest_error"] = repr(e)
+
     if rank == 0:
         # ---- checker + CPU baseline (oracle = C port of the reference path), outside the timed region ----
         ncpu = usable_cpus()
@@ -437,6 +448,101 @@ def main() -> None:
     barrier()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def write_fastq(txome, path, n, read_len, read_seed, wpr, np):
+    """n simulated reads as four-line FASTQ records "@r%09d" / bases / "+" / qualities; returns the file size"""
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    with open(path, "wb") as f:
+        for first in range(0, n, 1 << 20):
+            m = min(1 << 20, n - first)
+            tiles, _ = txome.simulate_host(read_len, read_seed, m, 0, first, wpr)
+            words = tiles.reshape(-1, wpr, 64).transpose(0, 2, 1).reshape(-1, wpr)[:m]    # [read][word]
+            shifts = (2 * np.arange(32, dtype=np.uint64))[None, None, :]
+            bases = ((words[:, :, None] >> shifts) & np.uint64(3)).astype(np.uint8).reshape(m, wpr * 32)[:, :read_len]
+            rec = np.empty((m, 16 + 2 * read_len), np.uint8)
+            ids = np.char.zfill(np.arange(first, first + m).astype("U9"), 9)
+            rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+            rec[:, 2:11] = np.frombuffer("".join(ids).encode(), np.uint8).reshape(m, 9)
+            rec[:, 11] = 10
+            rec[:, 12:12 + read_len] = lut[bases]
+            rec[:, 12 + read_len:15 + read_len] = np.frombuffer(b"\n+\n", np.uint8)
+            rec[:, 15 + read_len:15 + 2 * read_len] = ord("I")
+            rec[:, 15 + 2 * read_len] = 10
+            f.write(rec.tobytes())
+    return os.path.getsize(path)
+
+
+def ingest_leg(env, run, n):
+    """FASTQ text (page cache) -> the reference's Debug tuples -> /dev/null, through both drop-in forms. The host stages run one
+    after the other on the calling thread, each over the worker pool, while the GPU maps the batch before: the wall time is their
+    sum, and the stage with the most seconds is what bounds the rate on this box's CPU quota."""
+    pa, np = env["pa"], env["np"]
+    wl = run.wl
+    ncpu = usable_cpus()
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    fq = os.path.join(d, "pa_bench_ingest_%d.fq" % os.getpid())
+    try:
+        size = write_fastq(run.txome, fq, n, wl["read_len"], wl["read_seed"], run.wpr, np)
+        pa.process_reads(fq, run.aligner, "/dev/null", ncpu)           # warm-up: page cache, pinned buffers
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            got, _ = pa.process_reads(fq, run.aligner, "/dev/null", ncpu)
+            dt = time.perf_counter() - t0
+            assert got == n
+            st = pa.process_reads_stage_seconds()
+            if best is None or dt < best[0]:
+                best = (dt, st)
+        dt, st = best
+        stages = {k: round(st[k], 4) for k in ("scan_s", "pack_s", "gpu_wait_s", "launch_s", "render_s", "writer_wait_s", "total_s")}
+        bound = max(("scan_s", "pack_s", "gpu_wait_s", "render_s", "writer_wait_s"), key=lambda k: st[k])
+        bytes_per_read = {"scan_s": size / n, "pack_s": wl["read_len"] + 12.0, "render_s": 40.0}.get(bound)
+        out = {"ingest_reads_per_s": n / dt, "ingest_bound_stage": bound.replace("_s", ""),
+               "ingest": {"what": "pa_process_reads: %d reads of %d bp, %.2f GB FASTQ in the page cache -> tuples to /dev/null, %d worker threads (the box's CPU quota)"
+                                  % (n, wl["read_len"], size / 1e9, ncpu),
+                          "seconds": dt, "fastq_GBps": size / dt / 1e9, "stages": stages,
+                          "bound_stage_ns_per_read_per_thread": st[bound] * ncpu / n * 1e9,
+                          "bound_stage_bytes_per_read": bytes_per_read,
+                          "reference_counterparts": "one reader behind a mutex (utils.rs:152-157), one println! per read on the consumer thread (pseudoaligner.rs:490)"}}
+        # the record-stream form: the caller reads the file (here: numpy slices of the same text) and pushes records
+        text = np.fromfile(fq, np.uint8).reshape(n, 16 + 2 * wl["read_len"])
+        ids = np.ascontiguousarray(text[:, 1:11])
+        seqs = np.ascontiguousarray(text[:, 12:12 + wl["read_len"]])
+        rs = pa.RecordStream(run.aligner, ncpu)
+        import ctypes as C
+        chunk = 1 << 20
+        id_off = (np.arange(chunk + 1, dtype=np.uint64) * 10)
+        seq_off = (np.arange(chunk + 1, dtype=np.uint64) * wl["read_len"])
+        buf = C.create_string_buffer(1 << 24)
+        nb = C.c_size_t()
+        t0 = time.perf_counter()
+        pulled = 0
+        for lo in range(0, n, chunk):
+            m = min(chunk, n - lo)
+            pa.check(pa.lib().pa_records_push(rs._h, ids[lo:lo + m].ctypes.data, id_off.ctypes.data, seqs[lo:lo + m].ctypes.data, seq_off.ctypes.data, m))
+            while True:
+                pa.check(pa.lib().pa_records_pull(rs._h, buf, len(buf), C.byref(nb)))
+                if nb.value == 0:
+                    break
+                pulled += nb.value
+        rs.flush()
+        while True:
+            pa.check(pa.lib().pa_records_pull(rs._h, buf, len(buf), C.byref(nb)))
+            if nb.value == 0:
+                break
+            pulled += nb.value
+        dt_rs = time.perf_counter() - t0
+        st_rs = rs.stage_seconds()
+        assert rs.stats()[0] == n
+        rs.close()
+        out["ingest"]["record_stream"] = {"reads_per_s": n / dt_rs, "seconds": dt_rs, "tuple_bytes": pulled,
+                                          "stages": {k: round(st_rs[k], 4) for k in ("pack_s", "gpu_wait_s", "launch_s", "render_s", "total_s")},
+                                          "what": "pa_records_push / pull of the same reads in chunks of 1 Mi records (the copy into the batch and the pull are the caller's time)"}
+        return out
+    finally:
+        if os.path.exists(fq):
+            os.unlink(fq)
 
 
 def host_to_host_leg(env, run):

@@ -316,6 +316,15 @@ int pa_records_flush(pa_record_stream* s);
 int pa_record_stream_stats(const pa_record_stream* s, uint64_t* n_reads, uint64_t* n_flagged);
 void pa_record_stream_destroy(pa_record_stream* s);
 
+/* Measurement (bench.py's ingest leg): wall seconds the HOST stages of the last pa_process_reads call of this thread /
+ * of a record stream since its creation took — the stages run one after the other on the caller's thread, each spread over
+ * the worker pool, while the GPU works on the batch before: out[0] scan (record boundaries; 0 for a record stream),
+ * out[1] pack (records -> 2-bit tiles), out[2] waiting for the GPU, out[3] launch, out[4] render (Debug tuples),
+ * out[5] waiting for the writer (0 for a record stream), out[6] the whole call (streams: the sum of the others), out[7] reads. */
+#define PA_INGEST_STAGES 8
+int pa_process_reads_stage_seconds(double out[PA_INGEST_STAGES]);
+int pa_record_stream_stage_seconds(const pa_record_stream* s, double out[PA_INGEST_STAGES]);
+
 /* The scan stage of pa_process_reads by itself, without a GPU: the number of records of a FASTQ file (plain, gzip'ed or with
  * wrapped lines: same acceptance rules and errors as above) and, for the first `capacity` of them, where the record starts,
  * how many bytes its header line has before the line feed ('@' included, and the CR of a CRLF file) and how many bases its

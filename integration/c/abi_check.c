@@ -169,6 +169,8 @@ int main(int argc, char** argv) {
             EXPECT(pa_records_pull(rs, text, sizeof text, &nb) == PA_OK && nb > 0 && text[nb - 1] == '\n' && text[0] == '(');
             uint64_t rn = 0, rf = 0;
             EXPECT(pa_record_stream_stats(rs, &rn, &rf) == PA_OK && rn == 2);
+            { double st[PA_INGEST_STAGES]; EXPECT(pa_record_stream_stage_seconds(rs, st) == PA_OK && st[7] == 2.0 && st[6] >= 0.0);
+              EXPECT(pa_process_reads_stage_seconds(st) == PA_OK); }
             pa_record_stream_destroy(rs);
         }
         uint32_t nodes_flat[2 * 64], nodes_len[2];

@@ -77,6 +77,8 @@ extern "C" {
     pub fn pa_records_pull(s: *mut PaRecordStream, buf: *mut c_char, cap: usize, n_bytes: *mut usize) -> c_int;
     pub fn pa_records_flush(s: *mut PaRecordStream) -> c_int;
     pub fn pa_record_stream_stats(s: *const PaRecordStream, n_reads: *mut u64, n_flagged: *mut u64) -> c_int;
+    pub fn pa_record_stream_stage_seconds(s: *const PaRecordStream, out: *mut f64) -> c_int;      // double out[8]
+    pub fn pa_process_reads_stage_seconds(out: *mut f64) -> c_int;
     pub fn pa_record_stream_destroy(s: *mut PaRecordStream);
     pub fn pa_process_reads(idx: *mut PaIndex, fastq_path: *const c_char, out_path: *const c_char, num_threads: c_int,
                             n_reads: *mut u64, n_flagged: *mut u64) -> c_int;

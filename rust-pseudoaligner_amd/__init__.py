@@ -552,6 +552,11 @@ class RecordStream:
         check(lib().pa_record_stream_stats(self._h, C.byref(n), C.byref(f)))
         return n.value, f.value
 
+    def stage_seconds(self) -> dict:
+        st = (C.c_double * 8)()
+        check(lib().pa_record_stream_stage_seconds(self._h, st))
+        return dict(zip(INGEST_STAGES, st))
+
     def close(self) -> None:
         if self._h:
             lib().pa_record_stream_destroy(self._h)
@@ -595,6 +600,16 @@ class Comm:
                 self._h = vp()
         except Exception:
             pass
+
+
+INGEST_STAGES = ("scan_s", "pack_s", "gpu_wait_s", "launch_s", "render_s", "writer_wait_s", "total_s", "reads")
+
+
+def process_reads_stage_seconds() -> dict:
+    """host-stage wall seconds of this thread's last process_reads call (pa_process_reads_stage_seconds)"""
+    st = (C.c_double * 8)()
+    check(lib().pa_process_reads_stage_seconds(st))
+    return dict(zip(INGEST_STAGES, st))
 
 
 def process_reads(fastq_path: str, index: Pseudoaligner, out_path: str = "-", num_threads: int = 2) -> Tuple[int, int]:

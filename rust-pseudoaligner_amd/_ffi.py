@@ -87,6 +87,8 @@ SIGNATURES = {
     "pa_index_set_timing": (C.c_int, [vp, C.c_int]),
     "pa_map_kernel_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
     "pa_map_stage_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+    "pa_process_reads_stage_seconds": (C.c_int, [C.POINTER(C.c_double)]),
+    "pa_record_stream_stage_seconds": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "pa_map_arena_hint": (C.c_uint64, [vp, C.c_uint64]),
     "pa_map_batch": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.POINTER(vp)]),
     "pa_map_read": (C.c_int, [vp, C.c_char_p, C.c_uint32, vp, C.c_uint32, u32p, u32p]),

@@ -563,6 +563,10 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         if (rc == PA_OK && b >= 1) format(ctx[(b - 1) & 1]);
         t_format += now() - t0;
     }
+    {
+        double* st = pa::ingest::last_stage_seconds();
+        st[0] = t_scan; st[1] = t_pack; st[2] = t_finish; st[3] = t_launch; st[4] = t_format; st[5] = t_push; st[6] = now() - t_begin; st[7] = (double)nrec;
+    }
     if (verbose)
         fprintf(stderr, "\n[pa ingest] %llu reads, %d threads: scan %.3f s, pack %.3f s (records %.3f, alloc %.3f, tiles %.3f), wait GPU %.3f s, launch %.3f s, format %.3f s (writer wait %.3f), total %.3f s\n",
                 (unsigned long long)nrec, T, t_scan, t_pack, t_pack_rec, t_pack_alloc, t_pack_tiles, t_finish, t_launch, t_format, t_push, now() - t_begin);
@@ -591,4 +595,10 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     if (n_reads_out) *n_reads_out = reported;
     if (n_flagged_out) *n_flagged_out = flagged;
     return rc;
+}
+
+extern "C" int pa_process_reads_stage_seconds(double out[PA_INGEST_STAGES]) {
+    if (!out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    memcpy(out, pa::ingest::last_stage_seconds(), sizeof(double) * PA_INGEST_STAGES);
+    return PA_OK;
 }

@@ -277,6 +277,12 @@ inline void batch_pack_tiles(Pool& pool, BatchCtx& c, const char* text) {
 }
 
 // the GPU leg of a batch, asynchronous on `stream`: tiles H2D -> index.map_read for every read (:451) -> records D2H
+// wall seconds of the host stages of this thread's last pa_process_reads call (pa_process_reads_stage_seconds)
+inline double* last_stage_seconds() {
+    static thread_local double st[PA_INGEST_STAGES] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return st;
+}
+
 inline int batch_launch(pa_index* idx, BatchCtx& c, hipStream_t stream) {
     PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_tiles, c.h_tiles, pa_tiles_words(c.n, c.wpr) * 8, hipMemcpyHostToDevice, stream));
     PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_lens, c.h_lens, c.n * 4, hipMemcpyHostToDevice, stream));

@@ -23,7 +23,9 @@ namespace pa {
 enum : uint32_t { ST_EMPTY = 0, ST_SEEK = 1, ST_FWD = 2, ST_LEFT = 3, ST_ISECT = 4, ST_NONE = 5,
                   ST_F_LIGHT = 6, ST_F_SCAN = 7, ST_F_COOP = 8, ST_F_BITS = 9, ST_F_MASK = 10, ST_COUNT = 11 };
 enum : uint32_t { F_FRESH = 1u, F_FIRST_SEEK = 2u, F_LEFT_SEED = 4u, F_SPILL_OVERFLOW = 8u, F_CAREFUL = 16u, F_LISTS = 32u,
-                  F_SMALL_BASE = 64u };   // list mode: the shortest class met has <= 8 ids
+                  F_SMALL_BASE = 64u,   // list mode: the shortest class met has <= 8 ids
+                  F_SPEC = 128u };      // the scan for a k-mer is past a miss (or re-seeks behind a broken-off node visit): the next probe will
+                                        // probably miss too, so a step probes kmer_pos AND kmer_pos + 3 (evaluated in the scan's order: exact)
 constexpr uint32_t NO_CLASS = 0xFFFFFFFFu;
 constexpr uint32_t LDS_CLASSES = 4;   // list mode: distinct classes kept inline (one 16-byte vector each of refs, lengths, class ids)
 
@@ -488,10 +490,17 @@ PA_HD uint32_t pa_bucket_home(uint64_t kmer, uint32_t nbuckets, uint32_t& home) 
     return (uint32_t)(((m >> 32) * nbuckets) >> 32);
 #endif
 }
-PA_HD void seek_issue(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekProbe& q) {
-    const uint64_t kmer = read_window_in(rd, l_kp(s)) & ix.kmask;   // read_seq.get_kmer(kmer_pos) (:93); kmer_pos <= L - K
-    uint32_t b = pa_bucket_home(kmer, (uint32_t)ix.nbuckets, q.home) + l_probe(s);
+// does this step also probe kmer_pos + 3? (a lane past a miss, not in the middle of an overflow chain, with a k-mer left there)
+PA_HD bool seek_two(const Lane& s, uint32_t K) { return (l_flags(s) & F_SPEC) && l_probe(s) == 0 && l_kp(s) + PA_SEEK_STRIDE <= l_L(s) - K; }
+// the probe of the k-mer at kmer_pos + ahead (ahead = 0: at the lane's probe index; ahead = 3: the speculative second probe).
+// `live` = false (second probe of a lane that does not speculate): the load still goes out — a branch around it would put a full
+// wait behind the loads already in flight — but to the first line of the table, which all such lanes share; the probe is ignored
+PA_HD void seek_issue(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekProbe& q, uint32_t ahead = 0, bool live = true) {
+    const uint32_t at = live ? l_kp(s) + ahead : l_kp(s);
+    const uint64_t kmer = read_window_in(rd, at) & ix.kmask;   // read_seq.get_kmer(kmer_pos) (:93); kmer_pos <= L - K
+    uint32_t b = pa_bucket_home(kmer, (uint32_t)ix.nbuckets, q.home) + (ahead ? 0u : l_probe(s));
     if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
+    if (!live) { b = 0; q.home = 0; }
     q.bucket = ix.table + (uint64_t)b * BUCKET_WORDS;
     q.v = PA_LD(4, reinterpret_cast<const U4*>(q.bucket + SLOT_WORDS * q.home));
     q.klo = (uint32_t)kmer;
@@ -507,15 +516,37 @@ PA_HD const U4* seek_second_slot(const SeekProbe& q, uint32_t cand) {   // cand 
 }
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe);
 // `cand` = seek_second(q), `v2` = the first named slot (loaded by the caller when cand != 0)
-PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand, U4 v2) {
-    uint32_t h = NO_HANDLE, off = 0;
+PA_HD void seek_eval(const SeekProbe& q, uint32_t cand, U4 v2, uint32_t& h, uint32_t& off, bool& full) {
+    h = NO_HANDLE;
+    off = 0;
     if (slot_holds(q.v, q.klo, q.khi)) { h = q.v.z; off = q.v.w & SLOT_OFF_MASK; }
     while (cand) {                                                  // almost always at most one named slot
         if (slot_holds(v2, q.klo, q.khi)) { h = v2.z; off = v2.w & SLOT_OFF_MASK; break; }
         cand &= cand - 1;
         if (cand) v2 = *seek_second_slot(q, cand);
     }
-    seek_finish(s, K, h, off, (slot_flags(q.v) & SLOT_FLAG_OVERFLOW) != 0, l_probe(s));
+    full = (slot_flags(q.v) & SLOT_FLAG_OVERFLOW) != 0;
+}
+PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand, U4 v2) {
+    uint32_t h, off;
+    bool full;
+    seek_eval(q, cand, v2, h, off, full);
+    seek_finish(s, K, h, off, full, l_probe(s));
+}
+// the same with the speculative second probe (q1 / cand1 / v21: the k-mer at kmer_pos + 3, issued when seek_two(s)): it only
+// counts when the first probe is a definite miss — the scan of :92-111 in its own order
+PA_HD void seek_complete2(Lane& s, uint32_t K, const SeekProbe& q0, uint32_t cand0, U4 v20, bool two, const SeekProbe& q1, uint32_t cand1, U4 v21) {
+    uint32_t h, off;
+    bool full;
+    seek_eval(q0, cand0, v20, h, off, full);
+    const uint32_t probe = l_probe(s);
+    if (!two || h != NO_HANDLE || (full && probe < DICT_MAX_PROBES)) {
+        seek_finish(s, K, h, off, full, probe);
+        return;
+    }
+    l_set_kp(s, l_kp(s) + PA_SEEK_STRIDE);                          // :110 (kmer_pos + 3 <= L - K: seek_two)
+    seek_eval(q1, cand1, v21, h, off, full);
+    seek_finish(s, K, h, off, full, 0u);
 }
 
 // what a probe found -> the lane's next state (the tail of find_kmer_match and of :118-129). `h` = the chain block the k-mer
@@ -528,17 +559,17 @@ PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full,
         s.h = h;
         const uint32_t fl = l_flags(s), p = off & ENT_P_MASK;
         const uint32_t thr = L / 5;                                 // (0.2 * L as f64) as usize (:77) == L/5 for L < 2^31
-        if ((fl & F_FIRST_SEEK) && kp >= thr) {                     // :124-126
+        if ((fl & F_FIRST_SEEK) && kp >= thr) {                     // :124-126  (F_SPEC ends with the hit: fl is rebuilt below without it)
             const uint32_t back = (off >> ENT_BACK_SHIFT) & CH_BACK_MAX;
             s.rm = (s.rm & 0xFFFFu) | (kp << 16);                   // last_pos + 1 (:127)
             s.ph = h - back;                                        // :128 — the block with the most room to the left
             // prev_kmer_offset (:129): one base to the left of the k-mer — or, quirk Q1 kept, the k-mer's own first base when
             // it is the first k-mer of its node (kmer_offset == 0). Stored + 1; snp = 0
             s.rr = p + CH_STRIDE * back + ((off & ENT_NODE_START) ? 1u : 0u);
-            s.of = p | (((fl & ~F_FIRST_SEEK) | F_FRESH | F_LEFT_SEED) << 24);
+            s.of = p | (((fl & ~(F_FIRST_SEEK | F_SPEC)) | F_FRESH | F_LEFT_SEED) << 24);
             l_set_st(s, ST_LEFT);
         } else {
-            s.of = p | (((fl & ~F_FIRST_SEEK) | F_FRESH) << 24);
+            s.of = p | (((fl & ~(F_FIRST_SEEK | F_SPEC)) | F_FRESH) << 24);
             l_set_st(s, ST_FWD);
         }
         return;
@@ -549,6 +580,7 @@ PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full,
     }
     const uint32_t nkp = kp + PA_SEEK_STRIDE;                       // :110
     l_set_kp(s, nkp);
+    l_or_flags(s, F_SPEC);
     if (nkp > L - K) l_set_st(s, l_ncol(s) ? ST_ISECT : ST_NONE);   // None (:113) -> :294 break / :305-314
 }
 
@@ -574,12 +606,15 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
         seek_finish(s, K, h0 ? v0.x : h1 ? v1.x : NO_HANDLE, h0 ? v0.y : v1.y, v0.x != NO_HANDLE && v1.x != NO_HANDLE, probe);
         return;
     }
-    SeekProbe q;
+    SeekProbe q, q1;
+    const bool two = seek_two(s, K);
     seek_issue(s, ix, rd, q);
-    const uint32_t cand = seek_second(q);
-    U4 v2{0u, 0u, NO_HANDLE, 0u};
+    seek_issue(s, ix, rd, q1, PA_SEEK_STRIDE, two);
+    const uint32_t cand = seek_second(q), cand1 = two ? seek_second(q1) : 0u;
+    U4 v2{0u, 0u, NO_HANDLE, 0u}, v21{0u, 0u, NO_HANDLE, 0u};
     if (cand) v2 = *seek_second_slot(q, cand);
-    seek_complete(s, K, q, cand, v2);
+    if (cand1) v21 = *seek_second_slot(q1, cand1);
+    seek_complete2(s, K, q, cand, v2, two, q1, cand1, v21);
 }
 
 // ---------------------------------------------------------------------------------------------- FWD
@@ -728,6 +763,7 @@ PA_HD void fwd_finish_general(Lane& s, const DevIndexView& ix, ReadRef rd, ColRe
         if (careful) break;
     }
     nfl |= l_flags(s) & (F_SMALL_BASE | F_SPILL_OVERFLOW);           // (what push_node may have set)
+    if (st == ST_SEEK) nfl |= F_SPEC;                                 // a re-seek starts at the base the visit broke off at: a probable miss
     if (st == ST_FWD && !hopped) {                                    // goes on in this chain: the block whose window starts at most 64 bases before x
         const uint32_t adv = (x - 1) >> CH_STRIDE_LOG2;               // (x >= 1; a position that is a multiple of 64 stays the 64th of the block before:
         h += adv;                                                     //  a node that ends exactly there is still on that block's list)
@@ -808,7 +844,16 @@ PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, 
     const uint32_t eA = t0.x & SEG_E_MASK;
     const uint32_t nA = pa_min(pa_min(eA - x0, L - kp0), 128u);       // max_matchable_pos (:222-231), as far as this step goes
     const uint32_t pA = mism_prefix(dm, nA), cntA = pA;
-    const bool okA = snp0 + cntA <= allowed;                          // else: over budget somewhere in these bases, redo this node carefully
+    const bool okA = snp0 + cntA <= allowed;                          // else: the node visit breaks off inside these bases (:243-249)
+    uint32_t brk = 0;                                                 // ... at this base: the (allowed - snp0 + 1)-th mismatch of the visit
+    if (!okA) {
+        const uint32_t tol = allowed - snp0;                          // mismatches still within budget (seen_snp never exceeds allowed between steps)
+        const uint32_t w = (uint32_t)(tol >= dm.p0) + (uint32_t)(tol >= dm.p1) + (uint32_t)(tol >= dm.p2);   // the word that holds it (it lies among the first nA bases)
+        uint32_t skip = tol - sel4(w, 0u, dm.p0, dm.p1, dm.p2);
+        uint64_t mw = diff_word(dm, w);
+        for (; skip; --skip) mw &= mw - 1;
+        brk = 32u * w + (pa_ctz64(mw) >> 1);
+    }
     const uint32_t kpA = kp0 + nA, xA = x0 + nA;                      // :257
     const bool endA = okA && xA == eA && kpA < L;                     // node visit finished, read not (:259-261)
     // ---- A's end: the chain's next node, or the chain's right edges
@@ -855,16 +900,18 @@ PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, 
     }
     s.nc = (s.nc & ~NC_COL_MASK) | (np << 1) | (have ? 1u : 0u);
     // ---- the lane's next state
+    // A broken off: the breaking base is counted as a mismatch (:244) but not as matched (:247-249), the walk re-seeks from it or
+    // ends (:287-293). B over budget: nothing of B is consumed, the next step starts in it and breaks it off the same way
     const bool ended = useB ? kpB >= L : (okA && kpA >= L);           // :259-261
-    const uint32_t kp_dead = kpA;
-    uint32_t st = (ended || (dead && kp_dead > L - K)) ? (uint32_t)ST_ISECT : dead ? (uint32_t)ST_SEEK : (uint32_t)ST_FWD;
-    uint32_t kp = !okA ? kp0 : hop_edge ? kpA - (K - 1) : hopB ? (okB ? kpB : kp1) : kpA;
+    const uint32_t kp_dead = okA ? kpA : kp0 + brk;
+    const bool deadA = dead || !okA;
+    uint32_t st = (ended || (deadA && kp_dead > L - K)) ? (uint32_t)ST_ISECT : deadA ? (uint32_t)ST_SEEK : (uint32_t)ST_FWD;
+    uint32_t kp = !okA ? kp_dead : hop_edge ? kpA - (K - 1) : hopB ? (okB ? kpB : kp1) : kpA;
     uint32_t x = !okA ? x0 : hop_chain ? (linkA ? nx.y : 0u) : hopB ? (okB ? xB : x1) : xA;
-    const uint32_t cov = l_cov(s) + kadd + (okA ? nA : 0u) + (hopB ? 1u : 0u) + (useB ? nB : 0u) - (hop_edge ? K - 1 : 0u);   // :216, :254, :283
-    const uint32_t mism = l_mism(s) + (okA ? cntA : 0u) + (useB ? cntB : 0u);
-    const uint32_t snp = !okA ? snp0 : hopB ? (okB ? cntB : 0u) : snp0 + cntA;
-    const bool careful = !okA || (hopB && !okB);
-    const uint32_t nfl = (fl & ~(F_FRESH | F_CAREFUL)) | (careful ? F_CAREFUL : 0u) | (hop_edge ? F_FRESH : 0u);
+    const uint32_t cov = l_cov(s) + kadd + (okA ? nA : brk) + (hopB ? 1u : 0u) + (useB ? nB : 0u) - (hop_edge ? K - 1 : 0u);   // :216, :254, :283
+    const uint32_t mism = l_mism(s) + (okA ? cntA : allowed - snp0 + 1) + (useB ? cntB : 0u);
+    const uint32_t snp = hopB ? (okB ? cntB : 0u) : snp0 + cntA;
+    const uint32_t nfl = (fl & ~(F_FRESH | F_CAREFUL)) | (hop_edge ? F_FRESH : 0u) | (st == ST_SEEK ? F_SPEC : 0u);
     uint32_t h = hop_chain ? edge : s.h;
     if (st == ST_FWD && !hop_chain) {                                 // goes on in this chain (fwd_finish_general)
         const uint32_t adv = (x - 1) >> CH_STRIDE_LOG2;

@@ -541,14 +541,23 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             FwdLoad fl;
             PA_MARK("dual_state2");
             seek_issue(s2, ix, rr2, pq);                               // home slot of the k-mer (HBM)
+            // a lane whose scan is past a miss probes the next position of the scan as well (another line, in flight together)
+            // (only in steps where at least eight lanes do: the second k-mer and hash are the whole wave's instructions)
+            const bool two_l = active2 && seek_two(s2, K);
+            const bool pairs = __popcll(__ballot(two_l)) >= 8;
+            const bool two = two_l && pairs;
+            SeekProbe pq1;
+            pq1.bucket = ix.table; pq1.home = 0; pq1.klo = pq1.khi = 0; pq1.v = U4{0u, 0u, NO_HANDLE, 0u};
+            if (pairs) seek_issue(s2, ix, rr2, pq1, PA_SEEK_STRIDE, two);   // (a wave-uniform branch: the waits behind it stay exact)
             fwd_issue(s, ix, fl);                                      // node header + sequence words (MALL / L2)
             __builtin_amdgcn_sched_barrier(0);                         // (left alone the scheduler finishes the probe first and only then issues the node loads)
             PA_MARK("dual_issued");
             // the probe's second load, only for the lanes whose home slot holds another key and names other slots (same line,
             // now in the L1 / L2)
-            const uint32_t cand = active2 ? seek_second(pq) : 0u;
-            U4 pv2{0u, 0u, NO_HANDLE, 0u};
+            const uint32_t cand = active2 ? seek_second(pq) : 0u, cand1 = two ? seek_second(pq1) : 0u;
+            U4 pv2{0u, 0u, NO_HANDLE, 0u}, pv21{0u, 0u, NO_HANDLE, 0u};
             if (cand) pv2 = *seek_second_slot(pq, cand);
+            if (cand1) pv21 = *seek_second_slot(pq1, cand1);
             const unsigned long long t1 = PA_DBG ? __builtin_readcyclecounter() : 0ull;
             PA_MARK("dual_second");
             if (active) fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 dbg_clk[ST_COUNT + 1] += t1 - t_pop; dbg_clk[ST_COUNT + 3] += t3 - t1;
             }
             if (active2) {
-                seek_complete(s2, K, pq, cand, pv2);
+                seek_complete2(s2, K, pq, cand, pv2, two, pq1, cand1, pv21);
                 nq2 = queue_of(s2, K);   // (may rewrite the state: before the store)
                 stA[slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
                 stB[slot2] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};

@@ -13,6 +13,10 @@
 // exactly as in pa_process_reads; output order is input order (the reference's is completion order, :490).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <memory>
 #include <new>
@@ -23,6 +27,25 @@
 using namespace pa;
 using namespace pa::ingest;
 
+// bytes of a batch's records: grows without initialising what the copy is about to overwrite (a std::vector would zero it first)
+struct RawText {
+    char* p = nullptr;
+    size_t n = 0, cap = 0;
+    ~RawText() { free(p); }
+    bool grow(size_t extra) {
+        if (n + extra <= cap) return true;
+        size_t want = cap ? cap : (size_t)1 << 20;
+        while (want < n + extra) want *= 2;
+        char* q = (char*)realloc(p, want);
+        if (!q) return false;
+        p = q;
+        cap = want;
+        return true;
+    }
+    const char* data() const { return p; }
+    void clear() { n = 0; }
+};
+
 struct pa_record_stream {
     pa_index* idx = nullptr;
     std::unique_ptr<Pool> pool;
@@ -31,13 +54,14 @@ struct pa_record_stream {
     const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
     uint64_t batch_reads = 4u << 20;
     BatchCtx ctx[2];
-    std::vector<char> text[2];     // ids and sequences of the batch's records (Record offsets point into it)
+    RawText text[2];               // ids and sequences of the batch's records (Record offsets point into it)
     uint32_t maxlen[2] = {0, 0};
     bool inflight[2] = {false, false};
     int cur = 0;                   // the batch being filled
     std::deque<TextBuf> outq;      // rendered text in order; out_off = bytes of the front buffer already pulled
     size_t out_off = 0;
     uint64_t n_reads = 0, n_flagged = 0;
+    double stage[PA_INGEST_STAGES] = {0, 0, 0, 0, 0, 0, 0, 0};   // pa_record_stream_stage_seconds
     int rc = PA_OK;                // sticky: after a failure every call reports it
     std::string why;
 };
@@ -49,7 +73,10 @@ int fail_sticky(pa_record_stream* s, int rc) {
     return rc;
 }
 
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 void render(pa_record_stream* s, int k) {
+    const double t_render = now_s();
     BatchCtx& c = s->ctx[k];
     const int P = s->pool->size() * 4;
     std::vector<TextBuf> parts((size_t)P);
@@ -69,6 +96,8 @@ void render(pa_record_stream* s, int k) {
     c.n = 0;
     s->text[k].clear();
     s->maxlen[k] = 0;
+    s->stage[4] += now_s() - t_render;
+    s->stage[7] = (double)s->n_reads;
 }
 
 // the batch being filled goes to the GPU; the one before it is waited for and rendered. (Both batches share the stream and
@@ -83,9 +112,13 @@ int submit(pa_record_stream* s) {
     c.wpr = pa_words_per_read(s->maxlen[k] ? s->maxlen[k] : 1);
     int rc = batch_ensure(s->idx, c, c.n, c.wpr, s->batch_reads);
     if (rc != PA_OK) return rc;
+    double t0 = now_s();
     batch_pack_tiles(*s->pool, c, s->text[k].data());
+    s->stage[1] += now_s() - t0; t0 = now_s();
     if (s->inflight[o] && (rc = batch_finish(s->idx, s->ctx[o], s->stream)) != PA_OK) return rc;
+    s->stage[2] += now_s() - t0; t0 = now_s();
     if ((rc = batch_launch(s->idx, c, s->stream)) != PA_OK) return rc;
+    s->stage[3] += now_s() - t0;
     s->inflight[k] = true;
     if (s->inflight[o]) render(s, o);
     s->cur = o;
@@ -137,20 +170,39 @@ int pa_records_push(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_
         const uint64_t il = id_offsets[i + 1] - id_offsets[i], sl = seq_offsets[i + 1] - seq_offsets[i];
         if (il > 0xFFFFFFFFull || sl > 0xFFFFFFFFull || (il && !ids) || (sl && !seqs)) return fail(PA_ERR_INVALID_ARG, "record %llu: bad id or sequence", (unsigned long long)i);
     }
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t il = id_offsets[i + 1] - id_offsets[i], sl = seq_offsets[i + 1] - seq_offsets[i];
+    // the records go into the batch being filled as two blocks — all their ids, then all their sequences — copied and indexed
+    // by the worker pool (the caller's buffers are laid out like that already: a per-record copy cost 70 ns per record)
+    for (uint64_t i = 0; i < n;) {
         const int k = s->cur;
-        std::vector<char>& t = s->text[k];
-        Record r;
-        r.id_off = t.size();
-        r.id_len = (uint32_t)il;
-        if (il) t.insert(t.end(), (const char*)ids + id_offsets[i], (const char*)ids + id_offsets[i + 1]);
-        r.seq_off = t.size();
-        r.seq_len = (uint32_t)sl;
-        if (sl) t.insert(t.end(), (const char*)seqs + seq_offsets[i], (const char*)seqs + seq_offsets[i + 1]);
-        s->ctx[k].recs.push_back(r);
-        s->maxlen[k] = std::max(s->maxlen[k], r.seq_len);
-        if (s->ctx[k].recs.size() >= s->batch_reads) {
+        BatchCtx& c = s->ctx[k];
+        const uint64_t have = c.recs.size(), m = std::min<uint64_t>(n - i, s->batch_reads - have);
+        const uint64_t ib = id_offsets[i + m] - id_offsets[i], sb = seq_offsets[i + m] - seq_offsets[i];
+        RawText& t = s->text[k];
+        if (!t.grow(ib + sb)) return fail_sticky(s, fail(PA_ERR_OOM, "out of memory for %llu bytes of records", (unsigned long long)(ib + sb)));
+        const uint64_t id_base = t.n, seq_base = t.n + ib;
+        t.n += ib + sb;
+        c.recs.resize(have + m);
+        const int P = s->pool->size();
+        std::vector<uint32_t> tmax((size_t)P, 0);
+        s->pool->run(P, [&](int w) {
+            const uint64_t a = m * (uint64_t)w / P, b = m * (uint64_t)(w + 1) / P;
+            if (a == b) return;
+            if (ids) memcpy(t.p + id_base + (id_offsets[i + a] - id_offsets[i]), ids + id_offsets[i + a], id_offsets[i + b] - id_offsets[i + a]);
+            if (seqs) memcpy(t.p + seq_base + (seq_offsets[i + a] - seq_offsets[i]), seqs + seq_offsets[i + a], seq_offsets[i + b] - seq_offsets[i + a]);
+            uint32_t mx = 0;
+            for (uint64_t j = a; j < b; ++j) {
+                Record& r = c.recs[have + j];
+                r.id_off = id_base + (id_offsets[i + j] - id_offsets[i]);
+                r.id_len = (uint32_t)(id_offsets[i + j + 1] - id_offsets[i + j]);
+                r.seq_off = seq_base + (seq_offsets[i + j] - seq_offsets[i]);
+                r.seq_len = (uint32_t)(seq_offsets[i + j + 1] - seq_offsets[i + j]);
+                mx = std::max(mx, r.seq_len);
+            }
+            tmax[(size_t)w] = mx;
+        });
+        for (uint32_t v : tmax) s->maxlen[k] = std::max(s->maxlen[k], v);
+        i += m;
+        if (c.recs.size() >= s->batch_reads) {
             const int rc = submit(s);
             if (rc != PA_OK) return fail_sticky(s, rc);
         }
@@ -167,7 +219,9 @@ int pa_records_flush(pa_record_stream* s) {
     for (int k = 0; k < 2; ++k) {
         const int b = s->cur ^ 1 ^ k;   // the batch launched last is the one before `cur`
         if (!s->inflight[b]) continue;
+        const double t0 = now_s();
         if ((rc = batch_finish(s->idx, s->ctx[b], s->stream)) != PA_OK) return fail_sticky(s, rc);
+        s->stage[2] += now_s() - t0;
         render(s, b);
     }
     return PA_OK;
@@ -197,6 +251,13 @@ int pa_records_pull(pa_record_stream* s, char* buf, size_t cap, size_t* n_bytes)
         else break;   // the buffer is full up to a line boundary
     }
     *n_bytes = got;
+    return PA_OK;
+}
+
+int pa_record_stream_stage_seconds(const pa_record_stream* s, double out[PA_INGEST_STAGES]) {
+    if (!s || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    memcpy(out, s->stage, sizeof s->stage);
+    out[6] = out[1] + out[2] + out[3] + out[4];
     return PA_OK;
 }
 
