@@ -472,7 +472,11 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         // node lines are on their way: two round trips in flight per wave instead of one (K <= 32: the two-word dictionary
         // has no dependent second load to hide).
         const uint32_t n_seek_q = PA_CNT(ST_SEEK), n_fwd_q = PA_CNT(ST_FWD);
-        const bool dual = (sel == ST_FWD || sel == ST_SEEK) && K <= 32 && n_seek_q != 0 && n_fwd_q != 0 && !PA_ABLATE(4u);
+#ifndef PA_SEEK_MIN   // probes ride with a forward step only from this many waiting slots on (or when little forward work is left): the probe half is
+#define PA_SEEK_MIN 32u   // the whole wave's instructions however few lanes it serves (same-box A/B of 1 / 32 / 48: config 3 -1.8 %, config 5 -3.8 % time at 32)
+#endif
+        const bool seek_ok = n_seek_q >= PA_SEEK_MIN || n_fwd_q < 24;
+        const bool dual = (sel == ST_FWD || sel == ST_SEEK) && K <= 32 && n_seek_q != 0 && n_fwd_q != 0 && seek_ok && !PA_ABLATE(4u);
         if (dual) sel = ST_FWD;
         const uint32_t n_own = dual ? (n_fwd_q < 64 ? n_fwd_q : 64) : bestn < 64 ? bestn : 64;
         // an output step that does not fill the wave takes EMPTY slots into its idle lanes: they are refilled by the same text
@@ -540,7 +544,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             SeekProbe pq;
             FwdLoad fl;
             PA_MARK("dual_state2");
-            seek_issue(s2, ix, rr2, pq);                               // home slot of the k-mer (HBM)
+            pq.bucket = ix.table; pq.home = 0; pq.klo = pq.khi = 0; pq.v = U4{0u, 0u, NO_HANDLE, 0u};
+            if (n2) seek_issue(s2, ix, rr2, pq);                       // home slot of the k-mer (HBM); (n2: wave-uniform — a plain forward step skips the probe half)
             // a lane whose scan is past a miss probes the next position of the scan as well (another line, in flight together)
             // (only in steps where at least eight lanes do: the second k-mer and hash are the whole wave's instructions)
             const bool two_l = active2 && seek_two(s2, K);

@@ -31,6 +31,6 @@ for arg in sys.argv[1:]:
     out["workloads"][name] = {"reads_per_launch": reads, "kernels": per_kernel,
                               "FETCH_SIZE_KB": sum(k.get("FETCH_SIZE", 0.0) for k in per_kernel.values()),
                               "WRITE_SIZE_KB": sum(k.get("WRITE_SIZE", 0.0) for k in per_kernel.values()),
-                              "map_kernel_l2_misses": per_kernel.get("pa_map_pool", {}).get("TCC_MISS_sum"), "source": "profiles/r03_%s_pmc.txt" % name}
+                              "map_kernel_l2_misses": per_kernel.get("pa_map_pool", {}).get("TCC_MISS_sum"), "source": "profiles/r04_%s_pmc.txt" % name}
 json.dump(out, open(ROOT / "profiles" / "latest_pmc.json", "w"), indent=1)
 print(json.dumps({k: (v["FETCH_SIZE_KB"], v["WRITE_SIZE_KB"]) for k, v in out["workloads"].items()}))
