@@ -5,7 +5,8 @@
 //
 //   dictionary  (k <= 32) open addressing over 16-byte SLOTS, four to a 64-byte bucket line:
 //                 slot = {u32 key_lo, u32 key_hi, u32 handle (0xFFFFFFFF = empty), u32 off (bits 0..23) | ~flags << 24}
-//               bucket = mulhi32(fmix64(key) >> 32, nbuckets); every key also has a HOME slot in its bucket, j = fmix64(key) & 3.
+//               bucket = mulhi32(x, nbuckets) with x = a 32-bit multiplicative mix of the key's two words (lane_steps.hpp,
+//               pa_bucket_home); every key also has a HOME slot in its bucket, j = x & 3.
 //               A key sits in its home slot when that was free (78 % of the keys at load 0.5: the builders place all home
 //               keys first), else in another slot t of the bucket — then flag bit ((t - j - 1) & 3) of the HOME slot says so —
 //               else it overflows into the next bucket (flag bit 3 of the home slot) where the same rule applies. Flags are

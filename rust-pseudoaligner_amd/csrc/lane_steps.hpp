@@ -482,12 +482,18 @@ struct SeekProbe {
 };
 // bucket and home slot of a k-mer (one hash)
 PA_HD uint32_t pa_bucket_home(uint64_t kmer, uint32_t nbuckets, uint32_t& home) {
-    const uint64_t m = pa_mix64(kmer);
-    home = (uint32_t)m & 3u;
+    // three 32-bit multiplies (fmix64 is two 64-bit ones = eight quarter-rate instructions per probe): the dictionary's placement
+    // is as good with either on the config-3 keys (home slot 79 % / other slot of the bucket 17 % / next bucket 4 % at load 0.5,
+    // furthest key 14 buckets from home), and the mapping kernel is bound by instruction issue (config 5 -4 % time, config 3 +-0)
+    uint32_t x = (uint32_t)kmer * 0x9E3779B1u + (uint32_t)(kmer >> 32) * 0x85EBCA77u;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 13;
+    home = x & 3u;
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi((uint32_t)(m >> 32), nbuckets);
+    return __umulhi(x, nbuckets);
 #else
-    return (uint32_t)(((m >> 32) * nbuckets) >> 32);
+    return (uint32_t)(((uint64_t)x * nbuckets) >> 32);
 #endif
 }
 // does this step also probe kmer_pos + 3? (a lane past a miss, not in the middle of an overflow chain, with a k-mer left there)

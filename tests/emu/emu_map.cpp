@@ -42,6 +42,29 @@ uint64_t emu_index_info(const emu_index* e, int what) {
         case 1: return e->fd.nbuckets;
         case 2: return e->fd.blobs.size();
         case 4: return e->fd.num_chains;
+        case 5: return e->fd.seg_g.size();
+        case 6: {   // chain blocks that break a rule of device_layout.hpp: slots in order record [extension] [edges | link], ends ascending,
+                    // the record mask of slot 0 naming exactly the records, edges / link only behind a chain's last record
+            uint64_t bad = 0;
+            for (size_t b = 0; b + pa::CH_BLOCK <= e->fd.blobs.size(); b += pa::CH_BLOCK) {
+                const uint32_t* sl = reinterpret_cast<const uint32_t*>(e->fd.blobs.data() + b);
+                const uint32_t recmask = sl[0] >> pa::SEG_RECMASK_SHIFT;
+                uint32_t t = 0, seen = 0, prev_e = 0;
+                bool ok = (recmask & 1u) != 0, ended = false;
+                while (ok && t < pa::CH_SLOTS && ((recmask >> t) & 1u)) {
+                    const uint32_t w0 = sl[4 * t], e_rel = w0 & pa::SEG_E_MASK;
+                    ok = !ended && e_rel > prev_e;
+                    prev_e = e_rel;
+                    seen |= 1u << t;
+                    t += 1 + ((w0 & pa::SEG_WIDE) ? 1 : 0);
+                    if (w0 & (pa::SEG_EDGES | pa::SEG_LINK)) { ok = ok && (w0 & pa::SEG_LAST) && !((w0 & pa::SEG_EDGES) && (w0 & pa::SEG_LINK)); ++t; }
+                    if (w0 & pa::SEG_LAST) ended = true;
+                    ok = ok && t <= pa::CH_SLOTS;
+                }
+                if (!ok || seen != recmask) ++bad;
+            }
+            return bad;
+        }
         case 3: return e->fd.max_class_len;
         default: return 0;
     }

@@ -137,6 +137,17 @@ def test_device_dictionary_layout(small_index):
     assert info["nbuckets"] * 4 >= 2 * info["num_kmers"]   # load factor <= 0.5
 
 
+@pytest.mark.parametrize("k", [20, 31])
+def test_chain_block_layout_is_well_formed(small_index, k):
+    """chains merge nodes (fewer chains than nodes), tails add copies (more records than nodes), and every 128-byte block obeys the
+    slot grammar of device_layout.hpp (checked block by block inside the emulator library)"""
+    host = small_index(k)
+    info = helpers.Emu(host).info()
+    n = host.arrays()["num_nodes"]
+    assert 0 < info["num_chains"] < n < info["num_segs"]
+    assert info["blob_bytes"] % 128 == 64 and info["bad_blocks"] == 0   # (whole blocks + the 64-byte tail pad)
+
+
 def test_flatten_rejects_inconsistent_graphs(small_index):
     """a k-mer present in two nodes / a dangling extension must be refused at index creation."""
     host = small_index(20)
