@@ -158,26 +158,14 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
 
     // ---- classes: 16-byte aligned records {class id, id0, id1, ...} ----
     if (f.num_transcripts >= 0xFFFFFFFFu) return fail(PA_ERR_UNSUPPORTED, "too many transcripts");   // 0xFFFFFFFF pads the records
-    // A class of up to EC_SHORT_IDS ids (every class that fits ONE window of 32 does) has its record at EC_SHORT_STRIDE * class id:
-    // list mode finds it without a table lookup (a chain block's one-slot record carries the class id, not the record ref). Longer
-    // classes follow behind, addressed through class_ref like all of them
     out.class_ref.resize(f.num_classes);
     out.class_len.resize(f.num_classes);
-    if ((uint64_t)f.num_classes * EC_SHORT_STRIDE >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "too many classes");
-    out.ec.assign(4ull * EC_SHORT_STRIDE * f.num_classes, 0xFFFFFFFFu);
     for (uint32_t c = 0; c < f.num_classes; ++c) {
         const uint64_t len = f.ec_offset[c + 1] - f.ec_offset[c];
         if (len >= 0xFFFFFFFFull || out.ec.size() / 4 >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "class id lists too large");
+        out.class_ref[c] = (uint32_t)(out.ec.size() / 4);
         out.class_len[c] = (uint32_t)len;
         out.max_class_len = std::max(out.max_class_len, (uint32_t)len);
-        if (len <= EC_SHORT_IDS) {
-            out.class_ref[c] = EC_SHORT_STRIDE * c;
-            uint32_t* r = out.ec.data() + 4ull * out.class_ref[c];
-            r[0] = c;
-            std::copy(f.ec_ids + f.ec_offset[c], f.ec_ids + f.ec_offset[c + 1], r + 1);   // (the rest of the slot stays 0xFFFFFFFF padding)
-            continue;
-        }
-        out.class_ref[c] = (uint32_t)(out.ec.size() / 4);
         out.ec.push_back(c);
         out.ec.insert(out.ec.end(), f.ec_ids + f.ec_offset[c], f.ec_ids + f.ec_offset[c + 1]);
         while (out.ec.size() % 4 || out.ec.size() - 4ull * out.class_ref[c] < 8) out.ec.push_back(0xFFFFFFFFu);   // >= 8 words, 0xFFFFFFFF padded

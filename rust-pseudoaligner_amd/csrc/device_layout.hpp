@@ -64,9 +64,7 @@
 //   ec          class records, 16-byte aligned, at least 32 bytes, padded with 0xFFFFFFFF: record r = words [4r, ...) =
 //               {class id, id0, id1, ...} — the sorted transcript-id lists of eq_classes: Vec<Vec<u32>>
 //               (src/pseudoaligner.rs:29); a class of <= 7 ids is two 16-byte loads and needs no length checks.
-//               The record of a class of up to 35 ids sits at record ref 9 * class id (so list mode finds the record of a
-//               one-window class, whose block record carries only the class id, without a lookup); longer classes follow.
-//   class_ref/class_len  u32[num_classes] record ref and length by class id
+//   class_ref/class_len  u32[num_classes] record ref and length by class id (list mode: the record of a one-window class)
 //   wtable      window classes by content: open addressing over 64-byte lines of three {cmin, cmask, cmin2, cmask2, class
 //               id} entries (class id 0xFFFFFFFF = empty), line = mulhi32(hash(windows), wbuckets), linear probing —
 //               tells in ONE fetch whether a window result that is a strict subset of every class seen is itself a class
@@ -103,7 +101,6 @@ PA_HD uint32_t dict_entry_off(uint32_t c, bool node_start) {
     return (c & ENT_P_MASK) | (node_start ? ENT_NODE_START : 0u) | ((j < CH_BACK_MAX ? j : CH_BACK_MAX) << ENT_BACK_SHIFT);
 }
 constexpr uint32_t CLASS_WINDOW = 32;   // ids per class window (one mask word)
-constexpr uint32_t EC_SHORT_IDS = 35, EC_SHORT_STRIDE = 9;   // class records of up to 35 ids: at 9 * class id (16-byte units: {class id, 35 ids})
 constexpr uint32_t SLOTS_PER_BUCKET = 4;
 constexpr uint32_t BUCKET_WORDS = 16;
 constexpr uint32_t SLOT_WORDS = 4;                 // k <= 32: {key_lo, key_hi, handle, off | ~flags << 24}

@@ -391,9 +391,9 @@ PA_HD bool push_node(Lane& s, ColRef c, const DevIndexView& ix, const Seg& hd, u
     }
     // list mode: win = {ref of class 0, 1, 2, ref of the shortest class so far}, wcand = the shortest length (both in LDS:
     // the row in HBM is only written during the walk, never read). A one-window class does not carry its record ref in the
-    // block: it follows from the class id
+    // block: looked up here (a dependent load that only list-mode reads pay)
     const bool wide = (hd.flags & SEG_WIDE) != 0;
-    const uint32_t ec_ref = wide ? hd.ec_ref : EC_SHORT_STRIDE * hd.cid, ec_len = wide ? hd.ec_len : pa_popc32(hd.cmask);   // (a one-window class has <= 32 ids: device_layout.hpp, ec)
+    const uint32_t ec_ref = wide ? hd.ec_ref : ix.class_ref[hd.cid], ec_len = wide ? hd.ec_len : pa_popc32(hd.cmask);
     U4 r = *reinterpret_cast<const U4*>(c.win);
     const bool dup = (n > 0 && r.x == ec_ref) | (n > 1 && r.y == ec_ref) | (n > 2 && r.z == ec_ref) | (n > 0 && r.w == ec_ref);
     if (dup) return false;
