@@ -514,7 +514,7 @@ def ingest_leg(env, run, n):
         chunk = 1 << 20
         id_off = (np.arange(chunk + 1, dtype=np.uint64) * 10)
         seq_off = (np.arange(chunk + 1, dtype=np.uint64) * wl["read_len"])
-        buf = C.create_string_buffer(1 << 24)
+        buf = C.create_string_buffer(1 << 28)   # (one pull per rendered batch: the library copies big pieces on its worker pool)
         nb = C.c_size_t()
         t0 = time.perf_counter()
         pulled = 0

@@ -185,7 +185,7 @@ pub fn process_reads<K: Kmer + Sync + Send, P: AsRef<Path> + Debug>(
 
     let stdout = io::stdout();
     let mut out = io::BufWriter::with_capacity(1 << 22, stdout.lock());
-    let mut text = vec![0u8; 1 << 22];
+    let mut text = vec![0u8; 1 << 26];   // (big pulls are copied by the library's worker pool)
     let mut millions_reported = 0u64;
     let mut drain = |out: &mut dyn Write| -> Result<(), Error> {
         loop {

@@ -132,30 +132,6 @@ void for_each_newline(const char* d, uint64_t from, uint64_t to, F&& fn) {
         if (d[i] == '\n' && !fn(i)) return;
 }
 
-struct RecPos {   // where a record lies in the text: found by the scan, read by the pack stage
-    uint64_t start;      // of the '@'
-    uint32_t hdr, seq;   // bytes of the header line and of the sequence line (without their line breaks)
-};
-
-
-struct IngestCache {   // the two batches in flight; parked on the index between calls (pa_common.hpp)
-    BatchCtx ctx[2];
-    std::vector<RecPos> rec_pos;   // 16 bytes per record of the file: kept, or every call would page 256 MB in again
-    // the stream the batches run on travels with the buffers: its launch context inside the index (2 GB of list-mode rows)
-    // is then reused by the next call instead of being stranded behind a destroyed stream
-    pa_index* idx = nullptr;
-    hipStream_t stream = nullptr;
-    static void destroy(void* p) {
-        IngestCache* c = static_cast<IngestCache*>(p);
-        for (BatchCtx& b : c->ctx) b.release();
-        if (c->stream) {
-            if (c->idx) (void)pa_index_release_stream(c->idx, c->stream);
-            (void)hipStreamDestroy(c->stream);
-        }
-        delete c;
-    }
-};
-
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(PA_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
 
 // The parallel scan finds records by counting lines, four to a record. A file that does not have that shape — sequence or

@@ -277,6 +277,30 @@ inline void batch_pack_tiles(Pool& pool, BatchCtx& c, const char* text) {
 }
 
 // the GPU leg of a batch, asynchronous on `stream`: tiles H2D -> index.map_read for every read (:451) -> records D2H
+struct RecPos {   // where a record lies in the text: found by the scan, read by the pack stage
+    uint64_t start;      // of the '@'
+    uint32_t hdr, seq;   // bytes of the header line and of the sequence line (without their line breaks)
+};
+
+
+struct IngestCache {   // the two batches in flight of a pa_process_reads call or a record stream; parked on the index in between (pa_common.hpp)
+    BatchCtx ctx[2];
+    std::vector<RecPos> rec_pos;   // 16 bytes per record of the file: kept, or every call would page 256 MB in again
+    // the stream the batches run on travels with the buffers: its launch context inside the index (2 GB of list-mode rows)
+    // is then reused by the next call instead of being stranded behind a destroyed stream
+    pa_index* idx = nullptr;
+    hipStream_t stream = nullptr;
+    static void destroy(void* p) {
+        IngestCache* c = static_cast<IngestCache*>(p);
+        for (BatchCtx& b : c->ctx) b.release();
+        if (c->stream) {
+            if (c->idx) (void)pa_index_release_stream(c->idx, c->stream);
+            (void)hipStreamDestroy(c->stream);
+        }
+        delete c;
+    }
+};
+
 // wall seconds of the host stages of this thread's last pa_process_reads call (pa_process_reads_stage_seconds)
 inline double* last_stage_seconds() {
     static thread_local double st[PA_INGEST_STAGES] = {0, 0, 0, 0, 0, 0, 0, 0};

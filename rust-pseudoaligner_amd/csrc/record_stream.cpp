@@ -49,11 +49,12 @@ struct RawText {
 struct pa_record_stream {
     pa_index* idx = nullptr;
     std::unique_ptr<Pool> pool;
-    hipStream_t stream = nullptr;
+    IngestCache* cache = nullptr;   // the batches' pinned and device buffers and their HIP stream: taken from the index (warm, if a
+    hipStream_t stream = nullptr;   // pa_process_reads call or another record stream left them there) and parked there again at the end
     int device = 0;
     const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
     uint64_t batch_reads = 4u << 20;
-    BatchCtx ctx[2];
+    BatchCtx* ctx = nullptr;       // = cache->ctx
     RawText text[2];               // ids and sequences of the batch's records (Record offsets point into it)
     uint32_t maxlen[2] = {0, 0};
     bool inflight[2] = {false, false};
@@ -139,11 +140,18 @@ int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads
     int T = num_threads > 0 ? num_threads : usable_threads();
     if (T < 1) T = 1;
     s->pool.reset(new Pool(T));
-    if (hipSetDevice(s->device) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess) {
-        s->stream = nullptr;
+    s->cache = static_cast<IngestCache*>(index_take_ingest_cache(idx));   // buffers of an earlier call, if any: allocating them costs more than packing a batch
+    if (!s->cache) s->cache = new (std::nothrow) IngestCache();
+    if (!s->cache) { delete s; return fail(PA_ERR_OOM, "out of memory"); }
+    s->cache->idx = idx;
+    s->ctx = s->cache->ctx;
+    for (int k = 0; k < 2; ++k) { s->ctx[k].recs.clear(); s->ctx[k].n = 0; s->ctx[k].first = 0; }   // (a parked set still names its last batch)
+    if (hipSetDevice(s->device) != hipSuccess || (!s->cache->stream && hipStreamCreate(&s->cache->stream) != hipSuccess)) {
+        s->cache->stream = nullptr;
         pa_record_stream_destroy(s);
         return fail(PA_ERR_HIP, "hipStreamCreate failed");
     }
+    s->stream = s->cache->stream;
     *out = s;
     return PA_OK;
 }
@@ -151,11 +159,12 @@ int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads
 void pa_record_stream_destroy(pa_record_stream* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    if (s->stream) {
-        (void)pa_index_release_stream(s->idx, s->stream);   // (synchronises the stream; its launch context inside the index goes with it)
-        (void)hipStreamDestroy(s->stream);
+    if (s->cache) {
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        for (int k = 0; k < 2; ++k) { s->ctx[k].recs.clear(); s->ctx[k].n = 0; }
+        if (s->rc == PA_OK && s->stream) index_put_ingest_cache(s->idx, s->cache, IngestCache::destroy);   // the next stream / pa_process_reads call starts warm
+        else IngestCache::destroy(s->cache);   // (releases the stream's launch context inside the index and the stream)
     }
-    for (BatchCtx& b : s->ctx) b.release();
     delete s;
 }
 
@@ -244,7 +253,15 @@ int pa_records_pull(pa_record_stream* s, char* buf, size_t cap, size_t* n_bytes)
                 break;
             }
         }
-        memcpy(buf + got, f.mem.data() + s->out_off, take);
+        if (take >= ((size_t)4 << 20)) {   // a big piece: copied by the pool (it is idle while the caller pulls; one thread copies 8 GB/s, the tuples of 4 M reads are 0.23 GB)
+            const int P = s->pool->size();
+            const char* src = f.mem.data() + s->out_off;
+            char* dst = buf + got;
+            s->pool->run(P, [&](int w) {
+                const size_t a = take * (size_t)w / P, b = take * (size_t)(w + 1) / P;
+                if (b > a) memcpy(dst + a, src + a, b - a);
+            });
+        } else memcpy(buf + got, f.mem.data() + s->out_off, take);
         got += take;
         s->out_off += take;
         if (s->out_off == f.len) { s->outq.pop_front(); s->out_off = 0; }

@@ -385,6 +385,39 @@ def test_record_stream_is_process_reads_for_a_caller_that_holds_the_reader(align
         rs.close()
 
 
+def test_record_streams_and_process_reads_share_their_parked_buffers(aligners, tmp_path):
+    """the pinned / device buffers of the two batches in flight are parked on the index between calls and taken over by whichever
+    form of process_reads runs next: file -> stream -> two streams at once -> file, every output equal to the oracle's tuples"""
+    a = aligners(24)
+    ids, seqs = helpers.read_fastq()
+    ids, seqs = list(ids[:4000]), list(seqs[:4000])
+    want = _expected_lines(a, ids, seqs)
+    fq = tmp_path / "in.fq"
+    fq.write_text("".join("@%s\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in zip(ids, seqs)))
+
+    def by_file():
+        out = tmp_path / "out.txt"
+        assert pa.process_reads(str(fq), a, str(out), 3)[0] == len(ids)
+        return out.read_text().splitlines()
+
+    def by_stream(rs, lo, hi):
+        for i in range(lo, hi, 700):
+            rs.push(ids[i:min(i + 700, hi)], seqs[i:min(i + 700, hi)])
+        rs.flush()
+        return rs.drain().decode().splitlines()
+
+    assert by_file() == want
+    rs = pa.RecordStream(a, 2, 1024)
+    assert by_stream(rs, 0, 4000) == want
+    rs.close()
+    r1, r2 = pa.RecordStream(a, 2, 512), pa.RecordStream(a, 1, 2048)          # the second finds nothing parked and makes its own
+    got2 = by_stream(r2, 1000, 4000)
+    got1 = by_stream(r1, 0, 1000)
+    assert got1 + got2 == want
+    r1.close(); r2.close()
+    assert by_file() == want
+
+
 def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
     """the ingest pipeline of process_reads: many small batches, every thread count, CRLF, no final newline, trailing
     blank lines, ragged read lengths (words per read change between batches), lower case and N, empty input"""
