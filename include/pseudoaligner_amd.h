@@ -288,7 +288,7 @@ int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offs
  * wrapped over several lines, which bio's reader accepts) is first rewritten into that form by a sequential pass (as many
  * quality lines as sequence lines, as bio 1.5 reads them), then scanned in parallel like any other. PA_ERR_FORMAT with
  * the record number for text that is no FASTQ or ends inside a record. Read ids are cut at the first space, as record.id() does.
- * The pinned host and device buffers of the two batches in flight (about 0.4 GB of each for 4 M-read batches of 150-base
+ * The pinned host and device buffers of the two batches in flight (about 0.2 GB of each for 2 Mi-read batches of 150-base
  * reads) and the record positions of the file (16 bytes per read, at most 1 GB of them) stay parked on `idx` after a successful
  * call, so that the next file starts with warm buffers; concurrent calls on one index each use their own set;
  * pa_index_destroy frees them. */
@@ -299,7 +299,7 @@ int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path
  * (src/pseudoaligner.rs:420-425), so its drop-in replacement cannot ask for a path: the caller pushes the records it reads —
  * ids as record.id() returns them (:456), sequences as record.seq() (:449), both concatenated with offsets[n+1] — and pulls the
  * reference's Debug tuples (:490), one line per record, in PUSH order. Behind the two calls runs the batch pipeline of
- * pa_process_reads: a full batch (batch_reads, 0 = 4 Mi reads) is packed by `num_threads` workers (0 = all usable CPUs) and
+ * pa_process_reads: a full batch (batch_reads, 0 = 2 Mi reads) is packed by `num_threads` workers (0 = all usable CPUs) and
  * launched on the stream's own HIP stream while the caller goes on reading; the batch before it is rendered meanwhile.
  *   push   copies the records (the caller's buffers are free afterwards); may pack + launch a batch and render the previous one
  *   pull   copies rendered text into buf, whole lines only, never waits for the GPU; *n_bytes = 0: nothing ready yet

@@ -42,7 +42,7 @@ using namespace pa::ingest;
 
 namespace {
 
-constexpr uint64_t DEFAULT_BATCH_READS = 4u << 20;   // PA_INGEST_BATCH overrides (tests exercise the batch seams with small values)
+constexpr uint64_t DEFAULT_BATCH_READS = 2u << 20;   // (4 Mi reads left 1.3 GB of the mapping and 0.23 GB of text to the last, unoverlapped batch: 33 ms of tear-down per 8 M reads against 12)   // PA_INGEST_BATCH overrides (tests exercise the batch seams with small values)
 
 
 // in-order writer: buffers handed over by the main thread are written by a dedicated thread and then recycled

@@ -343,8 +343,9 @@ inline uint64_t format_records(const BatchCtx& c, uint64_t a, uint64_t b, const 
     uint64_t nflag = 0;
     // classes returned by reference are two dependent random reads into tables of tens of MB (class -> record -> ids):
     // both are prefetched a few reads ahead, or every read would wait for two cache misses
-    constexpr uint64_t PF_REF = 16, PF_IDS = 8;
+    constexpr uint64_t PF_REF = 16, PF_IDS = 8, PF_TEXT = 12;
     for (uint64_t i = a; i < b; ++i) {
+        if (i + PF_TEXT < b) __builtin_prefetch(text + c.recs[i + PF_TEXT].id_off);   // the read's id: a line of a multi-GB text last touched by the pack stage
         if (i + PF_REF < b) {
             const uint32_t off = c.h_results[i + PF_REF].class_off;
             if (off & PA_CLASS_REF) __builtin_prefetch(h_class_ref + (off & ~PA_CLASS_REF));

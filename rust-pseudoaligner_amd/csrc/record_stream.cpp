@@ -53,7 +53,7 @@ struct pa_record_stream {
     hipStream_t stream = nullptr;   // pa_process_reads call or another record stream left them there) and parked there again at the end
     int device = 0;
     const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
-    uint64_t batch_reads = 4u << 20;
+    uint64_t batch_reads = 2u << 20;
     BatchCtx* ctx = nullptr;       // = cache->ctx
     RawText text[2];               // ids and sequences of the batch's records (Record offsets point into it)
     uint32_t maxlen[2] = {0, 0};
