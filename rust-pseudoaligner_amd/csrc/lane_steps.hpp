@@ -972,6 +972,16 @@ PA_HD void left_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols,
     int32_t s_lo = below ? (int32_t)(slot_at(sl, prev).x & SEG_E_MASK) - (int32_t)(K - 1) : (back == 0 ? 0 : -1);
     if (s_lo < 0) s_lo = -1;
     const uint32_t lo = s_lo < 0 ? 0u : (uint32_t)s_lo;
+    // The node starts exactly at window position 0 of a block that is not its chain's first (the node before it still has its
+    // record here: below != 0, back > 0), and this step could reach that base: the base the extension test (:183) looks at lies
+    // one position to the left of this window. Step back FIRST, consuming nothing — in the earlier block the same node starts at
+    // 64 * back > 0 and its in-chain hop is the ordinary case below. (Window position 0 with records before it is never the
+    // chain's first base: only `!below && back == 0` is.)
+    if (below && s_lo == 0 && y1 <= 32u) {
+        s.ph -= back;
+        s.rr = (y1 + CH_STRIDE * back) | (snp << 24);
+        return;
+    }
     if (fl & F_FRESH) {
         if (!(fl & F_LEFT_SEED)) {
             if (push_node<TRACE>(s, cols, ix, seg_at(sl, cur), 64ull * s.ph + y)) {   // nodes.push(prev_node.node_id) (:199)

@@ -486,3 +486,39 @@ def thousands_of_classes_case(tmp_path, k=20, length=16383, step=3):
     host = pa.build_index(str(p), k, 8)
     reads = [T, T[5000:], T[: 3 * k], T[100:9000], T[:6000] + "A" + T[6001:]]
     return host, reads
+
+
+def long_chain_case(seed, tmp_path):
+    """fuzz family for the LEFT path across chain blocks: long transcripts, nested suffix / infix transcripts whose cuts (colour-only
+    node boundaries) fall on and around multiples of 64, reads of 300..500 bases with dense errors at their start (so that the first
+    hit is far into the read and the left extension walks > 192 bases), allowed in {6, 12}."""
+    rng = np.random.RandomState(9000 + seed)
+    k = int(rng.choice([16, 24, 31, 40]))
+    base = ["".join(rng.choice(list("ACGT"), rng.randint(600, 1500))) for _ in range(3)]
+    txs = list(base)
+    for b in base:
+        for _ in range(rng.randint(2, 6)):
+            cut = int(rng.choice([64, 128, 192, 256, 320, 63, 65, 127, 129, rng.randint(1, len(b) - k - 1)]))
+            cut = min(cut, len(b) - k - 1)
+            txs.append(b[cut:] if rng.rand() < 0.7 else b[cut: cut + rng.randint(k + 1, len(b) - cut)])
+    fa = tmp_path / ("lc%d.fa" % seed)
+    fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i, s) for i, s in enumerate(txs)))
+    host = pa.HostIndex.build_fasta(str(fa), k, 3)
+    allowed = int(rng.choice([6, 12]))
+    reads = []
+    for _ in range(300):
+        t = txs[rng.randint(len(txs))]
+        n = int(rng.randint(300, 501))
+        if len(t) < n + 2:
+            t = base[rng.randint(3)]
+        lo = rng.randint(0, len(t) - n)
+        r = list(t[lo:lo + n])
+        head = rng.randint(100, n - k - 5)            # errors spaced closer than k over the head: first hit behind it
+        step = rng.randint(max(2, k // 2), k)
+        for j in range(rng.randint(0, step), head, step):
+            r[j] = "ACGT"[("ACGT".index(r[j]) + 1 + rng.randint(3)) % 4]
+        for j in range(head, n):
+            if rng.rand() < 0.01:
+                r[j] = "ACGT"[rng.randint(4)]
+        reads.append("".join(r))
+    return host, reads, allowed

@@ -162,3 +162,34 @@ def test_flatten_rejects_inconsistent_graphs(small_index):
     h = C.c_void_p()
     assert helpers.emu_lib().emu_index_new(C.byref(flat), 2, C.byref(h)) != 0
     assert b"missing link" in helpers.emu_lib().emu_last_error()
+
+
+def _index_of(tmp_path, txs, k, name="lt.fa"):
+    fa = tmp_path / name
+    fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i, s) for i, s in enumerate(txs)))
+    return pa.HostIndex.build_fasta(str(fa), k, 3)
+
+
+def test_left_extension_into_a_node_that_starts_on_a_block_seam(tmp_path):
+    """T2 = T1[64:] cuts T1's unitig by colour exactly at chain position 64, i.e. at window position 0 of chain
+    block 1, where the node before it still has its record in the same block. A left extension that walks more than 192 bases
+    back has to take the in-chain hop there (has_ext(Left), src/pseudoaligner.rs:183-199), not look for a left EDGE of the chain."""
+    rng = np.random.RandomState(5)
+    T1 = "".join(rng.choice(list("ACGT"), 700))
+    host = _index_of(tmp_path, [T1, T1[64:]], 24)
+    read = list(T1[29:329])                       # 300 bases, chain positions 29..328
+    for j in range(0, 231, 23):                   # errors every 23 bases: no 24-mer hits before kmer_pos 231 (chain position 260)
+        read[j] = "ACGT"[("ACGT".index(read[j]) + 1) % 4]
+    reads = ["".join(read)] * 3
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    r, (o_res, o_coff, o_ids, ctr) = check(host, tiles, lens, wpr, allowed=12)
+    assert ctr["left_extensions"] == 3 and int(o_res["coverage"][0]) == 300
+    assert o_ids[o_coff[0]:o_coff[1]].tolist() == [0]   # the read starts before T2 does
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_long_chain_left_extensions(tmp_path, seed):
+    host, reads, allowed = helpers.long_chain_case(seed, tmp_path)
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    r, (o_res, _, _, ctr) = check(host, tiles, lens, wpr, allowed)
+    assert ctr["left_extensions"] > 50

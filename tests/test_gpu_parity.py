@@ -802,3 +802,13 @@ def test_per_barcode_counts_equal_the_histogram(aligners):
     want_keys, want_vals = np.unique((barcode.astype(np.uint64) << np.uint64(32)) | col, return_counts=True)
     assert np.array_equal(keys, want_keys) and np.array_equal(vals, want_vals.astype(np.uint32)) and int(vals.sum()) == n
     assert a.counts_by_barcode_device(d_res.data_ptr(), d_arena.data_ptr(), d_bc.data_ptr(), 0, d_keys.data_ptr(), d_vals.data_ptr()) == 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_long_chain_left_extensions(tmp_path, seed):
+    """helpers.long_chain_case: reads of 300..500 bases whose first hit lies far into the read, nested transcripts cut on and around
+    multiples of 64, allowed 6 / 12 — the LEFT path across chain blocks (a node that starts exactly on a block seam)"""
+    host, reads, allowed = helpers.long_chain_case(seed, tmp_path)
+    a = pa.Pseudoaligner(host)
+    _, _, _, ctr = gpu_vs_oracle(a, reads, allowed, "long chains seed %d" % seed)
+    assert ctr["left_extensions"] > 50
