@@ -2,9 +2,9 @@
 one: Txome.synthesize(58000, 203000, 7)) through the HIP path, against the oracle.
 
   config 3  K = 24, error-free 150 bp reads (seed 2): 2 M reads bit-exact incl. the fused class-count table; the full
-            100 M-read batch through size-independent properties
+            100 M-read batch bit-exact against the oracle (every read, 10 M at a time) + size-independent properties
   config 5  K = 31, 1 % substitutions (seed 4): the re-seek (src/pseudoaligner.rs:293-299) and left-extension (:124-205)
-            paths at scale: 2 M reads bit-exact incl. the count table; the full 100 M-read batch through properties
+            paths at scale: 2 M reads bit-exact incl. the count table; the full 100 M-read batch bit-exact (every read)
   config 4  is config 3 sharded over ranks: the shard arithmetic of bench.py (rank r maps reads [r*N, (r+1)*N) of ONE global
             stream) is checked here on one GPU — per-shard tables add up to the table of the whole range
 and the committed golden error-read fixtures (tests/golden/synth_err_k31.tsv, synth_err_k64.tsv) against the HIP path.
@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 GENES, TRANSCRIPTS, TX_SEED = 58000, 203000, 7
 FULL_BATCH = int(os.environ.get("PA_TEST_FULL_BATCH", 100_000_000))
+FULL_CHUNK = int(os.environ.get("PA_TEST_FULL_CHUNK", 10_000_000))   # reads per oracle comparison (multiple of 64)
 
 
 @pytest.fixture(scope="module")
@@ -112,7 +113,7 @@ def test_config4_shards_of_one_stream_add_up(txome, big):
 
 
 def _full_batch_properties(txome, host, aligner, oracle, read_len, seed, ppm, n, what):
-    """size-independent properties of one full batch + a bit-exact sample of its first 200 k reads"""
+    """one full batch: size-independent properties on the device, then ALL of its reads bit-exact against the oracle in chunks"""
     import torch
     dev = torch.device("cuda", 0)
     wpr = pa.lib().pa_words_per_read(read_len)
@@ -149,13 +150,25 @@ def _full_batch_properties(txome, host, aligner, oracle, read_len, seed, ppm, n,
     in_arena = mapped & (coff_col >= 0) & (clen > 0)
     assert bool((extra >= 0).all()) and int(extra.sum().item()) + int(counts[nc]) == int(in_arena.sum().item())
     checksum = (int(cov.sum().item()), int(mm.sum().item()), int(clen.sum().item()), int(mapped.sum().item()))
-    # first 200 k reads bit-exact against the oracle
-    sample_n = 200_000
-    sample = d_res[: sample_n * 4].cpu().numpy().view(pa.RESULT_DTYPE)
-    coff, cids = pa.gather_classes(sample, d_arena[: max(used, 1)].cpu().numpy().view(np.uint32), host)
-    h_tiles, h_lens = txome.simulate_host(read_len, seed, sample_n, ppm, 0, wpr)
-    o_res, o_coff, o_ids, _ = oracle.map_tiles(h_tiles, h_lens, wpr, 2, min(16, os.cpu_count() or 1))
-    helpers.assert_same_as_oracle(sample, coff, cids, o_res, o_coff, o_ids, what + " sample")
+    # EVERY read of the batch bit-exact against the oracle (src/pseudoaligner.rs:361-376), in chunks: the host simulator regenerates
+    # the chunk's tiles (checked against the device's), the oracle maps them on the box's threads, records and class ids are compared
+    arena_h = d_arena[: max(used, 1)].cpu().numpy().view(np.uint32)
+    threads = min(16, os.cpu_count() or 1)
+    chunk = min(n, FULL_CHUNK)
+    assert chunk % 64 == 0 or chunk == n
+    oracle_s = 0.0
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        part = d_res[lo * 4: (lo + m) * 4].cpu().numpy().view(pa.RESULT_DTYPE)
+        coff, cids = pa.gather_classes(part, arena_h, host)
+        h_tiles, h_lens = txome.simulate_host(read_len, seed, m, ppm, lo, wpr)
+        t_lo = lo // 64 * wpr * 64
+        assert np.array_equal(d_tiles[t_lo: t_lo + len(h_tiles)].cpu().numpy().view(np.uint64), h_tiles), what + ": device and host simulators disagree"
+        o_res, o_coff, o_ids, _ = oracle.map_tiles(h_tiles, h_lens, wpr, 2, threads)
+        oracle_s += oracle.last_seconds
+        helpers.assert_same_as_oracle(part, coff, cids, o_res, o_coff, o_ids, "%s reads [%d, %d)" % (what, lo, lo + m))
+        del part, coff, cids, h_tiles, h_lens, o_res, o_coff, o_ids
+    print("%s: all %d reads bit-exact vs the oracle (%.1f s of oracle time on %d threads)" % (what, n, oracle_s, threads))
     # idempotence: a second launch over the same tiles gives the same records (arena placement aside) and doubles the table
     del d_res, d_arena
     d_res2, d_arena2, used2, _ = _map_device(aligner, d_tiles, d_lens, n, wpr, 2, False)
