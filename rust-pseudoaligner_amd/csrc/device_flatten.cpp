@@ -484,8 +484,8 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
         KT km = KmerOps<KT>::get(node_seq, s, k);
         for (uint32_t o = 0; o < n; ++o) {
             if (o) km = (km >> 2) | ((KT)get_base(node_seq, s + o + k - 1) << topshift);
-            const uint32_t c = out.node_s[i] + o;
-            fn(km, out.handle[i] + (c >> CH_STRIDE_LOG2), dict_entry_off(c, o == 0));
+            const uint32_t c = out.node_s[i] + o, blk = out.handle[i] + (c >> CH_STRIDE_LOG2);
+            fn(km, blk, dict_entry_off(c, o == 0, block_slot_of(out.blobs.data() + (uint64_t)blk * CH_BLOCK, (c & (CH_STRIDE - 1)) + k - 1)));
         }
     };
     Dict<KT> dict{nullptr, 0};

@@ -21,6 +21,8 @@
 //                 bits 0..5  p      position of the k-mer's first base in that block's window (0..63)
 //                 bit  6     the k-mer is the FIRST k-mer of its node (kmer_offset == 0: the quirk of :129 needs to know)
 //                 bits 7..8  min(block index within the chain, 3): how many blocks a left extension may step back at once
+//                 bits 9..10 which of the block's four slots holds the record of the k-mer's node: the forward step loads the
+//                            slots ROTATED by it (slot 0 of what it loads = that record) instead of looking for it afterwards
 //
 //   chain blocks  Unitigs that the reference's graph cuts ONLY because the colour changes (A has one right extension, it
 //               leads to B, B has one left extension: 64-69 % of the nodes of a transcriptome) are laid out as ONE sequence,
@@ -94,11 +96,20 @@ constexpr uint32_t SEG_E_MASK = 0xFFFFu, SEG_E_FAR = 0xFFFFu;
 constexpr uint32_t SEG_WIDE = 1u << 16, SEG_LAST = 1u << 17, SEG_EDGES = 1u << 18, SEG_LINK = 1u << 19;
 constexpr uint32_t CH_TAIL = 128;           // bases of copied successor nodes after a chain's last node
 constexpr uint32_t SEG_BACK_SHIFT = 20, SEG_RECMASK_SHIFT = 28;
-constexpr uint32_t ENT_P_MASK = 63u, ENT_NODE_START = 64u, ENT_BACK_SHIFT = 7;   // dictionary entry, word `off`
-// second word of the dictionary entry of the k-mer that starts at chain position c (node_start: it is its node's first k-mer)
-PA_HD uint32_t dict_entry_off(uint32_t c, bool node_start) {
+constexpr uint32_t ENT_P_MASK = 63u, ENT_NODE_START = 64u, ENT_BACK_SHIFT = 7, ENT_CUR_SHIFT = 9;   // dictionary entry, word `off`
+// the slot of block `blk` that holds the first record whose node ends beyond window position y (the node of the k-mer ending at y)
+PA_HD uint32_t block_slot_of(const uint8_t* blk, uint32_t y) {
+    const uint32_t* sl = reinterpret_cast<const uint32_t*>(blk);
+    const uint32_t recmask = sl[0] >> SEG_RECMASK_SHIFT;
+    for (uint32_t t = 0; t < CH_SLOTS; ++t)
+        if (((recmask >> t) & 1u) && (sl[4 * t] & SEG_E_MASK) > y) return t;
+    return 0;   // (no such record: a malformed block; the builders' self-checks report it)
+}
+// second word of the dictionary entry of the k-mer that starts at chain position c (node_start: it is its node's first k-mer;
+// slot: block_slot_of(its block, (c & 63) + k - 1))
+PA_HD uint32_t dict_entry_off(uint32_t c, bool node_start, uint32_t slot) {
     const uint32_t j = c >> CH_STRIDE_LOG2;
-    return (c & ENT_P_MASK) | (node_start ? ENT_NODE_START : 0u) | ((j < CH_BACK_MAX ? j : CH_BACK_MAX) << ENT_BACK_SHIFT);
+    return (c & ENT_P_MASK) | (node_start ? ENT_NODE_START : 0u) | ((j < CH_BACK_MAX ? j : CH_BACK_MAX) << ENT_BACK_SHIFT) | (slot << ENT_CUR_SHIFT);
 }
 constexpr uint32_t CLASS_WINDOW = 32;   // ids per class window (one mask word)
 constexpr uint32_t SLOTS_PER_BUCKET = 4;

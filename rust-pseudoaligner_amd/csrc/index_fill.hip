@@ -110,12 +110,12 @@ __device__ __forceinline__ uint32_t node_of_kmer(const uint64_t* kcum, uint32_t 
     return lo;
 }
 
-__device__ __forceinline__ KmerAt kmer_at(const uint8_t* blobs, const uint32_t* handle, const uint32_t* node_s, const uint64_t* kcum, uint32_t num_nodes, uint64_t g) {
+__device__ __forceinline__ KmerAt kmer_at(const uint8_t* blobs, const uint32_t* handle, const uint32_t* node_s, const uint64_t* kcum, uint32_t num_nodes, uint64_t g, uint32_t k) {
     KmerAt a;
     a.node = node_of_kmer(kcum, num_nodes, g);
     const uint32_t o = (uint32_t)(g - kcum[a.node]), c = node_s[a.node] + o;
     a.block = handle[a.node] + (c >> CH_STRIDE_LOG2);
-    a.off = dict_entry_off(c, o == 0);
+    a.off = dict_entry_off(c, o == 0, block_slot_of(blobs + (uint64_t)a.block * CH_BLOCK, (c & (CH_STRIDE - 1)) + k - 1));
     a.seq = reinterpret_cast<const uint64_t*>(blobs + (uint64_t)a.block * CH_BLOCK + CH_SEQ_BYTES);
     a.rel = c & (CH_STRIDE - 1);
     return a;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void pa_fill_insert_kernel(const uint8_t* __re
                                                              uint32_t nbuckets, int pass) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nk) return;
-    const KmerAt a = kmer_at(blobs, handle, node_s, kcum, num_nodes, g);
+    const KmerAt a = kmer_at(blobs, handle, node_s, kcum, num_nodes, g, k);
     const KT km = FillOps<KT>::get(a.seq, a.rel, k);
     if constexpr (sizeof(KT) == 8) {   // k <= 32: pass 0 = home slots, pass 1 = the keys that did not get theirs (dict_slots.hpp)
         if (pass == 0) dict_insert_home<DeviceAtomics>(table, nbuckets, km, a.block, a.off);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void pa_fill_verify_kernel(const uint8_t* __re
                                                              const uint32_t* __restrict__ table, uint32_t nbuckets, uint32_t* __restrict__ flags) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nk) return;
-    const KmerAt a = kmer_at(blobs, handle, node_s, kcum, num_nodes, g);
+    const KmerAt a = kmer_at(blobs, handle, node_s, kcum, num_nodes, g, k);
     const KT km = FillOps<KT>::get(a.seq, a.rel, k);
     uint32_t fh = 0, fo = 0, probes = 0;
     if (!dict_find<KT>(table, nbuckets, km, fh, fo, probes) || fh != a.block || fo != a.off) atomicMin(flags, a.node);
