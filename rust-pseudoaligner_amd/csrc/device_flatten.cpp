@@ -13,6 +13,10 @@
 #include "lane_steps.hpp"
 #include "pa_common.hpp"
 
+#ifndef PA_BRANCH_TAILS   // A/B builds: -DPA_BRANCH_TAILS=0 (tails only behind nodes with ONE right extension, as in round 4)
+#define PA_BRANCH_TAILS 1
+#endif
+
 namespace pa {
 
 DevIndexView FlatDevice::host_view() const {
@@ -271,6 +275,8 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
     struct SegI {
         uint32_t node, s, e;   // e: where the node ends in the chain — or, link set, where the chain's copy of it ends
         bool link;             // a tail copy cut short: the walk goes on in the node's own chain
+        bool branch = false;   // the node has SEVERAL right extensions and what follows it here is a copy of the FAVOURED one: its record
+                               // is followed by its edge slot (the other extensions) although it is not the chain's last
     };
     std::vector<SegI> segs;             // every node, chain after chain
     segs.reserve(N);
@@ -284,7 +290,7 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
             if (g.e <= base) break;
             if (g.s >= base + CH_WINDOW) continue;
             cnt += 1 + (is_wide(g.node) ? 1u : 0u);
-            if (t + 1 == v.size() && (g.link || has_redge(g.node)) && g.e - base < CH_WINDOW) ++cnt;   // the edge / link slot, where a step can reach the chain's end
+            if ((g.branch || (t + 1 == v.size() && (g.link || has_redge(g.node)))) && g.e - base < CH_WINDOW) ++cnt;   // the edge / link slot, where a step can reach the node's end
         }
         return cnt;
     };
@@ -333,6 +339,15 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
             out.node_s[segs[t].node] = segs[t].s;
         }
 
+    // transcripts two classes share (sorted id lists)
+    auto shared_ids = [&](uint32_t ca, uint32_t cb) {
+        const uint32_t *a = f.ec_ids + f.ec_offset[ca], *ae = f.ec_ids + f.ec_offset[ca + 1], *b = f.ec_ids + f.ec_offset[cb], *be = f.ec_ids + f.ec_offset[cb + 1];
+        uint64_t n = 0;
+        while (a < ae && b < be) {
+            if (*a < *b) ++a; else if (*b < *a) ++b; else { ++n; ++a; ++b; }
+        }
+        return n;
+    };
     // ---- tails (device_layout.hpp): after a chain's last node Z, COPIES of the nodes a read can only go on to — Z's one
     // right extension, that node's one right extension, ... — for up to CH_TAIL bases, so that the step that runs over Z's end
     // finds them in the block it already holds. A copy that is cut short ends in a link to the same base of the node's own chain
@@ -347,12 +362,27 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
             const uint64_t limit = (uint64_t)fin.back().e + CH_TAIL;
             for (uint32_t cur = fin.back().node; limit < (1ull << 31);) {
                 const uint32_t re = f.node_exts[cur] & 15u;
-                if (re == 0 || (re & (re - 1))) break;
-                const uint32_t bn = redge[4 * cur + (uint32_t)__builtin_ctz(re)];
+                if (re == 0) break;
+                // several right extensions: the copy is of the FAVOURED one — the successor most transcripts of this node go on to
+                // (ties: the smaller base) — and the node's record keeps its edge slot for the others (SegI::branch)
+                const bool branch = (re & (re - 1)) != 0;
+                uint32_t bn = NO_HANDLE;
+                if (!branch) bn = redge[4 * cur + (uint32_t)__builtin_ctz(re)];
+                else if (PA_BRANCH_TAILS) {
+                    uint64_t best = 0;
+                    for (uint32_t b = 0; b < 4; ++b) {
+                        if (!(re & (1u << b))) continue;
+                        const uint32_t t = redge[4 * cur + b];
+                        const uint64_t c = 1 + shared_ids(f.node_colour[cur], f.node_colour[t]);
+                        if (c > best) { best = c; bn = t; }
+                    }
+                }
+                if (bn == NO_HANDLE) break;
                 const uint64_t sb = (uint64_t)fin.back().e - (k - 1), full = sb + f.node_len[bn];
                 if ((uint64_t)fin.back().e + 1 >= limit) break;          // no room for a base beyond the one the extension test looks at
                 const bool cut = full > limit;
-                if (!fits_after(fin, c0, SegI{bn, (uint32_t)sb, (uint32_t)(cut ? limit : full), cut})) break;
+                fin.back().branch = branch;
+                if (!fits_after(fin, c0, SegI{bn, (uint32_t)sb, (uint32_t)(cut ? limit : full), cut})) { fin.back().branch = false; break; }
                 if (cut) break;
                 cur = bn;
             }
@@ -371,7 +401,7 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
                     done = fits_after(fin, c0, g);                   // (one base shorter: its end may now be in reach of one more block)
                     if (!done) { g.e += 1; g.link = false; fin.push_back(g); }
                 }
-                if (!done) fin.pop_back();
+                if (!done) { fin.pop_back(); fin.back().branch = false; }   // (what is the last record now has no copy behind it)
             }
         }
         fin_first.push_back((uint32_t)fin.size());
@@ -422,8 +452,8 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
                 for (uint32_t t = tlo; t < t1 && segs[t].s < base + CH_WINDOW; ++t) {
                     const SegI& g = segs[t];
                     const U4 cw = cwin[f.node_colour[g.node]];
-                    const bool wide = is_wide(g.node), last = t + 1 == t1, reach = g.e - base < CH_WINDOW, edges = last && !g.link && has_redge(g.node) && reach,
-                               link = last && g.link && reach;
+                    const bool wide = is_wide(g.node), last = t + 1 == t1, reach = g.e - base < CH_WINDOW,
+                               edges = ((last && !g.link && has_redge(g.node)) || g.branch) && reach, link = last && g.link && reach;
                     if (slot + 1 + (wide ? 1 : 0) + (edges || link ? 1 : 0) > CH_SLOTS) { bad_slots.store(g.node); break; }   // (the merge rule keeps every block within its slots)
                     recmask |= 1u << slot;
                     uint32_t* r = sl + 4 * slot++;
@@ -455,6 +485,19 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
         }
     });
     if (bad_slots.load() != NO_HANDLE) return fail(PA_ERR_INTERNAL, "node %u: a chain block needs more than its four slots", bad_slots.load());
+    // a link also names the SLOT of the node it leads to in the block it leads to (word 2, as the lane state holds it: lane_steps.hpp,
+    // of_cur), so that the step behind it can load that block's slots rotated: a second pass, every block is in place now
+    par_ranges(threads, nblocks, [&](uint64_t ba, uint64_t bb, int) {
+        for (uint64_t b = ba; b < bb; ++b) {
+            uint32_t* sl = reinterpret_cast<uint32_t*>(out.blobs.data() + b * CH_BLOCK);
+            const uint32_t recmask = sl[0] >> SEG_RECMASK_SHIFT;
+            for (uint32_t t = 0; t < CH_SLOTS; ++t) {
+                if (!((recmask >> t) & 1u) || !(sl[4 * t] & SEG_LINK)) continue;
+                uint32_t* x = sl + 4 * (t + 1 + ((sl[4 * t] & SEG_WIDE) ? 1u : 0u));
+                x[2] = of_cur(block_slot_of(out.blobs.data() + (uint64_t)x[0] * CH_BLOCK, x[1] - 1), true);
+            }
+        }
+    });
     if (bad_edge.load() != NO_HANDLE) return fail(PA_ERR_FORMAT, "node %u: a right edge does not lead to the first k-mer of a chain", bad_edge.load());
 
     // ---- left edges by chain handle: where the extension goes on — the neighbour's last k-mer, in the block with the most

@@ -39,7 +39,8 @@
 //                 +0   four 16-byte SLOTS
 //                 +64  u64 seq[8]   bases [64 j, 64 j + 256) of the chain, 2-bit packed, LSB-first, zero beyond the chain's end
 //               Slots, in order: one RECORD per node with e > 64 j and s < 64 j + 256 (ascending), each followed by its
-//               extension slot if WIDE, the chain's last record also by the edge slot if it has one:
+//               extension slot if WIDE, the chain's last record also by the edge slot if it has one (and so a BRANCH record:
+//               EDGES without LAST, see TAILS):
 //                 record     {w0, class id, cmin, cmask}   the class as a WINDOW of 32 transcript ids {cmin + i : bit i of cmask}
 //                            w0 bits 0..15  e - 64 j, the node's end relative to the block (0xFFFF: further than that)
 //                               bit 16 WIDE     the next slot is this record's extension
@@ -58,6 +59,10 @@
 //               appends COPIES of what can only follow — Z's one successor, that node's one successor, ... — for up to 128
 //               bases (what a 150-base read can still need), records and sequence like any other node of the chain. A copy
 //               that does not fit whole ends in a LINK: at that position the walk goes on, mid-node, in the node's own chain.
+//               A node with SEVERAL right extensions is followed by a copy of the FAVOURED one (the successor most of its
+//               transcripts go on to): its record is a BRANCH record — EDGES set, LAST not — followed by its edge slot and then
+//               the copy's record. A read whose next base is the copy's goes on in the block; any other base takes the edge
+//               slot (has_ext / r_edges, :267-283, as at a chain's end).
 //               The dictionary, the left edges and the right edges only ever point at a node's own place, never at a copy.
 //   ledge       u32[8 * blocks] by CHAIN handle: {block handle, y + 1}[4] — where a left extension that leaves the chain's
 //               first node with base b goes on (Node::l_edges): the last k-mer of the neighbour chain's last node, as position

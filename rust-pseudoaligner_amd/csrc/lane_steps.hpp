@@ -35,7 +35,8 @@ struct Lane {
     uint32_t lk;    // L (bits 0..13) | kmer_pos (14..27) | state (28..31)                  (:70, :79)
     uint32_t cm;    // read_coverage (0..15) | mismatch_count (16..31)                      (:71-72)
     uint32_t h;     // forward search: the chain block it is in (node_id + kmer_offset of :118-121 as a place in a chain)
-    uint32_t of;    // position in that block's window (0..23): of the k-mer's first base (F_FRESH), else of the next base to compare | flags (24..31)
+    uint32_t of;    // position in that block's window (0..9): of the k-mer's first base (F_FRESH), else of the next base to compare |
+                    // slot of the block that holds the record of the node the lane stands in (10..11), valid when bit 12 is set (else 0) | flags (24..31)
     uint32_t rr;    // LEFT: position + 1 in the block's window of the next base to compare (0..23) | seen_snp (24..31)
     uint32_t rm;    // LEFT: read bases still to the left (16..31)
     uint32_t ph;    // LEFT: the chain block the extension is in                            (:128)
@@ -49,7 +50,10 @@ PA_HD void l_set_st(Lane& s, uint32_t st) { s.lk = (s.lk & 0x0FFFFFFFu) | (st <<
 PA_HD uint32_t l_flags(const Lane& s) { return s.of >> 24; }
 PA_HD void l_or_flags(Lane& s, uint32_t f) { s.of |= f << 24; }
 PA_HD void l_clr_flags(Lane& s, uint32_t f) { s.of &= ~(f << 24); }
-PA_HD uint32_t l_off(const Lane& s) { return s.of & 0xFFFFFFu; }
+constexpr uint32_t OF_X_MASK = 0x3FFu, OF_CUR_SHIFT = 10, OF_CUR_KNOWN = 1u << 12;
+PA_HD uint32_t l_off(const Lane& s) { return s.of & OF_X_MASK; }
+PA_HD uint32_t l_cur(const Lane& s) { return (s.of >> OF_CUR_SHIFT) & 3u; }   // 0 when not known
+PA_HD uint32_t of_cur(uint32_t slot, bool known) { return known ? (slot << OF_CUR_SHIFT) | OF_CUR_KNOWN : 0u; }
 PA_HD uint32_t l_L(const Lane& s) { return s.lk & 0x3FFFu; }
 PA_HD uint32_t l_kp(const Lane& s) { return (s.lk >> 14) & 0x3FFFu; }
 PA_HD void l_set_kp(Lane& s, uint32_t kp) { s.lk = (s.lk & 0xF0003FFFu) | (kp << 14); }
@@ -67,6 +71,7 @@ struct ReadRef {   // the lane's packed read: word w < wmax at p[w * stride]; wo
     const uint64_t* p;
     uint32_t stride;
     uint32_t wmax;
+    bool slack = false;   // the four words after the read's last may be loaded as well (LDS pool: whatever lies there is never looked at)
 };
 
 // The lane's record of the classes seen, in one of two modes:
@@ -563,7 +568,7 @@ PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full,
     s.nc &= ~(15u << NC_PROBE_SHIFT);                               // probe index back to 0
     if (h != NO_HANDLE) {                                           // Some((nid, offset)) (:106)
         s.h = h;
-        const uint32_t fl = l_flags(s), p = off & ENT_P_MASK;
+        const uint32_t fl = l_flags(s), p = (off & ENT_P_MASK) | of_cur((off >> ENT_CUR_SHIFT) & 3u, true);   // position + the slot of the k-mer's node
         const uint32_t thr = L / 5;                                 // (0.2 * L as f64) as usize (:77) == L/5 for L < 2^31
         if ((fl & F_FIRST_SEEK) && kp >= thr) {                     // :124-126  (F_SPEC ends with the hit: fl is rebuilt below without it)
             const uint32_t back = (off >> ENT_BACK_SHIFT) & CH_BACK_MAX;
@@ -571,7 +576,7 @@ PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full,
             s.ph = h - back;                                        // :128 — the block with the most room to the left
             // prev_kmer_offset (:129): one base to the left of the k-mer — or, quirk Q1 kept, the k-mer's own first base when
             // it is the first k-mer of its node (kmer_offset == 0). Stored + 1; snp = 0
-            s.rr = p + CH_STRIDE * back + ((off & ENT_NODE_START) ? 1u : 0u);
+            s.rr = (off & ENT_P_MASK) + CH_STRIDE * back + ((off & ENT_NODE_START) ? 1u : 0u);
             s.of = p | (((fl & ~(F_FIRST_SEEK | F_SPEC)) | F_FRESH | F_LEFT_SEED) << 24);
             l_set_st(s, ST_LEFT);
         } else {
@@ -643,7 +648,10 @@ PA_HD void fwd_issue(const Lane& s, const DevIndexView& ix, FwdLoad& f) {
     const uint32_t kp0 = l_kp(s) + (fresh ? K : 0u);                  // kmer_pos += kmer_length (:215)
     const uint8_t* blk = chain_block(ix, s.h);                        // dbg.get_node (:210)
     const U4* sp = reinterpret_cast<const U4*>(blk);
-    f.s0 = PA_LD(8, sp); f.s1 = PA_LD(8, sp + 1); f.s2 = PA_LD(8, sp + 2); f.s3 = PA_LD(8, sp + 3);
+    // the four slots ROTATED so that s0 is the record of the node the lane stands in, when the lane knows which slot that is (from the
+    // dictionary entry, a link, or the step before in the same block); else as they lie (rot = 0) and the step looks for the record
+    const uint32_t rot = l_cur(s);
+    f.s0 = PA_LD(8, sp + rot); f.s1 = PA_LD(8, sp + ((rot + 1) & 3u)); f.s2 = PA_LD(8, sp + ((rot + 2) & 3u)); f.s3 = PA_LD(8, sp + ((rot + 3) & 3u));
     // sequence words this step can need, known before the block arrives: at most the rest of the read, 128 bases per step
     // (the second and third 16-byte load only go out for the lanes that can need them: every load is an access of the vector L1)
     const uint32_t most = pa_min(L - kp0, 128u), nwords = ((xs & 31) + most + 31) >> 5;
@@ -680,8 +688,10 @@ PA_HD void fwd_finish_general(Lane& s, const DevIndexView& ix, ReadRef rd, ColRe
     uint32_t snp = s.rr >> 24, cov = l_cov(s), mism = l_mism(s);
     const uint32_t most = pa_min(L - kp0, 128u), nwords = ((xs & 31) + most + 31) >> 5;   // as in fwd_issue
     const uint64_t a[5] = {f.s01.a, f.s01.b, nwords > 2 ? f.s23.a : 0ull, nwords > 2 ? f.s23.b : 0ull, nwords > 4 ? f.s45.a : 0ull};
-    const Slots sl{f.s0, f.s1, f.s2, f.s3};
-    uint32_t cur = seg_find(sl, x - 1);                               // the node of the k-mer ending at x - 1 / of the base x
+    const Slots sl{f.s0, f.s1, f.s2, f.s3};                           // (rotated by l_cur(s): fwd_issue)
+    const bool known = s.of & OF_CUR_KNOWN;
+    const uint32_t rot = l_cur(s);
+    uint32_t cur = known ? 0u : seg_find(sl, x - 1);                  // the node of the k-mer ending at x - 1 / of the base x
     Seg g = seg_at(sl, cur);
     if (fresh) {
         cov += K;                                                     // :216
@@ -708,6 +718,7 @@ PA_HD void fwd_finish_general(Lane& s, const DevIndexView& ix, ReadRef rd, ColRe
     dm.p0 = pa_popc64(dm.m0); dm.p1 = dm.p0 + pa_popc64(dm.m1); dm.p2 = dm.p1 + pa_popc64(dm.m2); dm.p3 = dm.p2 + pa_popc64(dm.m3);
     const uint32_t lim = careful ? 32u : 128u;
     uint32_t consumed = 0, st = ST_FWD, h = s.h, nfl = fl & ~F_FRESH;
+    uint32_t ncur = 0xFFFFFFFFu;                                      // `of` bits of the next step's slot when a hop decides them
     bool premature = false, hopped = false;
     for (;;) {
         const uint32_t n = pa_min(pa_min(g.e - x, L - kp), lim - consumed);   // max_matchable_pos (:222-231), as far as this step goes
@@ -729,6 +740,7 @@ PA_HD void fwd_finish_general(Lane& s, const DevIndexView& ix, ReadRef rd, ColRe
             const U4 lk = slot_at(sl, cur + 1 + ((g.flags & SEG_WIDE) ? 1u : 0u));
             h = lk.x;
             x = lk.y;
+            ncur = lk.z;                                              // (slot of the node there, OF_CUR_KNOWN set: device_flatten.cpp)
             hopped = true;
             break;
         }
@@ -746,20 +758,35 @@ PA_HD void fwd_finish_general(Lane& s, const DevIndexView& ix, ReadRef rd, ColRe
                 kp -= K - 1;                                          // :282
                 cov -= K - 1;                                         // :283
                 nfl |= F_FRESH;
+                ncur = of_cur(0u, true);                              // a chain's first node is its first block's first record
                 hopped = true;
             } else st = kp > L - K ? ST_ISECT : ST_SEEK;              // :287-293
             break;
         }
         if (consumed >= 128u) break;                                  // the base of the extension test is not in this step's masks
+        const bool branch = (g.flags & SEG_EDGES) != 0;               // (not LAST:) several right extensions, the favoured one follows in the block
         {
-            if ((diff_word(dm, consumed >> 5) >> (2 * (consumed & 31u))) & 1ull) {              // the node's one right extension is another base: !has_ext (:267)
-                st = kp > L - K ? ST_ISECT : ST_SEEK;
+            if ((diff_word(dm, consumed >> 5) >> (2 * (consumed & 31u))) & 1ull) {              // the chain's next base is not the read's
+                uint32_t nh = NO_HANDLE;
+                if (branch) {                                         // another right extension? the record's edge slot (:267-278)
+                    const U4 ed = slot_at(sl, cur + 1 + ((g.flags & SEG_WIDE) ? 1u : 0u));
+                    nh = sel4(read_base(rd, kp), ed.x, ed.y, ed.z, ed.w);
+                }
+                if (nh != NO_HANDLE) {                                // over the edge, as at a chain's end
+                    h = nh;
+                    x = 0;                                            // :279
+                    kp -= K - 1;                                      // :282
+                    cov -= K - 1;                                     // :283
+                    nfl |= F_FRESH;
+                    ncur = of_cur(0u, true);
+                    hopped = true;
+                } else st = kp > L - K ? ST_ISECT : ST_SEEK;          // !has_ext (:267), :287-293
                 break;
             }
         }
         // the next node of the chain (:267-283 and the top of the loop :215-219): one base net, nothing of the K-1 overlap re-verified
         x += 1; kp += 1; cov += 1; consumed += 1;
-        cur += 1 + ((g.flags & SEG_WIDE) ? 1u : 0u);
+        cur += 1 + ((g.flags & SEG_WIDE) ? 1u : 0u) + (branch ? 1u : 0u);
         g = seg_at(sl, cur);
         if (push_node<TRACE>(s, cols, ix, g, 64ull * s.h + x - K)) {  // nodes.push (:219); the node's first k-mer starts at x - K
             restart_lists(s, K);
@@ -774,12 +801,13 @@ PA_HD void fwd_finish_general(Lane& s, const DevIndexView& ix, ReadRef rd, ColRe
         const uint32_t adv = (x - 1) >> CH_STRIDE_LOG2;               // (x >= 1; a position that is a multiple of 64 stays the 64th of the block before:
         h += adv;                                                     //  a node that ends exactly there is still on that block's list)
         x -= adv << CH_STRIDE_LOG2;
+        ncur = of_cur((rot + cur) & 3u, adv == 0);                    // the same block: the node's slot is known; another block: the next step looks for it
     }
     s.h = h;
     s.lk = l_pack_lk(L, kp, st);
     s.cm = cov | (mism << 16);
     s.rr = snp << 24;
-    s.of = x | (nfl << 24);
+    s.of = x | (st == ST_FWD ? ncur : 0u) | (nfl << 24);
 }
 
 // nodes.push in window mode on values held in registers (push_node's window branch without its memory traffic): w / cand /
@@ -817,25 +845,40 @@ PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, 
     const uint32_t kadd = fresh ? K : 0u;
     const uint32_t x0 = l_off(s) + kadd, kp0 = l_kp(s) + kadd;       // ref_offset (:227), kmer_pos += kmer_length (:215)
     const uint32_t snp0 = fresh ? 0u : s.rr >> 24;                    // :235
-    const uint32_t most = pa_min(L - kp0, 128u), nwords = ((x0 & 31) + most + 31) >> 5;   // as in fwd_issue
-    const uint64_t a0 = f.s01.a, a1 = f.s01.b, a2 = nwords > 2 ? f.s23.a : 0ull, a3 = nwords > 2 ? f.s23.b : 0ull, a4 = nwords > 4 ? f.s45.a : 0ull;
-    // the block's slots rotated so that t0 is the record of the node this step starts in (the first one that ends beyond x0 - 1)
-    const Slots sl{f.s0, f.s1, f.s2, f.s3};
-    const uint32_t cur = seg_find(sl, x0 - 1);
-    const bool c1 = cur & 1u, c2 = cur & 2u;
+    const uint64_t a0 = f.s01.a, a1 = f.s01.b, a2 = f.s23.a, a3 = f.s23.b, a4 = f.s45.a;   // (words fwd_issue did not load are zero there; never looked at)
+    // t0 = the record of the node this step starts in. A lane that knows its slot had the block's slots loaded rotated by it
+    // (fwd_issue); one that does not (it moved on to another block of its chain) finds the record — the first one that ends beyond
+    // x0 - 1 — and rotates what it loaded
+#ifdef PA_PROBE_KNOWN   // (tools/isa_probe.hip: the common lane's text alone)
+    const bool known = true;
+#else
+    const bool known = s.of & OF_CUR_KNOWN;
+#endif
+    U4 t0 = f.s0, t1 = f.s1, t2 = f.s2, t3 = f.s3;
+    uint32_t curp = l_cur(s);                                        // the slot of t0 in the block
+    if (!known) {
+        const Slots sl{f.s0, f.s1, f.s2, f.s3};
+        const uint32_t cur = seg_find(sl, x0 - 1);
+        const bool c1 = cur & 1u, c2 = cur & 2u;
 #define PA_ROT1(fld) const uint32_t u0##fld = c1 ? f.s1.fld : f.s0.fld, u1##fld = c1 ? f.s2.fld : f.s1.fld, u2##fld = c1 ? f.s3.fld : f.s2.fld, u3##fld = c1 ? f.s0.fld : f.s3.fld;
-    PA_ROT1(x) PA_ROT1(y) PA_ROT1(z) PA_ROT1(w)
+        PA_ROT1(x) PA_ROT1(y) PA_ROT1(z) PA_ROT1(w)
 #undef PA_ROT1
-    const U4 t0{c2 ? u2x : u0x, c2 ? u2y : u0y, c2 ? u2z : u0z, c2 ? u2w : u0w}, t1{c2 ? u3x : u1x, c2 ? u3y : u1y, c2 ? u3z : u1z, c2 ? u3w : u1w},
-             t2{c2 ? u0x : u2x, c2 ? u0y : u2y, c2 ? u0z : u2z, c2 ? u0w : u2w}, t3{c2 ? u1x : u3x, c2 ? u1y : u3y, c2 ? u1z : u3z, c2 ? u1w : u3w};
+        t0 = U4{c2 ? u2x : u0x, c2 ? u2y : u0y, c2 ? u2z : u0z, c2 ? u2w : u0w}; t1 = U4{c2 ? u3x : u1x, c2 ? u3y : u1y, c2 ? u3z : u1z, c2 ? u3w : u1w};
+        t2 = U4{c2 ? u0x : u2x, c2 ? u0y : u2y, c2 ? u0z : u2z, c2 ? u0w : u2w}; t3 = U4{c2 ? u1x : u3x, c2 ? u1y : u3y, c2 ? u1z : u3z, c2 ? u1w : u3w};
+        curp = cur;
+    }
     const bool wideA = t0.x & SEG_WIDE, lastA = t0.x & SEG_LAST;
-    const U4 nx{wideA ? t2.x : t1.x, wideA ? t2.y : t1.y, wideA ? t2.z : t1.z, wideA ? t2.w : t1.w};   // B's record — or A's right edges
-    const U4 xb{wideA ? t3.x : t2.x, wideA ? t3.y : t2.y, wideA ? t3.z : t2.z, wideA ? t3.w : t2.w};   // B's extension slot
+    const bool branchA = (t0.x & (SEG_EDGES | SEG_LAST)) == SEG_EDGES;   // several right extensions, a copy of the favoured one follows: record [ext] edges B [ext]
+    const U4 ed{wideA ? t2.x : t1.x, wideA ? t2.y : t1.y, wideA ? t2.z : t1.z, wideA ? t2.w : t1.w};   // the slot behind A's record: A's right edges / link — or B's record
+    const U4 e2{wideA ? t3.x : t2.x, wideA ? t3.y : t2.y, wideA ? t3.z : t2.z, wideA ? t3.w : t2.w};   // ... and the one behind that
+    const U4 nx{branchA ? e2.x : ed.x, branchA ? e2.y : ed.y, branchA ? e2.z : ed.z, branchA ? e2.w : ed.w};   // B's record
+    // B's extension slot (a wide B behind a wide branch record would be a fifth slot: the flattener never lays that out)
+    const U4 xb{branchA ? t3.x : e2.x, branchA ? t3.y : e2.y, branchA ? t3.z : e2.z, branchA ? t3.w : e2.w};
     const bool wideB = nx.x & SEG_WIDE;
     // five read words, all LDS reads in flight together (words beyond the read's last re-read the last one: never looked at)
     uint64_t r0, r1, r2, r3, r4;
     {
-        const uint32_t i0 = (kp0 >> 5) * rd.stride, ilast = (rd.wmax - 1) * rd.stride;
+        const uint32_t i0 = (kp0 >> 5) * rd.stride, ilast = rd.slack ? 0xFFFFFFFFu : (rd.wmax - 1) * rd.stride;
         r0 = rd.p[pa_min(i0, ilast)]; r1 = rd.p[pa_min(i0 + rd.stride, ilast)]; r2 = rd.p[pa_min(i0 + 2 * rd.stride, ilast)];
         r3 = rd.p[pa_min(i0 + 3 * rd.stride, ilast)]; r4 = rd.p[pa_min(i0 + 4 * rd.stride, ilast)];
     }
@@ -866,11 +909,12 @@ PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, 
     const bool bitA = (diff_word(dm, nA >> 5) >> (2 * (nA & 31u))) & 1ull;   // the chain's next base differs from the read's (nA < 128)
     const uint32_t bA = read_base(rd, pa_min(kpA, L - 1));            // :265
     const bool linkA = t0.x & SEG_LINK;                               // a copy cut short: the same node goes on in its own chain
-    const uint32_t edge = (t0.x & SEG_EDGES) ? sel4(bA, nx.x, nx.y, nx.z, nx.w) : linkA ? nx.x : NO_HANDLE;   // r_edges()[index].0 (:275-278)
-    const bool hop_chain = endA && lastA && edge != NO_HANDLE, hop_edge = hop_chain && !linkA;
+    const uint32_t edge = (t0.x & SEG_EDGES) ? sel4(bA, ed.x, ed.y, ed.z, ed.w) : linkA ? ed.x : NO_HANDLE;   // r_edges()[index].0 (:275-278)
     const bool in_masks = nA < 128u;
+    const bool other = endA && !lastA && in_masks && bitA;            // the chain's next base is not the read's: at a branch record another right extension may be
+    const bool hop_chain = endA && (lastA || (other && branchA)) && edge != NO_HANDLE, hop_edge = hop_chain && !linkA;
     const bool hopB = endA && !lastA && in_masks && !bitA;            // has_ext(Right, b) (:267): the chain's next node
-    const bool dead = endA && (lastA ? edge == NO_HANDLE : (in_masks && bitA));   // :287-293
+    const bool dead = endA && (lastA ? edge == NO_HANDLE : (other && !hop_chain));   // :287-293
     // ---- node B
     const uint32_t c1n = nA + 1, x1 = xA + 1, kp1 = kpA + 1;          // the hop: one base net (:282-283, :215-216)
     const uint32_t eB = nx.x & SEG_E_MASK;
@@ -913,22 +957,26 @@ PA_HD void fwd_finish(Lane& s, const DevIndexView& ix, ReadRef rd, ColRef cols, 
     const bool deadA = dead || !okA;
     uint32_t st = (ended || (deadA && kp_dead > L - K)) ? (uint32_t)ST_ISECT : deadA ? (uint32_t)ST_SEEK : (uint32_t)ST_FWD;
     uint32_t kp = !okA ? kp_dead : hop_edge ? kpA - (K - 1) : hopB ? (okB ? kpB : kp1) : kpA;
-    uint32_t x = !okA ? x0 : hop_chain ? (linkA ? nx.y : 0u) : hopB ? (okB ? xB : x1) : xA;
+    uint32_t x = !okA ? x0 : hop_chain ? (linkA ? ed.y : 0u) : hopB ? (okB ? xB : x1) : xA;
     const uint32_t cov = l_cov(s) + kadd + (okA ? nA : brk) + (hopB ? 1u : 0u) + (useB ? nB : 0u) - (hop_edge ? K - 1 : 0u);   // :216, :254, :283
     const uint32_t mism = l_mism(s) + (okA ? cntA : allowed - snp0 + 1) + (useB ? cntB : 0u);
     const uint32_t snp = hopB ? (okB ? cntB : 0u) : snp0 + cntA;
     const uint32_t nfl = (fl & ~(F_FRESH | F_CAREFUL)) | (hop_edge ? F_FRESH : 0u) | (st == ST_SEEK ? F_SPEC : 0u);
     uint32_t h = hop_chain ? edge : s.h;
+    // the slot of the node the next step starts in: a chain entered over an edge starts with its first record; a link names it
+    // (nx.z); in this block it is A's or B's slot; in another block of this chain the next step has to look for it
+    uint32_t ncur = linkA ? ed.z : of_cur(0u, true);
     if (st == ST_FWD && !hop_chain) {                                 // goes on in this chain (fwd_finish_general)
         const uint32_t adv = (x - 1) >> CH_STRIDE_LOG2;
         h += adv;
         x -= adv << CH_STRIDE_LOG2;
+        ncur = of_cur((curp + (hopB ? 1u + (wideA ? 1u : 0u) + (branchA ? 1u : 0u) : 0u)) & 3u, adv == 0);
     }
     s.h = h;
     s.lk = l_pack_lk(L, kp, st);
     s.cm = cov | (mism << 16);
     s.rr = snp << 24;
-    s.of = x | (nfl << 24);
+    s.of = x | (st == ST_FWD ? ncur : 0u) | (nfl << 24);
 }
 
 // Forward search (:209-301): one call = one chain block

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             s.rid = wc[2 * slot + 1];
             if (n_fill && lane >= n_own) s.lk = 0;   // an EMPTY slot taken along by an output step (its stored state may be stale)
         }
-        const ReadRef rr = GREAD ? ReadRef{p.tiles + ((uint64_t)(s.rid >> 6) * wpr) * 64 + (s.rid & 63), 64u, wpr} : ReadRef{(const uint64_t*)(rd + slot), S, wpr};
+        const ReadRef rr = GREAD ? ReadRef{p.tiles + ((uint64_t)(s.rid >> 6) * wpr) * 64 + (s.rid & 63), 64u, wpr} : ReadRef{(const uint64_t*)(rd + slot), S, wpr, true};
         const glb_u32w row = (glb_u32w)p.spill + (uint64_t)gslot * spill_cap;
         const ColRef cols{(uint32_t*)&win[slot], (uint32_t*)(wc + 2 * slot), (uint32_t*)row, (uint32_t*)(row + 4), (uint32_t*)(row + 8),
                           (uint32_t*)(row + LIST_ROW_HDR), spill_cap - LIST_ROW_HDR, (uint32_t*)row,

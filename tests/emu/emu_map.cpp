@@ -57,13 +57,24 @@ uint64_t emu_index_info(const emu_index* e, int what) {
                     prev_e = e_rel;
                     seen |= 1u << t;
                     t += 1 + ((w0 & pa::SEG_WIDE) ? 1 : 0);
-                    if (w0 & (pa::SEG_EDGES | pa::SEG_LINK)) { ok = ok && (w0 & pa::SEG_LAST) && !((w0 & pa::SEG_EDGES) && (w0 & pa::SEG_LINK)); ++t; }
+                    // an edge slot follows the chain's last record or a BRANCH record (EDGES without LAST: a copy of the favoured successor follows it); a link only the last
+                    if (w0 & (pa::SEG_EDGES | pa::SEG_LINK)) { ok = ok && ((w0 & pa::SEG_LAST) || !(w0 & pa::SEG_LINK)) && !((w0 & pa::SEG_EDGES) && (w0 & pa::SEG_LINK)); ++t; }
                     if (w0 & pa::SEG_LAST) ended = true;
                     ok = ok && t <= pa::CH_SLOTS;
                 }
                 if (!ok || seen != recmask) ++bad;
             }
             return bad;
+        }
+        case 7: {   // BRANCH records (layout statistics for the tests)
+            uint64_t n = 0;
+            for (size_t b = 0; b + pa::CH_BLOCK <= e->fd.blobs.size(); b += pa::CH_BLOCK) {
+                const uint32_t* sl = reinterpret_cast<const uint32_t*>(e->fd.blobs.data() + b);
+                const uint32_t recmask = sl[0] >> pa::SEG_RECMASK_SHIFT;
+                for (uint32_t t = 0; t < pa::CH_SLOTS; ++t)
+                    if (((recmask >> t) & 1u) && (sl[4 * t] & (pa::SEG_EDGES | pa::SEG_LAST)) == pa::SEG_EDGES) ++n;
+            }
+            return n;
         }
         case 3: return e->fd.max_class_len;
         default: return 0;

@@ -146,6 +146,7 @@ def test_chain_block_layout_is_well_formed(small_index, k):
     n = host.arrays()["num_nodes"]
     assert 0 < info["num_chains"] < n < info["num_segs"]
     assert info["blob_bytes"] % 128 == 64 and info["bad_blocks"] == 0   # (whole blocks + the 64-byte tail pad)
+    assert info["branch_records"] > 1000                                # nodes with several right extensions carry a copy of the favoured one
 
 
 def test_flatten_rejects_inconsistent_graphs(small_index):
