@@ -239,9 +239,12 @@ def roofline_of(run, ctr, stage_ms, step_ms):
             traffic_note = "profiles/latest_pmc.json holds %s reads per launch, this run %d" % (pmc.get("reads_per_launch"), B)
         else:
             raw = (pmc["FETCH_SIZE_KB"] + pmc["WRITE_SIZE_KB"]) * 1024.0
-            # gfx950's FETCH_SIZE tallies a coalesced stream at half its bytes (calibrated: profiles/r02_pmc_calibration.txt; random
-            # lines, stores and atomics are exact): the other half of the streamed input (read tiles + lengths) is added back
-            traffic = raw + 0.5 * (8.0 * run.wpr + 4.0) * B
+            # gfx950 fetches 128 bytes for EVERY memory-side read request — streams, random 64-byte lines, 16-byte dictionary slots, chain
+            # blocks (profiles/r05_pmc_calibration.txt: TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ in every pattern) — and FETCH_SIZE tallies
+            # each at 64 bytes. The bytes that crossed the memory interface are the requests by size (or 2 x FETCH_SIZE) + WRITE_SIZE
+            # (exact at 32-byte sectors in the same calibration).
+            rd_bytes = pmc.get("READ_REQUEST_BYTES") or 2.0 * pmc["FETCH_SIZE_KB"] * 1024.0
+            traffic = rd_bytes + pmc["WRITE_SIZE_KB"] * 1024.0
             raw_traffic = raw
             miss_block_bytes = 128.0 * pmc["map_kernel_l2_misses"] / B if pmc.get("map_kernel_l2_misses") else None
             per_launch = raw / 64.0
@@ -264,6 +267,9 @@ def roofline_of(run, ctr, stage_ms, step_ms):
             # rocprof HBM GB/s against the chip's peak (north_star): the counters' bytes of a step over its device time
             "traffic_gbps": (traffic / (step_avg * 1e-3) / 1e9) if traffic else None,
             "traffic_frac_of_peak": (traffic / (step_avg * 1e-3) / 1e9 / 8000.0) if traffic else None,
+            # ... and against what the chip's memory system sustains (6.29 TB/s float4 copy, MI355X_MICROARCH.md; 128-byte random gathers
+            # reach the same: tools/microbench/gather.hip, 49 G requests/s x 128 B)
+            "traffic_frac_of_achievable_6_3": (traffic / (step_avg * 1e-3) / 1e9 / 6290.0) if traffic else None,
             "l2_miss_block_bytes_per_read": miss_block_bytes,
             "kernel": "pa_map_pool_kernel + pa_resolve_kernel", "kernel_ms": kernel_avg_ms, "map_pool_kernel_ms": pool_avg_ms, "resolve_kernel_ms": resolve_avg_ms,
             "kernel_ms_min": min(map_ms) if map_ms else None, "kernel_ms_max": max(map_ms) if map_ms else None,
@@ -338,9 +344,16 @@ def main() -> None:
             dist.broadcast_object_list(box, src=0)
             comm = pa.Comm(local_rank, world, rank, box[0])
         except Exception as e:   # noqa: BLE001
+            # the reduce of the count table is part of the product: a run that cannot open the library's communicator is not
+            # the run BASELINE.json describes. PA_BENCH_ALLOW_TORCH_REDUCE=1 (diagnosis only) lets it go on through torch.distributed,
+            # and the line then says so (rccl_ranks 0)
+            if os.environ.get("PA_BENCH_ALLOW_TORCH_REDUCE") != "1":
+                raise SystemExit("bench.py: pa_comm_create failed on rank %d of %d: %r (PA_BENCH_ALLOW_TORCH_REDUCE=1 reduces through torch.distributed instead)" % (rank, world, e))
             log("pa_comm_create failed (%r): reducing through torch.distributed" % (e,))
             comm = None
     rccl_ranks = comm.size if comm is not None else 0
+    if world > 1 and backend == "nccl" and comm is not None:
+        assert rccl_ranks == world, "the product's RCCL communicator spans %d ranks, the job %d" % (rccl_ranks, world)
 
     env = dict(pa=pa, torch=torch, helpers=helpers, np=np, rank=rank, local_rank=local_rank, dev=dev)
     wl = WORKLOADS[args.workload]
@@ -362,6 +375,17 @@ def main() -> None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # every rank's own kernel times travel to rank 0 (north_star: reads/s AND HBM GB/s at every N): mean mapping-kernel, resolve,
+    # count and whole-step device time per rank
+    n_t = max(len(map_ms), 1)
+    mine = [sum(m[0] for m in map_ms) / n_t, sum(m[1] for m in map_ms) / n_t, sum(m[2] for m in map_ms) / n_t, sum(step_ms) / max(len(step_ms), 1)]
+    per_rank = [mine]
+    if dist is not None:
+        t = torch.tensor(mine, dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [g.tolist() for g in gathered]
 
     total_reads = K * B * n_gpus
     value = total_reads / elapsed
@@ -400,13 +424,36 @@ def main() -> None:
             log("ingest leg failed: %r" % (e,))
             out["ingest_error"] = repr(e)
 
+    if n_gpus == 1 and rank == 0 and not args.no_ingest and args.workload == "config3":
+        try:
+            out.update(per_call_leg(env, run))
+        except Exception as e:   # an extra report: never lose the bench line over it
+            log("per-call leg failed: %r" % (e,))
+            out["per_call_error"] = repr(e)
+
     if rank == 0:
         # ---- checker + CPU baseline (oracle = C port of the reference path), outside the timed region ----
         ncpu = usable_cpus()
         sample_n = 200_000
         oracle, ctr, first = run.check_sample(sample_n, ncpu)
         out["parity_sample"] = {"reads": sample_n, "bit_exact_vs_oracle": True}
+        if "_e2e_sample" in out:   # the host-to-host leg's own outputs (records and ids as they arrived on the host) against the oracle
+            part, coff, cids, nn, bb = out.pop("_e2e_sample")
+            e_first = (rank * (K + W) + bb) * B
+            e_tiles, e_lens = run.txome.simulate_host(read_len, wl["read_seed"], nn, wl["ppm"], e_first, run.wpr)
+            o_res, o_coff, o_ids, _ = oracle.map_tiles(e_tiles, e_lens, run.wpr, 2, ncpu)
+            helpers.assert_same_as_oracle(part, coff, cids, o_res, o_coff, o_ids, "host-to-host leg, first chunk")
+            out["e2e"]["parity_sample"] = {"reads": nn, "bit_exact_vs_oracle": True, "taken_from": "the host-side records and class ids of this leg"}
         out["roofline"] = roofline_of(run, ctr, map_ms, step_ms)
+        rf = out["roofline"]
+        kms = [r[0] + r[1] for r in per_rank]
+        out["per_rank"] = {"ranks": len(per_rank), "kernel_ms": [round(x, 3) for x in kms], "kernel_ms_min": min(kms), "kernel_ms_max": max(kms), "kernel_ms_mean": sum(kms) / len(kms),
+                           "step_device_ms": [round(r[3], 3) for r in per_rank],
+                           # achieved algorithmic GB/s and counter-derived HBM GB/s of every rank (each maps its own B reads per step)
+                           "achieved_gbps": [rf["algorithmic_bytes_per_read"] * B / (k * 1e-3) / 1e9 for k in kms],
+                           "traffic_gbps": [(rf["traffic"] / (r[3] * 1e-3) / 1e9) if rf.get("traffic") else None for r in per_rank],
+                           "what": "mapping stage (pa_map_pool_kernel + pa_resolve_kernel) and whole-step device time of every rank, means over the timed steps; "
+                                   "roofline{} above is rank 0's"}
         if n_gpus == 1 and not args.no_cpu_baseline:
             s_tiles, s_lens = run.txome.simulate_host(read_len, wl["read_seed"], sample_n, wl["ppm"], first, run.wpr)
             rate = sample_n / max(1e-9, _time_oracle(oracle, s_tiles, s_lens, run.wpr, ncpu))
@@ -443,6 +490,7 @@ def main() -> None:
             log("config5 leg failed: %r" % (e,))
             out["config5_error"] = repr(e)
 
+    out.pop("_e2e_sample", None)
     if rank == 0:
         print(json.dumps(out), flush=True)
     barrier()
@@ -546,60 +594,116 @@ def ingest_leg(env, run, n):
 
 
 def host_to_host_leg(env, run):
-    pa, torch, dev = env["pa"], env["torch"], env["dev"]
+    """SURVEY §8d's literal metric: the batch from PINNED HOST tiles to COMPLETE per-read outputs on the host — the 16-byte records, the
+    ids of every class that is not an index class (the used part of each chunk's arena) and the count table. Chunks of a few million
+    reads rotate over several streams of the one index handle: H2D of chunk i+1 and D2H of chunk i-1 overlap the kernels of chunk i.
+    The batch is uniform (every read has read_len bases): no length array crosses the link (pa_map_count_batch_uniform_device)."""
+    pa, torch, dev, np = env["pa"], env["torch"], env["dev"], env["np"]
     aligner, B, wpr = run.aligner, run.B, run.wpr
+    read_len = WORKLOADS[run.name]["read_len"]
     b = run.W % run.n_batches
     words = pa.lib().pa_tiles_words
     h_tiles = torch.empty(run.tile_words, dtype=torch.int64, pin_memory=True)
-    h_lens = torch.empty(B, dtype=torch.int32, pin_memory=True)
     h_results = torch.empty(B * 4, dtype=torch.int32, pin_memory=True)
     h_counts = torch.empty(aligner.counts_len(), dtype=torch.int64, pin_memory=True)
-    h_tiles.copy_(run.tiles[b]); h_lens.copy_(run.lens[b])
-    NS = int(os.environ.get("PA_E2E_STREAMS", "3"))   # chunks in flight (one stream + one set of staging buffers each)
-    chunk = min(B, int(os.environ.get("PA_E2E_CHUNK", str(min(B, 20_000_000)))))
+    h_tiles.copy_(run.tiles[b])
+    assert bool((run.lens[b] == read_len).all())
+    NS = int(os.environ.get("PA_E2E_STREAMS", "4"))   # chunks in flight (one stream + one set of staging buffers each)
+    chunk = min(B, int(os.environ.get("PA_E2E_CHUNK", str(min(B, 2_000_000))))) // 64 * 64 or B
     n_chunks = (B + chunk - 1) // chunk
+    arena_cap = aligner.arena_hint(chunk)
+    h_arena = torch.empty(min(arena_cap * n_chunks, max(arena_cap, B // 2)), dtype=torch.int32, pin_memory=True)   # the chunks' novel ids, back to back
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-    stage = [dict(tiles=torch.empty(words(chunk, wpr), dtype=torch.int64, device=dev), lens=torch.empty(chunk, dtype=torch.int32, device=dev),
-                  res=torch.empty(chunk * 4, dtype=torch.int32, device=dev), arena=torch.empty(aligner.arena_hint(chunk), dtype=torch.int32, device=dev),
-                  busy=False) for _ in range(NS)]
+    stage = [dict(tiles=torch.empty(words(chunk, wpr), dtype=torch.int64, device=dev), res=torch.empty(chunk * 4, dtype=torch.int32, device=dev),
+                  arena=torch.empty(arena_cap, dtype=torch.int32, device=dev), busy=-1) for _ in range(NS)]
     e_counts = torch.zeros(aligner.counts_len(), dtype=torch.int64, device=dev)
+    arena_base = np.zeros(n_chunks + 1, np.int64)      # chunk c's class_off values are relative to h_arena[arena_base[c]:]
+
+    def collect(st, S):
+        """chunk st['busy'] is done on its stream: its arena use is known, the ids follow its records to the host"""
+        c = st["busy"]
+        used = aligner.map_finish(S.cuda_stream)[0]
+        st["busy"] = -1
+        return c, used
 
     def host_to_host():
-        arena_ids = 0
         for st in stage:
-            st["busy"] = False
+            st["busy"] = -1
         e_counts.zero_()
+        arena_base[:] = 0
         torch.cuda.synchronize()
         t_e2e = time.perf_counter()
-        for c in range(n_chunks):
+        copied_upto, off = 0, 0
+        for c in range(n_chunks + NS):
             st, S = stage[c % NS], streams[c % NS]
-            lo, nn = c * chunk, min(chunk, B - c * chunk)          # chunk is a multiple of 64: tile aligned
-            if st["busy"]:
-                arena_ids += aligner.map_finish(S.cuda_stream)[0]   # the stream's previous chunk is done (its records are on the host)
-            with torch.cuda.stream(S):
-                st["tiles"][: words(nn, wpr)].copy_(h_tiles[(lo // 64) * wpr * 64: (lo // 64) * wpr * 64 + words(nn, wpr)], non_blocking=True)
-                st["lens"][:nn].copy_(h_lens[lo: lo + nn], non_blocking=True)
-                aligner.map_count_batch_device(st["tiles"].data_ptr(), st["lens"].data_ptr(), nn, wpr, st["res"].data_ptr(), st["arena"].data_ptr(),
-                                               st["arena"].numel(), e_counts.data_ptr(), 2, S.cuda_stream)
-                h_results[lo * 4: (lo + nn) * 4].copy_(st["res"][: nn * 4], non_blocking=True)
-            st["busy"] = True
-        for i in range(NS):
-            if stage[i]["busy"]:
-                arena_ids += aligner.map_finish(streams[i].cuda_stream)[0]
+            if st["busy"] >= 0:
+                cc, used = collect(st, S)
+                # chunks complete in launch order on their stream and streams are visited round-robin: cc == copied_upto
+                assert cc == copied_upto
+                if used:
+                    with torch.cuda.stream(S):
+                        h_arena[off: off + used].copy_(st["arena"][:used], non_blocking=True)
+                arena_base[cc] = off
+                off += used
+                copied_upto += 1
+            if c < n_chunks:
+                lo, nn = c * chunk, min(chunk, B - c * chunk)          # chunk is a multiple of 64: tile aligned
+                with torch.cuda.stream(S):
+                    st["tiles"][: words(nn, wpr)].copy_(h_tiles[(lo // 64) * wpr * 64: (lo // 64) * wpr * 64 + words(nn, wpr)], non_blocking=True)
+                    aligner.map_count_batch_uniform_device(st["tiles"].data_ptr(), read_len, nn, wpr, st["res"].data_ptr(), st["arena"].data_ptr(),
+                                                           st["arena"].numel(), e_counts.data_ptr(), 2, S.cuda_stream)
+                    h_results[lo * 4: (lo + nn) * 4].copy_(st["res"][: nn * 4], non_blocking=True)
+                st["busy"] = c
+        arena_base[n_chunks] = off
         h_counts.copy_(e_counts)
         torch.cuda.synchronize()
-        return time.perf_counter() - t_e2e, arena_ids
+        return time.perf_counter() - t_e2e, off
     host_to_host()                       # warm-up: the per-stream launch contexts (scratch rows, key streams) are created on first use
     e2e_s, arena_ids = host_to_host()
     assert os.environ.get("PA_MAP_ABLATE") or int(h_counts.sum()) == B
+    # parity of THIS leg's outputs: the first chunk's records + ids as they arrived on the host, against the oracle
+    nn = min(chunk, 100_000)
+    part = h_results[: nn * 4].numpy().view(pa.RESULT_DTYPE)
+    coff, cids = pa.gather_classes(part, h_arena[: int(arena_base[1])].numpy().view(np.uint32), run.host)
+    sample = (part.copy(), coff, cids, nn, b)       # compared with the oracle once it is built (main, checker section)
     for S in streams:                    # the leg's streams go away: so do their launch contexts inside the index
         aligner.release_stream(S.cuda_stream)
-    h2d_bytes = B * (wpr * 8 + 4)
-    return {"e2e_reads_per_s": B / e2e_s, "e2e_pcie_frac": h2d_bytes / e2e_s / 63e9,
+    h2d_bytes = B * wpr * 8
+    return {"e2e_reads_per_s": B / e2e_s, "e2e_pcie_frac": h2d_bytes / e2e_s / 63e9, "e2e_link_frac_of_measured_57": h2d_bytes / e2e_s / 57e9,
             "e2e": {"ms": 1000.0 * e2e_s, "chunks": n_chunks, "reads_per_chunk": chunk, "streams": NS, "h2d_bytes": h2d_bytes,
-                    "d2h_bytes": B * 16 + 8 * aligner.counts_len(), "novel_class_ids_left_on_device": int(arena_ids),
-                    "what": "pinned host 2-bit tiles -> H2D || kernels || D2H of the 16-byte records on several streams of one index handle "
-                            "-> records + count table on the host; link = PCIe Gen5 x16, 63 GB/s per direction"}}
+                    "d2h_bytes": B * 16 + 4 * int(arena_ids) + 8 * aligner.counts_len(), "novel_class_ids_on_host": int(arena_ids), "novel_class_ids_left_on_device": 0,
+                    "parity_sample": None,
+                    "what": "pinned host 2-bit tiles (uniform batch: no length array) -> H2D || kernels || D2H of the 16-byte records and of each chunk's novel "
+                            "class ids on several streams of one index handle -> records + ids + count table on the host; link = PCIe Gen5 x16, 63 GB/s per "
+                            "direction spec, 57 GB/s measured (profiles/r02_pcie_bw.json)"},
+            "_e2e_sample": sample}
+
+
+def per_call_leg(env, run, n_single=2000, n_batch=1_000_000):
+    """What a caller that loops over `map_read` pays (the reference's own test does: src/build_index.rs:309) against the batch form
+    of the same boundary: pa_map_read_packed, one call per read (H2D + launch + D2H each), and pa_map_batch_packed on n_batch reads
+    held 2-bit packed (what amd::map_reads binds). Extra keys: `map_read_us` (mean wall time of one call) and `map_reads_batch_reads_per_s`."""
+    pa, np = env["pa"], env["np"]
+    wl, wpr = WORKLOADS[run.name], run.wpr
+    tiles, lens = run.txome.simulate_host(wl["read_len"], wl["read_seed"], n_batch, wl["ppm"], 0, wpr)
+    words = np.ascontiguousarray(tiles.reshape(-1, wpr, 64).transpose(0, 2, 1).reshape(-1, wpr)[:n_batch])       # [read][word], LSB-first
+    a = run.aligner
+    for i in range(20):                                                                     # warm-up (the per-thread buffers of the single-read path)
+        a.map_read_packed(words[i], int(lens[i]))
+    t0 = time.perf_counter()
+    for i in range(n_single):
+        a.map_read_packed(words[i], int(lens[i]))
+    single_s = (time.perf_counter() - t0) / n_single
+    off = (np.arange(n_batch + 1, dtype=np.uint64) * np.uint64(wpr))
+    a.map_batch_packed(words.reshape(-1)[: 4096 * wpr], off[:4097], lens[:4096])
+    t0 = time.perf_counter()
+    res, coff, ids = a.map_batch_packed(words.reshape(-1), off, lens)
+    batch_s = time.perf_counter() - t0
+    one = a.map_read_packed(words[7], int(lens[7]))
+    assert one is not None and one[0] == ids[int(coff[7]):int(coff[8])].tolist() and one[1] == int(res["coverage"][7])
+    return {"map_read_us": 1e6 * single_s, "map_reads_batch_reads_per_s": n_batch / batch_s,
+            "per_call": {"calls": n_single, "batch_reads": n_batch, "what": "pa_map_read_packed once per read vs pa_map_batch_packed on host-resident packed reads "
+                                                                           "(pack to tiles, H2D, map, D2H, class ids resolved on the host), same index"}}
 
 
 def usable_cpus() -> int:

@@ -62,7 +62,8 @@ typedef enum pa_status {
     PA_ERR_OOM = -6,
     PA_ERR_ARENA_FULL = -7,    /* caller-provided class arena too small; required size reported */
     PA_ERR_UNSUPPORTED = -8,
-    PA_ERR_INTERNAL = -9
+    PA_ERR_INTERNAL = -9,
+    PA_ERR_BUFFER_TOO_SMALL = -10   /* pa_records_pull: the caller's buffer cannot hold even the next tuple; *n_bytes = the bytes it needs */
 } pa_status;
 
 /* ------------------------------------------------------------------------------------------
@@ -221,6 +222,11 @@ int pa_map_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* 
 int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads,
                               uint32_t words_per_read, uint32_t allowed_mismatches, pa_read_result* d_results,
                               uint32_t* d_arena, uint64_t arena_cap, uint64_t* d_counts, void* stream);
+/* The same launch for a batch whose reads all have `read_len` bases (what a sequencer run delivers): no per-read length array — 4 of
+ * the 44 bytes per 150-base read that cross PCIe in the host-to-host pipeline, and one request stream less inside the kernel. */
+int pa_map_count_batch_uniform_device(pa_index* idx, const uint64_t* d_tiles, uint32_t read_len, uint64_t n_reads,
+                                      uint32_t words_per_read, uint32_t allowed_mismatches, pa_read_result* d_results,
+                                      uint32_t* d_arena, uint64_t arena_cap, uint64_t* d_counts, void* stream);
 /* Synchronise and report: PA_OK, or PA_ERR_ARENA_FULL with *arena_needed set (re-run with a larger arena).
  * *arena_used = entries of d_arena that may hold ids (never more than the arena_cap of the launch). */
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed);
@@ -302,7 +308,9 @@ int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path
  * pa_process_reads: a full batch (batch_reads, 0 = 2 Mi reads) is packed by `num_threads` workers (0 = all usable CPUs) and
  * launched on the stream's own HIP stream while the caller goes on reading; the batch before it is rendered meanwhile.
  *   push   copies the records (the caller's buffers are free afterwards); may pack + launch a batch and render the previous one
- *   pull   copies rendered text into buf, whole lines only, never waits for the GPU; *n_bytes = 0: nothing ready yet
+ *   pull   copies rendered text into buf, whole lines only, never waits for the GPU; *n_bytes = 0: nothing ready yet. A buffer that
+ *          cannot hold even the next tuple gets PA_ERR_BUFFER_TOO_SMALL with *n_bytes = the bytes that tuple needs (nothing is lost:
+ *          pull again with a larger buffer; this failure is not sticky)
  *   flush  launches what is left, waits and renders: afterwards pull drains every record pushed so far
  * One thread at a time per stream object; several objects may share an index. A failure is sticky: every later call on the
  * object returns it. */

@@ -5,6 +5,7 @@
  * with a GPU the whole sequence runs on a toy transcriptome.
  *   usage: abi_check <fasta> <fastq> <scratch dir>          exit code 0 = every call behaved
  */
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -21,6 +22,22 @@ int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: %s <fasta> <fastq> <scratch dir>\n", argv[0]); return 2; }
     const char *fasta = argv[1], *fastq = argv[2], *dir = argv[3];
     char path[1024], report[256];
+
+    /* the struct layouts as THIS compiler sees them, for the test that checks the #[repr(C)] structs of integration/rust/src/amd_ffi.rs
+     * against them (tests/test_abi.py): "layout <struct> sizeof <n>" and "layout <struct>.<field> <offset>" */
+#define LAYOUT_STRUCT(T) printf("layout %s sizeof %zu\n", #T, sizeof(T))
+#define LAYOUT_FIELD(T, f) printf("layout %s.%s %zu\n", #T, #f, offsetof(T, f))
+    LAYOUT_STRUCT(pa_flat_index);
+    LAYOUT_FIELD(pa_flat_index, k); LAYOUT_FIELD(pa_flat_index, num_nodes); LAYOUT_FIELD(pa_flat_index, num_classes); LAYOUT_FIELD(pa_flat_index, num_transcripts);
+    LAYOUT_FIELD(pa_flat_index, seq_bases); LAYOUT_FIELD(pa_flat_index, node_seq); LAYOUT_FIELD(pa_flat_index, node_start); LAYOUT_FIELD(pa_flat_index, node_len);
+    LAYOUT_FIELD(pa_flat_index, node_exts); LAYOUT_FIELD(pa_flat_index, node_colour); LAYOUT_FIELD(pa_flat_index, ec_offset); LAYOUT_FIELD(pa_flat_index, ec_ids);
+    LAYOUT_FIELD(pa_flat_index, node_redge); LAYOUT_FIELD(pa_flat_index, node_ledge);
+    LAYOUT_STRUCT(pa_read_result);
+    LAYOUT_FIELD(pa_read_result, coverage); LAYOUT_FIELD(pa_read_result, mismatches); LAYOUT_FIELD(pa_read_result, class_off); LAYOUT_FIELD(pa_read_result, class_len);
+    LAYOUT_STRUCT(pa_index_stats);
+    LAYOUT_FIELD(pa_index_stats, num_kmers); LAYOUT_FIELD(pa_index_stats, table_slots); LAYOUT_FIELD(pa_index_stats, bytes_table); LAYOUT_FIELD(pa_index_stats, bytes_graph);
+    LAYOUT_FIELD(pa_index_stats, bytes_classes); LAYOUT_FIELD(pa_index_stats, bytes_total); LAYOUT_FIELD(pa_index_stats, num_nodes); LAYOUT_FIELD(pa_index_stats, num_classes);
+    LAYOUT_FIELD(pa_index_stats, k); LAYOUT_FIELD(pa_index_stats, max_class_len);
 
     /* ---- host half ---- */
     EXPECT(pa_abi_version() == PA_ABI_VERSION);
@@ -203,6 +220,25 @@ int main(int argc, char** argv) {
         EXPECT(pa_map_finish(idx, NULL, &used, &need) == PA_OK);
         { float kms = -1.0f, st[3] = {-1.0f, -1.0f, -1.0f}; EXPECT(pa_map_kernel_ms(idx, NULL, &kms) == PA_OK && kms > 0.0f);
           EXPECT(pa_map_stage_ms(idx, NULL, st) == PA_OK && st[0] > 0.0f && st[1] >= 0.0f && st[2] >= 0.0f); EXPECT(pa_index_set_timing(idx, 0) == PA_OK); }
+        {   /* the same batch as a uniform one (the simulator's reads all have 60 bases): the same records without a length array */
+            void* d_res2 = NULL;
+            pa_read_result *r1 = (pa_read_result*)malloc(nsim * sizeof(pa_read_result)), *r2 = (pa_read_result*)malloc(nsim * sizeof(pa_read_result));
+            EXPECT(pa_device_malloc(0, nsim * sizeof(pa_read_result), &d_res2) == PA_OK);
+            EXPECT(pa_map_count_batch_uniform_device(idx, (const uint64_t*)d_tiles, 0, nsim, sim_wpr, 2, (pa_read_result*)d_res2, (uint32_t*)d_arena, arena_cap,
+                                                     (uint64_t*)d_counts, NULL) == PA_ERR_INVALID_ARG);
+            EXPECT(pa_memcpy_d2h(r1, d_res, nsim * sizeof(pa_read_result), NULL) == PA_OK);
+            EXPECT(pa_map_count_batch_uniform_device(idx, (const uint64_t*)d_tiles, 60, nsim, sim_wpr, 2, (pa_read_result*)d_res2, (uint32_t*)d_arena, arena_cap,
+                                                     (uint64_t*)d_counts, NULL) == PA_OK);
+            EXPECT(pa_map_finish(idx, NULL, &used, &need) == PA_OK);
+            EXPECT(pa_memcpy_d2h(r2, d_res2, nsim * sizeof(pa_read_result), NULL) == PA_OK && pa_stream_synchronize(NULL) == PA_OK);
+            uint64_t same = 0;
+            for (uint64_t i = 0; i < nsim; ++i)
+                same += r1[i].coverage == r2[i].coverage && r1[i].mismatches == r2[i].mismatches && r1[i].class_len == r2[i].class_len &&
+                        ((r1[i].class_off & PA_CLASS_REF) ? r1[i].class_off == r2[i].class_off : !(r2[i].class_off & PA_CLASS_REF));
+            EXPECT(same == nsim);
+            EXPECT(pa_device_free(d_res2) == PA_OK);
+            free(r1); free(r2);
+        }
         EXPECT(pa_index_release_stream(idx, NULL) == PA_OK);   /* the null stream's launch context goes; the next launch makes a new one */
         EXPECT(pa_event_elapsed_ms(ev0, ev1, &ms) == PA_OK && ms >= 0.0f);
         EXPECT(pa_map_batch_device(idx, (const uint64_t*)d_tiles, (const uint32_t*)d_lens, nsim, sim_wpr, 2, (pa_read_result*)d_res, (uint32_t*)d_arena,
@@ -226,7 +262,7 @@ int main(int argc, char** argv) {
         EXPECT(pa_memcpy_d2h(h_counts, d_counts, counts_len * 8, NULL) == PA_OK);
         uint64_t total = 0;
         for (uint64_t i = 0; i < counts_len; ++i) total += h_counts[i];
-        EXPECT(total == 2 * nsim);                                   /* counted once by the fused launch, once by the count kernel */
+        EXPECT(total == 3 * nsim);                                   /* counted by the two fused launches (ragged form, uniform form) and once by the count kernel */
         const uint32_t* words = NULL;
         uint64_t nw = 0;
         EXPECT(pa_overflow_fetch(ovf, NULL, &words, &nw) == PA_OK && nw >= 2 && words[1] == nw);

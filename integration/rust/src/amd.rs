@@ -120,41 +120,96 @@ impl Drop for AmdIndex { fn drop(&mut self) { unsafe { pa_index_destroy(self.raw
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Drop-in entry points with the reference's EXACT signatures. The GPU copy of an index is made on first use and cached by the
-// CONTENT of the `Pseudoaligner` (k, node / class / transcript counts and a fingerprint of the class table and the node
-// lengths), not by its address: an index that was dropped and another one allocated in its place never meets a stale GPU copy,
-// a moved or cloned one finds its copy again. Callers keep passing `&Pseudoaligner<K>`.
+// CONTENT of the `Pseudoaligner`: k, node / class / transcript counts and a fingerprint of EVERY base of every node, every node's
+// colour and extension byte and EVERY id of every class — two indexes of the same shape with different sequence (SNP-personalised
+// transcriptomes) or classes such as [1,5,9] / [1,6,9] never share a GPU copy; an index that was dropped and another one
+// allocated in its place never meets a stale copy; a moved or cloned one finds its copy again. The cache holds at most
+// CACHE_MAX GPU copies (least recently used goes: `pa_index_destroy` frees its HBM when the last `Arc` is dropped).
 // ---------------------------------------------------------------------------------------------------------------------------
+const CACHE_MAX: usize = 2;
 type CacheKey = (usize, usize, usize, usize, u64);
 fn fingerprint<K: Kmer>(index: &Pseudoaligner<K>) -> u64 {
     let mut h = 0xcbf2_9ce4_8422_2325u64;                                  // FNV-1a over 64-bit words
     let mut mix = |v: u64| { h ^= v; h = h.wrapping_mul(0x0000_0100_0000_01b3); };
-    for c in &index.eq_classes {                                           // every class: its length, first and last id
+    for c in &index.eq_classes {                                           // every class: its length and every id
         mix(c.len() as u64);
-        if let (Some(a), Some(b)) = (c.first(), c.last()) { mix(((*a as u64) << 32) | *b as u64); }
+        for pair in c.chunks(2) { mix(((pair[0] as u64) << 32) | *pair.get(1).unwrap_or(&u32::MAX) as u64); }
     }
-    for node in index.dbg.iter_nodes() { mix(((node.sequence().len() as u64) << 32) | *node.data() as u64); }   // node lengths and colours
+    for node in index.dbg.iter_nodes() {                                   // every node: length, colour, extensions, every base
+        let s = node.sequence();
+        mix(((s.len() as u64) << 32) | *node.data() as u64);
+        mix(node.exts().val as u64);
+        let (mut w, mut n) = (0u64, 0u32);
+        for i in 0..s.len() {
+            w |= (s.get(i) as u64) << (2 * n); n += 1;
+            if n == 32 { mix(w); w = 0; n = 0; }
+        }
+        if n > 0 { mix(w); }
+    }
     h
 }
-fn cache() -> &'static Mutex<HashMap<CacheKey, Arc<AmdIndex>>> {
-    static CACHE: OnceLock<Mutex<HashMap<CacheKey, Arc<AmdIndex>>>> = OnceLock::new();
-    CACHE.get_or_init(|| Mutex::new(HashMap::new()))
+struct Cache { map: HashMap<CacheKey, Arc<AmdIndex>>, order: Vec<CacheKey> }   // order: least recently used first
+fn cache() -> &'static Mutex<Cache> {
+    static CACHE: OnceLock<Mutex<Cache>> = OnceLock::new();
+    CACHE.get_or_init(|| Mutex::new(Cache { map: HashMap::new(), order: Vec::new() }))
 }
 fn key_of<K: Kmer>(index: &Pseudoaligner<K>) -> CacheKey {
     (index.dbg.len(), index.eq_classes.len(), index.tx_names.len(), K::k(), fingerprint(index))
 }
-// (the fingerprint walks the graph once per call — a few ms at 200 k transcripts; `process_reads` looks its index up once per
-// run, a host that calls `map_read` per read keeps the `Arc<AmdIndex>` of `gpu_index` instead)
+// (the fingerprint walks every base once per call — tenths of a second at 200 k transcripts; `process_reads` and `map_reads` look
+// their index up once per call, a host that calls `map_read` per read keeps the `Arc<AmdIndex>` of `gpu_index` instead)
 fn device_of_env() -> i32 { std::env::var("PSEUDOALIGNER_AMD_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0) }
 
-/// the GPU copy of `index` (built once: 0.14 s for a 200 k-transcript index)
+/// the GPU copy of `index` (built once: about half a second for a 200 k-transcript index)
 pub fn gpu_index<K: Kmer>(index: &Pseudoaligner<K>) -> Result<Arc<AmdIndex>, Error> {
     let key = key_of(index);
-    if let Some(hit) = cache().lock().unwrap().get(&key) { return Ok(hit.clone()); }
+    {
+        let mut c = cache().lock().unwrap();
+        if let Some(hit) = c.map.get(&key).cloned() {
+            c.order.retain(|k| *k != key); c.order.push(key);
+            return Ok(hit);
+        }
+    }
     let made = Arc::new(AmdIndex::from_pseudoaligner(index, device_of_env())?);
-    Ok(cache().lock().unwrap().entry(key).or_insert(made).clone())
+    let mut c = cache().lock().unwrap();
+    let got = c.map.entry(key).or_insert(made).clone();
+    c.order.retain(|k| *k != key); c.order.push(key);
+    while c.order.len() > CACHE_MAX { let old = c.order.remove(0); c.map.remove(&old); }   // the GPU copy goes with its last Arc
+    Ok(got)
 }
 /// call before dropping a `Pseudoaligner` whose GPU copy should go too
-pub fn forget<K: Kmer>(index: &Pseudoaligner<K>) { cache().lock().unwrap().remove(&key_of(index)); }
+pub fn forget<K: Kmer>(index: &Pseudoaligner<K>) {
+    let key = key_of(index);
+    let mut c = cache().lock().unwrap();
+    c.map.remove(&key); c.order.retain(|k| *k != key);
+}
+
+/// MANY reads in one launch — what a caller that loops over `map_read` should call instead (the reference's own test maps every
+/// transcript one call at a time, src/build_index.rs:309). One `map_read` call is one H2D + one kernel launch + one D2H: tens of
+/// microseconds per read, slower than the CPU path it replaces; a batch amortises them over all its reads.
+/// Result i is what `map_read(&reads[i])` returns (src/pseudoaligner.rs:381-384).
+pub fn map_reads<K: Kmer + Sync + Send>(index: &Pseudoaligner<K>, reads: &[DnaString]) -> Result<Vec<Option<(Vec<u32>, usize)>>, Error> {
+    let gpu = gpu_index(index)?;
+    let (mut words, mut word_off, mut lens) = (Vec::new(), vec![0u64], Vec::with_capacity(reads.len()));
+    for r in reads {                                                       // every read starts on a word boundary, LSB-first words
+        let base = words.len();
+        words.resize(base + (r.len() + 31) / 32, 0u64);
+        for i in 0..r.len() { words[base + i / 32] |= (r.get(i) as u64) << (2 * (i % 32)); }
+        word_off.push(words.len() as u64);
+        lens.push(r.len() as u32);
+    }
+    words.push(0);
+    let mut results = vec![PaReadResult::default(); reads.len()];
+    let mut class_off = vec![0u64; reads.len() + 1];
+    let mut class_ids: *const u32 = std::ptr::null();
+    check(unsafe { pa_map_batch_packed(gpu.raw, words.as_ptr(), word_off.as_ptr(), lens.as_ptr(), reads.len() as u64, PA_PACKED_LSB_FIRST,
+                                       DEFAULT_ALLOWED_MISMATCHES as u32, results.as_mut_ptr(), class_off.as_mut_ptr(), &mut class_ids) })?;
+    Ok((0..reads.len()).map(|i| {
+        if results[i].mismatches & PA_MAPPED_BIT == 0 { return None; }
+        let ids = unsafe { std::slice::from_raw_parts(class_ids.add(class_off[i] as usize), (class_off[i + 1] - class_off[i]) as usize) };
+        Some((ids.to_vec(), results[i].coverage as usize))                 // (library-owned ids: copied before the next call on this index)
+    }).collect())
+}
 
 /// `Pseudoaligner::map_read` (src/pseudoaligner.rs:381), same arguments and result: replace its body by
 /// `crate::amd::map_read(self, read_seq)`. Panics where the reference panics (it has no error path, :307,446).
@@ -191,10 +246,10 @@ pub fn process_reads<K: Kmer + Sync + Send, P: AsRef<Path> + Debug>(
         loop {
             let mut n = 0usize;
             let rc = unsafe { pa_records_pull(stream, text.as_mut_ptr() as *mut _, text.len(), &mut n) };
-            if rc < 0 && n == 0 && text.len() < (1usize << 31) {
-                // one tuple longer than the buffer (a class of hundreds of thousands of ids): grow and ask again
-                let msg = unsafe { CStr::from_ptr(pa_last_error()) }.to_string_lossy().into_owned();
-                if msg.contains("smaller than one tuple") { text.resize(text.len() * 4, 0); continue; }
+            if rc == PA_ERR_BUFFER_TOO_SMALL && text.len() < (1usize << 31) {
+                // one tuple longer than the buffer (a class of hundreds of thousands of ids): n = the bytes it needs; grow and ask again
+                text.resize(n.max(text.len() * 2), 0);
+                continue;
             }
             check(rc)?;
             if n == 0 { break; }

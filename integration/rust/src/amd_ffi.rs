@@ -7,6 +7,7 @@ use std::os::raw::{c_char, c_int, c_void};
 
 pub const PA_OK: c_int = 0;
 pub const PA_ERR_ARENA_FULL: c_int = -7;
+pub const PA_ERR_BUFFER_TOO_SMALL: c_int = -10;
 pub const PA_MAPPED_BIT: u32 = 0x8000_0000;
 pub const PA_CLASS_REF: u32 = 0x8000_0000;
 pub const PA_MAX_ARENA_ENTRIES: u64 = 0x7FFF_FFFF;
@@ -93,6 +94,9 @@ extern "C" {
     pub fn pa_map_count_batch_device(idx: *mut PaIndex, d_tiles: *const u64, d_lens: *const u32, n_reads: u64,
                                      words_per_read: u32, allowed_mismatches: u32, d_results: *mut PaReadResult,
                                      d_arena: *mut u32, arena_cap: u64, d_counts: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn pa_map_count_batch_uniform_device(idx: *mut PaIndex, d_tiles: *const u64, read_len: u32, n_reads: u64,
+                                             words_per_read: u32, allowed_mismatches: u32, d_results: *mut PaReadResult,
+                                             d_arena: *mut u32, arena_cap: u64, d_counts: *mut u64, stream: *mut c_void) -> c_int;
     pub fn pa_map_finish(idx: *mut PaIndex, stream: *mut c_void, arena_used: *mut u64, arena_needed: *mut u64) -> c_int;
     pub fn pa_index_release_stream(idx: *mut PaIndex, stream: *mut c_void) -> c_int;
     pub fn pa_index_set_timing(idx: *mut PaIndex, on: c_int) -> c_int;

@@ -388,6 +388,12 @@ class Pseudoaligner:
         check(lib().pa_map_count_batch_device(self._h, d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena,
                                               arena_cap, d_counts, stream or None))
 
+    def map_count_batch_uniform_device(self, d_tiles: int, read_len: int, n_reads: int, words_per_read: int, d_results: int, d_arena: int,
+                                       arena_cap: int, d_counts: int, allowed_mismatches: int = PA_DEFAULT_ALLOWED_MISMATCHES, stream: int = 0) -> None:
+        """map_count_batch_device for a batch whose reads all have read_len bases: no length array"""
+        check(lib().pa_map_count_batch_uniform_device(self._h, d_tiles, read_len, n_reads, words_per_read, allowed_mismatches, d_results, d_arena,
+                                                      arena_cap, d_counts, stream or None))
+
     def map_finish(self, stream: int = 0) -> Tuple[int, int]:
         used, need = C.c_uint64(), C.c_uint64()
         check(lib().pa_map_finish(self._h, stream or None, C.byref(used), C.byref(need)))

@@ -12,6 +12,7 @@ vp = C.c_void_p
 PA_OK = 0
 PA_ERR_NO_DEVICE = -4
 PA_ERR_ARENA_FULL = -7
+PA_ERR_BUFFER_TOO_SMALL = -10
 PA_MAPPED_BIT = 0x80000000
 PA_DEFAULT_ALLOWED_MISMATCHES = 2
 PA_READ_COVERAGE_THRESHOLD = 32
@@ -74,6 +75,7 @@ SIGNATURES = {
     "pa_encode_reads_host": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, vp, vp]),
     "pa_map_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),
     "pa_map_count_batch_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),
+    "pa_map_count_batch_uniform_device": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp, vp]),
     "pa_map_finish": (C.c_int, [vp, vp, u64p, u64p]),
     "pa_index_release_stream": (C.c_int, [vp, vp]),
     "pa_map_batch_packed": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_uint32, vp, vp, C.POINTER(vp)]),

@@ -26,6 +26,7 @@ namespace {
 
 constexpr uint32_t NO_KEY = 0xFFFFFFFFu;
 constexpr uint32_t MAX_BINS = 256;                       // tables of up to 8.4 M slots; beyond, keys are counted with plain atomics
+constexpr uint64_t PA_COUNT_DIRECT_MAX_READS = 1u << 16; // ... and so are the keys of batches this small
 constexpr uint32_t BIN_SLOTS = 1u << PA_KEY_BIN_SHIFT;
 constexpr uint32_t CS_BLOCK = 1024;
 
@@ -248,7 +249,7 @@ size_t count_keys_ctl_bytes(uint64_t counts_len) {
 }
 
 int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top_ptr, uint64_t keys_cap, const unsigned long long* extra_top, uint64_t extra_cap,
-                      uint32_t* sorted, uint32_t* ctl, unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream) {
+                      uint32_t* sorted, uint32_t* ctl, unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream, uint64_t n_reads) {
     if (counts_len == 0) return 0;
     const KeyTops keys_top{keys_top_ptr, keys_cap, extra_top, extra_cap};
     const uint64_t nbins = (counts_len + BIN_SLOTS - 1) >> PA_KEY_BIN_SHIFT;
@@ -259,8 +260,11 @@ int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top_p
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pa_keys_count_raw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    if (nbins > MAX_BINS) {
-        hipLaunchKernelGGL(pa_keys_count_direct_kernel, dim3(cus * 8), dim3(256), 0, stream, keys, keys_top, counts);
+    // plain atomics per key: tables beyond MAX_BINS bins — and SMALL batches of a multi-bin table, where four kernels over a few
+    // thousand keys cost more than the atomics they avoid (one launch instead of four; every small-batch test runs this kernel)
+    if (nbins > MAX_BINS || (nbins > 1 && n_reads <= PA_COUNT_DIRECT_MAX_READS)) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)cus * 8, (keys_cap + extra_cap + 255) / 256 + 1);
+        hipLaunchKernelGGL(pa_keys_count_direct_kernel, dim3(blocks), dim3(256), 0, stream, keys, keys_top, counts);
         return (int)hipGetLastError();
     }
     if (nbins == 1) {

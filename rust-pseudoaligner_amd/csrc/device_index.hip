@@ -316,7 +316,7 @@ static int ctx_of(pa_index* idx, hipStream_t stream, std::shared_ptr<LaunchCtx>*
 
 static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_tiles, const uint32_t* d_lens, uint64_t n_reads, uint32_t wpr,
                              uint32_t allowed, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap, uint32_t* d_colour,
-                             uint64_t* d_counts, uint32_t* d_nodes, uint32_t* d_nodes_len, hipStream_t stream) {
+                             uint64_t* d_counts, uint32_t* d_nodes, uint32_t* d_nodes_len, hipStream_t stream, uint32_t uniform_len = 0) {
     if (n_reads >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "at most 2^32-2 reads per batch");
     if (wpr == 0 || wpr > (PA_MAX_READ_LEN + 31) / 32) return fail(PA_ERR_UNSUPPORTED, "words_per_read %u outside [1,%u]", wpr, (PA_MAX_READ_LEN + 31) / 32);
     uint32_t grid = 0;
@@ -339,6 +339,7 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     p.ix = idx->dv;
     p.tiles = d_tiles;
     p.lens = d_lens;
+    p.uniform_len = uniform_len;   // (d_lens == nullptr: every read has this many bases)
     p.n_reads = n_reads;
     p.wpr = wpr;
     p.allowed = allowed;
@@ -408,7 +409,7 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
     if (timing) HIP_TRY(hipEventRecord(cx->ev2, stream));
     if (d_counts) {
         const int e2 = launch_count_keys(p.keys, p.keys_top, keys_cap, p.defer_top, defer_cap, cx->keys_sorted.as<uint32_t>(), cx->keys_ctl.as<uint32_t>(),
-                                         reinterpret_cast<unsigned long long*>(d_counts), counts_len, idx->num_cus, stream);
+                                         reinterpret_cast<unsigned long long*>(d_counts), counts_len, idx->num_cus, stream, n_reads);
         if (e2) return fail(PA_ERR_HIP, "count launch: %s", hipGetErrorString((hipError_t)e2));
         if (ovf) {
             rc = overflow_after_map(ovf, p.novel_list, p.novel_ctr, p.novel_cap, d_arena, stream);
@@ -492,6 +493,21 @@ int pa_map_count_batch_device(pa_index* idx, const uint64_t* d_tiles, const uint
     HIP_TRY(hipSetDevice(idx->device));
     return map_launch_locked(idx, cx.get(), d_tiles, d_lens, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, nullptr,
                              d_counts, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int pa_map_count_batch_uniform_device(pa_index* idx, const uint64_t* d_tiles, uint32_t read_len, uint64_t n_reads, uint32_t words_per_read,
+                                      uint32_t allowed_mismatches, pa_read_result* d_results, uint32_t* d_arena, uint64_t arena_cap, uint64_t* d_counts,
+                                      void* stream) {
+    if (!idx || !d_counts || (n_reads && (!d_tiles || !d_results || !d_arena))) return fail(PA_ERR_INVALID_ARG, "null argument");
+    if (read_len == 0 || read_len > PA_MAX_READ_LEN || read_len > 32ull * words_per_read)
+        return fail(PA_ERR_INVALID_ARG, "read_len %u does not fit %u words per read (or exceeds %u bases)", read_len, words_per_read, PA_MAX_READ_LEN);
+    HIP_TRY(hipSetDevice(idx->device));
+    std::shared_ptr<LaunchCtx> cx;
+    int rc = ctx_of(idx, static_cast<hipStream_t>(stream), &cx);
+    if (rc != PA_OK) return rc;
+    std::lock_guard<std::mutex> g(cx->mu);
+    return map_launch_locked(idx, cx.get(), d_tiles, nullptr, n_reads, words_per_read, allowed_mismatches, d_results, d_arena, arena_cap, nullptr,
+                             d_counts, nullptr, nullptr, static_cast<hipStream_t>(stream), read_len);
 }
 
 int pa_map_finish(pa_index* idx, void* stream, uint64_t* arena_used, uint64_t* arena_needed) {

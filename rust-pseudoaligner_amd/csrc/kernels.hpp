@@ -20,7 +20,8 @@ constexpr unsigned long long PA_NOVEL_LIST_FULL = 4ull;   // OVF_STATUS_LIST_FUL
 struct MapParams {
     DevIndexView ix;
     const uint64_t* tiles;
-    const uint32_t* lens;
+    const uint32_t* lens;      // [n_reads], or nullptr: every read has uniform_len bases (pa_map_count_batch_uniform_device)
+    uint32_t uniform_len;
     uint64_t n_reads;
     uint32_t wpr;
     uint32_t allowed;
@@ -76,7 +77,7 @@ int pool_kernel_occupancy(size_t lds_bytes, int* blocks_per_cu);
 uint64_t key_stream_capacity(uint64_t n_reads, uint32_t nwaves);
 size_t count_keys_ctl_bytes(uint64_t counts_len);                  // bytes of `ctl`   // u32 entries `keys` must hold for a launch of nwaves waves
 int launch_count_keys(const uint32_t* keys, const unsigned long long* keys_top, uint64_t keys_cap, const unsigned long long* extra_top, uint64_t extra_cap,
-                      uint32_t* sorted, uint32_t* ctl, unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream);
+                      uint32_t* sorted, uint32_t* ctl, unsigned long long* counts, uint64_t counts_len, int num_cus, hipStream_t stream, uint64_t n_reads);
 // resolve.hip: the deferred content lookups of a launch (records by reference / in the arena, count keys into keys_b, colours, novel list)
 uint64_t defer_capacity(uint64_t n_reads, uint32_t nwaves);   // 32-byte entries `defer` must hold
 int launch_resolve(const MapParams& p, uint64_t defer_cap, uint64_t keys_cap, int num_cus, hipStream_t stream);

@@ -306,10 +306,20 @@ __device__ __forceinline__ uint32_t queue_of(Lane& s, uint32_t K) {
 template <bool GREAD>
 __device__ __forceinline__ void refill_slot(Lane& s, uint64_t rid, uint32_t slot, karg_ptr p, lds_u64 rd, lds_u32 wc, uint32_t S, uint32_t wpr,
                                             uint32_t K) {
-    uint32_t L = p->lens[rid];
+    const uint32_t* lens = p->lens;
+    uint32_t L = lens ? lens[rid] : p->uniform_len;   // (a wave-uniform choice: a uniform batch does not fetch lengths at all)
     if (L > wpr * 32) L = wpr * 32;
     if (!GREAD) {
         const uint64_t* src = p->tiles + ((rid >> 6) * wpr) * 64 + (rid & 63);
+        // the common read lengths in straight-line code (all loads in flight, then the LDS stores; a loop over a run-time word count
+        // costs a scalar branch around every load and every store): 100 bp = 4 words, 150 bp = 5
+        if (wpr == 5) {
+            const uint64_t v0 = PA_LD(1, src), v1 = PA_LD(1, src + 64), v2 = PA_LD(1, src + 128), v3 = PA_LD(1, src + 192), v4 = PA_LD(1, src + 256);
+            rd[slot] = v0; rd[S + slot] = v1; rd[2 * S + slot] = v2; rd[3 * S + slot] = v3; rd[4 * S + slot] = v4;
+        } else if (wpr == 4) {
+            const uint64_t v0 = PA_LD(1, src), v1 = PA_LD(1, src + 64), v2 = PA_LD(1, src + 128), v3 = PA_LD(1, src + 192);
+            rd[slot] = v0; rd[S + slot] = v1; rd[2 * S + slot] = v2; rd[3 * S + slot] = v3;
+        } else
         for (uint32_t w0 = 0; w0 < wpr; w0 += 8) {   // eight words in flight per round trip
             uint64_t v[8];
 #pragma unroll
@@ -451,17 +461,25 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         // of them: one ballot instead of ten in most iterations (the order of consideration is the same either way)
         constexpr uint32_t RARE = (1u << ST_LEFT) | (1u << ST_F_LIGHT) | (1u << ST_F_SCAN) | (1u << ST_F_COOP) | (1u << ST_F_MASK);
         const bool any_rare = __ballot((((RARE >> (st_lo & 31u)) | (RARE >> (st_hi & 31u))) & 1u) != 0) != 0;   // (0xFF, no slot: bit 31, not rare)
+        const uint32_t n_bits_q = PA_CNT(ST_F_BITS), n_seek_q = PA_CNT(ST_SEEK), n_fwd_q = PA_CNT(ST_FWD);
         if (any_rare) {
             PA_CONSIDER_RARE_MIN(ST_F_COOP, PA_CNT(ST_F_COOP), PA_COOP_MIN)   // (the wave takes its reads one at a time: nothing to gain from gathering them)
             PA_CONSIDER_RARE(ST_F_SCAN, PA_CNT(ST_F_SCAN))
             PA_CONSIDER_RARE(ST_F_LIGHT, PA_CNT(ST_F_LIGHT))
             PA_CONSIDER_RARE(ST_F_MASK, PA_CNT(ST_F_MASK))
+            PA_CONSIDER(ST_F_BITS, n_bits_q)
+            PA_CONSIDER(ST_FWD, n_fwd_q)
+            PA_CONSIDER_RARE(ST_LEFT, PA_CNT(ST_LEFT))
+            PA_CONSIDER(ST_SEEK, n_seek_q)
+            PA_CONSIDER(ST_EMPTY, nrefill)
+        } else {
+            // the common iteration (no slot in a rare state): the same rule on four populations, as scalar min / max — the first of
+            // output, forward, probe, refill that fills a wave, else the most populated (ties: the earlier one)
+            const uint32_t cb = min(n_bits_q, 64u), cf = min(n_fwd_q, 64u), cs = min(n_seek_q, 64u), ce = min(nrefill, 64u);
+            best = max(max(cb, cf), max(cs, ce));
+            sel = cb == best ? (uint32_t)ST_F_BITS : cf == best ? (uint32_t)ST_FWD : cs == best ? (uint32_t)ST_SEEK : (uint32_t)ST_EMPTY;
+            bestn = cb == best ? n_bits_q : cf == best ? n_fwd_q : cs == best ? n_seek_q : nrefill;
         }
-        PA_CONSIDER(ST_F_BITS, PA_CNT(ST_F_BITS))
-        PA_CONSIDER(ST_FWD, PA_CNT(ST_FWD))
-        if (any_rare) PA_CONSIDER_RARE(ST_LEFT, PA_CNT(ST_LEFT))
-        PA_CONSIDER(ST_SEEK, PA_CNT(ST_SEEK))
-        PA_CONSIDER(ST_EMPTY, nrefill)
 #undef PA_CONSIDER
 #undef PA_CONSIDER_RARE
 #undef PA_CONSIDER_RARE_MIN
@@ -471,7 +489,6 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         // the probe's slot load and the node fetch go out back to back, and does the probe's arithmetic while the
         // node lines are on their way: two round trips in flight per wave instead of one (K <= 32: the two-word dictionary
         // has no dependent second load to hide).
-        const uint32_t n_seek_q = PA_CNT(ST_SEEK), n_fwd_q = PA_CNT(ST_FWD);
 #ifndef PA_SEEK_MIN   // probes ride with a forward step only from this many waiting slots on (or when little forward work is left): the probe half is
 #define PA_SEEK_MIN 32u   // the whole wave's instructions however few lanes it serves (same-box A/B of 1 / 32 / 48: config 3 -1.8 %, config 5 -3.8 % time at 32)
 #endif

@@ -146,7 +146,11 @@ int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads
     s->cache->idx = idx;
     s->ctx = s->cache->ctx;
     for (int k = 0; k < 2; ++k) { s->ctx[k].recs.clear(); s->ctx[k].n = 0; s->ctx[k].first = 0; }   // (a parked set still names its last batch)
-    if (hipSetDevice(s->device) != hipSuccess || (!s->cache->stream && hipStreamCreate(&s->cache->stream) != hipSuccess)) {
+    if (hipSetDevice(s->device) != hipSuccess) {   // (a stream the parked cache brought along stays with it: destroy releases it and its launch context)
+        pa_record_stream_destroy(s);
+        return fail(PA_ERR_HIP, "hipSetDevice(%d) failed", s->device);
+    }
+    if (!s->cache->stream && hipStreamCreate(&s->cache->stream) != hipSuccess) {
         s->cache->stream = nullptr;
         pa_record_stream_destroy(s);
         return fail(PA_ERR_HIP, "hipStreamCreate failed");
@@ -249,7 +253,11 @@ int pa_records_pull(pa_record_stream* s, char* buf, size_t cap, size_t* n_bytes)
             const void* nl = memrchr(f.mem.data() + s->out_off, '\n', room);
             take = nl ? (size_t)((const char*)nl - (f.mem.data() + s->out_off)) + 1 : 0;
             if (take == 0) {
-                if (got == 0) return fail(PA_ERR_INVALID_ARG, "buffer of %zu bytes is smaller than one tuple", cap);
+                if (got == 0) {   // not even the next tuple fits: say how much it needs (the caller grows its buffer and pulls again)
+                    const void* end = memchr(f.mem.data() + s->out_off, '\n', left);
+                    if (n_bytes) *n_bytes = end ? (size_t)((const char*)end - (f.mem.data() + s->out_off)) + 1 : left;
+                    return fail(PA_ERR_BUFFER_TOO_SMALL, "buffer of %zu bytes is smaller than one tuple", cap);
+                }
                 break;
             }
         }

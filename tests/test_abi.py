@@ -138,7 +138,49 @@ def test_c_client_calls_every_entry_point(built, tmp_path):
     out = subprocess.run([str(exe), str(helpers.FASTA), str(helpers.FASTQ), str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failures" in out.stdout
+    # the #[repr(C)] structs of the Rust binding against what the C compiler laid out (sizeof / offsetof printed by abi_check.c)
+    import abi_sigs
+    got = {}
+    for line in out.stdout.splitlines():
+        f = line.split()
+        if len(f) >= 3 and f[0] == "layout":
+            got[f[1] if f[2] != "sizeof" else f[1] + ".sizeof"] = int(f[-1])
+    rs = abi_sigs.rust_structs(rust)
+    assert set(rs) == {"pa_flat_index", "pa_read_result", "pa_index_stats"}
+    for name, fields in rs.items():
+        offs, size = abi_sigs.layout(fields)
+        assert got[name + ".sizeof"] == size, (name, got[name + ".sizeof"], size)
+        for fld, off in offs.items():
+            assert got["%s.%s" % (name, fld)] == off, (name, fld, got.get("%s.%s" % (name, fld)), off)
     if pa.lib().pa_device_count() < 1:
         assert "no device" in out.stdout
     else:
         assert "device halves ok" in out.stdout
+
+
+def test_rust_binding_matches_the_header_signature_by_signature():
+    """integration/rust/src/amd_ffi.rs cannot be compiled here (no rustc): every `pub fn pa_*` prototype — arity, each parameter's
+    C type through a fixed Rust -> C map, the return type — every #[repr(C)] struct (field order, names, types) and every constant is
+    compared with include/pseudoaligner_amd.h; a drifted u32 / u64, a swapped argument or a missing `const` fails here"""
+    import abi_sigs
+    header = (helpers.ROOT / "include" / "pseudoaligner_amd.h").read_text()
+    rust = (helpers.ROOT / "integration" / "rust" / "src" / "amd_ffi.rs").read_text()
+    hp, rp = abi_sigs.header_prototypes(header), abi_sigs.rust_prototypes(rust)
+    assert len(rp) > 45 and len(hp) >= len(rp)
+    for name, sig in rp.items():
+        assert name in hp, "amd_ffi.rs binds %s, which the header does not declare" % name
+        assert hp[name] == sig, "%s: Rust says %s, the header %s" % (name, sig, hp[name])
+    hs, rs = abi_sigs.header_structs(header), abi_sigs.rust_structs(rust)
+    for name, fields in rs.items():
+        assert hs[name] == fields, "struct %s: Rust %s, header %s" % (name, fields, hs[name])
+    hc, rc = abi_sigs.header_consts(header), abi_sigs.rust_consts(rust)
+    for name, value in rc.items():
+        assert hc.get(name) == value, "constant %s: Rust %r, header %r" % (name, value, hc.get(name))
+    # the comparison is not vacuous: a drifted binding is caught
+    for bad_from, bad_to in (("n_reads: u64, allowed_mismatches: u32", "n_reads: u32, allowed_mismatches: u32"),
+                             ("pub coverage: u32, pub mismatches: u32", "pub mismatches: u32, pub coverage: u32"),
+                             ("d_tiles: *const u64, d_lens: *const u32, n_reads: u64,", "d_lens: *const u32, d_tiles: *const u64, n_reads: u64,")):
+        assert bad_from in rust
+        drift = rust.replace(bad_from, bad_to, 1)
+        same = all(hp[n] == s for n, s in abi_sigs.rust_prototypes(drift).items()) and all(hs[n] == f for n, f in abi_sigs.rust_structs(drift).items())
+        assert not same, "a drifted binding went unnoticed: %s" % bad_to

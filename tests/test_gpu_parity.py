@@ -375,8 +375,12 @@ def test_record_stream_is_process_reads_for_a_caller_that_holds_the_reader(align
             assert got == b""                                            # 5000 records never fill the default batch: nothing yet
         rs.flush()
         if batch == 0:
-            with pytest.raises(pa.PaError):
+            with pytest.raises(pa.PaError) as err:
                 rs.pull(8)                                               # smaller than one tuple: refused, nothing lost
+            assert err.value.code == pa._ffi.PA_ERR_BUFFER_TOO_SMALL     # ... with a status of its own and the size the tuple needs
+            n = C.c_size_t()
+            buf = C.create_string_buffer(8)
+            assert pa.lib().pa_records_pull(rs._h, buf, 8, C.byref(n)) == pa._ffi.PA_ERR_BUFFER_TOO_SMALL and n.value == len(want[0]) + 1
         got += rs.drain()
         assert rs.stats() == (len(ids), sum(1 for w in want if w.startswith("(true")))
         assert got.decode().splitlines() == want, (batch, threads)

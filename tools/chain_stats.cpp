@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
     alignas(16) uint32_t refs[4], lens4[4], cids4[4], win4[4];
     uint32_t wcand[2];
     std::vector<uint32_t> spill(8 * read_len + 64), trace(8 * read_len + 64), pend(8 * read_len + 64);
-    uint64_t n_seek = 0, n_fwd = 0, n_left = 0, n_blocks = 0, n_nodes = 0, n_lists = 0, hop_edges = 0, hop_unique = 0, hop_unique_rem = 0;
+    uint64_t n_unknown = 0, n_seek = 0, n_fwd = 0, n_left = 0, n_blocks = 0, n_nodes = 0, n_lists = 0, hop_edges = 0, hop_unique = 0, hop_unique_rem = 0;
     std::map<uint32_t, uint64_t> rem_hist;
     std::map<uint32_t, uint64_t> fwd_hist;
     for (uint64_t i = 0; i < n; ++i) {
@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
                 if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++n_seek; }
                 else if (l_st(s) == ST_FWD) {
                     blocks.push_back(s.h);
+                    if (!(s.of & OF_CUR_KNOWN)) ++n_unknown;
                     fwd_step<true>(s, ix, rr, cr, 2);
                     ++n_fwd; ++nf;
                     if (l_st(s) == ST_FWD && (l_flags(s) & F_FRESH) && l_ntrace(s)) {   // left its chain over an edge
@@ -112,6 +113,7 @@ int main(int argc, char** argv) {
            (double)n_fwd / n, (double)n_left / n, (double)n_blocks / n, (double)n_nodes / n, (double)n_lists / n);
     printf("per read: %.3f hops over an edge, %.3f of them from a node with ONE right extension (mean read bases left then: %.1f)\n", (double)hop_edges / n,
            (double)hop_unique / n, hop_unique ? (double)hop_unique_rem / hop_unique : 0.0);
+    printf("forward steps that had to look for their node's slot: %.4f per read\n", (double)n_unknown / n);
     printf("forward steps per read:");
     for (auto& kv : fwd_hist) printf(" %u:%.3f", kv.first, (double)kv.second / n);
     printf("\n");
