@@ -612,7 +612,8 @@ def host_to_host_leg(env, run):
     chunk = min(B, int(os.environ.get("PA_E2E_CHUNK", str(min(B, 2_000_000))))) // 64 * 64 or B
     n_chunks = (B + chunk - 1) // chunk
     arena_cap = aligner.arena_hint(chunk)
-    h_arena = torch.empty(min(arena_cap * n_chunks, max(arena_cap, B // 2)), dtype=torch.int32, pin_memory=True)   # the chunks' novel ids, back to back
+    # the chunks' novel ids, back to back (a chunk's arena use includes the unused tails of the waves' private slices: about 0.8 entries per read at 2 M reads per chunk)
+    h_arena = torch.empty(min(arena_cap * n_chunks, max(arena_cap, B + B // 4)), dtype=torch.int32, pin_memory=True)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     stage = [dict(tiles=torch.empty(words(chunk, wpr), dtype=torch.int64, device=dev), res=torch.empty(chunk * 4, dtype=torch.int32, device=dev),
                   arena=torch.empty(arena_cap, dtype=torch.int32, device=dev), busy=-1) for _ in range(NS)]
@@ -641,6 +642,8 @@ def host_to_host_leg(env, run):
                 # chunks complete in launch order on their stream and streams are visited round-robin: cc == copied_upto
                 assert cc == copied_upto
                 if used:
+                    if off + used > h_arena.numel():
+                        raise RuntimeError("host arena of %d entries is too small for the chunks' class ids (%d so far)" % (h_arena.numel(), off + used))
                     with torch.cuda.stream(S):
                         h_arena[off: off + used].copy_(st["arena"][:used], non_blocking=True)
                 arena_base[cc] = off

@@ -89,6 +89,12 @@ struct pa_index {
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
     std::vector<uint32_t> h_class_ids;
     std::vector<uint32_t> h_ec, h_class_ref;
+    // every index class rendered once as the reference prints it between the brackets ("1, 5, 9"): text of class c =
+    // h_class_text[h_class_text_off[c] .. h_class_text_off[c + 1]). Built on first use by the ingest pipelines (ingest.hpp): a read
+    // whose class comes back by reference then costs one copy instead of a table walk and a decimal conversion per id.
+    std::once_flag class_text_once;
+    std::vector<uint64_t> h_class_text_off;
+    std::vector<char> h_class_text;
     std::vector<uint32_t> h_arena;
     void* ingest_cache = nullptr;   // parked by fastq.cpp between pa_process_reads calls (guarded by `mu`)
     void (*ingest_cache_free)(void*) = nullptr;
@@ -125,6 +131,60 @@ void index_host_classes(const pa_index* idx, const uint32_t** ec, const uint32_t
     *ec = idx->h_ec.data();
     *class_ref = idx->h_class_ref.data();
     *device = idx->device;
+}
+void index_host_class_text(pa_index* idx, const uint64_t** off, const char** text) {
+    std::call_once(idx->class_text_once, [idx] {
+        const uint32_t nc = idx->stats.num_classes;
+        const uint32_t* ec = idx->h_ec.data();
+        const uint32_t* cref = idx->h_class_ref.data();
+        // class lengths: a record is {class id, ids..., 0xFFFFFFFF padding} (device_layout.hpp); the id lists are sorted and never hold 0xFFFFFFFF
+        auto digits = [](uint32_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; ++d; } return d; };
+        std::vector<uint64_t>& off_v = idx->h_class_text_off;
+        off_v.assign((size_t)nc + 1, 0);
+        const int T = std::max(1, std::min(16, usable_threads()));
+        auto ids_of = [&](uint32_t c, const uint32_t*& ids, uint32_t& n) {
+            ids = ec + 4ull * cref[c] + 1;
+            const uint32_t next = c + 1 < nc ? cref[c + 1] : (uint32_t)(idx->h_ec.size() / 4 - 2);   // (records lie in class order; the table ends with an 8-word pad)
+            n = 4 * (next - cref[c]) - 1;
+            while (n && ids[n - 1] == 0xFFFFFFFFu) --n;
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t] {
+                    for (uint64_t c = (uint64_t)nc * t / T; c < (uint64_t)nc * (t + 1) / T; ++c) {
+                        const uint32_t* ids; uint32_t n;
+                        ids_of((uint32_t)c, ids, n);
+                        uint64_t len = n ? 2ull * (n - 1) : 0;
+                        for (uint32_t j = 0; j < n; ++j) len += digits(ids[j]);
+                        off_v[c + 1] = len;
+                    }
+                });
+            for (auto& x : th) x.join();
+        }
+        for (uint32_t c = 0; c < nc; ++c) off_v[c + 1] += off_v[c];
+        idx->h_class_text.resize(off_v[nc] + 16);
+        {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t] {
+                    for (uint64_t c = (uint64_t)nc * t / T; c < (uint64_t)nc * (t + 1) / T; ++c) {
+                        const uint32_t* ids; uint32_t n;
+                        ids_of((uint32_t)c, ids, n);
+                        char* o = idx->h_class_text.data() + off_v[c];
+                        for (uint32_t j = 0; j < n; ++j) {
+                            if (j) { *o++ = ','; *o++ = ' '; }
+                            char b[10]; int k = 10; uint32_t v = ids[j];
+                            do { b[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+                            memcpy(o, b + k, (size_t)(10 - k)); o += 10 - k;
+                        }
+                    }
+                });
+            for (auto& x : th) x.join();
+        }
+    });
+    *off = idx->h_class_text_off.data();
+    *text = idx->h_class_text.data();
 }
 void* index_take_ingest_cache(pa_index* idx) {
     std::lock_guard<std::mutex> g(idx->mu);

@@ -246,7 +246,7 @@ int open_fastq(const char* fastq_path, FastqText& t) {
 
 // Records of the text: line breaks per byte range, then what every line is (scan of pa_process_reads; pa_fastq_scan_host runs
 // it alone). rec_pos[i] = where record i lies; a text that is not in four-line shape is rewritten once and scanned again.
-int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<RecPos>& rec_pos, uint64_t& nrec) {
+int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<RecPos>& rec_pos, uint64_t& nrec, std::vector<std::vector<uint32_t>>& brk) {
     const char*& data = t.data;
     uint64_t& fsize = t.fsize;
     bool& mapped = t.mapped;
@@ -258,14 +258,21 @@ int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<Rec
     for (int attempt = 0; attempt < 2; ++attempt) {
         std::atomic<uint64_t> odd_record{~0ull};   // first record whose first line lacks the '@' or whose third the '+'
         rc = PA_OK;
-        const int R = (int)std::min<uint64_t>((uint64_t)T * 4, fsize / (1 << 16) + 1);
+        // ONE pass over the text: every range notes where its line breaks are (32-bit offsets from the range's start: ranges are
+        // kept below 2 GiB); what every line is follows from these lists alone, once the prefix sum has given each range its first
+        // line number (a second pass over the text cost as much as the first: 2.5 GB per 8 M reads)
+        const int R = (int)std::min<uint64_t>(std::max<uint64_t>((uint64_t)T * 4, fsize / (1ull << 30) + 1), fsize / (1 << 16) + 1);
         std::vector<uint64_t> nl((size_t)R + 1, 0);
+        if (brk.size() < (size_t)R) brk.resize((size_t)R);   // (the caller keeps the lists between calls: 128 MB per 8 M reads that would otherwise be paged in again)
         auto range = [&](int r, uint64_t& a, uint64_t& b) { a = fsize * (uint64_t)r / R; b = fsize * (uint64_t)(r + 1) / R; };
         pool.run(R, [&](int r) {
-            uint64_t a, b, c = 0;
+            uint64_t a, b;
             range(r, a, b);
-            c = count_newlines(data, a, b);
-            nl[(size_t)r + 1] = c;
+            std::vector<uint32_t>& v = brk[(size_t)r];
+            v.clear();
+            v.reserve((size_t)((b - a) / 64 + 16));   // (FASTQ of 150-base reads: one line break per ~79 bytes)
+            for_each_newline(data, a, b, [&](uint64_t e) { v.push_back((uint32_t)(e - a)); return true; });
+            nl[(size_t)r + 1] = v.size();
         });
         for (int r = 0; r < R; ++r) nl[(size_t)r + 1] += nl[(size_t)r];
         // trailing empty lines are tolerated: lines = line breaks before the last content byte + 1
@@ -312,18 +319,25 @@ int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<Rec
                         default: break;
                     }
                 };
-                // the lines that START in [a, b): the first one begins after the first line break at or after a - 1
+                // the lines that START in [a, b): the first one begins after the first line break at or after a - 1. Their ends are
+                // this range's line breaks and, for the last of them, the first line break of the ranges behind it
                 uint64_t li = nl[(size_t)r], p = a;
                 bool started = a == 0 || data[a - 1] == '\n';
                 if (!started) li += 1;   // (the line break that ends the straddling line is counted in this range or a later one)
-                for_each_newline(data, a, fsize, [&](uint64_t e) {
-                    if (!started) { started = true; p = e + 1; return p < b; }
-                    line(p, e, li);
-                    p = e + 1;
-                    ++li;
-                    return p < b;
-                });
-                if (started && p < b && p < fsize) line(p, fsize, li);   // a last line without a line break
+                bool open = true;        // a line that started in this range still waits for its end
+                for (int q = r; q < R && open; ++q) {
+                    uint64_t qa, qb;
+                    range(q, qa, qb);
+                    for (const uint32_t rel : brk[(size_t)q]) {
+                        const uint64_t e = qa + rel;
+                        if (!started) { started = true; p = e + 1; if (p >= b) { open = false; break; } continue; }
+                        line(p, e, li);
+                        p = e + 1;
+                        ++li;
+                        if (p >= b) { open = false; break; }
+                    }
+                }
+                if (open && started && p < b && p < fsize) line(p, fsize, li);   // a last line without a line break
             });
         }
         if (rc == PA_OK && odd_record.load() == ~0ull) break;   // four lines to a record, markers in place
@@ -362,8 +376,9 @@ extern "C" int pa_fastq_scan_host(const char* fastq_path, int num_threads, uint6
     const bool was_gz = !text.mapped && text.fsize != 0;
     Pool pool(num_threads < 1 ? 1 : num_threads);
     std::vector<RecPos> rec_pos;
+    std::vector<std::vector<uint32_t>> brk;
     uint64_t nrec = 0;
-    rc = scan_fastq(fastq_path, text, pool, rec_pos, nrec);
+    rc = scan_fastq(fastq_path, text, pool, rec_pos, nrec, brk);
     if (rc == PA_OK) {
         *n_records = nrec;
         if (text_kind) *text_kind = !text.normalized.empty() ? 2 : was_gz ? 1 : 0;
@@ -389,6 +404,9 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
     int device = 0;
     index_host_classes(idx, &h_ec, &h_class_ref, &device);
+    const uint64_t* cls_off = nullptr;
+    const char* cls_txt = nullptr;
+    index_host_class_text(idx, &cls_off, &cls_txt);   // (rendered once per index)
     HIP_OK(hipSetDevice(device));
 
     // ---- map the file ----
@@ -422,7 +440,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     std::vector<RecPos>& rec_pos = cache->rec_pos;
 
     // ---- scan ----
-    rc = scan_fastq(fastq_path, text, pool, rec_pos, nrec);
+    rc = scan_fastq(fastq_path, text, pool, rec_pos, nrec, cache->brk);
     t_scan = now() - t_begin;
     // ---- batches ----
     BatchCtx* const ctx = cache->ctx;
@@ -482,11 +500,13 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         for (uint32_t m : tmax) maxlen = std::max(maxlen, m);
         if (maxlen > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
         c.wpr = pa_words_per_read(maxlen);
+        std::vector<uint64_t> part;
+        batch_offsets(pool, c, part);
         t_pack_rec += now() - t0; t0 = now();
         const int e = ensure(c, c.n, c.wpr);
         if (e != PA_OK) return e;
         t_pack_alloc += now() - t0; t0 = now();
-        batch_pack_tiles(pool, c, data);   // DnaString::from_dna_string (:450)
+        batch_gather_ascii(pool, c, data, part);   // the bytes of record.seq() (:449) for the GPU's DnaString::from_dna_string (:450)
         t_pack_tiles += now() - t0;
         return PA_OK;
     };
@@ -510,7 +530,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
             }
             const int t = task - extra;
             TextBuf buf = std::move((*parts)[(size_t)t]);   // thread-local while filling: neighbours share cache lines in the set
-            const uint64_t nflag = format_records(c, c.n * (uint64_t)t / P, c.n * (uint64_t)(t + 1) / P, data, h_ec, h_class_ref, buf);
+            const uint64_t nflag = format_records(c, c.n * (uint64_t)t / P, c.n * (uint64_t)(t + 1) / P, data, cls_off, cls_txt, buf);
             flags[(size_t)t] = nflag;
             (*parts)[(size_t)t] = std::move(buf);
         });
@@ -552,7 +572,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     const bool wrote = writer.finish();
     const double t_writer = now() - t0; t0 = now();
     if (rc == PA_OK && !wrote) rc = fail(PA_ERR_IO, "short write to %s", out_path);
-    if (cache->rec_pos.capacity() > ((size_t)64 << 20)) std::vector<RecPos>().swap(cache->rec_pos);   // (do not park more than 1 GB of it)
+    if (cache->rec_pos.capacity() > ((size_t)64 << 20)) { std::vector<RecPos>().swap(cache->rec_pos); std::vector<std::vector<uint32_t>>().swap(cache->brk); }   // (do not park more than 1 GB of it)
     if (rc == PA_OK) index_put_ingest_cache(idx, cache, IngestCache::destroy);   // the next call starts with warm buffers
     else IngestCache::destroy(cache);
     if (mapped && fsize > unmapped_to) munmap((void*)(data + unmapped_to), fsize - unmapped_to);

@@ -192,6 +192,12 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
     uint32_t* h_lens = nullptr;
     pa_read_result* h_results = nullptr;
     void *d_tiles = nullptr, *d_lens = nullptr, *d_results = nullptr, *d_arena = nullptr;
+    // the batch's sequences as the records hold them (ASCII, back to back) and their offsets: the 2-bit packing into tiles runs on the
+    // GPU (pa_encode_reads_device), the host only gathers the bytes into pinned memory
+    uint8_t* h_ascii = nullptr;
+    uint64_t* h_soff = nullptr;
+    void *d_ascii = nullptr, *d_soff = nullptr;
+    size_t ascii_cap = 0, ascii_bytes = 0;
     size_t tiles_bytes = 0, arena_entries = 0, reads_cap = 0;
     std::vector<uint32_t> h_arena;
     std::vector<Record> recs;
@@ -201,7 +207,9 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
         if (h_tiles) (void)hipHostFree(h_tiles);
         if (h_lens) (void)hipHostFree(h_lens);
         if (h_results) (void)hipHostFree(h_results);
-        for (void* p : {d_tiles, d_lens, d_results, d_arena})
+        if (h_ascii) (void)hipHostFree(h_ascii);
+        if (h_soff) (void)hipHostFree(h_soff);
+        for (void* p : {d_tiles, d_lens, d_results, d_arena, d_ascii, d_soff})
             if (p) (void)hipFree(p);
         *this = BatchCtx();
     }
@@ -211,29 +219,39 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
 inline int batch_ensure(pa_index* idx, BatchCtx& c, uint64_t n, uint32_t wpr, uint64_t cap_reads) {
     cap_reads = std::max<uint64_t>(n, cap_reads);
     const size_t tb = pa_tiles_words(n, wpr) * 8 + 8;
-    if (tb > c.tiles_bytes || !c.h_tiles) {
+    if (tb > c.tiles_bytes || !c.d_tiles) {   // (the tiles only exist on the device: pa_encode_reads_device writes them)
         const size_t want = pa_tiles_words(cap_reads, wpr) * 8 + 8;
-        if (c.h_tiles) (void)hipHostFree(c.h_tiles);
         if (c.d_tiles) (void)hipFree(c.d_tiles);
-        c.h_tiles = nullptr; c.d_tiles = nullptr;
+        c.d_tiles = nullptr;
         c.tiles_bytes = 0;
-        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_tiles, want, hipHostMallocDefault));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_tiles, want));
         c.tiles_bytes = want;
     }
     if (n + 64 > c.reads_cap) {
         const size_t cap = cap_reads + 64;
-        if (c.h_lens) (void)hipHostFree(c.h_lens);
         if (c.h_results) (void)hipHostFree(c.h_results);
+        if (c.h_soff) (void)hipHostFree(c.h_soff);
         if (c.d_lens) (void)hipFree(c.d_lens);
         if (c.d_results) (void)hipFree(c.d_results);
-        c.h_lens = nullptr; c.h_results = nullptr; c.d_lens = nullptr; c.d_results = nullptr;
+        if (c.d_soff) (void)hipFree(c.d_soff);
+        c.h_results = nullptr; c.h_soff = nullptr; c.d_lens = nullptr; c.d_results = nullptr; c.d_soff = nullptr;
         c.reads_cap = 0;
-        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_lens, cap * 4, hipHostMallocDefault));
         PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_results, cap * sizeof(pa_read_result), hipHostMallocDefault));
+        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_soff, (cap + 1) * 8, hipHostMallocDefault));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_lens, cap * 4));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_results, cap * sizeof(pa_read_result)));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_soff, (cap + 1) * 8));
         c.reads_cap = cap;
+    }
+    if (c.ascii_bytes + 64 > c.ascii_cap) {   // (ascii_bytes: set by the caller before this call — the sum of the batch's sequence lengths)
+        const size_t want = std::max<size_t>(c.ascii_bytes + c.ascii_bytes / 8 + 4096, (size_t)cap_reads * 32ull * wpr / 2);
+        if (c.h_ascii) (void)hipHostFree(c.h_ascii);
+        if (c.d_ascii) (void)hipFree(c.d_ascii);
+        c.h_ascii = nullptr; c.d_ascii = nullptr;
+        c.ascii_cap = 0;
+        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_ascii, want, hipHostMallocDefault));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_ascii, want));
+        c.ascii_cap = want;
     }
     const uint64_t hint = pa_map_arena_hint(idx, n);
     if (hint > c.arena_entries) {
@@ -245,35 +263,31 @@ inline int batch_ensure(pa_index* idx, BatchCtx& c, uint64_t n, uint32_t wpr, ui
     return PA_OK;
 }
 
-// DnaString::from_dna_string (:450) for the batch's records (sequences at text + rec.seq_off): A0 C1 G2 T3, anything else A,
-// either case, straight into the pinned tiles; parallel over whole tiles
-inline void batch_pack_tiles(Pool& pool, BatchCtx& c, const char* text) {
-    const uint64_t ntiles = (c.n + 63) / 64;
-    const uint32_t wpr = c.wpr;
+// The batch's sequences (at text + rec.seq_off) gathered back to back into pinned memory, with their offsets: what the GPU packs
+// (DnaString::from_dna_string, :450 -> pa_encode_reads_device). batch_offsets first (the caller sizes the buffers by ascii_bytes).
+inline void batch_offsets(Pool& pool, BatchCtx& c, std::vector<uint64_t>& part) {
+    const int ntask = pool.size() * 4;
+    part.assign((size_t)ntask + 1, 0);
+    pool.run(ntask, [&](int t) {
+        uint64_t sum = 0;
+        for (uint64_t i = c.n * (uint64_t)t / ntask; i < c.n * (uint64_t)(t + 1) / ntask; ++i) sum += c.recs[i].seq_len;
+        part[(size_t)t + 1] = sum;
+    });
+    for (int t = 0; t < ntask; ++t) part[(size_t)t + 1] += part[(size_t)t];
+    c.ascii_bytes = part[(size_t)ntask];
+}
+inline void batch_gather_ascii(Pool& pool, BatchCtx& c, const char* text, const std::vector<uint64_t>& part) {
     const int ntask = pool.size() * 4;
     pool.run(ntask, [&](int t) {
-        for (uint64_t tile = ntiles * (uint64_t)t / ntask; tile < ntiles * (uint64_t)(t + 1) / ntask; ++tile) {
-            uint64_t* tw = c.h_tiles + tile * wpr * 64;
-            for (uint32_t r = 0; r < 64; ++r) {
-                const uint64_t i = tile * 64 + r;
-                if (i >= c.n) {
-                    for (uint32_t w = 0; w < wpr; ++w) tw[(uint64_t)w * 64 + r] = 0;
-                    continue;
-                }
-                const Record& rec = c.recs[i];
-                const uint8_t* sq = (const uint8_t*)text + rec.seq_off;
-                c.h_lens[i] = rec.seq_len;
-                for (uint32_t w = 0; w < wpr; ++w) {
-                    uint64_t v = 0;
-                    const uint32_t b0 = 32 * w, nbases = rec.seq_len > b0 ? std::min<uint32_t>(32, rec.seq_len - b0) : 0;
-                    uint32_t j = 0;
-                    for (; j + 16 <= nbases; j += 16) v |= (uint64_t)pack16(sq + b0 + j) << (2 * j);
-                    for (; j < nbases; ++j) v |= (uint64_t)BASE_LUT.v[sq[b0 + j]] << (2 * j);
-                    tw[(uint64_t)w * 64 + r] = v;
-                }
-            }
+        uint64_t o = part[(size_t)t];
+        for (uint64_t i = c.n * (uint64_t)t / ntask; i < c.n * (uint64_t)(t + 1) / ntask; ++i) {
+            const Record& rec = c.recs[i];
+            c.h_soff[i] = o;
+            memcpy(c.h_ascii + o, text + rec.seq_off, rec.seq_len);
+            o += rec.seq_len;
         }
     });
+    c.h_soff[c.n] = c.ascii_bytes;
 }
 
 // the GPU leg of a batch, asynchronous on `stream`: tiles H2D -> index.map_read for every read (:451) -> records D2H
@@ -286,6 +300,7 @@ struct RecPos {   // where a record lies in the text: found by the scan, read by
 struct IngestCache {   // the two batches in flight of a pa_process_reads call or a record stream; parked on the index in between (pa_common.hpp)
     BatchCtx ctx[2];
     std::vector<RecPos> rec_pos;   // 16 bytes per record of the file: kept, or every call would page 256 MB in again
+    std::vector<std::vector<uint32_t>> brk;   // the scan's line-break lists (4 bytes per line), kept for the same reason
     // the stream the batches run on travels with the buffers: its launch context inside the index (2 GB of list-mode rows)
     // is then reused by the next call instead of being stranded behind a destroyed stream
     pa_index* idx = nullptr;
@@ -308,8 +323,10 @@ inline double* last_stage_seconds() {
 }
 
 inline int batch_launch(pa_index* idx, BatchCtx& c, hipStream_t stream) {
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_tiles, c.h_tiles, pa_tiles_words(c.n, c.wpr) * 8, hipMemcpyHostToDevice, stream));
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_lens, c.h_lens, c.n * 4, hipMemcpyHostToDevice, stream));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_ascii, c.h_ascii, c.ascii_bytes, hipMemcpyHostToDevice, stream));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_soff, c.h_soff, (c.n + 1) * 8, hipMemcpyHostToDevice, stream));
+    const int e0 = pa_encode_reads_device(idx, (const uint8_t*)c.d_ascii, (const uint64_t*)c.d_soff, c.n, c.wpr, (uint64_t*)c.d_tiles, (uint32_t*)c.d_lens, stream);   // :450
+    if (e0 != PA_OK) return e0;
     const int e = pa_map_batch_device(idx, (const uint64_t*)c.d_tiles, (const uint32_t*)c.d_lens, c.n, c.wpr, PA_DEFAULT_ALLOWED_MISMATCHES,
                                       (pa_read_result*)c.d_results, (uint32_t*)c.d_arena, c.arena_entries, nullptr, stream);
     if (e != PA_OK) return e;
@@ -337,25 +354,25 @@ inline int batch_finish(pa_index* idx, BatchCtx& c, hipStream_t stream) {
 }
 
 // records [a, b) of a finished batch as the reference prints them (:490): (flag, "id", [ids], coverage), flag by the rule of
-// :455; returns the number of flagged reads. Ids at text + rec.id_off; classes returned by reference come from the host copy
-// of the class table (h_ec / h_class_ref).
-inline uint64_t format_records(const BatchCtx& c, uint64_t a, uint64_t b, const char* text, const uint32_t* h_ec, const uint32_t* h_class_ref, TextBuf& buf) {
+// :455; returns the number of flagged reads. Ids at text + rec.id_off; classes returned by reference come from the index's
+// table of rendered classes (index_host_class_text).
+inline uint64_t format_records(const BatchCtx& c, uint64_t a, uint64_t b, const char* text, const uint64_t* cls_off, const char* cls_txt, TextBuf& buf) {
     uint64_t nflag = 0;
-    // classes returned by reference are two dependent random reads into tables of tens of MB (class -> record -> ids):
-    // both are prefetched a few reads ahead, or every read would wait for two cache misses
+    // a class returned by reference is copied from the index's table of rendered classes (one random read into tens of MB behind
+    // an offset table that stays in the cache): prefetched a few reads ahead, or every read would wait for the miss
     constexpr uint64_t PF_REF = 16, PF_IDS = 8, PF_TEXT = 12;
     for (uint64_t i = a; i < b; ++i) {
         if (i + PF_TEXT < b) __builtin_prefetch(text + c.recs[i + PF_TEXT].id_off);   // the read's id: a line of a multi-GB text last touched by the pack stage
         if (i + PF_REF < b) {
             const uint32_t off = c.h_results[i + PF_REF].class_off;
-            if (off & PA_CLASS_REF) __builtin_prefetch(h_class_ref + (off & ~PA_CLASS_REF));
+            if (off & PA_CLASS_REF) __builtin_prefetch(cls_off + (off & ~PA_CLASS_REF));
         }
         if (i + PF_IDS < b) {
             const pa_read_result& q = c.h_results[i + PF_IDS];
             if (q.class_off & PA_CLASS_REF) {
-                const uint32_t* ids = h_ec + 4ull * h_class_ref[q.class_off & ~PA_CLASS_REF] + 1;
-                __builtin_prefetch(ids);
-                if (q.class_len > 14) __builtin_prefetch(ids + 16);
+                const char* t = cls_txt + cls_off[q.class_off & ~PA_CLASS_REF];
+                __builtin_prefetch(t);
+                if (q.class_len > 7) __builtin_prefetch(t + 64);
             } else if (q.class_len) __builtin_prefetch(c.h_arena.data() + q.class_off);
         }
         const pa_read_result& r = c.h_results[i];
@@ -366,11 +383,17 @@ inline uint64_t format_records(const BatchCtx& c, uint64_t a, uint64_t b, const 
         char* o = flag ? put_lit(base, "(true, ") : put_lit(base, "(false, ");
         o = debug_id(o, text + c.recs[i].id_off, c.recs[i].id_len);
         o = put_lit(o, ", [");
-        const uint32_t* ids = (r.class_off & PA_CLASS_REF) ? h_ec + 4ull * h_class_ref[r.class_off & ~PA_CLASS_REF] + 1
-                                                           : c.h_arena.data() + r.class_off;
-        for (uint32_t j = 0; j < r.class_len; ++j) {
-            if (j) { *o++ = ','; *o++ = ' '; }
-            o = put_u32(o, ids[j]);
+        if (r.class_off & PA_CLASS_REF) {
+            const uint32_t cid = r.class_off & ~PA_CLASS_REF;
+            const size_t n = (size_t)(cls_off[cid + 1] - cls_off[cid]);
+            memcpy(o, cls_txt + cls_off[cid], n);
+            o += n;
+        } else {
+            const uint32_t* ids = c.h_arena.data() + r.class_off;
+            for (uint32_t j = 0; j < r.class_len; ++j) {
+                if (j) { *o++ = ','; *o++ = ' '; }
+                o = put_u32(o, ids[j]);
+            }
         }
         o = put_lit(o, "], ");
         o = put_u32(o, mapped_read ? r.coverage : 0u);   // None -> (false, id, [], 0) (:461)

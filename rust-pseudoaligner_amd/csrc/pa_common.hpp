@@ -19,6 +19,8 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 // host copy of the class records of a device index (device_index.hip): class c = ec[4 * class_ref[c] + 1 ...]; used to
 // resolve results returned by reference (PA_CLASS_REF) without a device round trip
 void index_host_classes(const pa_index* idx, const uint32_t** ec, const uint32_t** class_ref, int* device);
+// every index class rendered once as the reference prints its ids ("1, 5, 9", no brackets): class c = text[off[c] .. off[c + 1]). Built on first use.
+void index_host_class_text(pa_index* idx, const uint64_t** off, const char** text);
 // One opaque object the FASTQ driver parks on the index between calls (its pinned + device batch buffers: allocating them
 // costs more than packing a batch). take() hands it to the caller and empties the slot, so concurrent calls never share
 // it; put() stores it back (or frees it with `free_fn` when another call already parked one). pa_index_destroy frees it.

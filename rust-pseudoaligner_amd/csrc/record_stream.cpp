@@ -53,6 +53,8 @@ struct pa_record_stream {
     hipStream_t stream = nullptr;   // pa_process_reads call or another record stream left them there) and parked there again at the end
     int device = 0;
     const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
+    const uint64_t* cls_off = nullptr;   // the index's rendered classes (index_host_class_text)
+    const char* cls_txt = nullptr;
     uint64_t batch_reads = 2u << 20;
     BatchCtx* ctx = nullptr;       // = cache->ctx
     RawText text[2];               // ids and sequences of the batch's records (Record offsets point into it)
@@ -85,7 +87,7 @@ void render(pa_record_stream* s, int k) {
     const char* text = s->text[k].data();
     s->pool->run(P, [&](int t) {
         TextBuf buf;
-        flags[(size_t)t] = format_records(c, c.n * (uint64_t)t / P, c.n * (uint64_t)(t + 1) / P, text, s->h_ec, s->h_class_ref, buf);
+        flags[(size_t)t] = format_records(c, c.n * (uint64_t)t / P, c.n * (uint64_t)(t + 1) / P, text, s->cls_off, s->cls_txt, buf);
         parts[(size_t)t] = std::move(buf);
     });
     for (uint64_t f : flags) s->n_flagged += f;
@@ -111,10 +113,12 @@ int submit(pa_record_stream* s) {
     if (c.n == 0) return PA_OK;
     if (s->maxlen[k] > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
     c.wpr = pa_words_per_read(s->maxlen[k] ? s->maxlen[k] : 1);
+    double t0 = now_s();
+    std::vector<uint64_t> part;
+    batch_offsets(*s->pool, c, part);
     int rc = batch_ensure(s->idx, c, c.n, c.wpr, s->batch_reads);
     if (rc != PA_OK) return rc;
-    double t0 = now_s();
-    batch_pack_tiles(*s->pool, c, s->text[k].data());
+    batch_gather_ascii(*s->pool, c, s->text[k].data(), part);
     s->stage[1] += now_s() - t0; t0 = now_s();
     if (s->inflight[o] && (rc = batch_finish(s->idx, s->ctx[o], s->stream)) != PA_OK) return rc;
     s->stage[2] += now_s() - t0; t0 = now_s();
@@ -136,6 +140,7 @@ int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads
     if (!s) return fail(PA_ERR_OOM, "out of memory");
     s->idx = idx;
     index_host_classes(idx, &s->h_ec, &s->h_class_ref, &s->device);
+    index_host_class_text(idx, &s->cls_off, &s->cls_txt);
     if (batch_reads) s->batch_reads = std::max<uint64_t>(64, batch_reads / 64 * 64);
     int T = num_threads > 0 ? num_threads : usable_threads();
     if (T < 1) T = 1;
