@@ -96,6 +96,7 @@ struct pa_index {
     std::vector<uint64_t> h_class_text_off;
     std::vector<char> h_class_text;
     std::vector<uint32_t> h_arena;
+    void *d_class_text_off = nullptr, *d_class_text = nullptr;   // device copy of the rendered classes (uploaded on first use, under `mu`)
     void* ingest_cache = nullptr;   // parked by fastq.cpp between pa_process_reads calls (guarded by `mu`)
     void (*ingest_cache_free)(void*) = nullptr;
 };
@@ -186,6 +187,27 @@ void index_host_class_text(pa_index* idx, const uint64_t** off, const char** tex
     *off = idx->h_class_text_off.data();
     *text = idx->h_class_text.data();
 }
+int index_device_class_text(pa_index* idx, const uint64_t** d_off, const uint8_t** d_text) {
+    const uint64_t* off = nullptr;
+    const char* txt = nullptr;
+    index_host_class_text(idx, &off, &txt);
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (!idx->d_class_text) {
+        if (hipSetDevice(idx->device) != hipSuccess) return fail(PA_ERR_HIP, "hipSetDevice failed");
+        void *a = nullptr, *b = nullptr;
+        const size_t nb = idx->h_class_text.size(), no = idx->h_class_text_off.size() * 8;
+        if (hipMalloc(&a, no ? no : 16) != hipSuccess || hipMalloc(&b, nb ? nb : 16) != hipSuccess) { if (a) (void)hipFree(a); return fail(PA_ERR_OOM, "hipMalloc for the rendered class table"); }
+        if (hipMemcpy(a, off, no, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(b, txt, nb, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(a); (void)hipFree(b);
+            return fail(PA_ERR_HIP, "upload of the rendered class table failed");
+        }
+        idx->d_class_text_off = a;
+        idx->d_class_text = b;
+    }
+    *d_off = static_cast<const uint64_t*>(idx->d_class_text_off);
+    *d_text = static_cast<const uint8_t*>(idx->d_class_text);
+    return PA_OK;
+}
 void* index_take_ingest_cache(pa_index* idx) {
     std::lock_guard<std::mutex> g(idx->mu);
     void* c = idx->ingest_cache;
@@ -209,7 +231,8 @@ void index_put_ingest_cache(pa_index* idx, void* cache, void (*free_fn)(void*)) 
 void pa_index_destroy(pa_index* idx) {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
-    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_seg_g, idx->d_seg_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table, idx->d_wtable})
+    for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_seg_g, idx->d_seg_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table, idx->d_wtable,
+                    idx->d_class_text_off, idx->d_class_text})
         if (p) (void)hipFree(p);
     if (idx->ingest_cache && idx->ingest_cache_free) { idx->ingest_cache_free(idx->ingest_cache); idx->ingest_cache = nullptr; }   // (releases its stream's context)
     for (auto& kv : idx->ctxs) kv.second->release();

@@ -404,9 +404,6 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
     int device = 0;
     index_host_classes(idx, &h_ec, &h_class_ref, &device);
-    const uint64_t* cls_off = nullptr;
-    const char* cls_txt = nullptr;
-    index_host_class_text(idx, &cls_off, &cls_txt);   // (rendered once per index)
     HIP_OK(hipSetDevice(device));
 
     // ---- map the file ----
@@ -517,25 +514,31 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     // Formatting runs as 4T tasks handed out dynamically, plus one that gives the text of the batches already written back
     // to the kernel: unmapping 5 GB of page-cache mapping is 0.09 s of one thread's time, hidden here behind the others' work.
     uint64_t unmapped_to = 0;   // bytes of the mapping already given back (page-aligned)
+    int format_rc = PA_OK;
     auto format = [&](BatchCtx& c) {
-        const int P = T * 4;
+        // the batch's tuples were rendered on the GPU (batch_finish -> render.hip) and are on their way to pinned memory: wait for them, then
+        // copy them into a buffer set of the writer (the pinned buffer is the next batch-but-one's), the pool sharing the copy. One extra
+        // task gives the text of the batches already written back to the kernel: unmapping 5 GB of page-cache mapping is 0.09 s of one
+        // thread's time, hidden here behind the others' work.
+        if ((format_rc = batch_text_wait(c)) != PA_OK) return;
+        const int P = T * 2;
         TextSet* parts = writer.acquire((size_t)P);
-        std::vector<uint64_t> flags((size_t)P, 0);
         const uint64_t keep_from = mapped ? (rec_pos[c.first].start & ~4095ull) : 0;   // nothing before this batch is read again
         const int extra = keep_from > unmapped_to ? 1 : 0;
+        const size_t total = c.text_bytes;
         pool.run(P + extra, [&](int task) {
             if (task < extra) {
                 (void)munmap((void*)(data + unmapped_to), keep_from - unmapped_to);
                 return;
             }
             const int t = task - extra;
-            TextBuf buf = std::move((*parts)[(size_t)t]);   // thread-local while filling: neighbours share cache lines in the set
-            const uint64_t nflag = format_records(c, c.n * (uint64_t)t / P, c.n * (uint64_t)(t + 1) / P, data, cls_off, cls_txt, buf);
-            flags[(size_t)t] = nflag;
-            (*parts)[(size_t)t] = std::move(buf);
+            const size_t a = total * (size_t)t / P, b = total * (size_t)(t + 1) / P;
+            TextBuf& buf = (*parts)[(size_t)t];
+            memcpy(buf.room(b - a), c.h_text + a, b - a);
+            buf.len = b - a;
         });
         if (extra) unmapped_to = keep_from;
-        for (uint64_t f : flags) flagged += f;
+        flagged += c.flagged;
         reported += c.n;
         while (reported >= next_report) {   // :497-503
             fprintf(stderr, "\rDone Mapping %llu reads w/ Rate: %g", (unsigned long long)next_report,
@@ -556,7 +559,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         t_finish += now() - t0; t0 = now();
         if (rc == PA_OK && b < nb) rc = launch(ctx[b & 1]);
         t_launch += now() - t0; t0 = now();
-        if (rc == PA_OK && b >= 1) format(ctx[(b - 1) & 1]);
+        if (rc == PA_OK && b >= 1) { format(ctx[(b - 1) & 1]); rc = format_rc; }
         t_format += now() - t0;
     }
     {

@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include "kernels.hpp"
 #include "pa_common.hpp"
 
 namespace pa {
@@ -198,6 +199,16 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
     uint64_t* h_soff = nullptr;
     void *d_ascii = nullptr, *d_soff = nullptr;
     size_t ascii_cap = 0, ascii_bytes = 0;
+    // ... and the ids (record.id(), :456) for the render kernels (render.hip), which write the batch's output tuples: lengths, offsets
+    // (d_off[n] = bytes of the whole text), the text itself, and its copy in pinned memory
+    uint8_t* h_ids = nullptr;
+    uint64_t* h_idoff = nullptr;
+    void *d_ids = nullptr, *d_idoff = nullptr, *d_len = nullptr, *d_off = nullptr, *d_scan = nullptr, *d_flag = nullptr, *d_text = nullptr;
+    unsigned long long* h_tot = nullptr;   // pinned {text bytes, flagged reads}
+    char* h_text = nullptr;
+    size_t ids_cap = 0, ids_bytes = 0, scan_bytes = 0, text_cap = 0, text_bytes = 0;
+    uint64_t flagged = 0;
+    hipEvent_t ev_text = nullptr;
     size_t tiles_bytes = 0, arena_entries = 0, reads_cap = 0;
     std::vector<uint32_t> h_arena;
     std::vector<Record> recs;
@@ -209,7 +220,12 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
         if (h_results) (void)hipHostFree(h_results);
         if (h_ascii) (void)hipHostFree(h_ascii);
         if (h_soff) (void)hipHostFree(h_soff);
-        for (void* p : {d_tiles, d_lens, d_results, d_arena, d_ascii, d_soff})
+        if (h_ids) (void)hipHostFree(h_ids);
+        if (h_idoff) (void)hipHostFree(h_idoff);
+        if (h_tot) (void)hipHostFree(h_tot);
+        if (h_text) (void)hipHostFree(h_text);
+        if (ev_text) (void)hipEventDestroy(ev_text);
+        for (void* p : {d_tiles, d_lens, d_results, d_arena, d_ascii, d_soff, d_ids, d_idoff, d_len, d_off, d_scan, d_flag, d_text})
             if (p) (void)hipFree(p);
         *this = BatchCtx();
     }
@@ -231,17 +247,37 @@ inline int batch_ensure(pa_index* idx, BatchCtx& c, uint64_t n, uint32_t wpr, ui
         const size_t cap = cap_reads + 64;
         if (c.h_results) (void)hipHostFree(c.h_results);
         if (c.h_soff) (void)hipHostFree(c.h_soff);
-        if (c.d_lens) (void)hipFree(c.d_lens);
-        if (c.d_results) (void)hipFree(c.d_results);
-        if (c.d_soff) (void)hipFree(c.d_soff);
-        c.h_results = nullptr; c.h_soff = nullptr; c.d_lens = nullptr; c.d_results = nullptr; c.d_soff = nullptr;
+        if (c.h_idoff) (void)hipHostFree(c.h_idoff);
+        for (void** q : {&c.d_lens, &c.d_results, &c.d_soff, &c.d_idoff, &c.d_len, &c.d_off, &c.d_scan}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        c.h_results = nullptr; c.h_soff = nullptr; c.h_idoff = nullptr;
         c.reads_cap = 0;
         PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_results, cap * sizeof(pa_read_result), hipHostMallocDefault));
         PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_soff, (cap + 1) * 8, hipHostMallocDefault));
+        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_idoff, (cap + 1) * 8, hipHostMallocDefault));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_lens, cap * 4));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_results, cap * sizeof(pa_read_result)));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_soff, (cap + 1) * 8));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_idoff, (cap + 1) * 8));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_len, (cap + 1) * 4));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_off, (cap + 1) * 8));
+        c.scan_bytes = render_scan_bytes(cap);
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_scan, c.scan_bytes ? c.scan_bytes : 16));
         c.reads_cap = cap;
+    }
+    if (!c.h_tot) {
+        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_tot, 16, hipHostMallocDefault));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_flag, 16));
+        PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_text, hipEventDisableTiming));
+    }
+    if (c.ids_bytes + 64 > c.ids_cap) {
+        const size_t want = std::max<size_t>(c.ids_bytes + c.ids_bytes / 8 + 4096, (size_t)cap_reads * 16);
+        if (c.h_ids) (void)hipHostFree(c.h_ids);
+        if (c.d_ids) (void)hipFree(c.d_ids);
+        c.h_ids = nullptr; c.d_ids = nullptr;
+        c.ids_cap = 0;
+        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_ids, want, hipHostMallocDefault));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_ids, want));
+        c.ids_cap = want;
     }
     if (c.ascii_bytes + 64 > c.ascii_cap) {   // (ascii_bytes: set by the caller before this call — the sum of the batch's sequence lengths)
         const size_t want = std::max<size_t>(c.ascii_bytes + c.ascii_bytes / 8 + 4096, (size_t)cap_reads * 32ull * wpr / 2);
@@ -265,29 +301,39 @@ inline int batch_ensure(pa_index* idx, BatchCtx& c, uint64_t n, uint32_t wpr, ui
 
 // The batch's sequences (at text + rec.seq_off) gathered back to back into pinned memory, with their offsets: what the GPU packs
 // (DnaString::from_dna_string, :450 -> pa_encode_reads_device). batch_offsets first (the caller sizes the buffers by ascii_bytes).
-inline void batch_offsets(Pool& pool, BatchCtx& c, std::vector<uint64_t>& part) {
+inline void batch_offsets(Pool& pool, BatchCtx& c, std::vector<uint64_t>& part) {   // part: [sequence bytes | id bytes] before every task's records
     const int ntask = pool.size() * 4;
-    part.assign((size_t)ntask + 1, 0);
+    part.assign(2 * ((size_t)ntask + 1), 0);
+    uint64_t* ps = part.data();
+    uint64_t* pi = part.data() + ntask + 1;
     pool.run(ntask, [&](int t) {
-        uint64_t sum = 0;
-        for (uint64_t i = c.n * (uint64_t)t / ntask; i < c.n * (uint64_t)(t + 1) / ntask; ++i) sum += c.recs[i].seq_len;
-        part[(size_t)t + 1] = sum;
+        uint64_t sum = 0, isum = 0;
+        for (uint64_t i = c.n * (uint64_t)t / ntask; i < c.n * (uint64_t)(t + 1) / ntask; ++i) { sum += c.recs[i].seq_len; isum += c.recs[i].id_len; }
+        ps[(size_t)t + 1] = sum;
+        pi[(size_t)t + 1] = isum;
     });
-    for (int t = 0; t < ntask; ++t) part[(size_t)t + 1] += part[(size_t)t];
-    c.ascii_bytes = part[(size_t)ntask];
+    for (int t = 0; t < ntask; ++t) { ps[(size_t)t + 1] += ps[(size_t)t]; pi[(size_t)t + 1] += pi[(size_t)t]; }
+    c.ascii_bytes = ps[(size_t)ntask];
+    c.ids_bytes = pi[(size_t)ntask];
 }
 inline void batch_gather_ascii(Pool& pool, BatchCtx& c, const char* text, const std::vector<uint64_t>& part) {
     const int ntask = pool.size() * 4;
+    const uint64_t* ps = part.data();
+    const uint64_t* pi = part.data() + ntask + 1;
     pool.run(ntask, [&](int t) {
-        uint64_t o = part[(size_t)t];
+        uint64_t o = ps[(size_t)t], io = pi[(size_t)t];
         for (uint64_t i = c.n * (uint64_t)t / ntask; i < c.n * (uint64_t)(t + 1) / ntask; ++i) {
             const Record& rec = c.recs[i];
             c.h_soff[i] = o;
             memcpy(c.h_ascii + o, text + rec.seq_off, rec.seq_len);
             o += rec.seq_len;
+            c.h_idoff[i] = io;
+            memcpy(c.h_ids + io, text + rec.id_off, rec.id_len);
+            io += rec.id_len;
         }
     });
     c.h_soff[c.n] = c.ascii_bytes;
+    c.h_idoff[c.n] = c.ids_bytes;
 }
 
 // the GPU leg of a batch, asynchronous on `stream`: tiles H2D -> index.map_read for every read (:451) -> records D2H
@@ -325,13 +371,14 @@ inline double* last_stage_seconds() {
 inline int batch_launch(pa_index* idx, BatchCtx& c, hipStream_t stream) {
     PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_ascii, c.h_ascii, c.ascii_bytes, hipMemcpyHostToDevice, stream));
     PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_soff, c.h_soff, (c.n + 1) * 8, hipMemcpyHostToDevice, stream));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_ids, c.h_ids, c.ids_bytes, hipMemcpyHostToDevice, stream));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_idoff, c.h_idoff, (c.n + 1) * 8, hipMemcpyHostToDevice, stream));
     const int e0 = pa_encode_reads_device(idx, (const uint8_t*)c.d_ascii, (const uint64_t*)c.d_soff, c.n, c.wpr, (uint64_t*)c.d_tiles, (uint32_t*)c.d_lens, stream);   // :450
     if (e0 != PA_OK) return e0;
     const int e = pa_map_batch_device(idx, (const uint64_t*)c.d_tiles, (const uint32_t*)c.d_lens, c.n, c.wpr, PA_DEFAULT_ALLOWED_MISMATCHES,
                                       (pa_read_result*)c.d_results, (uint32_t*)c.d_arena, c.arena_entries, nullptr, stream);
     if (e != PA_OK) return e;
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_results, c.d_results, c.n * sizeof(pa_read_result), hipMemcpyDeviceToHost, stream));
-    return PA_OK;
+    return PA_OK;   // (the records stay on the device: the render kernels read them there)
 }
 
 // waits for the batch; an arena that turned out too small is regrown and the batch mapped again; the ids of the classes that
@@ -348,60 +395,42 @@ inline int batch_finish(pa_index* idx, BatchCtx& c, hipStream_t stream) {
         if (e == PA_OK) e = pa_map_finish(idx, stream, &used, &need);
     }
     if (e != PA_OK) return e;
-    c.h_arena.resize(used + 1);
-    if (used) PA_INGEST_HIP_OK(hipMemcpy(c.h_arena.data(), c.d_arena, used * 4, hipMemcpyDeviceToHost));
+    // the batch is mapped: its output tuples (:455-461, :490) are rendered where the records, the class table and the novel class ids
+    // are. Lengths + scan first (the host has to size the text), then the bytes and their copy to pinned memory, asynchronously:
+    // batch_text_wait collects them
+    const uint64_t* d_cls_off = nullptr;
+    const uint8_t* d_cls_txt = nullptr;
+    if ((e = index_device_class_text(idx, &d_cls_off, &d_cls_txt)) != PA_OK) return e;
+    PA_INGEST_HIP_OK(hipMemsetAsync(c.d_flag, 0, 8, stream));
+    int k = launch_render_len((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n,
+                              (uint32_t*)c.d_len, (uint64_t*)c.d_off, (unsigned long long*)c.d_flag, c.d_scan, c.scan_bytes, stream);
+    if (k) return fail(PA_ERR_HIP, "render (lengths): %s", hipGetErrorString((hipError_t)k));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_tot, (const uint64_t*)c.d_off + c.n, 8, hipMemcpyDeviceToHost, stream));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_tot + 1, c.d_flag, 8, hipMemcpyDeviceToHost, stream));
+    PA_INGEST_HIP_OK(hipStreamSynchronize(stream));
+    c.text_bytes = (size_t)c.h_tot[0];
+    c.flagged = c.h_tot[1];
+    if (c.text_bytes + 64 > c.text_cap) {
+        const size_t want = c.text_bytes + c.text_bytes / 4 + (1 << 20);
+        if (c.h_text) (void)hipHostFree(c.h_text);
+        if (c.d_text) (void)hipFree(c.d_text);
+        c.h_text = nullptr; c.d_text = nullptr;
+        c.text_cap = 0;
+        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_text, want, hipHostMallocDefault));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_text, want));
+        c.text_cap = want;
+    }
+    k = launch_render_write((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n,
+                            (const uint64_t*)c.d_off, (uint8_t*)c.d_text, stream);
+    if (k) return fail(PA_ERR_HIP, "render (text): %s", hipGetErrorString((hipError_t)k));
+    if (c.text_bytes) PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_text, c.d_text, c.text_bytes, hipMemcpyDeviceToHost, stream));
+    PA_INGEST_HIP_OK(hipEventRecord(c.ev_text, stream));
     return PA_OK;
 }
-
-// records [a, b) of a finished batch as the reference prints them (:490): (flag, "id", [ids], coverage), flag by the rule of
-// :455; returns the number of flagged reads. Ids at text + rec.id_off; classes returned by reference come from the index's
-// table of rendered classes (index_host_class_text).
-inline uint64_t format_records(const BatchCtx& c, uint64_t a, uint64_t b, const char* text, const uint64_t* cls_off, const char* cls_txt, TextBuf& buf) {
-    uint64_t nflag = 0;
-    // a class returned by reference is copied from the index's table of rendered classes (one random read into tens of MB behind
-    // an offset table that stays in the cache): prefetched a few reads ahead, or every read would wait for the miss
-    constexpr uint64_t PF_REF = 16, PF_IDS = 8, PF_TEXT = 12;
-    for (uint64_t i = a; i < b; ++i) {
-        if (i + PF_TEXT < b) __builtin_prefetch(text + c.recs[i + PF_TEXT].id_off);   // the read's id: a line of a multi-GB text last touched by the pack stage
-        if (i + PF_REF < b) {
-            const uint32_t off = c.h_results[i + PF_REF].class_off;
-            if (off & PA_CLASS_REF) __builtin_prefetch(cls_off + (off & ~PA_CLASS_REF));
-        }
-        if (i + PF_IDS < b) {
-            const pa_read_result& q = c.h_results[i + PF_IDS];
-            if (q.class_off & PA_CLASS_REF) {
-                const char* t = cls_txt + cls_off[q.class_off & ~PA_CLASS_REF];
-                __builtin_prefetch(t);
-                if (q.class_len > 7) __builtin_prefetch(t + 64);
-            } else if (q.class_len) __builtin_prefetch(c.h_arena.data() + q.class_off);
-        }
-        const pa_read_result& r = c.h_results[i];
-        const bool mapped_read = r.mismatches & PA_MAPPED_BIT;
-        const bool flag = mapped_read && r.coverage >= PA_READ_COVERAGE_THRESHOLD && r.class_len == 0;   // :455
-        nflag += flag;
-        char* const base = buf.room(6 * (size_t)c.recs[i].id_len + 12 * (size_t)r.class_len + 64);
-        char* o = flag ? put_lit(base, "(true, ") : put_lit(base, "(false, ");
-        o = debug_id(o, text + c.recs[i].id_off, c.recs[i].id_len);
-        o = put_lit(o, ", [");
-        if (r.class_off & PA_CLASS_REF) {
-            const uint32_t cid = r.class_off & ~PA_CLASS_REF;
-            const size_t n = (size_t)(cls_off[cid + 1] - cls_off[cid]);
-            memcpy(o, cls_txt + cls_off[cid], n);
-            o += n;
-        } else {
-            const uint32_t* ids = c.h_arena.data() + r.class_off;
-            for (uint32_t j = 0; j < r.class_len; ++j) {
-                if (j) { *o++ = ','; *o++ = ' '; }
-                o = put_u32(o, ids[j]);
-            }
-        }
-        o = put_lit(o, "], ");
-        o = put_u32(o, mapped_read ? r.coverage : 0u);   // None -> (false, id, [], 0) (:461)
-        *o++ = ')';
-        *o++ = '\n';
-        buf.len += (size_t)(o - base);
-    }
-    return nflag;
+// the batch's tuples have arrived in c.h_text[0 .. c.text_bytes)
+inline int batch_text_wait(BatchCtx& c) {
+    PA_INGEST_HIP_OK(hipEventSynchronize(c.ev_text));
+    return PA_OK;
 }
 
 }  // namespace ingest

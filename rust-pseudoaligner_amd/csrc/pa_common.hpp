@@ -21,6 +21,8 @@ int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 void index_host_classes(const pa_index* idx, const uint32_t** ec, const uint32_t** class_ref, int* device);
 // every index class rendered once as the reference prints its ids ("1, 5, 9", no brackets): class c = text[off[c] .. off[c + 1]). Built on first use.
 void index_host_class_text(pa_index* idx, const uint64_t** off, const char** text);
+// ... and its copy in HBM for the render kernels (render.hip); uploaded on first use. Returns a pa_status
+int index_device_class_text(pa_index* idx, const uint64_t** d_off, const uint8_t** d_text);
 // One opaque object the FASTQ driver parks on the index between calls (its pinned + device batch buffers: allocating them
 // costs more than packing a batch). take() hands it to the caller and empties the slot, so concurrent calls never share
 // it; put() stores it back (or frees it with `free_fn` when another call already parked one). pa_index_destroy frees it.

@@ -53,8 +53,6 @@ struct pa_record_stream {
     hipStream_t stream = nullptr;   // pa_process_reads call or another record stream left them there) and parked there again at the end
     int device = 0;
     const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
-    const uint64_t* cls_off = nullptr;   // the index's rendered classes (index_host_class_text)
-    const char* cls_txt = nullptr;
     uint64_t batch_reads = 2u << 20;
     BatchCtx* ctx = nullptr;       // = cache->ctx
     RawText text[2];               // ids and sequences of the batch's records (Record offsets point into it)
@@ -78,22 +76,27 @@ int fail_sticky(pa_record_stream* s, int rc) {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-void render(pa_record_stream* s, int k) {
+int render(pa_record_stream* s, int k) {
+    // the batch's tuples were rendered on the GPU (batch_finish -> render.hip): wait for their copy in pinned memory and move it into the
+    // output queue as ONE buffer (it ends with a line break; pull hands out whole lines), the pool sharing the copy
     const double t_render = now_s();
     BatchCtx& c = s->ctx[k];
-    const int P = s->pool->size() * 4;
-    std::vector<TextBuf> parts((size_t)P);
-    std::vector<uint64_t> flags((size_t)P, 0);
-    const char* text = s->text[k].data();
-    s->pool->run(P, [&](int t) {
+    const int rc = batch_text_wait(c);
+    if (rc != PA_OK) return rc;
+    if (c.text_bytes) {
         TextBuf buf;
-        flags[(size_t)t] = format_records(c, c.n * (uint64_t)t / P, c.n * (uint64_t)(t + 1) / P, text, s->cls_off, s->cls_txt, buf);
-        parts[(size_t)t] = std::move(buf);
-    });
-    for (uint64_t f : flags) s->n_flagged += f;
+        char* dst = buf.room(c.text_bytes);
+        const int P = s->pool->size() * 2;
+        const size_t total = c.text_bytes;
+        s->pool->run(P, [&](int t) {
+            const size_t a = total * (size_t)t / P, b = total * (size_t)(t + 1) / P;
+            memcpy(dst + a, c.h_text + a, b - a);
+        });
+        buf.len = total;
+        s->outq.push_back(std::move(buf));
+    }
+    s->n_flagged += c.flagged;
     s->n_reads += c.n;
-    for (TextBuf& b : parts)
-        if (b.len) s->outq.push_back(std::move(b));
     s->inflight[k] = false;
     c.recs.clear();
     c.n = 0;
@@ -101,6 +104,7 @@ void render(pa_record_stream* s, int k) {
     s->maxlen[k] = 0;
     s->stage[4] += now_s() - t_render;
     s->stage[7] = (double)s->n_reads;
+    return PA_OK;
 }
 
 // the batch being filled goes to the GPU; the one before it is waited for and rendered. (Both batches share the stream and
@@ -125,7 +129,7 @@ int submit(pa_record_stream* s) {
     if ((rc = batch_launch(s->idx, c, s->stream)) != PA_OK) return rc;
     s->stage[3] += now_s() - t0;
     s->inflight[k] = true;
-    if (s->inflight[o]) render(s, o);
+    if (s->inflight[o] && (rc = render(s, o)) != PA_OK) return rc;
     s->cur = o;
     return PA_OK;
 }
@@ -140,7 +144,6 @@ int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads
     if (!s) return fail(PA_ERR_OOM, "out of memory");
     s->idx = idx;
     index_host_classes(idx, &s->h_ec, &s->h_class_ref, &s->device);
-    index_host_class_text(idx, &s->cls_off, &s->cls_txt);
     if (batch_reads) s->batch_reads = std::max<uint64_t>(64, batch_reads / 64 * 64);
     int T = num_threads > 0 ? num_threads : usable_threads();
     if (T < 1) T = 1;
@@ -240,7 +243,7 @@ int pa_records_flush(pa_record_stream* s) {
         const double t0 = now_s();
         if ((rc = batch_finish(s->idx, s->ctx[b], s->stream)) != PA_OK) return fail_sticky(s, rc);
         s->stage[2] += now_s() - t0;
-        render(s, b);
+        if ((rc = render(s, b)) != PA_OK) return fail_sticky(s, rc);
     }
     return PA_OK;
 }
