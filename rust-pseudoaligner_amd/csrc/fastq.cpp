@@ -45,24 +45,20 @@ namespace {
 constexpr uint64_t DEFAULT_BATCH_READS = 2u << 20;   // (4 Mi reads left 1.3 GB of the mapping and 0.23 GB of text to the last, unoverlapped batch: 33 ms of tear-down per 8 M reads against 12)   // PA_INGEST_BATCH overrides (tests exercise the batch seams with small values)
 
 
-// in-order writer: buffers handed over by the main thread are written by a dedicated thread and then recycled
+// in-order writer: pieces of text (the batches' rendered tuples, in pinned memory) are written by a dedicated thread; the owner of a
+// piece waits for its job before it overwrites the bytes
 class Writer {
 public:
     explicit Writer(FILE* f) : f_(f), th_([this] { loop(); }) {}
-    TextSet* acquire(size_t nbuf) {   // a free set (at most three exist: being filled, queued, being written)
-        std::unique_lock<std::mutex> g(mu_);
-        room_.wait(g, [this] { return !free_.empty() || made_ < 3; });
-        TextSet* s;
-        if (!free_.empty()) { s = free_.back(); free_.pop_back(); }
-        else { sets_.emplace_back(new TextSet()); s = sets_.back().get(); ++made_; }
-        s->resize(nbuf);
-        for (TextBuf& b : *s) b.len = 0;
-        return s;
-    }
-    void push(TextSet* parts) {
+    uint64_t push(const char* p, size_t n) {   // returns the job's number (1, 2, ...)
         std::lock_guard<std::mutex> g(mu_);
-        q_.push_back(parts);
+        q_.push_back({p, n});
         cv_.notify_one();
+        return ++pushed_;
+    }
+    void wait(uint64_t job) {                  // until job `job` has been written
+        std::unique_lock<std::mutex> g(mu_);
+        room_.wait(g, [&] { return written_ >= job; });
     }
     bool finish() {
         { std::lock_guard<std::mutex> g(mu_); done_ = true; }
@@ -74,27 +70,24 @@ public:
 private:
     void loop() {
         for (;;) {
-            TextSet* parts;
+            std::pair<const char*, size_t> job;
             {
                 std::unique_lock<std::mutex> g(mu_);
                 cv_.wait(g, [this] { return done_ || !q_.empty(); });
                 if (q_.empty()) return;
-                parts = q_.front();
+                job = q_.front();
                 q_.pop_front();
             }
-            for (const TextBuf& b : *parts)
-                if (ok_ && b.len && fwrite(b.mem.data(), 1, b.len, f_) != b.len) ok_ = false;
-            { std::lock_guard<std::mutex> g(mu_); free_.push_back(parts); }
-            room_.notify_one();
+            if (ok_ && job.second && fwrite(job.first, 1, job.second, f_) != job.second) ok_ = false;
+            { std::lock_guard<std::mutex> g(mu_); ++written_; }
+            room_.notify_all();
         }
     }
     FILE* f_;
     std::mutex mu_;
     std::condition_variable cv_, room_;
-    std::deque<TextSet*> q_;
-    std::vector<TextSet*> free_;
-    std::vector<std::unique_ptr<TextSet>> sets_;
-    int made_ = 0;
+    std::deque<std::pair<const char*, size_t>> q_;
+    uint64_t pushed_ = 0, written_ = 0;
     bool done_ = false, ok_ = true;
     std::thread th_;
 };
@@ -268,6 +261,14 @@ int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<Rec
         pool.run(R, [&](int r) {
             uint64_t a, b;
             range(r, a, b);
+#ifdef MADV_POPULATE_READ
+            // a fresh mapping of a file in the page cache costs a minor fault per 4 KiB page on first touch (0.6 M of them for 8 M reads):
+            // let the kernel fill this range's page table entries in one call instead (Linux >= 5.14; elsewhere the faults simply happen)
+            if (mapped && attempt == 0) {
+                const uint64_t pa_ = a & ~4095ull;
+                (void)madvise((void*)(data + pa_), (size_t)(b - pa_), MADV_POPULATE_READ);
+            }
+#endif
             std::vector<uint32_t>& v = brk[(size_t)r];
             v.clear();
             v.reserve((size_t)((b - a) / 64 + 16));   // (FASTQ of 150-base reads: one line break per ~79 bytes)
@@ -426,7 +427,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     if (const char* v = getenv("PA_INGEST_BATCH")) { const long long x = atoll(v); if (x >= 64) BATCH_READS = (uint64_t)x / 64 * 64; }
     const bool verbose = getenv("PA_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_scan = 0, t_pack = 0, t_finish = 0, t_launch = 0, t_format = 0, t_pack_rec = 0, t_pack_alloc = 0, t_pack_tiles = 0, t_push = 0;
+    double t_text_wait = 0, t_scan = 0, t_pack = 0, t_finish = 0, t_launch = 0, t_format = 0, t_pack_rec = 0, t_pack_alloc = 0, t_pack_tiles = 0, t_push = 0;
     const double t_begin = now();
     Pool pool(num_threads);
     const int T = pool.size();
@@ -511,33 +512,25 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     auto launch = [&](BatchCtx& c) -> int { return batch_launch(idx, c, stream); };   // index.map_read (:451) for the whole batch
     auto finish = [&](BatchCtx& c) -> int { return batch_finish(idx, c, stream); };
 
-    // Formatting runs as 4T tasks handed out dynamically, plus one that gives the text of the batches already written back
-    // to the kernel: unmapping 5 GB of page-cache mapping is 0.09 s of one thread's time, hidden here behind the others' work.
     uint64_t unmapped_to = 0;   // bytes of the mapping already given back (page-aligned)
+    // The text of the batches already written goes back to the kernel piece by piece (unmapping 5 GB of page-cache mapping is 0.09 s of
+    // one thread's time): on a helper thread, so that no stage of the pipeline waits for it.
+    std::thread unmapper;
+    auto unmap_async = [&](uint64_t from, uint64_t to) {
+        if (unmapper.joinable()) unmapper.join();
+        const char* base = data;
+        unmapper = std::thread([base, from, to] { (void)munmap((void*)(base + from), to - from); });
+    };
     int format_rc = PA_OK;
-    auto format = [&](BatchCtx& c) {
-        // the batch's tuples were rendered on the GPU (batch_finish -> render.hip) and are on their way to pinned memory: wait for them, then
-        // copy them into a buffer set of the writer (the pinned buffer is the next batch-but-one's), the pool sharing the copy. One extra
-        // task gives the text of the batches already written back to the kernel: unmapping 5 GB of page-cache mapping is 0.09 s of one
-        // thread's time, hidden here behind the others' work.
+    uint64_t text_job[2] = {0, 0};   // the writer's job that reads ctx[k].h_text (0: none)
+    auto format = [&](BatchCtx& c, int k) {
+        // the batch's tuples were rendered on the GPU (batch_finish -> render.hip) and are on their way to pinned memory: wait for them and
+        // hand them to the writer where they are (finish() of the batch after next waits for that job before the buffer is written again)
+        double tw = now();
         if ((format_rc = batch_text_wait(c)) != PA_OK) return;
-        const int P = T * 2;
-        TextSet* parts = writer.acquire((size_t)P);
+        t_text_wait += now() - tw;
         const uint64_t keep_from = mapped ? (rec_pos[c.first].start & ~4095ull) : 0;   // nothing before this batch is read again
-        const int extra = keep_from > unmapped_to ? 1 : 0;
-        const size_t total = c.text_bytes;
-        pool.run(P + extra, [&](int task) {
-            if (task < extra) {
-                (void)munmap((void*)(data + unmapped_to), keep_from - unmapped_to);
-                return;
-            }
-            const int t = task - extra;
-            const size_t a = total * (size_t)t / P, b = total * (size_t)(t + 1) / P;
-            TextBuf& buf = (*parts)[(size_t)t];
-            memcpy(buf.room(b - a), c.h_text + a, b - a);
-            buf.len = b - a;
-        });
-        if (extra) unmapped_to = keep_from;
+        if (keep_from > unmapped_to) { unmap_async(unmapped_to, keep_from); unmapped_to = keep_from; }
         flagged += c.flagged;
         reported += c.n;
         while (reported >= next_report) {   // :497-503
@@ -545,9 +538,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
                     (double)((float)flagged * 100.0f / (float)reported));
             next_report += 1000000;
         }
-        const double t0 = now();
-        writer.push(parts);
-        t_push += now() - t0;
+        text_job[k] = writer.push(c.h_text, c.text_bytes);
     };
 
     // pack(b) overlaps GPU(b-1); format(b-1) overlaps GPU(b)
@@ -555,11 +546,15 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         double t0 = now();
         if (b < nb) rc = pack(ctx[b & 1], b);
         t_pack += now() - t0; t0 = now();
-        if (rc == PA_OK && b >= 1) rc = finish(ctx[(b - 1) & 1]);
+        if (rc == PA_OK && b >= 1) {
+            const int k = (int)((b - 1) & 1);
+            if (text_job[k]) { const double tw = now(); writer.wait(text_job[k]); t_push += now() - tw; text_job[k] = 0; }   // the text of batch b - 3 has left this context's pinned buffer
+            rc = finish(ctx[k]);
+        }
         t_finish += now() - t0; t0 = now();
         if (rc == PA_OK && b < nb) rc = launch(ctx[b & 1]);
         t_launch += now() - t0; t0 = now();
-        if (rc == PA_OK && b >= 1) { format(ctx[(b - 1) & 1]); rc = format_rc; }
+        if (rc == PA_OK && b >= 1) { format(ctx[(b - 1) & 1], (int)((b - 1) & 1)); rc = format_rc; }
         t_format += now() - t0;
     }
     {
@@ -567,8 +562,8 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         st[0] = t_scan; st[1] = t_pack; st[2] = t_finish; st[3] = t_launch; st[4] = t_format; st[5] = t_push; st[6] = now() - t_begin; st[7] = (double)nrec;
     }
     if (verbose)
-        fprintf(stderr, "\n[pa ingest] %llu reads, %d threads: scan %.3f s, pack %.3f s (records %.3f, alloc %.3f, tiles %.3f), wait GPU %.3f s, launch %.3f s, format %.3f s (writer wait %.3f), total %.3f s\n",
-                (unsigned long long)nrec, T, t_scan, t_pack, t_pack_rec, t_pack_alloc, t_pack_tiles, t_finish, t_launch, t_format, t_push, now() - t_begin);
+        fprintf(stderr, "\n[pa ingest] %llu reads, %d threads: scan %.3f s, pack %.3f s (records %.3f, alloc %.3f, tiles %.3f), wait GPU %.3f s, launch %.3f s, text %.3f s (waiting for the GPU's tuples %.3f; writer wait %.3f), total %.3f s\n",
+                (unsigned long long)nrec, T, t_scan, t_pack, t_pack_rec, t_pack_alloc, t_pack_tiles, t_finish, t_launch, t_format, t_text_wait, t_push, now() - t_begin);
     double t0 = now();
     if (stream) (void)hipStreamSynchronize(stream);   // (the stream stays with the parked buffers; IngestCache::destroy releases both)
     const double t_stream = now() - t0; t0 = now();
@@ -578,7 +573,12 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     if (cache->rec_pos.capacity() > ((size_t)64 << 20)) { std::vector<RecPos>().swap(cache->rec_pos); std::vector<std::vector<uint32_t>>().swap(cache->brk); }   // (do not park more than 1 GB of it)
     if (rc == PA_OK) index_put_ingest_cache(idx, cache, IngestCache::destroy);   // the next call starts with warm buffers
     else IngestCache::destroy(cache);
-    if (mapped && fsize > unmapped_to) munmap((void*)(data + unmapped_to), fsize - unmapped_to);
+    if (unmapper.joinable()) unmapper.join();
+    if (mapped && fsize > unmapped_to) {   // the rest of the mapping (the last batch's text): nobody reads it any more; given back without making the caller wait
+        const char* base = data;
+        const uint64_t from = unmapped_to, to = fsize;
+        std::thread([base, from, to] { (void)munmap((void*)(base + from), to - from); }).detach();
+    }
     const double t_unmap = now() - t0; t0 = now();
     if (out != stdout) { if (fclose(out) != 0 && rc == PA_OK) rc = fail(PA_ERR_IO, "close %s: %s", out_path, strerror(errno)); }
     else fflush(stdout);

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -74,11 +75,32 @@ private:
 
 // text of one batch: one growable byte buffer per formatting thread, reused from batch to batch (fresh memory would be
 // page-faulted in again every time)
+struct RawBytes {   // growable bytes that are NOT zero-filled when they grow (a std::vector would write every new byte once before the copy writes it again)
+    char* p = nullptr;
+    size_t cap = 0;
+    RawBytes() = default;
+    RawBytes(RawBytes&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    RawBytes& operator=(RawBytes&& o) noexcept { if (this != &o) { free(p); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    RawBytes(const RawBytes&) = delete;
+    RawBytes& operator=(const RawBytes&) = delete;
+    ~RawBytes() { free(p); }
+    char* data() { return p; }
+    const char* data() const { return p; }
+    size_t size() const { return cap; }
+    void grow(size_t want, size_t keep) {
+        char* q = (char*)malloc(want);
+        if (!q) throw std::bad_alloc();
+        if (keep) memcpy(q, p, keep);
+        free(p);
+        p = q;
+        cap = want;
+    }
+};
 struct TextBuf {
-    std::vector<char> mem;
+    RawBytes mem;
     size_t len = 0;
     char* room(size_t need) {   // at least `need` more bytes
-        if (len + need > mem.size()) mem.resize(std::max(mem.size() * 2, len + need + (1 << 16)));
+        if (len + need > mem.size()) mem.grow(std::max(mem.size() * 2, len + need + (1 << 16)), len);
         return mem.data() + len;
     }
 };
@@ -207,6 +229,7 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
     unsigned long long* h_tot = nullptr;   // pinned {text bytes, flagged reads}
     char* h_text = nullptr;
     size_t ids_cap = 0, ids_bytes = 0, scan_bytes = 0, text_cap = 0, text_bytes = 0;
+    size_t text_guess = 0, spec_bytes = 0;   // the text's expected length (from the batch before) and what was rendered + fetched ahead of knowing it
     uint64_t flagged = 0;
     hipEvent_t ev_text = nullptr;
     size_t tiles_bytes = 0, arena_entries = 0, reads_cap = 0;
@@ -368,6 +391,32 @@ inline double* last_stage_seconds() {
     return st;
 }
 
+// The batch's output tuples (:455-461, :490) rendered where the records, the class table and the novel class ids are (render.hip):
+// lengths + scan (d_off[n] = the text's bytes, copied to h_tot with the number of flagged reads), then — when buffers exist — the
+// bytes and their copy to pinned memory, c.spec_bytes of them: a guess from the batch before (the host only learns the exact length
+// when the batch is finished; a text that turns out longer is rendered again by batch_finish)
+inline int batch_render_enqueue(pa_index* idx, BatchCtx& c, hipStream_t stream) {
+    const uint64_t* d_cls_off = nullptr;
+    const uint8_t* d_cls_txt = nullptr;
+    int e = index_device_class_text(idx, &d_cls_off, &d_cls_txt);
+    if (e != PA_OK) return e;
+    PA_INGEST_HIP_OK(hipMemsetAsync(c.d_flag, 0, 8, stream));
+    int k = launch_render_len((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n, c.arena_entries,
+                              (uint32_t*)c.d_len, (uint64_t*)c.d_off, (unsigned long long*)c.d_flag, c.d_scan, c.scan_bytes, stream);
+    if (k) return fail(PA_ERR_HIP, "render (lengths): %s", hipGetErrorString((hipError_t)k));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_tot, (const uint64_t*)c.d_off + c.n, 8, hipMemcpyDeviceToHost, stream));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_tot + 1, c.d_flag, 8, hipMemcpyDeviceToHost, stream));
+    c.spec_bytes = 0;
+    if (c.text_cap && c.text_guess) {
+        c.spec_bytes = std::min(c.text_cap, c.text_guess);
+        k = launch_render_write((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n, c.arena_entries,
+                                (const uint64_t*)c.d_off, (uint8_t*)c.d_text, c.spec_bytes, stream);
+        if (k) return fail(PA_ERR_HIP, "render (text): %s", hipGetErrorString((hipError_t)k));
+        PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_text, c.d_text, c.spec_bytes, hipMemcpyDeviceToHost, stream));
+    }
+    return PA_OK;
+}
+
 inline int batch_launch(pa_index* idx, BatchCtx& c, hipStream_t stream) {
     PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_ascii, c.h_ascii, c.ascii_bytes, hipMemcpyHostToDevice, stream));
     PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_soff, c.h_soff, (c.n + 1) * 8, hipMemcpyHostToDevice, stream));
@@ -378,11 +427,11 @@ inline int batch_launch(pa_index* idx, BatchCtx& c, hipStream_t stream) {
     const int e = pa_map_batch_device(idx, (const uint64_t*)c.d_tiles, (const uint32_t*)c.d_lens, c.n, c.wpr, PA_DEFAULT_ALLOWED_MISMATCHES,
                                       (pa_read_result*)c.d_results, (uint32_t*)c.d_arena, c.arena_entries, nullptr, stream);
     if (e != PA_OK) return e;
-    return PA_OK;   // (the records stay on the device: the render kernels read them there)
+    return batch_render_enqueue(idx, c, stream);   // (the records stay on the device: the render kernels read them there)
 }
 
-// waits for the batch; an arena that turned out too small is regrown and the batch mapped again; the ids of the classes that
-// are no index classes come to the host
+// waits for the batch; an arena that turned out too small is regrown and the batch mapped (and rendered) again. Afterwards the batch's
+// tuples are in c.h_text[0 .. c.text_bytes) — or on their way there (batch_text_wait)
 inline int batch_finish(pa_index* idx, BatchCtx& c, hipStream_t stream) {
     uint64_t used = 0, need = 0;
     int e = pa_map_finish(idx, stream, &used, &need);
@@ -395,35 +444,29 @@ inline int batch_finish(pa_index* idx, BatchCtx& c, hipStream_t stream) {
         if (e == PA_OK) e = pa_map_finish(idx, stream, &used, &need);
     }
     if (e != PA_OK) return e;
-    // the batch is mapped: its output tuples (:455-461, :490) are rendered where the records, the class table and the novel class ids
-    // are. Lengths + scan first (the host has to size the text), then the bytes and their copy to pinned memory, asynchronously:
-    // batch_text_wait collects them
-    const uint64_t* d_cls_off = nullptr;
-    const uint8_t* d_cls_txt = nullptr;
-    if ((e = index_device_class_text(idx, &d_cls_off, &d_cls_txt)) != PA_OK) return e;
-    PA_INGEST_HIP_OK(hipMemsetAsync(c.d_flag, 0, 8, stream));
-    int k = launch_render_len((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n,
-                              (uint32_t*)c.d_len, (uint64_t*)c.d_off, (unsigned long long*)c.d_flag, c.d_scan, c.scan_bytes, stream);
-    if (k) return fail(PA_ERR_HIP, "render (lengths): %s", hipGetErrorString((hipError_t)k));
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_tot, (const uint64_t*)c.d_off + c.n, 8, hipMemcpyDeviceToHost, stream));
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_tot + 1, c.d_flag, 8, hipMemcpyDeviceToHost, stream));
-    PA_INGEST_HIP_OK(hipStreamSynchronize(stream));
+    // (pa_map_finish synchronised the stream: the lengths — and the speculative text, if any — have arrived)
     c.text_bytes = (size_t)c.h_tot[0];
     c.flagged = c.h_tot[1];
-    if (c.text_bytes + 64 > c.text_cap) {
-        const size_t want = c.text_bytes + c.text_bytes / 4 + (1 << 20);
-        if (c.h_text) (void)hipHostFree(c.h_text);
-        if (c.d_text) (void)hipFree(c.d_text);
-        c.h_text = nullptr; c.d_text = nullptr;
-        c.text_cap = 0;
-        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_text, want, hipHostMallocDefault));
-        PA_INGEST_HIP_OK(hipMalloc(&c.d_text, want));
-        c.text_cap = want;
+    c.text_guess = c.text_bytes + c.text_bytes / 8 + (64 << 10);
+    if (c.text_bytes > c.spec_bytes) {   // no guess yet (first batches) or a text longer than guessed: size the buffers, write it, fetch it
+        if (c.text_bytes + 64 > c.text_cap) {
+            const size_t want = c.text_bytes + c.text_bytes / 4 + (1 << 20);
+            if (c.h_text) (void)hipHostFree(c.h_text);
+            if (c.d_text) (void)hipFree(c.d_text);
+            c.h_text = nullptr; c.d_text = nullptr;
+            c.text_cap = 0;
+            PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_text, want, hipHostMallocDefault));
+            PA_INGEST_HIP_OK(hipMalloc(&c.d_text, want));
+            c.text_cap = want;
+        }
+        const uint64_t* d_cls_off = nullptr;
+        const uint8_t* d_cls_txt = nullptr;
+        if ((e = index_device_class_text(idx, &d_cls_off, &d_cls_txt)) != PA_OK) return e;
+        const int k = launch_render_write((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n, c.arena_entries,
+                                          (const uint64_t*)c.d_off, (uint8_t*)c.d_text, c.text_cap, stream);
+        if (k) return fail(PA_ERR_HIP, "render (text): %s", hipGetErrorString((hipError_t)k));
+        if (c.text_bytes) PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_text, c.d_text, c.text_bytes, hipMemcpyDeviceToHost, stream));
     }
-    k = launch_render_write((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n,
-                            (const uint64_t*)c.d_off, (uint8_t*)c.d_text, stream);
-    if (k) return fail(PA_ERR_HIP, "render (text): %s", hipGetErrorString((hipError_t)k));
-    if (c.text_bytes) PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_text, c.d_text, c.text_bytes, hipMemcpyDeviceToHost, stream));
     PA_INGEST_HIP_OK(hipEventRecord(c.ev_text, stream));
     return PA_OK;
 }

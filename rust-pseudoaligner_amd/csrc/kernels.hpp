@@ -92,10 +92,10 @@ int launch_count(const pa_read_result* results, const uint32_t* arena, const uin
 // the reference's output tuples rendered on the GPU (render.hip)
 size_t render_scan_bytes(uint64_t n);
 int launch_render_len(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint64_t* d_cls_off,
-                      const uint8_t* d_cls_txt, uint64_t n, uint32_t* d_len, uint64_t* d_off, unsigned long long* d_flagged, void* d_tmp, size_t tmp_bytes,
+                      const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, uint32_t* d_len, uint64_t* d_off, unsigned long long* d_flagged, void* d_tmp, size_t tmp_bytes,
                       hipStream_t stream);
 int launch_render_write(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint64_t* d_cls_off,
-                        const uint8_t* d_cls_txt, uint64_t n, const uint64_t* d_off, uint8_t* d_text, hipStream_t stream);
+                        const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, const uint64_t* d_off, uint8_t* d_text, uint64_t text_cap, hipStream_t stream);
 
 // per-barcode counts (barcode_counts.hip)
 int barcode_counts(const DevIndexView& ix, const uint32_t* class_table, uint64_t class_table_size, const pa_read_result* d_results,

@@ -60,6 +60,7 @@ struct pa_record_stream {
     bool inflight[2] = {false, false};
     int cur = 0;                   // the batch being filled
     std::deque<TextBuf> outq;      // rendered text in order; out_off = bytes of the front buffer already pulled
+    std::vector<TextBuf> spare;    // buffers the caller has pulled empty: the next batches' text goes into them (fresh memory is paged in again every time)
     size_t out_off = 0;
     uint64_t n_reads = 0, n_flagged = 0;
     double stage[PA_INGEST_STAGES] = {0, 0, 0, 0, 0, 0, 0, 0};   // pa_record_stream_stage_seconds
@@ -85,6 +86,7 @@ int render(pa_record_stream* s, int k) {
     if (rc != PA_OK) return rc;
     if (c.text_bytes) {
         TextBuf buf;
+        if (!s->spare.empty()) { buf = std::move(s->spare.back()); s->spare.pop_back(); buf.len = 0; }
         char* dst = buf.room(c.text_bytes);
         const int P = s->pool->size() * 2;
         const size_t total = c.text_bytes;
@@ -280,7 +282,11 @@ int pa_records_pull(pa_record_stream* s, char* buf, size_t cap, size_t* n_bytes)
         } else memcpy(buf + got, f.mem.data() + s->out_off, take);
         got += take;
         s->out_off += take;
-        if (s->out_off == f.len) { s->outq.pop_front(); s->out_off = 0; }
+        if (s->out_off == f.len) {
+            if (s->spare.size() < 3) s->spare.push_back(std::move(f));
+            s->outq.pop_front();
+            s->out_off = 0;
+        }
         else break;   // the buffer is full up to a line boundary
     }
     *n_bytes = got;

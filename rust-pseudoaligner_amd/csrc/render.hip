@@ -65,7 +65,12 @@ struct RenderArgs {
     const uint64_t* cls_off;      // [num_classes + 1] into cls_txt
     const uint8_t* cls_txt;
     uint64_t n;
+    uint64_t arena_cap;           // entries of `arena`: a launch whose arena overflowed leaves records that point beyond it (the host maps that batch
+                                  // again with a larger one, PA_ERR_ARENA_FULL); such a class is rendered as empty here, never read
 };
+__device__ __forceinline__ uint32_t arena_len(const RenderArgs& a, const pa_read_result& r) {
+    return (uint64_t)r.class_off + r.class_len <= a.arena_cap ? r.class_len : 0u;
+}
 
 __device__ __forceinline__ bool flag_of(const pa_read_result& r) {
     return (r.mismatches & PA_MAPPED_BIT) && r.coverage >= PA_READ_COVERAGE_THRESHOLD && r.class_len == 0;   // :455
@@ -88,10 +93,10 @@ __global__ __launch_bounds__(256) void pa_render_len_kernel(const RenderArgs a, 
             if (r.class_off & PA_CLASS_REF) {
                 const uint32_t c = r.class_off & ~PA_CLASS_REF;
                 l += (uint32_t)(a.cls_off[c + 1] - a.cls_off[c]);
-            } else if (r.class_len) {
+            } else if (const uint32_t cl = arena_len(a, r)) {
                 const uint32_t* ids = a.arena + r.class_off;
-                l += 2u * (r.class_len - 1);
-                for (uint32_t j = 0; j < r.class_len; ++j) l += dec_digits(ids[j]);
+                l += 2u * (cl - 1);
+                for (uint32_t j = 0; j < cl; ++j) l += dec_digits(ids[j]);
             }
             l += 3u + dec_digits(mapped ? r.coverage : 0u) + 2u;              // "], " coverage ")\n"  (None -> (false, id, [], 0), :461)
         }
@@ -102,9 +107,9 @@ __global__ __launch_bounds__(256) void pa_render_len_kernel(const RenderArgs a, 
     if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_flagged, (unsigned long long)__popcll(m));
 }
 
-__global__ __launch_bounds__(256) void pa_render_write_kernel(const RenderArgs a, const uint64_t* __restrict__ off, uint8_t* __restrict__ text) {
+__global__ __launch_bounds__(256) void pa_render_write_kernel(const RenderArgs a, const uint64_t* __restrict__ off, uint8_t* __restrict__ text, uint64_t cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+    if (i >= a.n || off[a.n] > cap) return;   // (a text that does not fit the buffer is not written at all: the host sees its length and renders it again)
     const pa_read_result r = a.results[i];
     const bool mapped = r.mismatches & PA_MAPPED_BIT;
     uint8_t* o = text + off[i];
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(256) void pa_render_write_kernel(const RenderArgs a
         for (uint32_t j = 0; j < n; ++j) *o++ = t[j];
     } else {
         const uint32_t* ids = a.arena + r.class_off;
-        for (uint32_t j = 0; j < r.class_len; ++j) {
+        for (uint32_t j = 0, cl = arena_len(a, r); j < cl; ++j) {
             if (j) { *o++ = ','; *o++ = ' '; }
             o = put_dec(o, ids[j]);
         }
@@ -141,9 +146,9 @@ size_t render_scan_bytes(uint64_t n) {
 
 // lengths + offsets of the tuples of a finished batch: d_len[n + 1], d_off[n + 1] (d_off[n] = bytes of the whole text), *d_flagged += flagged reads
 int launch_render_len(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint64_t* d_cls_off,
-                      const uint8_t* d_cls_txt, uint64_t n, uint32_t* d_len, uint64_t* d_off, unsigned long long* d_flagged, void* d_tmp, size_t tmp_bytes,
+                      const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, uint32_t* d_len, uint64_t* d_off, unsigned long long* d_flagged, void* d_tmp, size_t tmp_bytes,
                       hipStream_t stream) {
-    const RenderArgs a{d_results, d_arena, d_ids, d_id_off, d_cls_off, d_cls_txt, n};
+    const RenderArgs a{d_results, d_arena, d_ids, d_id_off, d_cls_off, d_cls_txt, n, arena_cap};
     hipLaunchKernelGGL(pa_render_len_kernel, dim3((uint32_t)((n + 1 + 255) / 256)), dim3(256), 0, stream, a, d_len, d_flagged);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -152,10 +157,10 @@ int launch_render_len(const pa_read_result* d_results, const uint32_t* d_arena, 
 }
 
 int launch_render_write(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint64_t* d_cls_off,
-                        const uint8_t* d_cls_txt, uint64_t n, const uint64_t* d_off, uint8_t* d_text, hipStream_t stream) {
+                        const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, const uint64_t* d_off, uint8_t* d_text, uint64_t text_cap, hipStream_t stream) {
     if (n == 0) return 0;
-    const RenderArgs a{d_results, d_arena, d_ids, d_id_off, d_cls_off, d_cls_txt, n};
-    hipLaunchKernelGGL(pa_render_write_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, a, d_off, d_text);
+    const RenderArgs a{d_results, d_arena, d_ids, d_id_off, d_cls_off, d_cls_txt, n, arena_cap};
+    hipLaunchKernelGGL(pa_render_write_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, a, d_off, d_text, text_cap);
     return (int)hipGetLastError();
 }
 
