@@ -30,7 +30,7 @@
 #define PA_COOP_MIN 2u
 #endif
 #ifndef PA_RARE_MIN   // A/B builds: -DPA_RARE_MIN=0 (rare states compete by population only)
-#define PA_RARE_MIN 10u
+#define PA_RARE_MIN 16u   // (round 5, same-box A/B of 10 / 16 / 24 on the chain-block layout: config 5 -2.1 % time at 16, config 2 -1.4 %, config 3 -0.5 %; 24 is slower than 10)
 #endif
 
 // -DPA_ISA_MARKS: comments in the ISA listing that tools/isa_sections.py counts instructions between (static cost of the
