@@ -382,7 +382,7 @@ def main() -> None:
     mine = [sum(m[0] for m in map_ms) / n_t, sum(m[1] for m in map_ms) / n_t, sum(m[2] for m in map_ms) / n_t, sum(step_ms) / max(len(step_ms), 1)]
     per_rank = [mine]
     if dist is not None:
-        t = torch.tensor(mine, dtype=torch.float64, device=dev)
+        t = torch.tensor(mine, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")   # (the gloo rehearsal gathers on the host)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         per_rank = [g.tolist() for g in gathered]
