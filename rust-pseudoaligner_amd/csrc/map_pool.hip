@@ -29,6 +29,9 @@
 #ifndef PA_COOP_MIN
 #define PA_COOP_MIN 2u
 #endif
+#ifndef PA_REFILL_ALIGN   // A/B builds: -DPA_REFILL_ALIGN=16 (refills take whole 128-byte lines of the read tiles; measured and not kept: see the output step)
+#define PA_REFILL_ALIGN 1u
+#endif
 #ifndef PA_RARE_MIN   // A/B builds: -DPA_RARE_MIN=0 (rare states compete by population only)
 #define PA_RARE_MIN 16u   // (round 5, same-box A/B of 10 / 16 / 24 on the chain-block layout: config 5 -2.1 % time at 16, config 2 -1.4 %, config 3 -0.5 %; 24 is slower than 10)
 #endif
@@ -495,7 +498,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         const bool seek_ok = n_seek_q >= PA_SEEK_MIN || n_fwd_q < 24;
         const bool dual = (sel == ST_FWD || sel == ST_SEEK) && K <= 32 && n_seek_q != 0 && n_fwd_q != 0 && seek_ok && !PA_ABLATE(4u);
         if (dual) sel = ST_FWD;
-        const uint32_t n_own = dual ? (n_fwd_q < 64 ? n_fwd_q : 64) : bestn < 64 ? bestn : 64;
+        uint32_t n_own = dual ? (n_fwd_q < 64 ? n_fwd_q : 64) : bestn < 64 ? bestn : 64;
+        if (PA_REFILL_ALIGN > 1 && sel == ST_EMPTY && n_own >= PA_REFILL_ALIGN && (uint64_t)n_own < left) n_own &= ~(PA_REFILL_ALIGN - 1u);   // (A/B builds: see the output step)
         // an output step that does not fill the wave takes EMPTY slots into its idle lanes: they are refilled by the same text
         // (slots freed by the rare finishing steps otherwise wait, parked, for a refill step of their own)
         const uint32_t n_fill = (PA_FILL && sel == ST_F_BITS && left != 0) ? (64 - n_own < nempty ? 64 - n_own : nempty) : 0u;
@@ -633,7 +637,11 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             {
                 const uint64_t freed = __ballot(active && s.lk == 0);
                 const uint32_t nfree = (uint32_t)__popcll(freed);
-                const uint32_t take = (uint32_t)(left < (uint64_t)nfree ? left : (uint64_t)nfree);
+                uint32_t take = (uint32_t)(left < (uint64_t)nfree ? left : (uint64_t)nfree);
+                // (measured, round 5: whole lines save 0.06 read requests per read — a refill that ends inside a line leaves the rest to the
+                // next one, by which time the line has left the L2 — and cost more in slots left EMPTY for an iteration: config 3 +0.5 %,
+                // config 5 +2 % time. Not the default.)
+                if (PA_REFILL_ALIGN > 1 && take >= PA_REFILL_ALIGN && (uint64_t)take < left) take &= ~(PA_REFILL_ALIGN - 1u);
                 if (take && !PA_ABLATE(8u)) {
                     if (active && s.lk == 0 && rank_in(freed) < take) refill_slot<GREAD>(s, next + rank_in(freed), slot, kp, rd, wc, S, wpr, K);
                     next += take;
