@@ -310,12 +310,24 @@ int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<Rec
                     const uint64_t rec = li >> 2;
                     if (rec >= nrec) return;
                     switch (li & 3) {
-                        case 0:
+                        case 0: {
                             rp[rec].start = p;
                             rp[rec].hdr = (uint32_t)std::min<uint64_t>(e - p, 0xFFFFFFFFull);
                             if (data[p] != '@') odd(rec);
+                            // record.id() (:456) = header[1..].trim_end().splitn(2, ' ').next() in bio 1.5: cut at the first SPACE only (a tab stays
+                            // part of the id), after trailing white space was trimmed. Found here, while the header's bytes are in the cache
+                            uint64_t hend = e, ide = p + 1;
+                            while (hend > p + 1 && (data[hend - 1] == '\r' || data[hend - 1] == ' ' || data[hend - 1] == '\t' || data[hend - 1] == '\n')) --hend;
+                            while (ide < hend && data[ide] != ' ') ++ide;
+                            rp[rec].id_len = e > p ? (uint32_t)std::min<uint64_t>(ide - (p + 1), 0xFFFFFFFFull) : 0u;
                             break;
-                        case 1: rp[rec].seq = (uint32_t)std::min<uint64_t>(e - p, 0xFFFFFFFFull); break;
+                        }
+                        case 1: {
+                            const uint64_t len = e - p;
+                            rp[rec].seq = (uint32_t)std::min<uint64_t>(len, 0xFFFFFFFFull);
+                            rp[rec].seq_len = (uint32_t)std::min<uint64_t>(len && data[e - 1] == '\r' ? len - 1 : len, 0xFFFFFFFFull);
+                            break;
+                        }
                         case 2: if (data[p] != '+') odd(rec); break;
                         default: break;
                     }
@@ -384,11 +396,9 @@ extern "C" int pa_fastq_scan_host(const char* fastq_path, int num_threads, uint6
         *n_records = nrec;
         if (text_kind) *text_kind = !text.normalized.empty() ? 2 : was_gz ? 1 : 0;
         for (uint64_t i = 0; i < nrec && i < capacity; ++i) {
-            const char* l2e = text.data + rec_pos[i].start + rec_pos[i].hdr + 1 + rec_pos[i].seq;   // a CR before the line break is not sequence
-            const bool cr = rec_pos[i].seq && l2e[-1] == '\r';
             if (starts) starts[i] = rec_pos[i].start;
             if (header_len) header_len[i] = rec_pos[i].hdr;
-            if (seq_len) seq_len[i] = rec_pos[i].seq - (cr ? 1u : 0u);
+            if (seq_len) seq_len[i] = rec_pos[i].seq_len;   // a CR before the line break is not sequence
         }
     }
     text.release();
@@ -448,7 +458,6 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     Writer writer(out);
     uint64_t flagged = 0, next_report = 1000000, reported = 0;
     const uint64_t nb = (nrec + BATCH_READS - 1) / BATCH_READS;
-    std::atomic<uint64_t> bad_record{~0ull};
 
     auto ensure = [&](BatchCtx& c, uint64_t n, uint32_t wpr) -> int { return batch_ensure(idx, c, n, wpr, std::min<uint64_t>(BATCH_READS, nrec)); };
 
@@ -460,40 +469,19 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         c.recs.resize(c.n);
         std::vector<uint32_t> tmax((size_t)T * 4, 0);
         const int ntask = T * 4;
-        pool.run(ntask, [&](int t) {   // records + lengths
+        pool.run(ntask, [&](int t) {   // records + lengths: from what the scan noted, no byte of the text is touched here
             uint32_t mx = 0;
             for (uint64_t i = c.n * (uint64_t)t / ntask; i < c.n * (uint64_t)(t + 1) / ntask; ++i) {
-                const char* end = data + fsize;
-                const RecPos& rp = rec_pos[c.first + i];   // the scan walked every line break once: nothing is searched for again
-                const char* p = data + rp.start;
-                const char* l1e = p + rp.hdr;
-                const char* l2 = l1e < end ? l1e + 1 : end;
-                const char* l2e = std::min(l2 + rp.seq, end);
-                const char* l3 = l2e < end ? l2e + 1 : end;
-                if (*p != '@' || l3 >= end || *l3 != '+') {
-                    uint64_t cur = bad_record.load();
-                    while (c.first + i < cur && !bad_record.compare_exchange_weak(cur, c.first + i)) {}
-                    continue;
-                }
-                const char* ide = p + 1;
-                // record.id() (:456) = header[1..].trim_end().splitn(2, ' ').next() in bio 1.5: cut at the first SPACE only (a tab
-                // stays part of the id), after trailing whitespace was trimmed
-                const char* hend = l1e;
-                while (hend > p + 1 && (hend[-1] == '\r' || hend[-1] == ' ' || hend[-1] == '\t' || hend[-1] == '\n')) --hend;
-                while (ide < hend && *ide != ' ') ++ide;
-                const char* se = l2e;
-                if (se > l2 && se[-1] == '\r') --se;
+                const RecPos& rp = rec_pos[c.first + i];
                 Record& rec = c.recs[i];
-                rec.id_off = (uint64_t)(p + 1 - data);
-                rec.id_len = (uint32_t)(ide - (p + 1));
-                rec.seq_off = (uint64_t)(l2 - data);
-                rec.seq_len = (uint32_t)std::min<uint64_t>((uint64_t)(se - l2), 0xFFFFFFFFull);
+                rec.id_off = rp.start + 1;
+                rec.id_len = rp.id_len;
+                rec.seq_off = std::min<uint64_t>(rp.start + rp.hdr + 1, fsize);
+                rec.seq_len = (uint32_t)std::min<uint64_t>(rp.seq_len, fsize - rec.seq_off);
                 mx = std::max(mx, rec.seq_len);
             }
             tmax[(size_t)t] = mx;
         });
-        if (bad_record.load() != ~0ull)
-            return fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu", fastq_path, (unsigned long long)bad_record.load());
         uint32_t maxlen = 1;
         for (uint32_t m : tmax) maxlen = std::max(maxlen, m);
         if (maxlen > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);

@@ -360,15 +360,17 @@ inline void batch_gather_ascii(Pool& pool, BatchCtx& c, const char* text, const 
 }
 
 // the GPU leg of a batch, asynchronous on `stream`: tiles H2D -> index.map_read for every read (:451) -> records D2H
-struct RecPos {   // where a record lies in the text: found by the scan, read by the pack stage
+struct RecPos {   // where a record lies in the text and what of it counts: found by the scan (the only stage that looks at every byte), read by the gather stage
     uint64_t start;      // of the '@'
-    uint32_t hdr, seq;   // bytes of the header line and of the sequence line (without their line breaks)
+    uint32_t hdr, seq;   // bytes of the header line and of the sequence line (without their line breaks; a CR before the break still counted)
+    uint32_t id_len;     // record.id() (:456): header[1..] up to its first space, trailing white space trimmed first (bio 1.5)
+    uint32_t seq_len;    // record.seq() (:449): the sequence line without a CR before its line break
 };
 
 
 struct IngestCache {   // the two batches in flight of a pa_process_reads call or a record stream; parked on the index in between (pa_common.hpp)
     BatchCtx ctx[2];
-    std::vector<RecPos> rec_pos;   // 16 bytes per record of the file: kept, or every call would page 256 MB in again
+    std::vector<RecPos> rec_pos;   // 24 bytes per record of the file: kept, or every call would page 200 MB in again
     std::vector<std::vector<uint32_t>> brk;   // the scan's line-break lists (4 bytes per line), kept for the same reason
     // the stream the batches run on travels with the buffers: its launch context inside the index (2 GB of list-mode rows)
     // is then reused by the next call instead of being stranded behind a destroyed stream
