@@ -106,7 +106,7 @@ struct HostAtomics {
 
 template <>
 struct Dict<uint64_t> {   // host-side builder/reader of the 16-byte slots described in device_layout.hpp (dict_slots.hpp)
-    static constexpr double LOAD = 0.5;
+    static constexpr double LOAD = DICT_LOAD;
     static constexpr uint32_t SLOTS = SLOTS_PER_BUCKET;
     uint32_t* words;
     uint64_t nbuckets;

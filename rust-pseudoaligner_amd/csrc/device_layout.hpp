@@ -7,14 +7,19 @@
 //                 slot = {u32 key_lo, u32 key_hi, u32 handle (0xFFFFFFFF = empty), u32 off (bits 0..23) | ~flags << 24}
 //               bucket = mulhi32(x, nbuckets) with x = a 32-bit multiplicative mix of the key's two words (lane_steps.hpp,
 //               pa_bucket_home); every key also has a HOME slot in its bucket, j = x & 3.
-//               A key sits in its home slot when that was free (78 % of the keys at load 0.5: the builders place all home
-//               keys first), else in another slot t of the bucket — then flag bit ((t - j - 1) & 3) of the HOME slot says so —
+//               A key sits in its home slot when that was free (88 % of the keys at the load of 0.25 the table is built with;
+//               78 % at 0.5: the builders place all home keys first), else in another slot t of the bucket — then flag bit ((t - j - 1) & 3) of the HOME slot says so —
 //               else it overflows into the next bucket (flag bit 3 of the home slot) where the same rule applies. Flags are
 //               stored inverted (a set flag is a cleared bit) so that an all-ones fill is "empty, no flags". A lookup is ONE
 //               16-byte load — the home slot holds the whole key and the answer — and only when the home slot holds another
 //               key AND names other slots, one more load from the same line (21 % of the hits, 9 % of the misses). The
 //               dictionary stores whole keys, so unlike the reference's MPHF (src/pseudoaligner.rs:96-107) no node sequence
-//               has to be fetched to confirm a hit.
+//               has to be fetched to confirm a hit. The table is SPARSE on purpose (DICT_LOAD = 0.25: 64 bytes per k-mer, 6.6 GB
+//               at config 3 of 288 GB): the second load and the overflow bucket are dependent round trips of a whole wave's
+//               step, and halving the load from 0.5 takes 4 % (config 3) / 2 % (config 5) off the mapping kernel's time
+//               (profiles/r05_dict_load.txt). One 16-byte load per probe is also what keeps a table of this size usable at all:
+//               beyond ~4 GB of randomly accessed footprint every load instruction is an address-translation miss, and
+//               several loads per random block then run at a quarter of the rate (profiles/r05_tlb_footprint.txt).
 //               k > 32 (two-word k-mers): a line holds two whole entries {key word 0..3, handle, off, -, -}, handle
 //               0xFFFFFFFF = empty, load <= 1/3, linear probing over lines (a line with a free entry ends the probe sequence).
 //               What an entry says (both forms): handle = the chain BLOCK the k-mer starts in (below), off = where:
@@ -123,6 +128,7 @@ constexpr uint32_t SLOT_WORDS = 4;                 // k <= 32: {key_lo, key_hi, 
 constexpr uint32_t SLOT_OFF_MASK = 0xFFFFFFu;
 constexpr uint32_t SLOT_FLAG_SHIFT = 24;           // flags 0..2: slot (home + 1 + i) & 3 holds a key of this home; flag 3: one overflowed to the next bucket
 constexpr uint32_t SLOT_FLAG_OVERFLOW = 8u;
+constexpr double DICT_LOAD = 0.25;                 // k <= 32: keys per slot the builders aim for (see above)
 constexpr uint32_t DICT_MAX_PROBES = 15;           // buckets a key may overflow through (the builders keep every chain shorter)
 
 struct alignas(16) U4 {

@@ -34,7 +34,7 @@ PA_HD void dict_insert_rest(uint32_t* table, uint32_t nbuckets, uint64_t km, uin
         const uint32_t* hs = table + (uint64_t)b * BUCKET_WORDS + SLOT_WORDS * home;   // written in pass 1 if at all
         if (hs[2] != NO_HANDLE && hs[0] == (uint32_t)km && hs[1] == (uint32_t)(km >> 32)) return;
     }
-    for (bool first = true;; first = false) {   // load <= 1/2: a free slot exists
+    for (bool first = true;; first = false) {   // load <= 1/2 (DICT_LOAD): a free slot exists
         uint32_t* line = table + (uint64_t)b * BUCKET_WORDS;
         uint32_t* hs = line + SLOT_WORDS * home;
         if (!first && slot_claim<A>(hs, km, handle, off)) return;   // (in a later bucket the home slot may be free)

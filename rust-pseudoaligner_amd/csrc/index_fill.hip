@@ -33,7 +33,7 @@ __device__ __forceinline__ uint64_t win32(const uint64_t* w, uint32_t pos) {
 template <class KT> struct FillOps;
 template <> struct FillOps<uint64_t> {
     static constexpr uint32_t SLOTS = SLOTS_PER_BUCKET;
-    static constexpr double LOAD = 0.5;
+    static constexpr double LOAD = DICT_LOAD;
     __host__ __device__ static uint64_t mask(uint32_t k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1); }
     __device__ static uint64_t get(const uint64_t* seq, uint32_t o, uint32_t k) { return win32(seq, o) & mask(k); }
     // (the k <= 32 dictionary is built and read by dict_slots.hpp: two insertion passes)
@@ -179,6 +179,11 @@ int fill_t(const FlatDevice& fd, void* d_blobs, void** d_table, uint64_t* nbucke
     FILL_TRY(hipMemcpy(d_kcum, fd.node_kcum.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
     uint64_t nbuckets = 0;
     double load0 = FillOps<KT>::LOAD;
+    {   // a device short of memory gets the denser table (it costs 4 % of the mapping rate, device_layout.hpp, not the index)
+        size_t free_b = 0, total_b = 0;
+        const double dense = sizeof(KT) == 8 ? 0.5 : FillOps<KT>::LOAD;
+        if (load0 < dense && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)nk / (FillOps<KT>::SLOTS * load0) * BUCKET_WORDS * 4 > (double)free_b / 4) load0 = dense;
+    }
     if (const char* v = knob_str("PA_DICT_LOAD")) { const double x = atof(v); if (x > 0.01 && x <= 0.95) load0 = x; }   // A/B runs only
     for (double load = load0;; load *= 0.75) {
         nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (FillOps<KT>::SLOTS * load)) + 1);
