@@ -38,7 +38,7 @@ struct Lane {
     uint32_t of;    // position in that block's window (0..9): of the k-mer's first base (F_FRESH), else of the next base to compare |
                     // slot of the block that holds the record of the node the lane stands in (10..11), valid when bit 12 is set (else 0) | flags (24..31)
     uint32_t rr;    // LEFT: position + 1 in the block's window of the next base to compare (0..23) | seen_snp (24..31)
-    uint32_t rm;    // LEFT: read bases still to the left (16..31)
+    uint32_t rm;    // SEEK: named slots of the bucket this probe has looked at (0..1, l_skip) | LEFT: read bases still to the left (16..31)
     uint32_t ph;    // LEFT: the chain block the extension is in                            (:128)
     uint32_t nc;    // classes collected (0..13) | dictionary probe index (14..17) | TRACE: nodes.len() (18..31)
                     // (a read of L <= 16383 bases visits at most L nodes — every visit consumes a base — so 14 bits hold both counts).
@@ -519,44 +519,59 @@ PA_HD void seek_issue(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekPro
 }
 PA_HD bool slot_holds(const U4& v, uint32_t klo, uint32_t khi) { return v.z != NO_HANDLE && v.x == klo && v.y == khi; }
 PA_HD uint32_t slot_flags(const U4& v) { return (~v.w >> SLOT_FLAG_SHIFT) & 15u; }
-// the other slots of the bucket that hold keys of this home, as a mask over i = 0..2 (slot (home + 1 + i) & 3); 0 when the
-// home slot already answers (a hit there, or nothing named)
-PA_HD uint32_t seek_second(const SeekProbe& q) { return slot_holds(q.v, q.klo, q.khi) ? 0u : slot_flags(q.v) & 7u; }
+// the other slots of the bucket that hold keys of this home, as a mask over i = 0..2 (slot (home + 1 + i) & 3), without the first
+// `skip` of them (the ones an earlier step of this probe has looked at: l_skip); 0 when the home slot already answers (a hit there,
+// or nothing named)
+PA_HD uint32_t seek_second(const SeekProbe& q, uint32_t skip = 0) {
+    uint32_t c = slot_holds(q.v, q.klo, q.khi) ? 0u : slot_flags(q.v) & 7u;
+    c = skip > 0 ? c & (c - 1) : c;
+    c = skip > 1 ? c & (c - 1) : c;
+    return c;
+}
 PA_HD const U4* seek_second_slot(const SeekProbe& q, uint32_t cand) {   // cand != 0: the first named slot
     return reinterpret_cast<const U4*>(q.bucket + SLOT_WORDS * ((q.home + 1 + pa_ctz32(cand)) & 3u));
 }
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe);
-// `cand` = seek_second(q), `v2` = the first named slot (loaded by the caller when cand != 0)
-PA_HD void seek_eval(const SeekProbe& q, uint32_t cand, U4 v2, uint32_t& h, uint32_t& off, bool& full) {
+// named slots of the bucket this probe has already looked at (a probe looks at ONE named slot per step: a home slot that names two or
+// three and whose first is another key's costs the lane another step, not the wave a dependent load at the end of its iteration)
+PA_HD uint32_t l_skip(const Lane& s) { return s.rm & 3u; }
+// `cand` = seek_second(q, skip), `v2` = the first named slot (loaded by the caller when cand != 0). again: neither the home slot nor
+// v2 holds the key and the home slot names further slots — the probe goes on in the next step
+PA_HD void seek_eval(const SeekProbe& q, uint32_t cand, U4 v2, uint32_t& h, uint32_t& off, bool& full, bool& again) {
     h = NO_HANDLE;
     off = 0;
+    again = false;
     if (slot_holds(q.v, q.klo, q.khi)) { h = q.v.z; off = q.v.w & SLOT_OFF_MASK; }
-    while (cand) {                                                  // almost always at most one named slot
-        if (slot_holds(v2, q.klo, q.khi)) { h = v2.z; off = v2.w & SLOT_OFF_MASK; break; }
-        cand &= cand - 1;
-        if (cand) v2 = *seek_second_slot(q, cand);
+    else if (cand) {
+        if (slot_holds(v2, q.klo, q.khi)) { h = v2.z; off = v2.w & SLOT_OFF_MASK; }
+        else again = (cand & (cand - 1)) != 0;
     }
     full = (slot_flags(q.v) & SLOT_FLAG_OVERFLOW) != 0;
 }
 PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand, U4 v2) {
     uint32_t h, off;
-    bool full;
-    seek_eval(q, cand, v2, h, off, full);
+    bool full, again;
+    seek_eval(q, cand, v2, h, off, full, again);
+    if (again) { s.rm += 1; return; }
     seek_finish(s, K, h, off, full, l_probe(s));
 }
 // the same with the speculative second probe (q1 / cand1 / v21: the k-mer at kmer_pos + 3, issued when seek_two(s)): it only
 // counts when the first probe is a definite miss — the scan of :92-111 in its own order
 PA_HD void seek_complete2(Lane& s, uint32_t K, const SeekProbe& q0, uint32_t cand0, U4 v20, bool two, const SeekProbe& q1, uint32_t cand1, U4 v21) {
     uint32_t h, off;
-    bool full;
-    seek_eval(q0, cand0, v20, h, off, full);
+    bool full, again;
+    seek_eval(q0, cand0, v20, h, off, full, again);
+    if (again) { s.rm += 1; return; }
     const uint32_t probe = l_probe(s);
     if (!two || h != NO_HANDLE || (full && probe < DICT_MAX_PROBES)) {
         seek_finish(s, K, h, off, full, probe);
         return;
     }
     l_set_kp(s, l_kp(s) + PA_SEEK_STRIDE);                          // :110 (kmer_pos + 3 <= L - K: seek_two)
-    seek_eval(q1, cand1, v21, h, off, full);
+    seek_eval(q1, cand1, v21, h, off, full, again);
+    s.rm &= ~3u;
+    s.nc &= ~(15u << NC_PROBE_SHIFT);
+    if (again) { s.rm += 1; l_or_flags(s, F_SPEC); return; }        // the probe at the new kmer_pos goes on with its second named slot
     seek_finish(s, K, h, off, full, 0u);
 }
 
@@ -566,6 +581,7 @@ PA_HD void seek_complete2(Lane& s, uint32_t K, const SeekProbe& q0, uint32_t can
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe) {
     const uint32_t L = l_L(s), kp = l_kp(s);
     s.nc &= ~(15u << NC_PROBE_SHIFT);                               // probe index back to 0
+    s.rm &= ~3u;                                                    // ... and the named slots looked at (l_skip)
     if (h != NO_HANDLE) {                                           // Some((nid, offset)) (:106)
         s.h = h;
         const uint32_t fl = l_flags(s), p = (off & ENT_P_MASK) | of_cur((off >> ENT_CUR_SHIFT) & 3u, true);   // position + the slot of the k-mer's node
@@ -621,7 +637,7 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
     const bool two = seek_two(s, K);
     seek_issue(s, ix, rd, q);
     seek_issue(s, ix, rd, q1, PA_SEEK_STRIDE, two);
-    const uint32_t cand = seek_second(q), cand1 = two ? seek_second(q1) : 0u;
+    const uint32_t cand = seek_second(q, l_skip(s)), cand1 = two ? seek_second(q1) : 0u;
     U4 v2{0u, 0u, NO_HANDLE, 0u}, v21{0u, 0u, NO_HANDLE, 0u};
     if (cand) v2 = *seek_second_slot(q, cand);
     if (cand1) v21 = *seek_second_slot(q1, cand1);

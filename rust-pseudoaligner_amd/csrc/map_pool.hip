@@ -580,7 +580,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             PA_MARK("dual_issued");
             // the probe's second load, only for the lanes whose home slot holds another key and names other slots (same line,
             // now in the L1 / L2)
-            const uint32_t cand = active2 ? seek_second(pq) : 0u, cand1 = two ? seek_second(pq1) : 0u;
+            const uint32_t cand = active2 ? seek_second(pq, l_skip(s2)) : 0u, cand1 = two ? seek_second(pq1) : 0u;
             U4 pv2{0u, 0u, NO_HANDLE, 0u}, pv21{0u, 0u, NO_HANDLE, 0u};
             if (cand) pv2 = *seek_second_slot(pq, cand);
             if (cand1) pv21 = *seek_second_slot(pq1, cand1);
