@@ -348,7 +348,9 @@ constexpr uint32_t SLOT_FIXED_BYTES = 32 + 16 + 8;   // lane state, class window
 #ifndef PA_MAP_MIN_BLOCKS
 #define PA_MAP_MIN_BLOCKS 3   // workgroups per CU the register budget is sized for (A/B builds: -DPA_MAP_MIN_BLOCKS=4)
 #endif
-template <bool TRACE, bool GREAD, bool DBG>
+// S128: the pool has 128 slots per wave (reads of up to 5 words: every short-read batch) — the stride of the LDS rows of read words is
+// then a shift instead of a quarter-rate multiply in every step that touches the read.
+template <bool TRACE, bool GREAD, bool DBG, bool S128 = false>
 __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_kernel(const MapParams p_arg) {
     // The ~50 words of parameters are NOT kept in registers across the loop (the allocator would spill most of them to
     // VGPR lanes and pay a v_readlane + hazard nops at every use): each iteration re-reads what its step needs from the
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
     const uint32_t waves_per_block = PA_MAP_BLOCK / 64;
     const uint32_t wave = blockIdx.x * waves_per_block + wave_in_block;
     const uint32_t nwaves = gridDim.x * waves_per_block;
-    const uint32_t S = p.pool_slots, wpr = p.wpr;
+    const uint32_t S = S128 ? 128u : p.pool_slots, wpr = p.wpr;
     const uint32_t lwpr = GREAD ? 0u : wpr;   // words of a read kept in LDS
 
     const uint32_t wave_bytes = (POOL_FIXED + S * (8 * lwpr + SLOT_FIXED_BYTES) + 15) & ~15u;
@@ -999,14 +1001,14 @@ size_t pool_lds_bytes(uint32_t wpr, uint32_t slots) {
     return wave_bytes * (PA_MAP_BLOCK / 64);
 }
 
-template <bool TRACE, bool GREAD, bool DBG>
+template <bool TRACE, bool GREAD, bool DBG, bool S128 = false>
 static int launch_one(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStream_t stream) {
-    const void* fn = reinterpret_cast<const void*>(&pa_map_pool_kernel<TRACE, GREAD, DBG>);
+    const void* fn = reinterpret_cast<const void*>(&pa_map_pool_kernel<TRACE, GREAD, DBG, S128>);
     if (lds_bytes > 48 * 1024) {   // opt in to more than the default dynamic LDS limit
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((pa_map_pool_kernel<TRACE, GREAD, DBG>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
+    hipLaunchKernelGGL((pa_map_pool_kernel<TRACE, GREAD, DBG, S128>), dim3(grid), dim3(PA_MAP_BLOCK), lds_bytes, stream, p);
     return (int)hipGetLastError();
 }
 
@@ -1017,6 +1019,7 @@ int launch_map_pool(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStre
 #ifdef PA_DEBUG_KNOBS   // the statistics / ablation instantiation exists in A/B builds only
     if (p.dbg || p.ablate) return launch_one<false, false, true>(p, grid, lds_bytes, stream);
 #endif
+    if (p.pool_slots == 128) return launch_one<false, false, false, true>(p, grid, lds_bytes, stream);
     return launch_one<false, false, false>(p, grid, lds_bytes, stream);
 }
 
