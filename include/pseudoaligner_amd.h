@@ -337,7 +337,8 @@ int pa_record_stream_stage_seconds(const pa_record_stream* s, double out[PA_INGE
  * wrapped lines: same acceptance rules and errors as above) and, for the first `capacity` of them, where the record starts,
  * how many bytes its header line has before the line feed ('@' included, and the CR of a CRLF file) and how many bases its
  * sequence has. The sequence begins at start + header_len + 1. Offsets refer to the text as scanned: *text_kind = 0 the file itself, 1 the inflated gzip stream, 2 the text
- * rewritten into four-line records. Every output pointer but n_records may be NULL. */
+ * rewritten into four-line records (a file that is in four-line shape at first and wrapped further on is rewritten from the first scan
+ * window that is not in shape: offsets of the records from there on refer to the rewritten rest). Every output pointer but n_records may be NULL. */
 int pa_fastq_scan_host(const char* fastq_path, int num_threads, uint64_t* n_records, uint64_t* starts, uint32_t* header_len,
                        uint32_t* seq_len, uint64_t capacity, int* text_kind);
 

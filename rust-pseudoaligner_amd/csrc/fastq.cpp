@@ -184,8 +184,11 @@ struct FastqText {   // the text of a FASTQ file as the scan sees it: the mapped
     bool mapped = false;
     std::vector<char> inflated;     // a gzip'ed FASTQ (utils::open_with_gz, src/utils.rs:45-57) is inflated into memory first
     std::vector<char> normalized;   // the text rewritten into four-line records, if it did not have that shape
+    uint64_t off = 0;               // text before this offset has been handed out as records (windowed scan of pa_process_reads)
+    const char* map_base = nullptr; // the mapping as mmap returned it (data moves on when the rest of a file is rewritten)
+    uint64_t map_size = 0;
     void release() {
-        if (mapped) munmap((void*)data, fsize);
+        if (mapped) munmap((void*)map_base, map_size);
         mapped = false;
         data = nullptr;
         fsize = 0;
@@ -232,23 +235,36 @@ int open_fastq(const char* fastq_path, FastqText& t) {
         (void)madvise(m, fsize, MADV_SEQUENTIAL);
         data = (const char*)m;
         mapped = true;
+        t.map_base = data;
+        t.map_size = fsize;
     }
     close(fd);
     return PA_OK;
 }
 
-// Records of the text: line breaks per byte range, then what every line is (scan of pa_process_reads; pa_fastq_scan_host runs
-// it alone). rec_pos[i] = where record i lies; a text that is not in four-line shape is rewritten once and scanned again.
-int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<RecPos>& rec_pos, uint64_t& nrec, std::vector<std::vector<uint32_t>>& brk) {
-    const char*& data = t.data;
-    uint64_t& fsize = t.fsize;
+constexpr int SCAN_NOT_FOUR_LINE = 1, SCAN_WINDOW_TOO_SMALL = 2;   // (what a window's scan may answer besides a pa_status)
+
+// Records of the text t.data[t.off, t.off + avail): line breaks per byte range, then what every line is (scan of pa_process_reads;
+// pa_fastq_scan_host runs it alone, over the whole text). rec_pos[i] = where record i lies, counted from t.data + t.off.
+//   last   the text ends with these bytes: trailing blank lines are tolerated, a last record may lack its quality line, and a text that
+//          is not in four-line shape is rewritten once (t.data / t.fsize / t.off then describe the rewritten text) and scanned again
+//   !last  a WINDOW of a longer text: only whole records are taken, *consumed = the bytes they are (the next window starts behind them).
+//          SCAN_NOT_FOUR_LINE: a record of the window lacks its '@' or '+' — the caller scans the rest of the file as one text;
+//          SCAN_WINDOW_TOO_SMALL: the window holds no whole record
+// rec_base: records before this text (error messages count records from the file's first).
+int scan_fastq(const char* fastq_path, FastqText& t, uint64_t avail, bool last, uint64_t rec_base, Pool& pool, std::vector<RecPos>& rec_pos, uint64_t& nrec,
+               std::vector<std::vector<uint32_t>>& brk, uint64_t* consumed) {
     bool& mapped = t.mapped;
     std::vector<char>& inflated = t.inflated;
     std::vector<char>& normalized = t.normalized;
     const int T = pool.size();
     int rc = PA_OK;
+    nrec = 0;
+    if (consumed) *consumed = 0;
     // ---- scan: line breaks per byte range, then the start of every fourth line ----
     for (int attempt = 0; attempt < 2; ++attempt) {
+        const char* const data = t.data + t.off;
+        const uint64_t fsize = attempt == 0 ? avail : t.fsize - t.off;
         std::atomic<uint64_t> odd_record{~0ull};   // first record whose first line lacks the '@' or whose third the '+'
         rc = PA_OK;
         // ONE pass over the text: every range notes where its line breaks are (32-bit offsets from the range's start: ranges are
@@ -265,8 +281,8 @@ int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<Rec
             // a fresh mapping of a file in the page cache costs a minor fault per 4 KiB page on first touch (0.6 M of them for 8 M reads):
             // let the kernel fill this range's page table entries in one call instead (Linux >= 5.14; elsewhere the faults simply happen)
             if (mapped && attempt == 0) {
-                const uint64_t pa_ = a & ~4095ull;
-                (void)madvise((void*)(data + pa_), (size_t)(b - pa_), MADV_POPULATE_READ);
+                const uint64_t pa_ = (uint64_t)(data + a - t.map_base) & ~4095ull;   // (page-aligned in the mapping)
+                (void)madvise((void*)(t.map_base + pa_), (size_t)((uint64_t)(data + b - t.map_base) - pa_), MADV_POPULATE_READ);
             }
 #endif
             std::vector<uint32_t>& v = brk[(size_t)r];
@@ -276,10 +292,21 @@ int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<Rec
             nl[(size_t)r + 1] = v.size();
         });
         for (int r = 0; r < R; ++r) nl[(size_t)r + 1] += nl[(size_t)r];
+        uint64_t content_lines = 0;
+        if (!last) {   // a window: the whole records among its lines; the next window starts behind their last line break
+            nrec = nl[(size_t)R] / 4;
+            if (nrec == 0) return SCAN_WINDOW_TOO_SMALL;
+            content_lines = 4 * nrec;
+            int r = 0;
+            while (nl[(size_t)r + 1] < content_lines) ++r;
+            uint64_t a, b;
+            range(r, a, b);
+            *consumed = a + brk[(size_t)r][(size_t)(content_lines - 1 - nl[(size_t)r])] + 1;
+        } else {
         // trailing empty lines are tolerated: lines = line breaks before the last content byte + 1
         uint64_t tail = fsize, trailing_nl = 0;
         while (tail > 0 && (data[tail - 1] == '\n' || data[tail - 1] == '\r')) { trailing_nl += data[tail - 1] == '\n'; --tail; }
-        uint64_t content_lines = tail ? nl[(size_t)R] - trailing_nl + 1 : 0;
+        content_lines = tail ? nl[(size_t)R] - trailing_nl + 1 : 0;
         if (content_lines % 4 == 3) {
             // a last record with an EMPTY sequence: its empty quality line looks like a trailing blank line (or is missing
             // altogether when the file ends after the '+'; bio's reader reads nothing there and hands the record out). Taken as
@@ -293,8 +320,10 @@ int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<Rec
             }
         }
         if (content_lines % 4 != 0)
-            rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu (file ends inside a record)", fastq_path, (unsigned long long)(content_lines / 4));
+            rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu (file ends inside a record)", fastq_path, (unsigned long long)(rec_base + content_lines / 4));
         nrec = content_lines / 4;
+        if (consumed) *consumed = fsize;
+        }
         if (rc == PA_OK && nrec) {
             rec_pos.resize(nrec);   // (every field is written below: each line starts in exactly one range)
             RecPos* const rp = rec_pos.data();
@@ -354,25 +383,67 @@ int scan_fastq(const char* fastq_path, FastqText& t, Pool& pool, std::vector<Rec
             });
         }
         if (rc == PA_OK && odd_record.load() == ~0ull) break;   // four lines to a record, markers in place
+        if (!last) return SCAN_NOT_FOUR_LINE;
         if (attempt == 1) {
-            if (rc == PA_OK) rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu", fastq_path, (unsigned long long)odd_record.load());
+            if (rc == PA_OK) rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu", fastq_path, (unsigned long long)(rec_base + odd_record.load()));
             break;
         }
         // not that shape: wrapped sequence / quality lines? rewrite and scan again
         uint64_t bad = 0;
-        if (!normalize_fastq(data, fsize, normalized, bad)) {
-            rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu (no '@' header, or the file ends inside the record)", fastq_path, (unsigned long long)bad);
+        std::vector<char> rewritten;
+        if (!normalize_fastq(data, fsize, rewritten, bad)) {
+            rc = fail(PA_ERR_FORMAT, "%s: malformed FASTQ record %llu (no '@' header, or the file ends inside the record)", fastq_path, (unsigned long long)(rec_base + bad));
             break;
         }
-        if (mapped) { munmap((void*)data, fsize); mapped = false; }
+        t.release();   // (the mapping, if the text was one)
         inflated = std::vector<char>();
-        data = normalized.data();
-        fsize = normalized.size();
+        normalized.swap(rewritten);
+        t.data = normalized.data();
+        t.fsize = normalized.size();
+        t.off = 0;
         nrec = 0;
     }
 
     return rc;
 }
+
+// The text in WINDOWS: a mapped file is scanned a window at a time (PA_INGEST_WINDOW bytes), so that pa_process_reads has its first batch on
+// the GPU while the rest of the file is still being scanned; a window ends behind its last whole record. A text held in memory (gzip), a
+// window that is not in four-line shape (then: the rest of the file as one text, rewritten) and the last window are scanned as one text.
+struct WindowScan {
+    FastqText& text;
+    uint64_t window = 256ull << 20;
+    bool windowed, done = false;
+    uint64_t nrec = 0;            // records of the current window
+    const char* base = nullptr;   // the window's text: rec_pos counts from here
+    uint64_t size = 0;            // its bytes
+    uint64_t abs = ~0ull;         // its offset in the file's mapping (~0: not part of one)
+    explicit WindowScan(FastqText& t) : text(t), windowed(t.mapped) {
+        if (const char* v = getenv("PA_INGEST_WINDOW")) { const long long x = atoll(v); if (x >= 1) window = (uint64_t)x; }
+    }
+    // the next window with records in it (nrec = 0: the text has ended). records_before: records of the windows before (error messages)
+    int next(const char* fastq_path, uint64_t records_before, Pool& pool, std::vector<RecPos>& rec_pos, std::vector<std::vector<uint32_t>>& brk) {
+        nrec = 0;
+        while (!done) {
+            const uint64_t rest = text.fsize - text.off;
+            if (rest == 0) { done = true; break; }
+            const uint64_t avail = windowed ? std::min<uint64_t>(window, rest) : rest;
+            const bool last = avail == rest;
+            uint64_t consumed = 0;
+            const int r = scan_fastq(fastq_path, text, avail, last, records_before, pool, rec_pos, nrec, brk, &consumed);
+            if (r == SCAN_WINDOW_TOO_SMALL) { window *= 2; continue; }   // (a record longer than the window)
+            if (r == SCAN_NOT_FOUR_LINE) { windowed = false; continue; }
+            if (r != PA_OK) return r;
+            base = text.data + text.off;
+            size = consumed;
+            abs = text.mapped ? (uint64_t)(base - text.map_base) : ~0ull;
+            text.off += consumed;
+            if (last) done = true;
+            if (nrec) break;
+        }
+        return PA_OK;
+    }
+};
 
 }  // namespace
 
@@ -390,16 +461,24 @@ extern "C" int pa_fastq_scan_host(const char* fastq_path, int num_threads, uint6
     Pool pool(num_threads < 1 ? 1 : num_threads);
     std::vector<RecPos> rec_pos;
     std::vector<std::vector<uint32_t>> brk;
+    // window by window, as pa_process_reads walks the text. Offsets refer to the text the LAST window was part of: when a window turns out
+    // not to be in four-line shape the rest of the file is rewritten, and records from there on lie in the rewritten text (*text_kind 2)
     uint64_t nrec = 0;
-    rc = scan_fastq(fastq_path, text, pool, rec_pos, nrec, brk);
+    WindowScan ws(text);
+    while (rc == PA_OK) {
+        rc = ws.next(fastq_path, nrec, pool, rec_pos, brk);
+        if (rc != PA_OK || ws.nrec == 0) break;
+        const uint64_t at = (uint64_t)(ws.base - text.data);   // of the window in the text it belongs to
+        for (uint64_t i = 0; i < ws.nrec && nrec + i < capacity; ++i) {
+            if (starts) starts[nrec + i] = at + rec_pos[i].start;
+            if (header_len) header_len[nrec + i] = rec_pos[i].hdr;
+            if (seq_len) seq_len[nrec + i] = rec_pos[i].seq_len;   // a CR before the line break is not sequence
+        }
+        nrec += ws.nrec;
+    }
     if (rc == PA_OK) {
         *n_records = nrec;
         if (text_kind) *text_kind = !text.normalized.empty() ? 2 : was_gz ? 1 : 0;
-        for (uint64_t i = 0; i < nrec && i < capacity; ++i) {
-            if (starts) starts[i] = rec_pos[i].start;
-            if (header_len) header_len[i] = rec_pos[i].hdr;
-            if (seq_len) seq_len[i] = rec_pos[i].seq_len;   // a CR before the line break is not sequence
-        }
     }
     text.release();
     return rc;
@@ -423,11 +502,8 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         const int orc = open_fastq(fastq_path, text);
         if (orc != PA_OK) return orc;
     }
-    const char*& data = text.data;
-    uint64_t& fsize = text.fsize;
-    bool& mapped = text.mapped;
     FILE* out = strcmp(out_path, "-") == 0 ? stdout : fopen(out_path, "wb");
-    if (!out) { if (mapped) munmap((void*)data, fsize); return fail(PA_ERR_IO, "cannot create %s: %s", out_path, strerror(errno)); }
+    if (!out) { text.release(); return fail(PA_ERR_IO, "cannot create %s: %s", out_path, strerror(errno)); }
     // a private 4 MiB stdio buffer only for a file this function opened (and closes before the buffer dies); the process-wide
     // stdout keeps its own buffering: handing it a function-local buffer would leave it dangling after the return
     std::vector<char> obuf(out != stdout ? (size_t)1 << 22 : 0);
@@ -447,9 +523,9 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     if (!cache) cache = new IngestCache();
     std::vector<RecPos>& rec_pos = cache->rec_pos;
 
-    // ---- scan ----
-    rc = scan_fastq(fastq_path, text, pool, rec_pos, nrec, cache->brk);
-    t_scan = now() - t_begin;
+    // ---- the text in windows (WindowScan): the scan of a window runs inside the pack stage of its first batch ----
+    WindowScan ws(text);
+    uint64_t wnext = 0;   // the next record of the window to be packed
     // ---- batches ----
     BatchCtx* const ctx = cache->ctx;
     cache->idx = idx;
@@ -457,14 +533,28 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     const hipStream_t stream = cache->stream;
     Writer writer(out);
     uint64_t flagged = 0, next_report = 1000000, reported = 0;
-    const uint64_t nb = (nrec + BATCH_READS - 1) / BATCH_READS;
 
-    auto ensure = [&](BatchCtx& c, uint64_t n, uint32_t wpr) -> int { return batch_ensure(idx, c, n, wpr, std::min<uint64_t>(BATCH_READS, nrec)); };
+    auto ensure = [&](BatchCtx& c, uint64_t n, uint32_t wpr) -> int { return batch_ensure(idx, c, n, wpr, std::min<uint64_t>(BATCH_READS, ws.nrec)); };
 
-    // parse + pack batch b (parallel over whole tiles)
-    auto pack = [&](BatchCtx& c, uint64_t b) -> int {
-        c.first = b * BATCH_READS;
-        c.n = std::min<uint64_t>(BATCH_READS, nrec - c.first);
+    // the next batch of the text into c: its records (of the current window, or the next one: scanned now), parsed + packed (parallel over
+    // whole tiles). c.n = 0 at the end of the text
+    auto pack = [&](BatchCtx& c) -> int {
+        c.n = 0;
+        if (wnext == ws.nrec) {
+            const double ts = now();
+            const int wr = ws.next(fastq_path, nrec, pool, rec_pos, cache->brk);
+            t_scan += now() - ts;
+            wnext = 0;
+            if (wr != PA_OK) return wr;
+            if (ws.nrec == 0) return PA_OK;
+        }
+        const char* const data = ws.base;
+        const uint64_t fsize = ws.size;
+        c.first = wnext;
+        c.n = std::min<uint64_t>(BATCH_READS, ws.nrec - wnext);
+        wnext += c.n;
+        nrec += c.n;
+        c.text_abs = ws.abs == ~0ull ? ~0ull : ws.abs + rec_pos[c.first].start;
         double t0 = now();
         c.recs.resize(c.n);
         std::vector<uint32_t> tmax((size_t)T * 4, 0);
@@ -506,7 +596,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     std::thread unmapper;
     auto unmap_async = [&](uint64_t from, uint64_t to) {
         if (unmapper.joinable()) unmapper.join();
-        const char* base = data;
+        const char* base = text.map_base;
         unmapper = std::thread([base, from, to] { (void)munmap((void*)(base + from), to - from); });
     };
     int format_rc = PA_OK;
@@ -517,7 +607,7 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         double tw = now();
         if ((format_rc = batch_text_wait(c)) != PA_OK) return;
         t_text_wait += now() - tw;
-        const uint64_t keep_from = mapped ? (rec_pos[c.first].start & ~4095ull) : 0;   // nothing before this batch is read again
+        const uint64_t keep_from = (text.mapped && c.text_abs != ~0ull) ? (c.text_abs & ~4095ull) : 0;   // nothing before this batch is read again
         if (keep_from > unmapped_to) { unmap_async(unmapped_to, keep_from); unmapped_to = keep_from; }
         flagged += c.flagged;
         reported += c.n;
@@ -529,21 +619,31 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
         text_job[k] = writer.push(c.h_text, c.text_bytes);
     };
 
-    // pack(b) overlaps GPU(b-1); format(b-1) overlaps GPU(b)
-    for (uint64_t b = 0; rc == PA_OK && b <= nb && nb > 0; ++b) {
+    // pack(b) — and the scan of its window — overlaps GPU(b-1); format(b-1) overlaps GPU(b)
+    bool have_prev = false;
+    for (uint64_t b = 0; rc == PA_OK; ++b) {
+        BatchCtx& cur = ctx[b & 1];
+        BatchCtx& prev = ctx[(b + 1) & 1];
+        const int kp = (int)((b + 1) & 1);
         double t0 = now();
-        if (b < nb) rc = pack(ctx[b & 1], b);
-        t_pack += now() - t0; t0 = now();
-        if (rc == PA_OK && b >= 1) {
-            const int k = (int)((b - 1) & 1);
-            if (text_job[k]) { const double tw = now(); writer.wait(text_job[k]); t_push += now() - tw; text_job[k] = 0; }   // the text of batch b - 3 has left this context's pinned buffer
-            rc = finish(ctx[k]);
-        }
+        const double scan_before = t_scan;
+        rc = pack(cur);
+        t_pack += now() - t0 - (t_scan - scan_before); t0 = now();
+        const bool have = rc == PA_OK && cur.n != 0;
+        if (rc == PA_OK && have_prev) rc = finish(prev);
         t_finish += now() - t0; t0 = now();
-        if (rc == PA_OK && b < nb) rc = launch(ctx[b & 1]);
+        if (rc == PA_OK && have) {
+            // the launch ends with the speculative copy of this batch's tuples into the context's pinned text buffer (batch_render_enqueue):
+            // the writer must be done with what the buffer held before — the text of batch b - 2
+            const int kc = (int)(b & 1);
+            if (text_job[kc]) { const double tw = now(); writer.wait(text_job[kc]); t_push += now() - tw; text_job[kc] = 0; }
+            rc = launch(cur);
+        }
         t_launch += now() - t0; t0 = now();
-        if (rc == PA_OK && b >= 1) { format(ctx[(b - 1) & 1], (int)((b - 1) & 1)); rc = format_rc; }
+        if (rc == PA_OK && have_prev) { format(prev, kp); rc = format_rc; }
         t_format += now() - t0;
+        have_prev = have;
+        if (!have) break;
     }
     {
         double* st = pa::ingest::last_stage_seconds();
@@ -562,9 +662,10 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     if (rc == PA_OK) index_put_ingest_cache(idx, cache, IngestCache::destroy);   // the next call starts with warm buffers
     else IngestCache::destroy(cache);
     if (unmapper.joinable()) unmapper.join();
-    if (mapped && fsize > unmapped_to) {   // the rest of the mapping (the last batch's text): nobody reads it any more; given back without making the caller wait
-        const char* base = data;
-        const uint64_t from = unmapped_to, to = fsize;
+    if (text.mapped && text.map_size > unmapped_to) {   // the rest of the mapping (the last batch's text): nobody reads it any more; given back without making the caller wait
+        const char* base = text.map_base;
+        const uint64_t from = unmapped_to, to = text.map_size;
+        text.mapped = false;
         std::thread([base, from, to] { (void)munmap((void*)(base + from), to - from); }).detach();
     }
     const double t_unmap = now() - t0; t0 = now();

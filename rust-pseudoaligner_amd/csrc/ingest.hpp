@@ -236,6 +236,7 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
     std::vector<uint32_t> h_arena;
     std::vector<Record> recs;
     uint64_t first = 0, n = 0;
+    uint64_t text_abs = ~0ull;   // pa_process_reads: where the batch's first record lies in the file's mapping (~0: not in one)
     uint32_t wpr = 1;
     void release() {
         if (h_tiles) (void)hipHostFree(h_tiles);

@@ -55,6 +55,32 @@ def test_scan_matches_python_reading(tmp_path, threads):
         assert np.all(np.diff(starts.astype(np.int64)) > 0)
 
 
+@pytest.mark.parametrize("window", [1, 300, 5000])
+def test_scan_in_windows(tmp_path, monkeypatch, window):
+    """the scan walks a mapped file a window at a time (PA_INGEST_WINDOW; pa_process_reads packs a window's records while the next is
+    still unread): the records found are those of the one-window scan, whatever the window cuts through"""
+    rng = np.random.default_rng(3)
+    ids, seqs = _records(2000, rng, empty_every=53)
+    for name, text in (("lf", _text(ids, seqs)), ("crlf", _text(ids, seqs, nl="\r\n")), ("no_final_newline", _text(ids, seqs)[:-1]),
+                       ("trailing_blank", _text(ids, seqs) + "\n\n\n"), ("empty_last", _text(ids, seqs) + "@last\n\n+\n\n\n")):
+        p = tmp_path / (name + ".fq")
+        p.write_text(text, newline="")
+        monkeypatch.delenv("PA_INGEST_WINDOW", raising=False)
+        s0, h0, q0, k0 = pa.fastq_scan(str(p), 3)
+        monkeypatch.setenv("PA_INGEST_WINDOW", str(window))
+        s1, h1, q1, k1 = pa.fastq_scan(str(p), 3)
+        assert k0 == k1 == 0 and np.array_equal(s0, s1) and np.array_equal(h0, h1) and np.array_equal(q0, q1), (name, window)
+        assert len(s0) == len(ids) + (name == "empty_last")
+    # four-line records first, wrapped ones behind them: the rest of the file is rewritten from the first window that is not in shape
+    half = 1000
+    mixed = _text(ids[:half], seqs[:half]) + _text(ids[half:], seqs[half:], wrap=30)
+    p = tmp_path / "mixed.fq"
+    p.write_text(mixed, newline="")
+    starts, hdr, seq, kind = pa.fastq_scan(str(p), 3)
+    assert kind == 2 and len(starts) == len(ids)
+    assert np.array_equal(seq, np.array([len(s) for s in seqs], np.uint32))
+
+
 def test_scan_last_record_with_empty_sequence(tmp_path):
     rng = np.random.default_rng(5)
     ids, seqs = _records(50, rng)

@@ -494,6 +494,46 @@ def test_process_reads_pipeline_seams(aligners, tmp_path, monkeypatch):
         pa.process_reads(str(trunc), a, str(out), 2)
 
 
+@pytest.mark.parametrize("window", [1, 300, 5000, 100000])
+def test_process_reads_scan_windows(aligners, tmp_path, monkeypatch, window):
+    """pa_process_reads scans a mapped file a window at a time (PA_INGEST_WINDOW bytes; a window ends behind its last whole record, the
+    next one starts there): whatever the window — one record per window, a few, windows that end inside every kind of line — the
+    output is the output of the one-window scan, for four-line text, CRLF, wrapped records (a window that is not in four-line shape
+    hands the rest of the file to the rewriting scan), a missing final line break, trailing blank lines and an empty last record"""
+    a = aligners(24)
+    ids, seqs = helpers.read_fastq()
+    ids, seqs = list(ids[:1500]), list(seqs[:1500])
+    for i in range(0, 1500, 5):
+        seqs[i] = seqs[i][: 1 + (7 * i) % len(seqs[i])]
+    want = _expected_lines(a, ids, [s.upper().replace("N", "A") for s in seqs])
+    wrap = lambda t, w: "\n".join(t[j:j + w] for j in range(0, len(t), w)) if t else ""
+    plain = "".join("@%s extra words\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in zip(ids, seqs))
+    half = len(ids) // 2
+    variants = {
+        "plain": (plain, want),
+        "crlf": (plain.replace("\n", "\r\n"), want),
+        "no_final_newline": (plain[:-1], want),
+        "trailing_blank_lines": (plain + "\n\n\n", want),
+        "empty_last": (plain + "@last\n\n+\n\n\n", want + ['(false, "last", [], 0)']),
+        # four-line records first, wrapped ones behind them: the windows before the first wrapped record are taken as they are
+        "wrapped_second_half": ("".join("@%s x\n%s\n+\n%s\n" % (i, s if k < half else wrap(s, 25), "I" * len(s) if k < half else wrap("I" * len(s), 25))
+                                        for k, (i, s) in enumerate(zip(ids, seqs))), want),
+    }
+    out = tmp_path / "o.txt"
+    monkeypatch.setenv("PA_INGEST_WINDOW", str(window))
+    for name, (text, lines) in variants.items():
+        fq = tmp_path / (name + ".fq")
+        fq.write_text(text, newline="")
+        for batch, threads in ((64, 1), (1 << 22, 5)):
+            monkeypatch.setenv("PA_INGEST_BATCH", str(batch))
+            n, _ = pa.process_reads(str(fq), a, str(out), threads)
+            assert n == len(lines) and out.read_text().splitlines() == lines, (name, window, batch, threads)
+    bad = tmp_path / "bad.fq"
+    bad.write_text(plain + "not a record\n")
+    with pytest.raises(pa.PaError):
+        pa.process_reads(str(bad), a, str(out), 2)
+
+
 def test_process_reads_concurrent_calls_one_index(aligners, tmp_path, monkeypatch):
     """pa_process_reads parks its batch buffers on the index between calls (include/pseudoaligner_amd.h): calls that overlap
     on one index each get their own set, and a later call that needs bigger batches grows the parked one"""
