@@ -537,7 +537,9 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
         out.node_kcum[0] = 0;
         for (uint32_t i = 0; i < N; ++i) out.node_kcum[i + 1] = out.node_kcum[i] + (f.node_len[i] - k + 1);
     }
-    for (double load = Dict<KT>::LOAD; !device_dict; load *= 0.75) {
+    double load0 = Dict<KT>::LOAD;
+    if (const char* v = knob_str("PA_DICT_LOAD")) { const double x = atof(v); if (x > 0.01 && x <= 0.95) load0 = x; }   // (knobs builds and the test emulator: dense tables exercise the probe's rare paths)
+    for (double load = load0; !device_dict; load *= 0.75) {
         out.nbuckets = std::max<uint64_t>(1, (uint64_t)((double)nk / (Dict<KT>::SLOTS * load)) + 1);
         if (out.nbuckets >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "dictionary exceeds 2^32 buckets");
         out.table.assign(out.nbuckets * BUCKET_WORDS, 0xFFFFFFFFu);   // empty slots, no flags

@@ -13,7 +13,9 @@ def build_emu(force: bool = False) -> Path:
     deps = srcs + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
     if force or not EMU_SO.exists() or any(s.stat().st_mtime > EMU_SO.stat().st_mtime for s in deps):
         EMU_SO.parent.mkdir(parents=True, exist_ok=True)
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-function"] + [str(s) for s in srcs] + ["-o", str(EMU_SO)]
+        # (-DPA_DEBUG_KNOBS: the emulator's flattener honours PA_DICT_LOAD, so that the tests can build DENSE dictionaries — keys in other
+        # slots of their bucket, in the next buckets — which the shipped library's sparse table hardly ever produces)
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-function", "-DPA_DEBUG_KNOBS"] + [str(s) for s in srcs] + ["-o", str(EMU_SO)]
         proc = subprocess.run(cmd, capture_output=True, text=True)
         if proc.returncode != 0:
             raise RuntimeError("emulator build failed:\n" + proc.stderr)

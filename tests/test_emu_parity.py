@@ -131,6 +131,21 @@ def test_golden_synthetic_error_reads(small_index, k):
     assert [g.rstrip("\n") for g in got] == lines
 
 
+@pytest.mark.parametrize("seed", [8, 10, 11, 12, 14, 27, 31])   # k = 21, 8, 32, 32, 16, 11, 21
+def test_dense_dictionary_probe_paths(seed, tmp_path, monkeypatch):
+    """the probe's rare paths — a key in another slot of its bucket than the first one named, in the next bucket, several buckets on —
+    hardly occur in the table the library ships (load 0.25); a dictionary built at load 0.9 (the emulator's flattener honours
+    PA_DICT_LOAD) makes them common: same results"""
+    monkeypatch.setenv("PA_DICT_LOAD", "0.9")
+    host, k, reads, clean, allowed = helpers.random_txome_case(seed, tmp_path)
+    if host is None or k > 32:
+        pytest.skip("no k <= 32 dictionary in this case")
+    info = helpers.Emu(host).info()
+    assert info["nbuckets"] * 4 < 2 * info["num_kmers"]            # denser than load 0.5
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    check(host, tiles, lens, wpr, allowed)
+
+
 def test_device_dictionary_layout(small_index):
     info = helpers.Emu(small_index(24)).info()
     assert info["num_kmers"] == 1165762
