@@ -38,7 +38,7 @@ struct Lane {
     uint32_t of;    // position in that block's window (0..9): of the k-mer's first base (F_FRESH), else of the next base to compare |
                     // slot of the block that holds the record of the node the lane stands in (10..11), valid when bit 12 is set (else 0) | flags (24..31)
     uint32_t rr;    // LEFT: position + 1 in the block's window of the next base to compare (0..23) | seen_snp (24..31)
-    uint32_t rm;    // SEEK: named slots of the bucket this probe has looked at (0..1, l_skip) | LEFT: read bases still to the left (16..31)
+    uint32_t rm;    // SEEK: what a probe that goes on remembers (0..3, l_pending) | LEFT: read bases still to the left (16..31)
     uint32_t ph;    // LEFT: the chain block the extension is in                            (:128)
     uint32_t nc;    // classes collected (0..13) | dictionary probe index (14..17) | TRACE: nodes.len() (18..31)
                     // (a read of L <= 16383 bases visits at most L nodes — every visit consumes a base — so 14 bits hold both counts).
@@ -476,15 +476,18 @@ PA_HD void mask_pending(Lane& s, const DevIndexView& ix, ColRef c) {
 // ---------------------------------------------------------------------------------------------- SEEK
 // One dictionary probe of find_kmer_match (:91-114), K <= 32 (layout: device_layout.hpp), in the pieces the kernel interleaves
 // with other work:
-//   seek_issue     k-mer -> bucket and home slot, the 16-byte load of the home slot goes out
-//   seek_second    home slot holds another key and names other slots of the bucket: which one to load next (rare)
-//   seek_complete  the answer, further named slots (rarer), the lane's next state
+//   seek_issue     k-mer -> bucket and slot; ONE 16-byte load goes out: the key's home slot, or — when an earlier step of this probe found
+//                  another key there — the first of the slots the home slot named
+//   seek_complete  the answer, or the slots still to look at (the lane then stays in SEEK: one slot per step, so that nothing of a
+//                  probe depends on a second load and its state is gone before the forward half of the iteration computes)
 struct SeekProbe {
-    const uint32_t* bucket;  // the bucket line
-    uint32_t home;           // home slot of the key in it
-    U4 v;                    // the home slot
+    U4 v;                    // the slot loaded
     uint32_t klo, khi;       // the k-mer
+    uint32_t pending;        // l_pending of the lane at issue (0: v is the home slot)
 };
+// what a probe that goes on remembers (Lane::rm bits 0..3): the named slots still to look at as a mask over i = 0..2 (slot (home + 1 + i) & 3)
+// and the home slot's overflow flag
+constexpr uint32_t SK_NAMED = 7u, SK_FULL = 8u, SK_MASK = 15u;
 // bucket and home slot of a k-mer (one hash)
 PA_HD uint32_t pa_bucket_home(uint64_t kmer, uint32_t nbuckets, uint32_t& home) {
     // three 32-bit multiplies (fmix64 is two 64-bit ones = eight quarter-rate instructions per probe): the dictionary's placement
@@ -503,75 +506,64 @@ PA_HD uint32_t pa_bucket_home(uint64_t kmer, uint32_t nbuckets, uint32_t& home) 
 }
 // does this step also probe kmer_pos + 3? (a lane past a miss, not in the middle of an overflow chain, with a k-mer left there)
 PA_HD bool seek_two(const Lane& s, uint32_t K) { return (l_flags(s) & F_SPEC) && l_probe(s) == 0 && l_kp(s) + PA_SEEK_STRIDE <= l_L(s) - K; }
-// the probe of the k-mer at kmer_pos + ahead (ahead = 0: at the lane's probe index; ahead = 3: the speculative second probe).
-// `live` = false (second probe of a lane that does not speculate): the load still goes out — a branch around it would put a full
-// wait behind the loads already in flight — but to the first line of the table, which all such lanes share; the probe is ignored
+PA_HD uint32_t l_pending(const Lane& s) { return s.rm & SK_MASK; }
+// the probe of the k-mer at kmer_pos + ahead (ahead = 0: at the lane's probe index; ahead = 3: the speculative second probe, always a
+// home slot). `live` = false (second probe of a lane that does not speculate): the load still goes out — a branch around it would put a
+// full wait behind the loads already in flight — but to the first line of the table, which all such lanes share; the probe is ignored
 PA_HD void seek_issue(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekProbe& q, uint32_t ahead = 0, bool live = true) {
     const uint32_t at = live ? l_kp(s) + ahead : l_kp(s);
     const uint64_t kmer = read_window_in(rd, at) & ix.kmask;   // read_seq.get_kmer(kmer_pos) (:93); kmer_pos <= L - K
-    uint32_t b = pa_bucket_home(kmer, (uint32_t)ix.nbuckets, q.home) + (ahead ? 0u : l_probe(s));
+    uint32_t home;
+    uint32_t b = pa_bucket_home(kmer, (uint32_t)ix.nbuckets, home) + (ahead ? 0u : l_probe(s));
     if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
-    if (!live) { b = 0; q.home = 0; }
-    q.bucket = ix.table + (uint64_t)b * BUCKET_WORDS;
-    q.v = PA_LD(4, reinterpret_cast<const U4*>(q.bucket + SLOT_WORDS * q.home));
+    q.pending = ahead ? 0u : l_pending(s);
+    const uint32_t named = q.pending & SK_NAMED;
+    uint32_t slot = named ? (home + 1u + pa_ctz32(named)) & 3u : home;
+    if (!live) { b = 0; slot = 0; }
+    q.v = PA_LD(4, reinterpret_cast<const U4*>(ix.table + (uint64_t)b * BUCKET_WORDS + SLOT_WORDS * slot));
     q.klo = (uint32_t)kmer;
     q.khi = (uint32_t)(kmer >> 32);
 }
 PA_HD bool slot_holds(const U4& v, uint32_t klo, uint32_t khi) { return v.z != NO_HANDLE && v.x == klo && v.y == khi; }
 PA_HD uint32_t slot_flags(const U4& v) { return (~v.w >> SLOT_FLAG_SHIFT) & 15u; }
-// the other slots of the bucket that hold keys of this home, as a mask over i = 0..2 (slot (home + 1 + i) & 3), without the first
-// `skip` of them (the ones an earlier step of this probe has looked at: l_skip); 0 when the home slot already answers (a hit there,
-// or nothing named)
-PA_HD uint32_t seek_second(const SeekProbe& q, uint32_t skip = 0) {
-    uint32_t c = slot_holds(q.v, q.klo, q.khi) ? 0u : slot_flags(q.v) & 7u;
-    c = skip > 0 ? c & (c - 1) : c;
-    c = skip > 1 ? c & (c - 1) : c;
-    return c;
-}
-PA_HD const U4* seek_second_slot(const SeekProbe& q, uint32_t cand) {   // cand != 0: the first named slot
-    return reinterpret_cast<const U4*>(q.bucket + SLOT_WORDS * ((q.home + 1 + pa_ctz32(cand)) & 3u));
-}
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe);
-// named slots of the bucket this probe has already looked at (a probe looks at ONE named slot per step: a home slot that names two or
-// three and whose first is another key's costs the lane another step, not the wave a dependent load at the end of its iteration)
-PA_HD uint32_t l_skip(const Lane& s) { return s.rm & 3u; }
-// `cand` = seek_second(q, skip), `v2` = the first named slot (loaded by the caller when cand != 0). again: neither the home slot nor
-// v2 holds the key and the home slot names further slots — the probe goes on in the next step
-PA_HD void seek_eval(const SeekProbe& q, uint32_t cand, U4 v2, uint32_t& h, uint32_t& off, bool& full, bool& again) {
+// what the slot of a probe says: a hit (h != NO_HANDLE), or `pending` != 0 — other slots of the bucket may hold the key: the probe goes
+// on with them in the next step — or a miss, with `full` = a key of this home went on to the next bucket
+PA_HD void seek_eval(const SeekProbe& q, uint32_t& h, uint32_t& off, bool& full, uint32_t& pending) {
     h = NO_HANDLE;
     off = 0;
-    again = false;
-    if (slot_holds(q.v, q.klo, q.khi)) { h = q.v.z; off = q.v.w & SLOT_OFF_MASK; }
-    else if (cand) {
-        if (slot_holds(v2, q.klo, q.khi)) { h = v2.z; off = v2.w & SLOT_OFF_MASK; }
-        else again = (cand & (cand - 1)) != 0;
-    }
-    full = (slot_flags(q.v) & SLOT_FLAG_OVERFLOW) != 0;
+    const bool hit = slot_holds(q.v, q.klo, q.khi);
+    if (hit) { h = q.v.z; off = q.v.w & SLOT_OFF_MASK; }
+    const uint32_t named = q.pending & SK_NAMED;
+    // the home slot: its flags name the other slots and the overflow; a named slot: the rest of what the home slot named
+    const uint32_t next = named ? (named & (named - 1u)) | (q.pending & SK_FULL) : slot_flags(q.v);
+    pending = hit ? 0u : (next & SK_NAMED) ? next : 0u;
+    full = (next & SK_FULL) != 0;
 }
-PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q, uint32_t cand, U4 v2) {
-    uint32_t h, off;
-    bool full, again;
-    seek_eval(q, cand, v2, h, off, full, again);
-    if (again) { s.rm += 1; return; }
+PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q) {
+    uint32_t h, off, pending;
+    bool full;
+    seek_eval(q, h, off, full, pending);
+    if (pending) { s.rm = (s.rm & ~SK_MASK) | pending; return; }
     seek_finish(s, K, h, off, full, l_probe(s));
 }
-// the same with the speculative second probe (q1 / cand1 / v21: the k-mer at kmer_pos + 3, issued when seek_two(s)): it only
+// the same with the speculative second probe (q1: the home slot of the k-mer at kmer_pos + 3, issued when seek_two(s)): it only
 // counts when the first probe is a definite miss — the scan of :92-111 in its own order
-PA_HD void seek_complete2(Lane& s, uint32_t K, const SeekProbe& q0, uint32_t cand0, U4 v20, bool two, const SeekProbe& q1, uint32_t cand1, U4 v21) {
-    uint32_t h, off;
-    bool full, again;
-    seek_eval(q0, cand0, v20, h, off, full, again);
-    if (again) { s.rm += 1; return; }
+PA_HD void seek_complete2(Lane& s, uint32_t K, const SeekProbe& q0, bool two, const SeekProbe& q1) {
+    uint32_t h, off, pending;
+    bool full;
+    seek_eval(q0, h, off, full, pending);
+    if (pending) { s.rm = (s.rm & ~SK_MASK) | pending; return; }
     const uint32_t probe = l_probe(s);
     if (!two || h != NO_HANDLE || (full && probe < DICT_MAX_PROBES)) {
         seek_finish(s, K, h, off, full, probe);
         return;
     }
     l_set_kp(s, l_kp(s) + PA_SEEK_STRIDE);                          // :110 (kmer_pos + 3 <= L - K: seek_two)
-    seek_eval(q1, cand1, v21, h, off, full, again);
-    s.rm &= ~3u;
+    seek_eval(q1, h, off, full, pending);
+    s.rm &= ~SK_MASK;
     s.nc &= ~(15u << NC_PROBE_SHIFT);
-    if (again) { s.rm += 1; l_or_flags(s, F_SPEC); return; }        // the probe at the new kmer_pos goes on with its second named slot
+    if (pending) { s.rm |= pending; l_or_flags(s, F_SPEC); return; }   // the probe at the new kmer_pos goes on with the slots its home slot named
     seek_finish(s, K, h, off, full, 0u);
 }
 
@@ -581,7 +573,7 @@ PA_HD void seek_complete2(Lane& s, uint32_t K, const SeekProbe& q0, uint32_t can
 PA_HD void seek_finish(Lane& s, uint32_t K, uint32_t h, uint32_t off, bool full, uint32_t probe) {
     const uint32_t L = l_L(s), kp = l_kp(s);
     s.nc &= ~(15u << NC_PROBE_SHIFT);                               // probe index back to 0
-    s.rm &= ~3u;                                                    // ... and the named slots looked at (l_skip)
+    s.rm &= ~SK_MASK;                                               // ... and nothing of a probe pending (l_pending)
     if (h != NO_HANDLE) {                                           // Some((nid, offset)) (:106)
         s.h = h;
         const uint32_t fl = l_flags(s), p = (off & ENT_P_MASK) | of_cur((off >> ENT_CUR_SHIFT) & 3u, true);   // position + the slot of the k-mer's node
@@ -637,11 +629,7 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
     const bool two = seek_two(s, K);
     seek_issue(s, ix, rd, q);
     seek_issue(s, ix, rd, q1, PA_SEEK_STRIDE, two);
-    const uint32_t cand = seek_second(q, l_skip(s)), cand1 = two ? seek_second(q1) : 0u;
-    U4 v2{0u, 0u, NO_HANDLE, 0u}, v21{0u, 0u, NO_HANDLE, 0u};
-    if (cand) v2 = *seek_second_slot(q, cand);
-    if (cand1) v21 = *seek_second_slot(q1, cand1);
-    seek_complete2(s, K, q, cand, v2, two, q1, cand1, v21);
+    seek_complete2(s, K, q, two, q1);
 }
 
 // ---------------------------------------------------------------------------------------------- FWD

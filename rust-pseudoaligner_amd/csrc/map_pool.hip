@@ -492,8 +492,8 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
         // DUAL iteration: a forward step and a dictionary probe are each one dependent round trip and touch different parts
         // of the memory system (node blobs: MALL / L2; dictionary: HBM). When both queues hold work the wave pops BOTH, lets
         // the probe's slot load and the node fetch go out back to back, and does the probe's arithmetic while the
-        // node lines are on their way: two round trips in flight per wave instead of one (K <= 32: the two-word dictionary
-        // has no dependent second load to hide).
+        // node lines are on their way: two round trips in flight per wave instead of one (K <= 32 only: the two-word dictionary's
+        // probe is a step of its own).
 #ifndef PA_SEEK_MIN   // probes ride with a forward step only from this many waiting slots on (or when little forward work is left): the probe half is
 #define PA_SEEK_MIN 32u   // the whole wave's instructions however few lanes it serves (same-box A/B of 1 / 32 / 48: config 3 -1.8 %, config 5 -3.8 % time at 32)
 #endif
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             // One text for the plain forward step and the DUAL iteration (n2 = 0: the probe half runs on all-zero states and is
             // thrown away). Straight-line issue: every lane executes every load (a lane without a slot carries an all-zero state:
             // blob 0, bucket of whatever slot 0 holds) and nothing branches between the loads and their first use, so that the
-            // waits stay exact: first the probe's slot, then the node, then the probe's second slot (the few lanes that need one).
+            // waits stay exact: first the probe's slot, then the node.
             Lane s2;
             {
                 const u32x4 a = stA[slot2], b = stB[slot2];
@@ -567,25 +567,28 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             SeekProbe pq;
             FwdLoad fl;
             PA_MARK("dual_state2");
-            pq.bucket = ix.table; pq.home = 0; pq.klo = pq.khi = 0; pq.v = U4{0u, 0u, NO_HANDLE, 0u};
-            if (n2) seek_issue(s2, ix, rr2, pq);                       // home slot of the k-mer (HBM); (n2: wave-uniform — a plain forward step skips the probe half)
+            pq.klo = pq.khi = pq.pending = 0; pq.v = U4{0u, 0u, NO_HANDLE, 0u};
+            if (n2) seek_issue(s2, ix, rr2, pq);                       // one slot of the k-mer's bucket (HBM); (n2: wave-uniform — a plain forward step skips the probe half)
             // a lane whose scan is past a miss probes the next position of the scan as well (another line, in flight together)
             // (only in steps where at least eight lanes do: the second k-mer and hash are the whole wave's instructions)
             const bool two_l = active2 && seek_two(s2, K);
             const bool pairs = __popcll(__ballot(two_l)) >= 8;
             const bool two = two_l && pairs;
             SeekProbe pq1;
-            pq1.bucket = ix.table; pq1.home = 0; pq1.klo = pq1.khi = 0; pq1.v = U4{0u, 0u, NO_HANDLE, 0u};
+            pq1.klo = pq1.khi = pq1.pending = 0; pq1.v = U4{0u, 0u, NO_HANDLE, 0u};
             if (pairs) seek_issue(s2, ix, rr2, pq1, PA_SEEK_STRIDE, two);   // (a wave-uniform branch: the waits behind it stay exact)
             fwd_issue(s, ix, fl);                                      // node header + sequence words (MALL / L2)
             __builtin_amdgcn_sched_barrier(0);                         // (left alone the scheduler finishes the probe first and only then issues the node loads)
             PA_MARK("dual_issued");
-            // the probe's second load, only for the lanes whose home slot holds another key and names other slots (same line,
-            // now in the L1 / L2)
-            const uint32_t cand = active2 ? seek_second(pq, l_skip(s2)) : 0u, cand1 = two ? seek_second(pq1) : 0u;
-            U4 pv2{0u, 0u, NO_HANDLE, 0u}, pv21{0u, 0u, NO_HANDLE, 0u};
-            if (cand) pv2 = *seek_second_slot(pq, cand);
-            if (cand1) pv21 = *seek_second_slot(pq1, cand1);
+            // the probe half completes first: its loads are the oldest of the iteration, a probe never needs a second one (a key that is
+            // not in the slot looked at costs the lane another step: lane_steps.hpp), and its registers are free before the forward half computes
+            if (active2) {
+                seek_complete2(s2, K, pq, two, pq1);
+                nq2 = queue_of(s2, K);   // (may rewrite the state: before the store)
+                stA[slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
+                stB[slot2] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const unsigned long long t1 = PA_DBG ? __builtin_readcyclecounter() : 0ull;
             PA_MARK("dual_second");
             if (active) fwd_finish<TRACE>(s, ix, rr, cols, allowed, fl);
@@ -594,12 +597,6 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 const unsigned long long t3 = __builtin_readcyclecounter();
                 dbg[ST_COUNT + 1] += 1; dbg[ST_COUNT + 3] += 1;
                 dbg_clk[ST_COUNT + 1] += t1 - t_pop; dbg_clk[ST_COUNT + 3] += t3 - t1;
-            }
-            if (active2) {
-                seek_complete2(s2, K, pq, cand, pv2, two, pq1, cand1, pv21);
-                nq2 = queue_of(s2, K);   // (may rewrite the state: before the store)
-                stA[slot2] = u32x4{s2.lk, s2.cm, s2.h, s2.of};
-                stB[slot2] = u32x4{s2.rr, s2.rm, s2.ph, s2.nc};
             }
             PA_MARK("dual_seek_done");
         } else if (sel == ST_LEFT) {
