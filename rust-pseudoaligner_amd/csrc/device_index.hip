@@ -249,7 +249,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     FlatDevice fd;
     int threads = usable_threads();
     if (threads < 1) threads = 1;
-    // classes, window table, edges, chains and their blocks on the host; the dictionary (3.3 GB at config 3) is built on the GPU
+    // classes, window table, edges, chains and their blocks on the host; the dictionary (6.6 GB at config 3) is built on the GPU
     // from the uploaded blocks (index_fill.hip) — nothing of the table exists on the host or crosses PCIe
     rc = flatten_for_device(*flat, threads, fd, /*device_dict=*/true);
     if (rc != PA_OK) return rc;

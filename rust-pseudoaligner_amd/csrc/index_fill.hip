@@ -1,5 +1,5 @@
 // pa_index_create's device side: the k-mer dictionary is filled and verified ON the GPU, from the chain blocks already
-// resident in HBM — nothing of the 3.3 GB table (config 3) is built on the host or crosses PCIe.
+// resident in HBM — nothing of the 6.6 GB table (config 3) is built on the host or crosses PCIe.
 //
 // Replaces make_dbg_index (src/build_index.rs:182-221: boomphf MPHF + (node id, offset) scatter over every k-mer of every
 // node):

@@ -491,8 +491,8 @@ constexpr uint32_t SK_NAMED = 7u, SK_FULL = 8u, SK_MASK = 15u;
 // bucket and home slot of a k-mer (one hash)
 PA_HD uint32_t pa_bucket_home(uint64_t kmer, uint32_t nbuckets, uint32_t& home) {
     // three 32-bit multiplies (fmix64 is two 64-bit ones = eight quarter-rate instructions per probe): the dictionary's placement
-    // is as good with either on the config-3 keys (home slot 79 % / other slot of the bucket 17 % / next bucket 4 % at load 0.5,
-    // furthest key 14 buckets from home), and the mapping kernel is bound by instruction issue (config 5 -4 % time, config 3 +-0)
+    // is as good with either on the config-3 keys (measured at load 0.5: home slot 79 % / other slot of the bucket 17 % / next bucket 4 %,
+    // furthest key 14 buckets from home; the table is now built at 0.25), and the mapping kernel is bound by instruction issue (config 5 -4 % time, config 3 +-0)
     uint32_t x = (uint32_t)kmer * 0x9E3779B1u + (uint32_t)(kmer >> 32) * 0x85EBCA77u;
     x ^= x >> 15;
     x *= 0x2C1B3C6Du;
@@ -540,33 +540,30 @@ PA_HD void seek_eval(const SeekProbe& q, uint32_t& h, uint32_t& off, bool& full,
     pending = hit ? 0u : (next & SK_NAMED) ? next : 0u;
     full = (next & SK_FULL) != 0;
 }
-PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q) {
+// The probe q of the k-mer at the lane's kmer_pos settles the lane's next state — a hit, the named slots or the next bucket still to
+// look at, the end of the scan — and returns true; or it is a definite miss while another probe of this step covers kmer_pos + 3
+// (`more`): then kmer_pos moves on (:110) and the caller evaluates that probe — the scan of :92-111 in its own order
+PA_HD bool seek_settle(Lane& s, uint32_t K, const SeekProbe& q, bool more) {
     uint32_t h, off, pending;
     bool full;
     seek_eval(q, h, off, full, pending);
-    if (pending) { s.rm = (s.rm & ~SK_MASK) | pending; return; }
-    seek_finish(s, K, h, off, full, l_probe(s));
-}
-// the same with the speculative second probe (q1: the home slot of the k-mer at kmer_pos + 3, issued when seek_two(s)): it only
-// counts when the first probe is a definite miss — the scan of :92-111 in its own order
-PA_HD void seek_complete2(Lane& s, uint32_t K, const SeekProbe& q0, bool two, const SeekProbe& q1) {
-    uint32_t h, off, pending;
-    bool full;
-    seek_eval(q0, h, off, full, pending);
-    if (pending) { s.rm = (s.rm & ~SK_MASK) | pending; return; }
+    if (pending) { s.rm = (s.rm & ~SK_MASK) | pending; return true; }
     const uint32_t probe = l_probe(s);
-    if (!two || h != NO_HANDLE || (full && probe < DICT_MAX_PROBES)) {
+    if (!more || h != NO_HANDLE || (full && probe < DICT_MAX_PROBES)) {
         seek_finish(s, K, h, off, full, probe);
-        return;
+        return true;
     }
     l_set_kp(s, l_kp(s) + PA_SEEK_STRIDE);                          // :110 (kmer_pos + 3 <= L - K: seek_two)
-    seek_eval(q1, h, off, full, pending);
     s.rm &= ~SK_MASK;
     s.nc &= ~(15u << NC_PROBE_SHIFT);
-    if (pending) { s.rm |= pending; l_or_flags(s, F_SPEC); return; }   // the probe at the new kmer_pos goes on with the slots its home slot named
-    seek_finish(s, K, h, off, full, 0u);
+    return false;
 }
-
+PA_HD void seek_complete(Lane& s, uint32_t K, const SeekProbe& q) { (void)seek_settle(s, K, q, false); }
+// with the speculative second probe (q1: the home slot of the k-mer at kmer_pos + 3, issued when seek_two(s))
+PA_HD void seek_complete2(Lane& s, uint32_t K, const SeekProbe& q0, bool two, const SeekProbe& q1) {
+    if (seek_settle(s, K, q0, two)) return;
+    (void)seek_settle(s, K, q1, false);
+}
 // what a probe found -> the lane's next state (the tail of find_kmer_match and of :118-129). `h` = the chain block the k-mer
 // starts in, `off` = the entry's second word (device_layout.hpp: position in the block, first-k-mer-of-its-node flag, blocks
 // before this one in the chain)
