@@ -554,6 +554,14 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
             // thrown away). Straight-line issue: every lane executes every load (a lane without a slot carries an all-zero state:
             // blob 0, bucket of whatever slot 0 holds) and nothing branches between the loads and their first use, so that the
             // waits stay exact: first the probe's slot, then the node.
+            // Nothing the wave asked memory for is to be in flight when this iteration's loads go out. Every load of an iteration is consumed
+            // inside it, but the compiler cannot prove that across the loop's back edge (fwd_finish sits behind `if (active)`: for all it
+            // knows a wave may skip it and carry the block's loads along), so it guarded the first write to one of their registers in the
+            // NEXT iteration with a wait for everything in flight — and that write came a few instructions behind the dictionary probe's
+            // load: a whole memory round trip before the block's loads even went out, two round trips in series per iteration instead of
+            // the two in flight together this step is built for. An explicit wait here (free: at most the stores of an output step are
+            // still on their way) tells the compiler where it stands.
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), nothing else
             Lane s2;
             {
                 const u32x4 a = stA[slot2], b = stB[slot2];
