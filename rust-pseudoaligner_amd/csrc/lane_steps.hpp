@@ -490,7 +490,7 @@ struct SeekProbe {
 constexpr uint32_t SK_NAMED = 7u, SK_FULL = 8u, SK_MASK = 15u;
 // bucket and home slot of a k-mer (one hash)
 PA_HD uint32_t pa_bucket_home(uint64_t kmer, uint32_t nbuckets, uint32_t& home) {
-    // three 32-bit multiplies (fmix64 is two 64-bit ones = eight quarter-rate instructions per probe): the dictionary's placement
+    // three 32-bit multiplies (fmix64 is two 64-bit ones = eight multiply instructions and their adds per probe): the dictionary's placement
     // is as good with either on the config-3 keys (measured at load 0.5: home slot 79 % / other slot of the bucket 17 % / next bucket 4 %,
     // furthest key 14 buckets from home; the table is now built at 0.25), and the mapping kernel is bound by instruction issue (config 5 -4 % time, config 3 +-0)
     uint32_t x = (uint32_t)kmer * 0x9E3779B1u + (uint32_t)(kmer >> 32) * 0x85EBCA77u;

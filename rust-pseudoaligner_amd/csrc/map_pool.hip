@@ -349,7 +349,7 @@ constexpr uint32_t SLOT_FIXED_BYTES = 32 + 16 + 8;   // lane state, class window
 #define PA_MAP_MIN_BLOCKS 3   // workgroups per CU the register budget is sized for (A/B builds: -DPA_MAP_MIN_BLOCKS=4)
 #endif
 // S128: the pool has 128 slots per wave (reads of up to 5 words: every short-read batch) — the stride of the LDS rows of read words is
-// then a shift instead of a quarter-rate multiply in every step that touches the read.
+// then a shift instead of a multiply in every step that touches the read (and the compiler keeps fewer scalars: 16 spilled instead of 26).
 template <bool TRACE, bool GREAD, bool DBG, bool S128 = false>
 __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_kernel(const MapParams p_arg) {
     // The ~50 words of parameters are NOT kept in registers across the loop (the allocator would spill most of them to
