@@ -564,22 +564,30 @@ def ingest_leg(env, run, n):
         seq_off = (np.arange(chunk + 1, dtype=np.uint64) * wl["read_len"])
         buf = C.create_string_buffer(1 << 28)   # (one pull per rendered batch: the library copies big pieces on its worker pool)
         nb = C.c_size_t()
-        t0 = time.perf_counter()
-        pulled = 0
-        for lo in range(0, n, chunk):
-            m = min(chunk, n - lo)
-            pa.check(pa.lib().pa_records_push(rs._h, ids[lo:lo + m].ctypes.data, id_off.ctypes.data, seqs[lo:lo + m].ctypes.data, seq_off.ctypes.data, m))
+        def stream_all(rs):
+            pulled = 0
+            for lo in range(0, n, chunk):
+                m = min(chunk, n - lo)
+                pa.check(pa.lib().pa_records_push(rs._h, ids[lo:lo + m].ctypes.data, id_off.ctypes.data, seqs[lo:lo + m].ctypes.data, seq_off.ctypes.data, m))
+                while True:
+                    pa.check(pa.lib().pa_records_pull(rs._h, buf, len(buf), C.byref(nb)))
+                    if nb.value == 0:
+                        break
+                    pulled += nb.value
+            rs.flush()
             while True:
                 pa.check(pa.lib().pa_records_pull(rs._h, buf, len(buf), C.byref(nb)))
                 if nb.value == 0:
                     break
                 pulled += nb.value
-        rs.flush()
-        while True:
-            pa.check(pa.lib().pa_records_pull(rs._h, buf, len(buf), C.byref(nb)))
-            if nb.value == 0:
-                break
-            pulled += nb.value
+            return pulled
+        # warm-up, as for pa_process_reads above: the stream shares its pinned batch buffers with pa_process_reads through the index, and
+        # its batches (2 Mi reads) are larger than the windows that call scans (buffers sized by those are regrown on first use)
+        stream_all(rs)
+        rs.close()
+        rs = pa.RecordStream(run.aligner, ncpu)
+        t0 = time.perf_counter()
+        pulled = stream_all(rs)
         dt_rs = time.perf_counter() - t0
         st_rs = rs.stage_seconds()
         assert rs.stats()[0] == n

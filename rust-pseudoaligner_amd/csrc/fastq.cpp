@@ -534,7 +534,12 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
     Writer writer(out);
     uint64_t flagged = 0, next_report = 1000000, reported = 0;
 
-    auto ensure = [&](BatchCtx& c, uint64_t n, uint32_t wpr) -> int { return batch_ensure(idx, c, n, wpr, std::min<uint64_t>(BATCH_READS, ws.nrec)); };
+    // buffers are sized once, for the batches this FILE will need — a whole batch when the text goes on behind the window (the record
+    // stream shares the parked buffers and pushes whole batches: sized by the window alone they were regrown there, pinned memory and all)
+    auto ensure = [&](BatchCtx& c, uint64_t n, uint32_t wpr) -> int {
+        const uint64_t est = ws.size ? (uint64_t)((double)ws.nrec * (double)(text.fsize - (uint64_t)(ws.base - text.data)) / (double)ws.size) : ws.nrec;
+        return batch_ensure(idx, c, n, wpr, std::min<uint64_t>(BATCH_READS, std::max<uint64_t>(ws.nrec, est)));
+    };
 
     // the next batch of the text into c: its records (of the current window, or the next one: scanned now), parsed + packed (parallel over
     // whole tiles). c.n = 0 at the end of the text
