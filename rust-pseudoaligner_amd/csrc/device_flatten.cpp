@@ -38,6 +38,7 @@ DevIndexView FlatDevice::host_view() const {
     v.num_nodes = num_nodes;
     v.num_classes = num_classes;
     v.num_segs = (uint32_t)seg_g.size();
+    v.stream_nt = 0;
     return v;
 }
 

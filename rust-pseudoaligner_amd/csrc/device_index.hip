@@ -293,6 +293,9 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     idx->dv.class_ref = static_cast<const uint32_t*>(idx->d_class_ref);
     idx->dv.class_len = static_cast<const uint32_t*>(idx->d_class_len);
     idx->dv.wtable = static_cast<const uint32_t*>(idx->d_wtable);
+    // a dictionary beyond the Infinity Cache (256 MB) is streamed past the caches (ld_stream): every line of it is used once per probe,
+    // and left to itself it evicts the chain blocks, which every read comes back to
+    idx->dv.stream_nt = (fd.k <= 32 && fd.nbuckets * BUCKET_WORDS * 4 > (512ull << 20)) ? 1u : 0u;   // (the two-word dictionary's probe is four loads of one line: slower with the hint)
     pa_index_stats& s = idx->stats;
     s.num_kmers = fd.num_kmers;
     s.table_slots = fd.nbuckets * SLOTS_PER_BUCKET;

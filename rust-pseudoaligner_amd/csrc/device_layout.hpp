@@ -158,6 +158,7 @@ struct DevIndexView {
     uint32_t k;
     uint32_t num_nodes, num_classes;
     uint32_t num_segs;        // entries of seg_g / seg_nid (nodes and their copies in tails)
+    uint32_t stream_nt;       // 1: the dictionary is larger than the caches — its lines and the read words are loaded non-temporal (lane_steps.hpp, ld_stream)
 };
 
 }  // namespace pa

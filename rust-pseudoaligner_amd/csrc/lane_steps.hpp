@@ -213,6 +213,19 @@ PA_HD U4 ld_nt(const U4* p) { return *p; }
 PA_HD uint64_t ld_nt(const uint64_t* p) { return *p; }
 #endif
 #define PA_LD(bit, ptr) ((PA_NT & (bit)) ? ld_nt(ptr) : *(ptr))
+// ... and decided per INDEX at run time (DevIndexView::stream_nt, wave-uniform): dictionary lines and read words of an index whose
+// dictionary is larger than the caches are loaded non-temporal, so that they do not push the chain blocks — 0.4 GB that every read
+// comes back to — out of the L2 and the Infinity Cache (round 5: config 3 -3 %, config 5 -4...5 % kernel time; an index that fits the
+// caches, config 2, is 2 % faster WITHOUT the hint: profiles/r05_nontemporal_ab.txt)
+template <class T>
+PA_HD T ld_stream(const T* p, bool nt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_readfirstlane((int)nt)) return ld_nt(p);
+#else
+    (void)nt;
+#endif
+    return *p;
+}
 
 // first byte of chain block `h`
 PA_HD const uint8_t* chain_block(const DevIndexView& ix, uint32_t h) { return ix.blobs + (uint64_t)h * CH_BLOCK; }
@@ -520,7 +533,7 @@ PA_HD void seek_issue(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekPro
     const uint32_t named = q.pending & SK_NAMED;
     uint32_t slot = named ? (home + 1u + pa_ctz32(named)) & 3u : home;
     if (!live) { b = 0; slot = 0; }
-    q.v = PA_LD(4, reinterpret_cast<const U4*>(ix.table + (uint64_t)b * BUCKET_WORDS + SLOT_WORDS * slot));
+    q.v = ld_stream(reinterpret_cast<const U4*>(ix.table + (uint64_t)b * BUCKET_WORDS + SLOT_WORDS * slot), (PA_NT & 4) || ix.stream_nt);
     q.klo = (uint32_t)kmer;
     q.khi = (uint32_t)(kmer >> 32);
 }
@@ -615,7 +628,7 @@ PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
 #endif
         if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
         const U4* line = reinterpret_cast<const U4*>(ix.table + (uint64_t)b * BUCKET_WORDS);
-        const U4 k0 = line[0], v0 = line[1], k1 = line[2], v1 = line[3];
+        const U4 k0 = line[0], v0 = line[1], k1 = line[2], v1 = line[3];   // (never non-temporal: four loads of one line, config 3 at K = 64 +9 % time with the hint)
         const uint32_t w0 = (uint32_t)klo, w1 = (uint32_t)(klo >> 32), w2 = (uint32_t)khi, w3 = (uint32_t)(khi >> 32);
         const bool h0 = k0.x == w0 && k0.y == w1 && k0.z == w2 && k0.w == w3 && v0.x != NO_HANDLE,
                    h1 = k1.x == w0 && k1.y == w1 && k1.z == w2 && k1.w == w3 && v1.x != NO_HANDLE;

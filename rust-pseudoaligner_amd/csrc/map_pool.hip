@@ -71,7 +71,7 @@ __device__ __forceinline__ DevIndexView view_of(karg_ptr p) {   // member-wise: 
     DevIndexView v;
     v.table = p->ix.table; v.nbuckets = p->ix.nbuckets; v.blobs = p->ix.blobs; v.ledge = p->ix.ledge;
     v.seg_g = p->ix.seg_g; v.seg_nid = p->ix.seg_nid; v.ec = p->ix.ec; v.class_ref = p->ix.class_ref; v.class_len = p->ix.class_len;
-    v.wtable = p->ix.wtable; v.wbuckets = p->ix.wbuckets; v.kmask = p->ix.kmask; v.kmask_hi = p->ix.kmask_hi; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes; v.num_segs = p->ix.num_segs;
+    v.wtable = p->ix.wtable; v.wbuckets = p->ix.wbuckets; v.kmask = p->ix.kmask; v.kmask_hi = p->ix.kmask_hi; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes; v.num_segs = p->ix.num_segs; v.stream_nt = p->ix.stream_nt;
     return v;
 }
 
@@ -317,10 +317,12 @@ __device__ __forceinline__ void refill_slot(Lane& s, uint64_t rid, uint32_t slot
         // the common read lengths in straight-line code (all loads in flight, then the LDS stores; a loop over a run-time word count
         // costs a scalar branch around every load and every store): 100 bp = 4 words, 150 bp = 5
         if (wpr == 5) {
-            const uint64_t v0 = PA_LD(1, src), v1 = PA_LD(1, src + 64), v2 = PA_LD(1, src + 128), v3 = PA_LD(1, src + 192), v4 = PA_LD(1, src + 256);
+            const bool nt = (PA_NT & 1) || p->ix.stream_nt;
+            const uint64_t v0 = ld_stream(src, nt), v1 = ld_stream(src + 64, nt), v2 = ld_stream(src + 128, nt), v3 = ld_stream(src + 192, nt), v4 = ld_stream(src + 256, nt);
             rd[slot] = v0; rd[S + slot] = v1; rd[2 * S + slot] = v2; rd[3 * S + slot] = v3; rd[4 * S + slot] = v4;
         } else if (wpr == 4) {
-            const uint64_t v0 = PA_LD(1, src), v1 = PA_LD(1, src + 64), v2 = PA_LD(1, src + 128), v3 = PA_LD(1, src + 192);
+            const bool nt = (PA_NT & 1) || p->ix.stream_nt;
+            const uint64_t v0 = ld_stream(src, nt), v1 = ld_stream(src + 64, nt), v2 = ld_stream(src + 128, nt), v3 = ld_stream(src + 192, nt);
             rd[slot] = v0; rd[S + slot] = v1; rd[2 * S + slot] = v2; rd[3 * S + slot] = v3;
         } else
         for (uint32_t w0 = 0; w0 < wpr; w0 += 8) {   // eight words in flight per round trip
