@@ -522,3 +522,114 @@ def long_chain_case(seed, tmp_path):
                 r[j] = "ACGT"[rng.randint(4)]
         reads.append("".join(r))
     return host, reads, allowed
+
+
+# ---- foreign flat indexes (the arrays a Rust exporter hands over are NOT laid out by the product's builders) ----
+def unpack_bases(words, n):
+    """2-bit packed words (LSB-first) -> uint8 codes[n]"""
+    pos = np.arange(n, dtype=np.int64)
+    return ((np.asarray(words)[pos >> 5] >> ((pos & 31) * 2).astype(np.uint64)) & np.uint64(3)).astype(np.uint8)
+
+
+def pack_bases(codes):
+    """uint8 codes -> packed words (+2 pad words)"""
+    n = len(codes)
+    padded = np.zeros(((n + 31) // 32 + 2) * 32, np.uint64)
+    padded[:n] = codes
+    return (padded.reshape(-1, 32) << (2 * np.arange(32, dtype=np.uint64))[None, :]).sum(axis=1, dtype=np.uint64)
+
+
+def flat_from_arrays(arr, k, num_tx):
+    """a FlatIndex over numpy arrays (kept alive by the returned dict), as an exporter on the Rust side would fill it
+    (integration/rust/src/amd.rs: export_flat)"""
+    f = pa._ffi.FlatIndex()
+    keep = {n: np.ascontiguousarray(arr[n]) for n in ("node_seq", "node_start", "node_len", "node_exts", "node_colour", "ec_offset", "ec_ids")}
+    f.k, f.num_nodes, f.num_classes, f.num_transcripts = k, len(keep["node_len"]), len(keep["ec_offset"]) - 1, num_tx
+    f.seq_bases = int(keep["node_start"][-1])
+    for n, v in keep.items():
+        setattr(f, n, v.ctypes.data)
+    f.node_redge = f.node_ledge = None
+    return f, keep
+
+
+def foreign_index(host, seed, cut_frac=0.5, max_cuts=3):
+    """The SAME coloured De Bruijn graph as `host` in a layout the product's builders never produce: nodes in a random order,
+    classes renumbered by a random permutation, and about `cut_frac` of the unitigs that hold more than one k-mer cut at random
+    k-mer boundaries into 2..max_cuts+1 same-colour pieces that overlap by k-1 bases (non-maximal unitigs: a different builder's
+    break points; every piece gets the one extension bit that leads to its neighbour piece). Returns a HostIndex made by
+    pa_host_index_from_flat — the oracle and the product are then both built from THESE arrays."""
+    a = host.arrays()
+    k, nn, nc = int(a["k"]), int(a["num_nodes"]), int(a["num_classes"])
+    rng = np.random.RandomState(seed)
+    start, ln = a["node_start"].astype(np.int64), a["node_len"].astype(np.int64)
+    bases = unpack_bases(a["node_seq"], int(start[-1]))
+    nk = ln - k + 1
+    ncut = np.where((rng.rand(nn) < cut_frac) & (nk > 1), rng.randint(1, max_cuts + 1, nn), 0)
+    ncut = np.minimum(ncut, nk - 1)
+    p_node, p_lo, p_hi = [], [], []          # piece = k-mers [lo, hi) of node p_node
+    for n in np.flatnonzero(ncut):
+        cuts = np.sort(rng.choice(np.arange(1, nk[n]), int(ncut[n]), replace=False))
+        b = np.r_[0, cuts, nk[n]]
+        p_node += [n] * (len(b) - 1); p_lo += b[:-1].tolist(); p_hi += b[1:].tolist()
+    whole = np.flatnonzero(ncut == 0)
+    p_node = np.r_[np.array(p_node, np.int64), whole]
+    p_lo = np.r_[np.array(p_lo, np.int64), np.zeros(len(whole), np.int64)]
+    p_hi = np.r_[np.array(p_hi, np.int64), nk[whole]]
+    order = rng.permutation(len(p_node))
+    p_node, p_lo, p_hi = p_node[order], p_lo[order], p_hi[order]
+    p_len = p_hi - p_lo + k - 1
+    p_src = start[p_node] + p_lo
+    exts = a["node_exts"][p_node].astype(np.int64)
+    inner_l, inner_r = p_lo > 0, p_hi < nk[p_node]
+    e = np.where(inner_l, 16 << bases[np.maximum(p_src - 1, 0)].astype(np.int64), exts & 0xF0)
+    e |= np.where(inner_r, 1 << bases[np.minimum(p_src + p_len, len(bases) - 1)].astype(np.int64), exts & 0x0F)
+    new_start = np.zeros(len(p_node) + 1, np.uint64)
+    new_start[1:] = np.cumsum(p_len)
+    idx = np.repeat(p_src, p_len) + (np.arange(int(p_len.sum()), dtype=np.int64) - np.repeat(new_start[:-1].astype(np.int64), p_len))
+    perm = rng.permutation(nc)                                     # class c is renumbered perm[c]
+    off = a["ec_offset"].astype(np.int64)
+    clen = off[1:] - off[:-1]
+    inv = np.argsort(perm)                                         # new class j is old class inv[j]
+    ec_offset = np.zeros(nc + 1, np.uint64)
+    ec_offset[1:] = np.cumsum(clen[inv])
+    gidx = np.repeat(off[inv], clen[inv]) + (np.arange(int(clen.sum()), dtype=np.int64) - np.repeat(ec_offset[:-1].astype(np.int64), clen[inv]))
+    arr = dict(node_seq=pack_bases(bases[idx]), node_start=new_start, node_len=p_len.astype(np.uint32), node_exts=e.astype(np.uint8),
+               node_colour=perm[a["node_colour"][p_node]].astype(np.uint32), ec_offset=ec_offset, ec_ids=a["ec_ids"][gidx].astype(np.uint32))
+    f, keep = flat_from_arrays(arr, k, int(a["num_transcripts"]))
+    out = pa.HostIndex.from_flat(f)
+    return out, int((ncut > 0).sum())
+
+
+def index_from_node_set(nodes, k, num_tx, seed=0):
+    """a flat index from a SET of (sequence, class id tuple, left ext letters, right ext letters) — the form
+    tests/test_reference_build_order.reference_order_nodes emulates the reference's two-pass build in — nodes in the set's
+    (shuffled) order, classes numbered by first appearance"""
+    rng = np.random.RandomState(seed)
+    nodes = sorted(nodes)
+    nodes = [nodes[i] for i in rng.permutation(len(nodes))]
+    lut = {c: i for i, c in enumerate("ACGT")}
+    classes, colour, exts = {}, [], []
+    for seq, cls, le, re in nodes:
+        colour.append(classes.setdefault(cls, len(classes)))
+        exts.append(sum(16 << lut[c] for c in le) | sum(1 << lut[c] for c in re))
+    ln = np.array([len(n[0]) for n in nodes], np.int64)
+    start = np.zeros(len(nodes) + 1, np.uint64)
+    start[1:] = np.cumsum(ln)
+    l8 = np.zeros(256, np.uint8)
+    for c, v in lut.items():
+        l8[ord(c)] = v
+    codes = l8[np.frombuffer("".join(n[0] for n in nodes).encode(), np.uint8)]
+    lists = sorted(classes, key=classes.get)
+    ec_offset = np.zeros(len(lists) + 1, np.uint64)
+    ec_offset[1:] = np.cumsum([len(l) for l in lists])
+    arr = dict(node_seq=pack_bases(codes), node_start=start, node_len=ln.astype(np.uint32), node_exts=np.array(exts, np.uint8),
+               node_colour=np.array(colour, np.uint32), ec_offset=ec_offset, ec_ids=np.array([i for l in lists for i in l], np.uint32))
+    f, keep = flat_from_arrays(arr, k, num_tx)
+    return pa.HostIndex.from_flat(f)
+
+
+def error_reads(host, read_len, n, ppm, seed):
+    """n simulated reads (tiles, lens, wpr) of the index's own transcripts with ppm substitutions per million bases"""
+    tx = pa.Txome.from_host_index(host)
+    tiles, lens = tx.simulate_host(read_len, seed, n, ppm)
+    return tiles, lens, pa.lib().pa_words_per_read(read_len)

@@ -70,8 +70,9 @@ def perm_table(mode):
     return perm
 
 
-def reference_order_nodes(seqs, k, perm_mode, min_shard=2000):
-    """-> (set of (sequence, class tuple, left exts, right exts), number of shards, k-mers on pure cycles, nodes after pass 1)"""
+def reference_order_nodes(seqs, k, perm_mode, min_shard=2000, pass_one_only=False):
+    """-> (set of (sequence, class tuple, left exts, right exts), number of shards, k-mers on pure cycles, nodes after pass 1);
+    pass_one_only: the nodes as assemble_shard leaves them (before merge_shard_dbgs), with the extension bits of their end k-mers"""
     perm = perm_table(perm_mode)
     km_all, ext_all, tx_all, bucket_all, piece_start = [], [], [], [], []
     for t, s in enumerate(seqs):
@@ -163,6 +164,8 @@ def reference_order_nodes(seqs, k, perm_mode, min_shard=2000):
         if y >= 0 and y in head_of:
             node_succ[i] = head_of[y]
     final, cyc2 = chains(node_succ)                                                   # (a loop that pass 1 cut at shard seams closes again here)
+    if pass_one_only:
+        final, cyc2 = [[i] for i in range(len(nodes1))], np.zeros(0, np.int64)
     bases = "ACGT"
     out = set()
     for chain in final:
