@@ -294,12 +294,23 @@ int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offs
  * wrapped over several lines, which bio's reader accepts) is first rewritten into that form by a sequential pass (as many
  * quality lines as sequence lines, as bio 1.5 reads them), then scanned in parallel like any other. PA_ERR_FORMAT with
  * the record number for text that is no FASTQ or ends inside a record. Read ids are cut at the first space, as record.id() does.
- * The pinned host and device buffers of the two batches in flight (about 0.2 GB of each for 2 Mi-read batches of 150-base
- * reads) and the record positions of the file (16 bytes per read, at most 1 GB of them) stay parked on `idx` after a successful
- * call, so that the next file starts with warm buffers; concurrent calls on one index each use their own set;
- * pa_index_destroy frees them. */
+ * How it runs (round 6): the host does not look at the text. Worker threads read WINDOWS of the file into pinned memory (pread; 128 MiB
+ * each, PA_INGEST_WINDOW overrides), a window goes to HBM as it is on a copy stream, the GPU finds its records (line breaks, '@' / '+'
+ * markers, record.id(), record.seq(): csrc/fastq_scan.hip) and the encode / map / render kernels read sequences and ids where they lie;
+ * a window ends where the file offset says, the unfinished record is read again as the head of the next window. The last piece of the
+ * text and any text that is not in four-line shape go through the host's tolerant scan (and the same kernels).
+ * The pinned host and device buffers of the four windows in flight (about 0.15 GB of each per window for 150-base reads) stay parked
+ * on `idx` after a successful call, so that the next file starts with warm buffers; concurrent calls on one index each use their own
+ * set; pa_index_destroy frees them. */
 int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads,
                      uint64_t* n_reads_out, uint64_t* n_flagged_out);
+/* process_reads on every GPU it is given — the reference's driver uses every worker it is given (src/pseudoaligner.rs:434-474).
+ * idx[0 .. n_idx) are replicas of ONE index (pa_index_create_multi: one handle per GPU of the node); the windows of the text are dealt
+ * round-robin to the handles, each with its own streams and buffers, and the tuples are written in INPUT order: the output is byte for
+ * byte that of pa_process_reads on one handle. A handle may be listed more than once (it then serves several windows at a time on
+ * streams of its own: two lanes on one GPU). PA_ERR_INVALID_ARG when the handles are not replicas (k, nodes, classes, k-mers). */
+int pa_process_reads_multi(pa_index* const* idx, int n_idx, const char* fastq_path, const char* out_path, int num_threads,
+                           uint64_t* n_reads_out, uint64_t* n_flagged_out);
 
 /* process_reads for a caller that HOLDS the reader. The reference's signature consumes an open fastq::Reader
  * (src/pseudoaligner.rs:420-425), so its drop-in replacement cannot ask for a path: the caller pushes the records it reads —
@@ -324,11 +335,13 @@ int pa_records_flush(pa_record_stream* s);
 int pa_record_stream_stats(const pa_record_stream* s, uint64_t* n_reads, uint64_t* n_flagged);
 void pa_record_stream_destroy(pa_record_stream* s);
 
-/* Measurement (bench.py's ingest leg): wall seconds the HOST stages of the last pa_process_reads call of this thread /
+/* Measurement (bench.py's ingest leg): wall seconds the HOST stages of the last pa_process_reads[_multi] call of this thread /
  * of a record stream since its creation took — the stages run one after the other on the caller's thread, each spread over
- * the worker pool, while the GPU works on the batch before: out[0] scan (record boundaries; 0 for a record stream),
- * out[1] pack (records -> 2-bit tiles), out[2] waiting for the GPU, out[3] launch, out[4] render (Debug tuples),
- * out[5] waiting for the writer (0 for a record stream), out[6] the whole call (streams: the sum of the others), out[7] reads. */
+ * the worker pool, while the GPU works on the windows before: out[0] scan (record boundaries found by the HOST: the end of the text,
+ * text that is not in four-line shape; 0 for a record stream), out[1] pack (pa_process_reads: reading the windows' text into pinned
+ * memory; a record stream: gathering ids and sequences), out[2] waiting for the GPU (a window's scan, its kernels), out[3] launch,
+ * out[4] waiting for the rendered tuples, out[5] waiting for the writer (0 for a record stream), out[6] the whole call (streams: the
+ * sum of the others), out[7] reads. */
 #define PA_INGEST_STAGES 8
 int pa_process_reads_stage_seconds(double out[PA_INGEST_STAGES]);
 int pa_record_stream_stage_seconds(const pa_record_stream* s, double out[PA_INGEST_STAGES]);

@@ -195,6 +195,8 @@ int main(int argc, char** argv) {
         snprintf(path, sizeof path, "%s/abi_check_tuples.txt", dir);
         uint64_t nreads = 0, nflag = 0;
         EXPECT(pa_process_reads(idx, fastq, path, 2, &nreads, &nflag) == PA_OK && nreads > 0);
+        { pa_index* two[2]; uint64_t n2 = 0, f2 = 0; two[0] = idx; two[1] = idx;   /* two lanes on one GPU */
+          EXPECT(pa_process_reads_multi(two, 2, fastq, path, 2, &n2, &f2) == PA_OK && n2 == nreads && f2 == nflag); }
         /* device-resident batch: simulate on the device, map with the fused count table, overflow table, RCCL world of one */
         pa_txome_device* td = NULL;
         EXPECT(pa_txome_upload(tx2, 60, 0, &td) == PA_OK);

@@ -83,6 +83,8 @@ extern "C" {
     pub fn pa_record_stream_destroy(s: *mut PaRecordStream);
     pub fn pa_process_reads(idx: *mut PaIndex, fastq_path: *const c_char, out_path: *const c_char, num_threads: c_int,
                             n_reads: *mut u64, n_flagged: *mut u64) -> c_int;
+    pub fn pa_process_reads_multi(idx: *const *mut PaIndex, n_idx: c_int, fastq_path: *const c_char, out_path: *const c_char, num_threads: c_int,
+                                  n_reads: *mut u64, n_flagged: *mut u64) -> c_int;
     pub fn pa_fastq_scan_host(fastq_path: *const c_char, num_threads: c_int, n_records: *mut u64, starts: *mut u64, header_len: *mut u32,
                               seq_len: *mut u32, capacity: u64, text_kind: *mut c_int) -> c_int;
 

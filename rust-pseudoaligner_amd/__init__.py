@@ -20,7 +20,7 @@ from . import _build, _ffi
 from ._ffi import (PA_DEFAULT_ALLOWED_MISMATCHES, PA_ERR_ARENA_FULL, PA_MAPPED_BIT, PA_OK, PA_READ_COVERAGE_THRESHOLD, FlatIndex,
                    IndexStats, PaError, ReadResult, check, lib, vp)
 
-__all__ = ["HostIndex", "Txome", "Pseudoaligner", "build_index", "process_reads", "PaError", "lib", "concat_reads",
+__all__ = ["HostIndex", "Txome", "Pseudoaligner", "build_index", "process_reads", "process_reads_multi", "PaError", "lib", "concat_reads",
            "gather_classes", "unpack_tiles", "RESULT_DTYPE", "PA_MAPPED_BIT", "PA_DEFAULT_ALLOWED_MISMATCHES",
            "PA_READ_COVERAGE_THRESHOLD", "PA_CLASS_REF", "Overflow", "Comm", "parse_overflow", "serialise_overflow", "overflow_merge"]
 
@@ -623,6 +623,15 @@ def process_reads(fastq_path: str, index: Pseudoaligner, out_path: str = "-", nu
     Returns (reads, reads flagged true by the rule at :455)."""
     n, flagged = C.c_uint64(), C.c_uint64()
     check(lib().pa_process_reads(index._h, str(fastq_path).encode(), str(out_path).encode(), num_threads, C.byref(n), C.byref(flagged)))
+    return n.value, flagged.value
+
+
+def process_reads_multi(fastq_path: str, indexes: Sequence[Pseudoaligner], out_path: str = "-", num_threads: int = 2) -> Tuple[int, int]:
+    """pa_process_reads_multi: process_reads over several handles of one index (the GPUs of a node; a handle listed twice = two lanes
+    on its GPU); the output is byte for byte that of process_reads on one handle"""
+    n, flagged = C.c_uint64(), C.c_uint64()
+    hs = (vp * len(indexes))(*[a._h for a in indexes])
+    check(lib().pa_process_reads_multi(hs, len(indexes), str(fastq_path).encode(), str(out_path).encode(), num_threads, C.byref(n), C.byref(flagged)))
     return n.value, flagged.value
 
 

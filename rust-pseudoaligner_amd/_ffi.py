@@ -98,6 +98,7 @@ SIGNATURES = {
     "pa_map_read_to_nodes": (C.c_int, [vp, C.c_char_p, C.c_uint32, C.c_uint32, vp, C.c_uint32, u32p, u32p, u32p]),
     "pa_map_batch_nodes": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32, vp]),
     "pa_process_reads": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]),
+    "pa_process_reads_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.c_char_p, C.c_int, u64p, u64p]),
     "pa_fastq_scan_host": (C.c_int, [C.c_char_p, C.c_int, u64p, u64p, u32p, u32p, C.c_uint64, C.POINTER(C.c_int)]),
     "pa_counts_len": (C.c_uint64, [vp]),
     "pa_counts_accumulate_device": (C.c_int, [vp, vp, vp, vp, C.c_uint64, vp, vp]),

@@ -23,6 +23,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
+#include <string>
 #include <cerrno>
 #include <condition_variable>
 #include <cstdio>
@@ -187,8 +189,11 @@ struct FastqText {   // the text of a FASTQ file as the scan sees it: the mapped
     uint64_t off = 0;               // text before this offset has been handed out as records (windowed scan of pa_process_reads)
     const char* map_base = nullptr; // the mapping as mmap returned it (data moves on when the rest of a file is rewritten)
     uint64_t map_size = 0;
+    int fd = -1;                    // of a mapped file: pa_process_reads reads its windows with pread (no page of the mapping is touched for them)
     void release() {
-        if (mapped) munmap((void*)map_base, map_size);
+        if (mapped) munmap((void*)map_base, map_size);   // (the whole mapping: nobody gives parts of it back any more)
+        if (fd >= 0) close(fd);
+        fd = -1;
         mapped = false;
         data = nullptr;
         fsize = 0;
@@ -237,6 +242,8 @@ int open_fastq(const char* fastq_path, FastqText& t) {
         mapped = true;
         t.map_base = data;
         t.map_size = fsize;
+        t.fd = fd;
+        return PA_OK;
     }
     close(fd);
     return PA_OK;
@@ -484,19 +491,222 @@ extern "C" int pa_fastq_scan_host(const char* fastq_path, int num_threads, uint6
     return rc;
 }
 
-extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads, uint64_t* n_reads_out,
-                                uint64_t* n_flagged_out) {
-    if (!idx || !fastq_path || !out_path) return fail(PA_ERR_INVALID_ARG, "null argument");
-    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+namespace {
+
+// f32 as Rust's `{}` prints it (the progress line of :497-503): the shortest digits that read back as the same float, never an exponent
+std::string rust_f32(float v) {
+    if (v != v) return "NaN";
+    if (v == 0.0f) return std::signbit(v) ? "-0" : "0";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[64];
+    int prec = 0;
+    for (; prec < 9; ++prec) {
+        snprintf(buf, sizeof buf, "%.*e", prec, (double)v);
+        if (strtof(buf, nullptr) == v) break;
+    }
+    // buf = [-]d[.ddd]e[+-]xx  ->  digits and a decimal exponent
+    std::string digits;
+    const char* q = buf;
+    const bool neg = *q == '-';
+    if (neg) ++q;
+    for (; *q && *q != 'e'; ++q)
+        if (*q != '.') digits.push_back(*q);
+    const int exp10 = atoi(q + 1);
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    std::string out = neg ? "-" : "";
+    const int nd = (int)digits.size();
+    if (exp10 < 0) {
+        out += "0.";
+        out.append((size_t)(-exp10 - 1), '0');
+        out += digits;
+    } else if (exp10 + 1 >= nd) {
+        out += digits;
+        out.append((size_t)(exp10 + 1 - nd), '0');
+    } else {
+        out += digits.substr(0, (size_t)exp10 + 1) + "." + digits.substr((size_t)exp10 + 1);
+    }
+    return out;
+}
+
+// ---- process_reads over WINDOWS of raw text ----
+// The host does not look at the text: worker threads read a window of the file into pinned memory (pread: one copy out of the page
+// cache, no page faults), the window goes to HBM as it is on a copy stream, the GPU finds its records (fastq_scan.hip) and the encode /
+// map / render kernels read sequences and ids where they lie. A window ends where the file offset says, not where a record does: the
+// scan reports how many bytes its whole records take, and the unfinished record is read once more as the HEAD of the next window.
+// Windows are dealt round-robin to LANES — one per index handle (pa_process_reads_multi: the GPUs of a node; the same handle twice
+// gives two streams on one GPU) — and their tuples are written in input order. What the GPU scan does not take goes through the
+// host's tolerant scan (scan_fastq) and the same in-place kernels: the last piece of the text (a missing final line break, trailing
+// blank lines, an empty last record) and text that is not in four-line shape (wrapped records: rewritten first).
+constexpr int LANE_SLOTS = 4;            // windows of a lane in flight: read | scan | map + render | write
+constexpr uint32_t FLAG_BUCKETS = PA_RENDER_FLAG_BUCKETS;
+
+struct Lane {
+    pa_index* idx = nullptr;
+    int device = 0;
+    IngestCache* cache = nullptr;
+    hipStream_t stream = nullptr, copy = nullptr;
+    int64_t unfinished = -1;             // the window whose kernels were launched last on `stream` and have not been waited for
+    uint64_t text_job[LANE_SLOTS] = {0, 0, 0, 0};   // the writer's job that reads the slot's pinned text (0: none)
+};
+
+struct Win {
+    uint64_t id = 0;
+    int lane = 0, slot = 0;
+    uint64_t from = 0;          // text offset of its first record
+    uint64_t first_read = 0;    // number of the reads before it
+};
+
+struct TextPipe {
+    const char* fastq_path;
+    FastqText& text;
+    Pool& pool;
+    Writer& writer;
+    std::vector<Lane>& lanes;
+    uint64_t batch_reads;
+    std::deque<Win> wins;       // launched or about to be, in order; the front is written first
+    uint64_t next_id = 0, launched_reads = 0, reported = 0, flagged = 0, next_report = 1000000;
+    double t_scan = 0, t_read = 0, t_wait = 0, t_launch = 0, t_text = 0, t_push = 0;
+    uint64_t gpu_windows = 0, host_windows = 0, rescans = 0;
+
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    int L() const { return (int)lanes.size(); }
+    Lane& lane_of(uint64_t id) { return lanes[(size_t)(id % (uint64_t)L())]; }
+    int slot_of(uint64_t id) const { return (int)((id / (uint64_t)L()) % LANE_SLOTS); }
+    BatchCtx& ctx_of(const Win& w) { return lanes[(size_t)w.lane].cache->ctx[w.slot]; }
+    int use(const Lane& l) { return hipSetDevice(l.device) == hipSuccess ? PA_OK : fail(PA_ERR_HIP, "hipSetDevice(%d) failed", l.device); }
+
+    // bytes [off, off + len) of the text into dst (pinned): pread for a file (no page of a mapping is touched), memcpy for text in memory
+    int read_text(uint64_t off, uint64_t len, uint8_t* dst) {
+        if (len == 0) return PA_OK;
+        const uint64_t PIECE = 2ull << 20;
+        const int ntask = (int)std::min<uint64_t>((len + PIECE - 1) / PIECE, 1u << 20);
+        std::atomic<int> bad{0};
+        auto piece = [&](int t) {
+            const uint64_t a = off + len * (uint64_t)t / (uint64_t)ntask, b = off + len * (uint64_t)(t + 1) / (uint64_t)ntask;
+            if (text.mapped && text.fd >= 0 && text.data == text.map_base) {
+                uint64_t p = a;
+                while (p < b) {
+                    const ssize_t got = pread(text.fd, dst + (p - off), (size_t)(b - p), (off_t)p);
+                    if (got < 0 && errno == EINTR) continue;
+                    if (got <= 0) { bad.store(1); return; }
+                    p += (uint64_t)got;
+                }
+            } else memcpy(dst + (a - off), text.data + a, (size_t)(b - a));
+        };
+        if (ntask == 1) piece(0);
+        else pool.run(ntask, piece);
+        return bad.load() ? fail(PA_ERR_IO, "%s: read failed: %s", fastq_path, strerror(errno)) : PA_OK;
+    }
+
+    // the kernels of the window launched before on this lane's stream: waited for (they share the stream's launch context inside the index)
+    int finish_lane(Lane& l) {
+        if (l.unfinished < 0) return PA_OK;
+        for (Win& w : wins)
+            if ((int64_t)w.id == l.unfinished) {
+                const double t0 = now();
+                int e = use(l);
+                if (e == PA_OK) e = batch_finish(l.idx, ctx_of(w), l.stream);
+                t_wait += now() - t0;
+                l.unfinished = -1;
+                return e;
+            }
+        l.unfinished = -1;
+        return PA_OK;
+    }
+
+    // the tuples of the windows whose kernels have been waited for: to the writer, in order, with the progress line of :497-503.
+    // upto: also wait for the kernels of every window with id < upto (all of them at the end of the text)
+    int retire_finished(uint64_t upto) {
+        while (!wins.empty()) {
+            Win& w = wins.front();
+            Lane& l = lanes[(size_t)w.lane];
+            if (l.unfinished == (int64_t)w.id) {
+                if (w.id >= upto) break;
+                const int e = finish_lane(l);
+                if (e != PA_OK) return e;
+            }
+            BatchCtx& c = ctx_of(w);
+            const double t0 = now();
+            int e = use(l);
+            if (e == PA_OK) e = batch_text_wait(c);
+            t_text += now() - t0;
+            if (e != PA_OK) return e;
+            uint64_t cum = 0, bucket = 0;
+            while (next_report <= w.first_read + c.n) {   // :497-503: the counts of exactly the first 10^6 m reads
+                if (bucket < FLAG_BUCKETS) cum += c.h_tot[1 + bucket];
+                ++bucket;
+                fprintf(stderr, "\rDone Mapping %llu reads w/ Rate: %s", (unsigned long long)next_report,
+                        rust_f32((float)(flagged + cum) * 100.0f / (float)next_report).c_str());
+                fflush(stderr);
+                next_report += 1000000;
+            }
+            flagged += c.flagged;
+            reported += c.n;
+            l.text_job[w.slot] = writer.push(c.h_text, c.text_bytes);
+            wins.pop_front();
+        }
+        return PA_OK;
+    }
+
+    // the slot of window `id`: the window that had it before (LANE_SLOTS windows of this lane earlier) has been handed to the writer
+    int acquire(uint64_t id, BatchCtx** out) {
+        const uint64_t span = (uint64_t)L() * LANE_SLOTS;
+        if (id >= span) {
+            const int e = retire_finished(id - span + 1);
+            if (e != PA_OK) return e;
+        }
+        Lane& l = lane_of(id);
+        BatchCtx& c = l.cache->ctx[slot_of(id)];
+        int e = use(l);
+        if (e != PA_OK) return e;
+        if ((e = window_ensure_events(c)) != PA_OK) return e;
+        *out = &c;
+        return PA_OK;
+    }
+
+    // index.map_read (:451) for the window's records (c.n of them, c.wpr words each, found by the GPU scan or filled in by the host)
+    int launch(Win& w) {
+        Lane& l = lanes[(size_t)w.lane];
+        BatchCtx& c = ctx_of(w);
+        int e = finish_lane(l);
+        if (e != PA_OK) return e;
+        if ((e = retire_finished(0)) != PA_OK) return e;
+        double t0 = now();
+        if (l.text_job[w.slot]) { writer.wait(l.text_job[w.slot]); l.text_job[w.slot] = 0; }   // (the launch ends with the speculative copy of the tuples into the slot's pinned text)
+        t_push += now() - t0; t0 = now();
+        if ((e = use(l)) != PA_OK) return e;
+        c.in_place = true;
+        w.first_read = launched_reads;
+        c.flag_mark = 1000000 - launched_reads % 1000000;
+        if ((e = batch_ensure(l.idx, c, c.n, c.wpr, std::min<uint64_t>(std::max<uint64_t>(c.n + c.n / 8, 1 << 16), std::max<uint64_t>(batch_reads, c.n)))) != PA_OK) return e;
+        if ((e = batch_launch(l.idx, c, l.stream)) != PA_OK) return e;
+        l.unfinished = (int64_t)w.id;
+        launched_reads += c.n;
+        t_launch += now() - t0;
+        return PA_OK;
+    }
+};
+
+constexpr int WIN_OK = 0, WIN_ODD = 1, WIN_EMPTY = 2;
+
+int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, const char* out_path, int num_threads, uint64_t* n_reads_out, uint64_t* n_flagged_out) {
+    if (!idxs || nidx < 1 || !fastq_path || !out_path) return fail(PA_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < nidx; ++i)
+        if (!idxs[i]) return fail(PA_ERR_INVALID_ARG, "null index handle");
+    const double t_enter = TextPipe::now();
     if (num_threads < 1) num_threads = 1;
     if (n_reads_out) *n_reads_out = 0;
     if (n_flagged_out) *n_flagged_out = 0;
-    const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
-    int device = 0;
-    index_host_classes(idx, &h_ec, &h_class_ref, &device);
-    HIP_OK(hipSetDevice(device));
+    {
+        pa_index_stats s0, si;
+        if (pa_index_get_stats(idxs[0], &s0) != PA_OK) return PA_ERR_INVALID_ARG;
+        for (int i = 1; i < nidx; ++i) {
+            if (pa_index_get_stats(idxs[i], &si) != PA_OK) return PA_ERR_INVALID_ARG;
+            if (si.k != s0.k || si.num_nodes != s0.num_nodes || si.num_classes != s0.num_classes || si.num_kmers != s0.num_kmers)
+                return fail(PA_ERR_INVALID_ARG, "handle %d is not a replica of handle 0 (k / nodes / classes / k-mers differ)", i);
+        }
+    }
 
-    // ---- map the file ----
     FastqText text;
     {
         const int orc = open_fastq(fastq_path, text);
@@ -511,183 +721,272 @@ extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const cha
 
     uint64_t BATCH_READS = DEFAULT_BATCH_READS;
     if (const char* v = getenv("PA_INGEST_BATCH")) { const long long x = atoll(v); if (x >= 64) BATCH_READS = (uint64_t)x / 64 * 64; }
+    uint64_t W = 128ull << 20;   // bytes of a window the GPU scans (PA_INGEST_WINDOW; never more than 256 bytes per read of a batch: the tests' small batches give small windows)
+    if (const char* v = getenv("PA_INGEST_WINDOW")) { const long long x = atoll(v); if (x >= 1) W = (uint64_t)x; }
+    W = std::min<uint64_t>(std::min<uint64_t>(W, BATCH_READS * 256), 1ull << 31);
     const bool verbose = getenv("PA_VERBOSE") != nullptr;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_text_wait = 0, t_scan = 0, t_pack = 0, t_finish = 0, t_launch = 0, t_format = 0, t_pack_rec = 0, t_pack_alloc = 0, t_pack_tiles = 0, t_push = 0;
-    const double t_begin = now();
+    const bool host_only = getenv("PA_INGEST_HOST_SCAN") != nullptr;   // (diagnosis: every window through the host's scan)
+    const double t_begin = TextPipe::now();
     Pool pool(num_threads);
-    const int T = pool.size();
     int rc = PA_OK;
-    uint64_t nrec = 0;
-    IngestCache* cache = static_cast<IngestCache*>(index_take_ingest_cache(idx));   // buffers of the previous call, if any
-    if (!cache) cache = new IngestCache();
-    std::vector<RecPos>& rec_pos = cache->rec_pos;
 
-    // ---- the text in windows (WindowScan): the scan of a window runs inside the pack stage of its first batch ----
-    WindowScan ws(text);
-    uint64_t wnext = 0;   // the next record of the window to be packed
-    // ---- batches ----
-    BatchCtx* const ctx = cache->ctx;
-    cache->idx = idx;
-    if (rc == PA_OK && !cache->stream && hipStreamCreate(&cache->stream) != hipSuccess) { cache->stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); }
-    const hipStream_t stream = cache->stream;
+    // ---- lanes: one per handle; buffers and streams of an earlier call are taken from the handle ----
+    std::vector<Lane> lanes((size_t)nidx);
+    for (int i = 0; i < nidx && rc == PA_OK; ++i) {
+        Lane& l = lanes[(size_t)i];
+        l.idx = idxs[i];
+        const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
+        index_host_classes(l.idx, &h_ec, &h_class_ref, &l.device);
+        if (hipSetDevice(l.device) != hipSuccess) { rc = fail(PA_ERR_HIP, "hipSetDevice(%d) failed", l.device); break; }
+        l.cache = static_cast<IngestCache*>(index_take_ingest_cache(l.idx));
+        if (!l.cache) l.cache = new IngestCache();
+        l.cache->idx = l.idx;
+        if (!l.cache->stream && hipStreamCreate(&l.cache->stream) != hipSuccess) { l.cache->stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); break; }
+        if (!l.cache->copy_stream && hipStreamCreate(&l.cache->copy_stream) != hipSuccess) { l.cache->copy_stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); break; }
+        l.stream = l.cache->stream;
+        l.copy = l.cache->copy_stream;
+    }
+
     Writer writer(out);
-    uint64_t flagged = 0, next_report = 1000000, reported = 0;
+    TextPipe tp{fastq_path, text, pool, writer, lanes, BATCH_READS};
+    const uint64_t fsize0 = text.fsize;
+    const uint64_t KEEP = std::max<uint64_t>(4096, std::min<uint64_t>(W / 4, 1ull << 20));   // the end of the text is the host's: its rules for the last record live there
+    uint64_t rec_start = 0;   // text offset of the first record no window has taken yet (known once the window before has been scanned)
+    uint64_t read_to = 0;     // text read so far
+    bool gpu_mode = rc == PA_OK && !host_only && fsize0 > KEEP;
+    bool have_pending = false;
+    Win pending;              // the window whose records the GPU is finding
 
-    // buffers are sized once, for the batches this FILE will need — a whole batch when the text goes on behind the window (the record
-    // stream shares the parked buffers and pushes whole batches: sized by the window alone they were regrown there, pinned memory and all)
-    auto ensure = [&](BatchCtx& c, uint64_t n, uint32_t wpr) -> int {
-        const uint64_t est = ws.size ? (uint64_t)((double)ws.nrec * (double)(text.fsize - (uint64_t)(ws.base - text.data)) / (double)ws.size) : ws.nrec;
-        return batch_ensure(idx, c, n, wpr, std::min<uint64_t>(BATCH_READS, std::max<uint64_t>(ws.nrec, est)));
-    };
-
-    // the next batch of the text into c: its records (of the current window, or the next one: scanned now), parsed + packed (parallel over
-    // whole tiles). c.n = 0 at the end of the text
-    auto pack = [&](BatchCtx& c) -> int {
-        c.n = 0;
-        if (wnext == ws.nrec) {
-            const double ts = now();
-            const int wr = ws.next(fastq_path, nrec, pool, rec_pos, cache->brk);
-            t_scan += now() - ts;
-            wnext = 0;
-            if (wr != PA_OK) return wr;
-            if (ws.nrec == 0) return PA_OK;
-        }
-        const char* const data = ws.base;
-        const uint64_t fsize = ws.size;
-        c.first = wnext;
-        c.n = std::min<uint64_t>(BATCH_READS, ws.nrec - wnext);
-        wnext += c.n;
-        nrec += c.n;
-        c.text_abs = ws.abs == ~0ull ? ~0ull : ws.abs + rec_pos[c.first].start;
-        double t0 = now();
-        c.recs.resize(c.n);
-        std::vector<uint32_t> tmax((size_t)T * 4, 0);
-        const int ntask = T * 4;
-        pool.run(ntask, [&](int t) {   // records + lengths: from what the scan noted, no byte of the text is touched here
-            uint32_t mx = 0;
-            for (uint64_t i = c.n * (uint64_t)t / ntask; i < c.n * (uint64_t)(t + 1) / ntask; ++i) {
-                const RecPos& rp = rec_pos[c.first + i];
-                Record& rec = c.recs[i];
-                rec.id_off = rp.start + 1;
-                rec.id_len = rp.id_len;
-                rec.seq_off = std::min<uint64_t>(rp.start + rp.hdr + 1, fsize);
-                rec.seq_len = (uint32_t)std::min<uint64_t>(rp.seq_len, fsize - rec.seq_off);
-                mx = std::max(mx, rec.seq_len);
-            }
-            tmax[(size_t)t] = mx;
-        });
-        uint32_t maxlen = 1;
-        for (uint32_t m : tmax) maxlen = std::max(maxlen, m);
-        if (maxlen > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
-        c.wpr = pa_words_per_read(maxlen);
-        std::vector<uint64_t> part;
-        batch_offsets(pool, c, part);
-        t_pack_rec += now() - t0; t0 = now();
-        const int e = ensure(c, c.n, c.wpr);
+    // the pending window's scan: waited for; its records are launched, the next window's first record is known
+    auto resolve = [&]() -> int {
+        Lane& l = lanes[(size_t)pending.lane];
+        BatchCtx& c = l.cache->ctx[pending.slot];
+        have_pending = false;
+        int e = tp.use(l);
         if (e != PA_OK) return e;
-        t_pack_alloc += now() - t0; t0 = now();
-        batch_gather_ascii(pool, c, data, part);   // the bytes of record.seq() (:449) for the GPU's DnaString::from_dna_string (:450)
-        t_pack_tiles += now() - t0;
-        return PA_OK;
-    };
-
-    auto launch = [&](BatchCtx& c) -> int { return batch_launch(idx, c, stream); };   // index.map_read (:451) for the whole batch
-    auto finish = [&](BatchCtx& c) -> int { return batch_finish(idx, c, stream); };
-
-    uint64_t unmapped_to = 0;   // bytes of the mapping already given back (page-aligned)
-    // The text of the batches already written goes back to the kernel piece by piece (unmapping 5 GB of page-cache mapping is 0.09 s of
-    // one thread's time): on a helper thread, so that no stage of the pipeline waits for it.
-    std::thread unmapper;
-    auto unmap_async = [&](uint64_t from, uint64_t to) {
-        if (unmapper.joinable()) unmapper.join();
-        const char* base = text.map_base;
-        unmapper = std::thread([base, from, to] { (void)munmap((void*)(base + from), to - from); });
-    };
-    int format_rc = PA_OK;
-    uint64_t text_job[2] = {0, 0};   // the writer's job that reads ctx[k].h_text (0: none)
-    auto format = [&](BatchCtx& c, int k) {
-        // the batch's tuples were rendered on the GPU (batch_finish -> render.hip) and are on their way to pinned memory: wait for them and
-        // hand them to the writer where they are (finish() of the batch after next waits for that job before the buffer is written again)
-        double tw = now();
-        if ((format_rc = batch_text_wait(c)) != PA_OK) return;
-        t_text_wait += now() - tw;
-        const uint64_t keep_from = (text.mapped && c.text_abs != ~0ull) ? (c.text_abs & ~4095ull) : 0;   // nothing before this batch is read again
-        if (keep_from > unmapped_to) { unmap_async(unmapped_to, keep_from); unmapped_to = keep_from; }
-        flagged += c.flagged;
-        reported += c.n;
-        while (reported >= next_report) {   // :497-503
-            fprintf(stderr, "\rDone Mapping %llu reads w/ Rate: %g", (unsigned long long)next_report,
-                    (double)((float)flagged * 100.0f / (float)reported));
-            next_report += 1000000;
+        for (int attempt = 0;; ++attempt) {
+            const double t0 = TextPipe::now();
+            if (hipEventSynchronize(c.ev_info) != hipSuccess) return fail(PA_ERR_HIP, "waiting for the FASTQ scan failed");
+            tp.t_wait += TextPipe::now() - t0;
+            if (!c.h_info->overflow) break;
+            if (attempt == 2) return fail(PA_ERR_INTERNAL, "FASTQ scan: line table too small after regrowing");
+            ++tp.rescans;   // more lines than guessed (short reads): grow the line table, fill it again from the counts already there
+            if ((e = window_ensure_scan(c, c.h_info->lines)) != PA_OK) return e;
+            if ((e = window_scan_enqueue(c, true, l.stream)) != PA_OK) return e;
         }
-        text_job[k] = writer.push(c.h_text, c.text_bytes);
+        if (c.h_info->odd) return WIN_ODD;
+        if (c.h_info->n == 0) return WIN_EMPTY;
+        if (c.h_info->max_seq > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
+        c.n = c.h_info->n;
+        c.wpr = pa_words_per_read(c.h_info->max_seq ? c.h_info->max_seq : 1);
+        rec_start = pending.from + c.h_info->consumed;
+        tp.wins.push_back(pending);
+        ++tp.gpu_windows;
+        return tp.launch(tp.wins.back());
     };
 
-    // pack(b) — and the scan of its window — overlaps GPU(b-1); format(b-1) overlaps GPU(b)
-    bool have_prev = false;
-    for (uint64_t b = 0; rc == PA_OK; ++b) {
-        BatchCtx& cur = ctx[b & 1];
-        BatchCtx& prev = ctx[(b + 1) & 1];
-        const int kp = (int)((b + 1) & 1);
-        double t0 = now();
-        const double scan_before = t_scan;
-        rc = pack(cur);
-        t_pack += now() - t0 - (t_scan - scan_before); t0 = now();
-        const bool have = rc == PA_OK && cur.n != 0;
-        if (rc == PA_OK && have_prev) rc = finish(prev);
-        t_finish += now() - t0; t0 = now();
-        if (rc == PA_OK && have) {
-            // the launch ends with the speculative copy of this batch's tuples into the context's pinned text buffer (batch_render_enqueue):
-            // the writer must be done with what the buffer held before — the text of batch b - 2
-            const int kc = (int)(b & 1);
-            if (text_job[kc]) { const double tw = now(); writer.wait(text_job[kc]); t_push += now() - tw; text_job[kc] = 0; }
-            rc = launch(cur);
+    try {
+    // ---- windows the GPU scans ----
+    while (rc == PA_OK && gpu_mode) {
+        if (read_to + KEEP >= text.fsize) { gpu_mode = false; break; }
+        const uint64_t main_len = std::min<uint64_t>(W, text.fsize - KEEP - read_to);
+        const uint64_t id = tp.next_id;
+        BatchCtx* cp = nullptr;
+        if ((rc = tp.acquire(id, &cp)) != PA_OK) break;
+        BatchCtx& c = *cp;
+        Lane& l = tp.lane_of(id);
+        if ((rc = window_ensure_raw(c, WINDOW_HEAD_ROOM + main_len)) != PA_OK) break;
+        double t0 = TextPipe::now();
+        if ((rc = tp.read_text(read_to, main_len, c.h_raw + WINDOW_HEAD_ROOM)) != PA_OK) break;
+        tp.t_read += TextPipe::now() - t0;
+        if (hipMemcpyAsync((uint8_t*)c.d_raw + WINDOW_HEAD_ROOM, c.h_raw + WINDOW_HEAD_ROOM, main_len, hipMemcpyHostToDevice, l.copy) != hipSuccess ||
+            hipEventRecord(c.ev_h2d, l.copy) != hipSuccess) { rc = fail(PA_ERR_HIP, "copy of a text window to the GPU failed"); break; }
+        const uint64_t main_from = read_to;
+        read_to += main_len;
+        bool discard = false;
+        if (have_pending) {
+            const int r = resolve();
+            if (r == WIN_ODD) { gpu_mode = false; discard = true; rec_start = pending.from; tp.next_id = pending.id; }               // not four-line text from here on: the host's scan takes over
+            else if (r == WIN_EMPTY) { W = std::max<uint64_t>(2 * W, 2 * (main_from - pending.from)); discard = true; rec_start = pending.from; tp.next_id = pending.id; }   // no whole record in the window: a longer one
+            else if (r != PA_OK) { rc = r; break; }
+            if (rc == PA_OK && (rc = tp.use(l)) != PA_OK) break;
         }
-        t_launch += now() - t0; t0 = now();
-        if (rc == PA_OK && have_prev) { format(prev, kp); rc = format_rc; }
-        t_format += now() - t0;
-        have_prev = have;
-        if (!have) break;
+        const uint64_t head = main_from - rec_start;   // the unfinished record of the window before
+        if (!discard && head > WINDOW_HEAD_ROOM) { W = std::max<uint64_t>(W, 2 * head); discard = true; }
+        if (discard) {   // this window's text is read again, from the first record not yet taken
+            (void)hipStreamSynchronize(l.copy);
+            read_to = rec_start;
+            if (W > (1ull << 31)) gpu_mode = false;   // (a record of gigabytes: the host's scan says what it is)
+            continue;
+        }
+        t0 = TextPipe::now();
+        if (head) {
+            if ((rc = tp.read_text(rec_start, head, c.h_raw + WINDOW_HEAD_ROOM - head)) != PA_OK) break;
+            if (hipMemcpyAsync((uint8_t*)c.d_raw + WINDOW_HEAD_ROOM - head, c.h_raw + WINDOW_HEAD_ROOM - head, head, hipMemcpyHostToDevice, l.stream) != hipSuccess) { rc = fail(PA_ERR_HIP, "copy of a window's head failed"); break; }
+        }
+        tp.t_read += TextPipe::now() - t0; t0 = TextPipe::now();
+        c.raw_begin = WINDOW_HEAD_ROOM - head;
+        c.raw_end = WINDOW_HEAD_ROOM + main_len;
+        if ((rc = window_ensure_scan(c, 0)) != PA_OK) break;
+        if (hipStreamWaitEvent(l.stream, c.ev_h2d, 0) != hipSuccess) { rc = fail(PA_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        if ((rc = window_scan_enqueue(c, false, l.stream)) != PA_OK) break;
+        tp.t_launch += TextPipe::now() - t0;
+        pending = Win();
+        pending.id = id;
+        pending.lane = (int)(id % (uint64_t)nidx);
+        pending.slot = tp.slot_of(id);
+        pending.from = rec_start;
+        have_pending = true;
+        tp.next_id = id + 1;
+        if ((rc = tp.retire_finished(0)) != PA_OK) break;
+    }
+    if (rc == PA_OK && have_pending) {
+        const int r = resolve();
+        if (r == WIN_ODD || r == WIN_EMPTY) { rec_start = pending.from; tp.next_id = pending.id; }
+        else if (r != PA_OK) rc = r;
+    }
+
+    // ---- the rest of the text (its end; all of it when it is not in four-line shape): the host's scan, the same kernels ----
+    if (rc == PA_OK) {
+        IngestCache* const hc = lanes[0].cache;   // (the scan's lists are parked with lane 0's buffers)
+        text.off = rec_start;
+        WindowScan ws(text);
+        uint64_t records_before = tp.launched_reads;
+        for (;;) {
+            double t0 = TextPipe::now();
+            rc = ws.next(fastq_path, records_before, pool, hc->rec_pos, hc->brk);
+            tp.t_scan += TextPipe::now() - t0;
+            if (rc != PA_OK || ws.nrec == 0) break;
+            records_before += ws.nrec;
+            const RecPos* const rp = hc->rec_pos.data();
+            for (uint64_t i0 = 0; i0 < ws.nrec && rc == PA_OK;) {
+                // a batch of whole records whose text fits a window of 2 GiB (offsets into it are 32 bits)
+                uint64_t i1 = std::min<uint64_t>(ws.nrec, i0 + BATCH_READS);
+                const uint64_t first = rp[i0].start;
+                auto end_of = [&](uint64_t i) { return i < ws.nrec ? rp[i].start : ws.size; };
+                while (i1 > i0 + 1 && end_of(i1) - first > (1ull << 31)) i1 = i0 + (i1 - i0) / 2;
+                const uint64_t bytes = end_of(i1) - first, n = i1 - i0;
+                if (bytes > (3ull << 30)) { rc = fail(PA_ERR_UNSUPPORTED, "%s: record %llu is longer than 3 GiB", fastq_path, (unsigned long long)(tp.launched_reads)); break; }
+                const uint64_t id = tp.next_id;
+                BatchCtx* cp = nullptr;
+                if ((rc = tp.acquire(id, &cp)) != PA_OK) break;
+                BatchCtx& c = *cp;
+                Lane& l = tp.lane_of(id);
+                if ((rc = window_ensure_raw(c, WINDOW_HEAD_ROOM + bytes)) != PA_OK) break;
+                if ((rc = window_ensure_recs(c, n, true)) != PA_OK) break;
+                t0 = TextPipe::now();
+                {   // the batch's text and where its records lie in it
+                    const char* const src = ws.base + first;
+                    const uint64_t PIECE = 2ull << 20;
+                    const int ntask = (int)std::max<uint64_t>(1, std::min<uint64_t>((bytes + PIECE - 1) / PIECE, 1u << 20));
+                    pool.run(ntask, [&](int t) {
+                        const uint64_t a = bytes * (uint64_t)t / (uint64_t)ntask, b = bytes * (uint64_t)(t + 1) / (uint64_t)ntask;
+                        memcpy(c.h_raw + WINDOW_HEAD_ROOM + a, src + a, (size_t)(b - a));
+                    });
+                }
+                const int T4 = pool.size() * 4;
+                std::vector<uint32_t> tmax((size_t)T4, 0);
+                pool.run(T4, [&](int t) {
+                    uint32_t mx = 0;
+                    for (uint64_t i = n * (uint64_t)t / (uint64_t)T4; i < n * (uint64_t)(t + 1) / (uint64_t)T4; ++i) {
+                        const RecPos& r = rp[i0 + i];
+                        const uint64_t seq_off = std::min<uint64_t>(r.start + r.hdr + 1, ws.size);
+                        const uint32_t seq_len = (uint32_t)std::min<uint64_t>(r.seq_len, ws.size - seq_off);
+                        c.h_rec[i] = make_uint4((uint32_t)(WINDOW_HEAD_ROOM + r.start + 1 - first), r.id_len, (uint32_t)(WINDOW_HEAD_ROOM + seq_off - first), seq_len);
+                        mx = std::max(mx, seq_len);
+                    }
+                    tmax[(size_t)t] = mx;
+                });
+                uint32_t maxlen = 1;
+                for (uint32_t m : tmax) maxlen = std::max(maxlen, m);
+                tp.t_read += TextPipe::now() - t0;
+                if (maxlen > PA_MAX_READ_LEN) { rc = fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN); break; }
+                // (the copies ride on the lane's kernel stream: this path is bound by the host's scan, not by the link)
+                if (hipMemcpyAsync((uint8_t*)c.d_raw + WINDOW_HEAD_ROOM, c.h_raw + WINDOW_HEAD_ROOM, bytes, hipMemcpyHostToDevice, l.stream) != hipSuccess ||
+                    hipMemcpyAsync(c.d_rec, c.h_rec, n * sizeof(uint4), hipMemcpyHostToDevice, l.stream) != hipSuccess) { rc = fail(PA_ERR_HIP, "copy of a text window to the GPU failed"); break; }
+                c.raw_begin = WINDOW_HEAD_ROOM;
+                c.raw_end = WINDOW_HEAD_ROOM + bytes;
+                c.n = n;
+                c.wpr = pa_words_per_read(maxlen);
+                Win w;
+                w.id = id;
+                w.lane = (int)(id % (uint64_t)nidx);
+                w.slot = tp.slot_of(id);
+                w.from = 0;
+                tp.next_id = id + 1;
+                tp.wins.push_back(w);
+                ++tp.host_windows;
+                rc = tp.launch(tp.wins.back());
+                i0 = i1;
+            }
+            if (rc != PA_OK) break;
+        }
+    }
+    if (rc == PA_OK) rc = tp.retire_finished(~0ull);
+    } catch (const std::bad_alloc&) {
+        rc = fail(PA_ERR_OOM, "out of host memory in pa_process_reads");
+    } catch (const std::exception& ex) {
+        rc = fail(PA_ERR_INTERNAL, "pa_process_reads: %s", ex.what());
     }
     {
         double* st = pa::ingest::last_stage_seconds();
-        st[0] = t_scan; st[1] = t_pack; st[2] = t_finish; st[3] = t_launch; st[4] = t_format; st[5] = t_push; st[6] = now() - t_begin; st[7] = (double)nrec;
+        st[0] = tp.t_scan; st[1] = tp.t_read; st[2] = tp.t_wait; st[3] = tp.t_launch; st[4] = tp.t_text; st[5] = tp.t_push; st[6] = TextPipe::now() - t_begin; st[7] = (double)tp.reported;
     }
     if (verbose)
-        fprintf(stderr, "\n[pa ingest] %llu reads, %d threads: scan %.3f s, pack %.3f s (records %.3f, alloc %.3f, tiles %.3f), wait GPU %.3f s, launch %.3f s, text %.3f s (waiting for the GPU's tuples %.3f; writer wait %.3f), total %.3f s\n",
-                (unsigned long long)nrec, T, t_scan, t_pack, t_pack_rec, t_pack_alloc, t_pack_tiles, t_finish, t_launch, t_format, t_text_wait, t_push, now() - t_begin);
-    double t0 = now();
-    if (stream) (void)hipStreamSynchronize(stream);   // (the stream stays with the parked buffers; IngestCache::destroy releases both)
-    const double t_stream = now() - t0; t0 = now();
-    const bool wrote = writer.finish();
-    const double t_writer = now() - t0; t0 = now();
-    if (rc == PA_OK && !wrote) rc = fail(PA_ERR_IO, "short write to %s", out_path);
-    if (cache->rec_pos.capacity() > ((size_t)64 << 20)) { std::vector<RecPos>().swap(cache->rec_pos); std::vector<std::vector<uint32_t>>().swap(cache->brk); }   // (do not park more than 1 GB of it)
-    if (rc == PA_OK) index_put_ingest_cache(idx, cache, IngestCache::destroy);   // the next call starts with warm buffers
-    else IngestCache::destroy(cache);
-    if (unmapper.joinable()) unmapper.join();
-    if (text.mapped && text.map_size > unmapped_to) {   // the rest of the mapping (the last batch's text): nobody reads it any more; given back without making the caller wait
-        const char* base = text.map_base;
-        const uint64_t from = unmapped_to, to = text.map_size;
-        text.mapped = false;
-        std::thread([base, from, to] { (void)munmap((void*)(base + from), to - from); }).detach();
+        fprintf(stderr, "\n[pa ingest] %llu reads, %d threads, %d lane(s): %llu windows scanned on the GPU (%llu scanned twice), %llu batches by the host; host scan %.3f s, read %.3f s, wait GPU %.3f s, launch %.3f s, wait text %.3f s, wait writer %.3f s, total %.3f s (before the first window %.3f s)\n",
+                (unsigned long long)tp.reported, pool.size(), nidx, (unsigned long long)tp.gpu_windows, (unsigned long long)tp.rescans, (unsigned long long)tp.host_windows, tp.t_scan, tp.t_read, tp.t_wait,
+                tp.t_launch, tp.t_text, tp.t_push, TextPipe::now() - t_begin, t_begin - t_enter);
+    if (tp.reported >= 1000000) fputc('\n', stderr);   // (`eprintln!()` behind the progress line, :508)
+    for (Lane& l : lanes) {
+        if (!l.cache) continue;
+        (void)hipSetDevice(l.device);
+        if (l.copy) (void)hipStreamSynchronize(l.copy);
+        if (l.stream) (void)hipStreamSynchronize(l.stream);   // (the streams stay with the parked buffers; IngestCache::destroy releases them)
     }
-    const double t_unmap = now() - t0; t0 = now();
+    bool wrote = true;
+    try { wrote = writer.finish(); } catch (...) { wrote = false; }
+    if (rc == PA_OK && !wrote) rc = fail(PA_ERR_IO, "short write to %s", out_path);
+    const std::string why = rc != PA_OK ? last_error_ref() : std::string();
+    for (Lane& l : lanes) {
+        if (!l.cache) continue;
+        (void)hipSetDevice(l.device);
+        if (l.cache->rec_pos.capacity() > ((size_t)64 << 20)) { std::vector<RecPos>().swap(l.cache->rec_pos); std::vector<std::vector<uint32_t>>().swap(l.cache->brk); }   // (do not park more than 1 GB of it)
+        if (rc == PA_OK) index_put_ingest_cache(l.idx, l.cache, IngestCache::destroy);   // the next call starts with warm buffers
+        else IngestCache::destroy(l.cache);
+        l.cache = nullptr;
+    }
+    text.release();
     if (out != stdout) { if (fclose(out) != 0 && rc == PA_OK) rc = fail(PA_ERR_IO, "close %s: %s", out_path, strerror(errno)); }
     else fflush(stdout);
-    if (verbose) {
-        struct rusage ru;
-        getrusage(RUSAGE_SELF, &ru);
-        fprintf(stderr, "[pa ingest] process CPU so far: user %.2f s, system %.2f s, minor faults %ld\n", ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec,
-                ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec, ru.ru_minflt);
-    }
-    if (verbose)
-        fprintf(stderr, "[pa ingest] teardown: stream %.3f s, writer %.3f s, unmap %.3f s, close %.3f s; before the scan %.3f s\n", t_stream, t_writer, t_unmap,
-                now() - t0, t_begin - t_enter);
-    if (n_reads_out) *n_reads_out = reported;
-    if (n_flagged_out) *n_flagged_out = flagged;
+    if (rc != PA_OK && !why.empty()) last_error_ref() = why;
+    if (n_reads_out) *n_reads_out = tp.reported;
+    if (n_flagged_out) *n_flagged_out = tp.flagged;
     return rc;
+}
+
+}  // namespace
+
+extern "C" int pa_process_reads(pa_index* idx, const char* fastq_path, const char* out_path, int num_threads, uint64_t* n_reads_out,
+                                uint64_t* n_flagged_out) {
+    pa_index* one[1] = {idx};
+    try {
+        return process_reads_impl(one, 1, fastq_path, out_path, num_threads, n_reads_out, n_flagged_out);
+    } catch (const std::bad_alloc&) {
+        return fail(PA_ERR_OOM, "out of host memory in pa_process_reads");
+    } catch (const std::exception& ex) {   // (thread creation: std::system_error) — nothing crosses the C ABI
+        return fail(PA_ERR_INTERNAL, "pa_process_reads: %s", ex.what());
+    }
+}
+
+extern "C" int pa_process_reads_multi(pa_index* const* idx, int n_idx, const char* fastq_path, const char* out_path, int num_threads, uint64_t* n_reads_out,
+                                      uint64_t* n_flagged_out) {
+    try {
+        return process_reads_impl(idx, n_idx, fastq_path, out_path, num_threads, n_reads_out, n_flagged_out);
+    } catch (const std::bad_alloc&) {
+        return fail(PA_ERR_OOM, "out of host memory in pa_process_reads_multi");
+    } catch (const std::exception& ex) {
+        return fail(PA_ERR_INTERNAL, "pa_process_reads_multi: %s", ex.what());
+    }
 }
 
 extern "C" int pa_process_reads_stage_seconds(double out[PA_INGEST_STAGES]) {

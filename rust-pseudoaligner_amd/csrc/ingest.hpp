@@ -4,7 +4,6 @@
 // (src/pseudoaligner.rs:455-461, :490). Pure host code around the C ABI's device entry points; header-only, internal.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <emmintrin.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -104,89 +103,6 @@ struct TextBuf {
         return mem.data() + len;
     }
 };
-typedef std::vector<TextBuf> TextSet;
-
-// Rust `impl Debug for str`: quotes, backslash escapes for \t \r \n \\ \" and \u{..} for other control bytes; at most
-// 6 * n + 2 bytes
-inline char* debug_str(char* o, const char* s, size_t n) {
-    *o++ = '"';
-    for (size_t i = 0; i < n; ++i) {
-        const unsigned char c = (unsigned char)s[i];
-        if (c >= 0x20 && c != 0x7f && c != '\\' && c != '"') { *o++ = (char)c; continue; }
-        *o++ = '\\';
-        switch (c) {
-            case '\t': *o++ = 't'; break;
-            case '\r': *o++ = 'r'; break;
-            case '\n': *o++ = 'n'; break;
-            case '\\': *o++ = '\\'; break;
-            case '"': *o++ = '"'; break;
-            default: o += snprintf(o, 8, "u{%x}", c);
-        }
-    }
-    *o++ = '"';
-    return o;
-}
-
-// decimal digits two at a time from a 200-byte table
-struct DigitPairs {
-    char d[200];
-    DigitPairs() { for (int i = 0; i < 100; ++i) { d[2 * i] = (char)('0' + i / 10); d[2 * i + 1] = (char)('0' + i % 10); } }
-};
-static const DigitPairs DIGIT_PAIRS;
-inline char* put_u32(char* o, uint32_t v) {
-    char b[10];
-    int n = 10;
-    while (v >= 100) { const uint32_t q = v / 100, r = v - q * 100; v = q; n -= 2; memcpy(b + n, DIGIT_PAIRS.d + 2 * r, 2); }
-    if (v >= 10) { n -= 2; memcpy(b + n, DIGIT_PAIRS.d + 2 * v, 2); }
-    else b[--n] = (char)('0' + v);
-    memcpy(o, b + n, (size_t)(10 - n));
-    return o + (10 - n);
-}
-
-template <size_t N>
-inline char* put_lit(char* o, const char (&lit)[N]) {   // a string literal, copied with its known length
-    memcpy(o, lit, N - 1);
-    return o + (N - 1);
-}
-inline char* put_str(char* o, const char* s) {
-    while (*s) *o++ = *s++;
-    return o;
-}
-
-// does the id need no escaping at all (the usual case)? eight bytes at a time: no byte below 0x20, none of 0x7f \\ "
-inline bool plain_text(const char* s, size_t n) {
-    const uint64_t ones = 0x0101010101010101ull, high = 0x8080808080808080ull;
-    auto haszero = [&](uint64_t x) { return (x - ones) & ~x & high; };
-    size_t i = 0;
-    uint64_t bad = 0;
-    for (; i + 8 <= n; i += 8) {
-        uint64_t x;
-        memcpy(&x, s + i, 8);
-        bad |= (x & high)                                   // bytes >= 0x80: left to the byte loop (which copies them)
-               | ((x - 0x20 * ones) & ~x & high)             // a byte below 0x20
-               | haszero(x ^ (0x7Full * ones)) | haszero(x ^ ((uint64_t)'\\' * ones)) | haszero(x ^ ((uint64_t)'"' * ones));
-    }
-    for (; i < n; ++i) {
-        const unsigned char c = (unsigned char)s[i];
-        bad |= (uint64_t)(c < 0x20 || c >= 0x7f || c == '\\' || c == '"');
-    }
-    return bad == 0;
-}
-inline char* debug_id(char* o, const char* s, size_t n) {
-    if (!plain_text(s, n)) return debug_str(o, s, n);
-    *o++ = '"';
-    memcpy(o, s, n);
-    o += n;
-    *o++ = '"';
-    return o;
-}
-
-// DnaString::from_dna_string (:450) as a table: A0 C1 G2 T3 in either case, anything else A
-struct BaseLut {
-    uint8_t v[256];
-    BaseLut() { memset(v, 0, sizeof v); v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; }
-};
-static const BaseLut BASE_LUT;
 
 struct Record {   // one record inside a text (the mapped FASTQ file, or the bytes a caller pushed): offsets into that text
     uint64_t id_off;
@@ -195,61 +111,49 @@ struct Record {   // one record inside a text (the mapped FASTQ file, or the byt
 };
 
 
-// sixteen bases -> 32 bits, the table of BaseLut in registers (SSE2): code = ((c >> 1) ^ (c >> 2)) & 3 is A0 C1 G2 T3 in either
-// case; every other byte becomes A like in the table
-inline uint32_t pack16(const uint8_t* p) {
-    const __m128i v = _mm_loadu_si128((const __m128i*)p);
-    __m128i t = _mm_and_si128(_mm_xor_si128(_mm_srli_epi16(v, 1), _mm_srli_epi16(v, 2)), _mm_set1_epi8(3));
-    const __m128i u = _mm_and_si128(v, _mm_set1_epi8((char)0xDF));
-    const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, _mm_set1_epi8('A')), _mm_cmpeq_epi8(u, _mm_set1_epi8('C'))),
-                                    _mm_or_si128(_mm_cmpeq_epi8(u, _mm_set1_epi8('G')), _mm_cmpeq_epi8(u, _mm_set1_epi8('T'))));
-    t = _mm_and_si128(t, ok);
-    t = _mm_and_si128(_mm_or_si128(t, _mm_srli_epi16(t, 6)), _mm_set1_epi16(0x000F));    // 2 bases per 16-bit lane
-    t = _mm_and_si128(_mm_or_si128(t, _mm_srli_epi32(t, 12)), _mm_set1_epi32(0x000000FF)); // 4 per 32-bit lane
-    t = _mm_or_si128(t, _mm_srli_epi64(t, 24));                                             // 8 per 64-bit lane (low 16 bits)
-    return ((uint32_t)_mm_cvtsi128_si32(t) & 0xFFFFu) | ((uint32_t)_mm_extract_epi16(t, 4) << 16);
-}
-
 struct BatchCtx {   // pinned host buffers + device buffers of one batch in flight
-    uint64_t* h_tiles = nullptr;
-    uint32_t* h_lens = nullptr;
-    pa_read_result* h_results = nullptr;
     void *d_tiles = nullptr, *d_lens = nullptr, *d_results = nullptr, *d_arena = nullptr;
-    // the batch's sequences as the records hold them (ASCII, back to back) and their offsets: the 2-bit packing into tiles runs on the
-    // GPU (pa_encode_reads_device), the host only gathers the bytes into pinned memory
+    // (a) record stream: the batch's sequences as the records hold them (ASCII, back to back) and their offsets: the 2-bit packing into
+    // tiles runs on the GPU (pa_encode_reads_device), the host only gathers the bytes into pinned memory
     uint8_t* h_ascii = nullptr;
     uint64_t* h_soff = nullptr;
     void *d_ascii = nullptr, *d_soff = nullptr;
-    size_t ascii_cap = 0, ascii_bytes = 0;
+    size_t ascii_cap = 0, ascii_bytes = 0, soff_cap = 0;
     // ... and the ids (record.id(), :456) for the render kernels (render.hip), which write the batch's output tuples: lengths, offsets
     // (d_off[n] = bytes of the whole text), the text itself, and its copy in pinned memory
     uint8_t* h_ids = nullptr;
     uint64_t* h_idoff = nullptr;
     void *d_ids = nullptr, *d_idoff = nullptr, *d_len = nullptr, *d_off = nullptr, *d_scan = nullptr, *d_flag = nullptr, *d_text = nullptr;
-    unsigned long long* h_tot = nullptr;   // pinned {text bytes, flagged reads}
+    unsigned long long* h_tot = nullptr;   // pinned {text bytes, flagged reads by bucket [PA_RENDER_FLAG_BUCKETS]}: bucket 0 = the reads before flag_mark, bucket j = the j-th million behind it
     char* h_text = nullptr;
     size_t ids_cap = 0, ids_bytes = 0, scan_bytes = 0, text_cap = 0, text_bytes = 0;
     size_t text_guess = 0, spec_bytes = 0;   // the text's expected length (from the batch before) and what was rendered + fetched ahead of knowing it
-    uint64_t flagged = 0;
+    uint64_t flagged = 0, flag_mark = 0;
     hipEvent_t ev_text = nullptr;
     size_t tiles_bytes = 0, arena_entries = 0, reads_cap = 0;
-    std::vector<uint32_t> h_arena;
     std::vector<Record> recs;
     uint64_t first = 0, n = 0;
-    uint64_t text_abs = ~0ull;   // pa_process_reads: where the batch's first record lies in the file's mapping (~0: not in one)
     uint32_t wpr = 1;
+    // (b) pa_process_reads: a WINDOW of the FASTQ text as the file holds it — pinned copy, copy in HBM — whose records are found where they
+    // lie: by the GPU (fastq_scan.hip: d_chunk / d_first / d_ls scratch, d_rec the records, d_info -> h_info what the host needs to go on) or,
+    // for text the GPU scan does not take (the end of the file, wrapped records), by the host's scan (h_rec). Sequences and ids are
+    // then read in place: no gather, no second copy
+    bool in_place = false;
+    uint8_t* h_raw = nullptr;
+    void* d_raw = nullptr;
+    size_t raw_cap = 0;
+    uint64_t raw_begin = 0, raw_end = 0;   // the window's bytes are [raw_begin, raw_end) of h_raw / d_raw
+    void *d_chunk = nullptr, *d_first = nullptr, *d_fq_tmp = nullptr, *d_ls = nullptr, *d_rec = nullptr, *d_info = nullptr;
+    size_t chunk_cap = 0, fq_tmp_bytes = 0, ls_cap = 0, rec_cap = 0, h_rec_cap = 0;
+    uint4* h_rec = nullptr;
+    FqInfo* h_info = nullptr;
+    hipEvent_t ev_h2d = nullptr, ev_info = nullptr;
     void release() {
-        if (h_tiles) (void)hipHostFree(h_tiles);
-        if (h_lens) (void)hipHostFree(h_lens);
-        if (h_results) (void)hipHostFree(h_results);
-        if (h_ascii) (void)hipHostFree(h_ascii);
-        if (h_soff) (void)hipHostFree(h_soff);
-        if (h_ids) (void)hipHostFree(h_ids);
-        if (h_idoff) (void)hipHostFree(h_idoff);
-        if (h_tot) (void)hipHostFree(h_tot);
-        if (h_text) (void)hipHostFree(h_text);
-        if (ev_text) (void)hipEventDestroy(ev_text);
-        for (void* p : {d_tiles, d_lens, d_results, d_arena, d_ascii, d_soff, d_ids, d_idoff, d_len, d_off, d_scan, d_flag, d_text})
+        for (void* p : {(void*)h_ascii, (void*)h_soff, (void*)h_ids, (void*)h_idoff, (void*)h_tot, (void*)h_text, (void*)h_raw, (void*)h_rec, (void*)h_info})
+            if (p) (void)hipHostFree(p);
+        for (hipEvent_t e : {ev_text, ev_h2d, ev_info})
+            if (e) (void)hipEventDestroy(e);
+        for (void* p : {d_tiles, d_lens, d_results, d_arena, d_ascii, d_soff, d_ids, d_idoff, d_len, d_off, d_scan, d_flag, d_text, d_raw, d_chunk, d_first, d_fq_tmp, d_ls, d_rec, d_info})
             if (p) (void)hipFree(p);
         *this = BatchCtx();
     }
@@ -269,19 +173,10 @@ inline int batch_ensure(pa_index* idx, BatchCtx& c, uint64_t n, uint32_t wpr, ui
     }
     if (n + 64 > c.reads_cap) {
         const size_t cap = cap_reads + 64;
-        if (c.h_results) (void)hipHostFree(c.h_results);
-        if (c.h_soff) (void)hipHostFree(c.h_soff);
-        if (c.h_idoff) (void)hipHostFree(c.h_idoff);
-        for (void** q : {&c.d_lens, &c.d_results, &c.d_soff, &c.d_idoff, &c.d_len, &c.d_off, &c.d_scan}) { if (*q) (void)hipFree(*q); *q = nullptr; }
-        c.h_results = nullptr; c.h_soff = nullptr; c.h_idoff = nullptr;
+        for (void** q : {&c.d_lens, &c.d_results, &c.d_len, &c.d_off, &c.d_scan}) { if (*q) (void)hipFree(*q); *q = nullptr; }
         c.reads_cap = 0;
-        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_results, cap * sizeof(pa_read_result), hipHostMallocDefault));
-        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_soff, (cap + 1) * 8, hipHostMallocDefault));
-        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_idoff, (cap + 1) * 8, hipHostMallocDefault));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_lens, cap * 4));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_results, cap * sizeof(pa_read_result)));
-        PA_INGEST_HIP_OK(hipMalloc(&c.d_soff, (cap + 1) * 8));
-        PA_INGEST_HIP_OK(hipMalloc(&c.d_idoff, (cap + 1) * 8));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_len, (cap + 1) * 4));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_off, (cap + 1) * 8));
         c.scan_bytes = render_scan_bytes(cap);
@@ -289,29 +184,44 @@ inline int batch_ensure(pa_index* idx, BatchCtx& c, uint64_t n, uint32_t wpr, ui
         c.reads_cap = cap;
     }
     if (!c.h_tot) {
-        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_tot, 16, hipHostMallocDefault));
-        PA_INGEST_HIP_OK(hipMalloc(&c.d_flag, 16));
+        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_tot, (1 + PA_RENDER_FLAG_BUCKETS) * 8, hipHostMallocDefault));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_flag, PA_RENDER_FLAG_BUCKETS * 8));
         PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_text, hipEventDisableTiming));
     }
-    if (c.ids_bytes + 64 > c.ids_cap) {
-        const size_t want = std::max<size_t>(c.ids_bytes + c.ids_bytes / 8 + 4096, (size_t)cap_reads * 16);
-        if (c.h_ids) (void)hipHostFree(c.h_ids);
-        if (c.d_ids) (void)hipFree(c.d_ids);
-        c.h_ids = nullptr; c.d_ids = nullptr;
-        c.ids_cap = 0;
-        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_ids, want, hipHostMallocDefault));
-        PA_INGEST_HIP_OK(hipMalloc(&c.d_ids, want));
-        c.ids_cap = want;
-    }
-    if (c.ascii_bytes + 64 > c.ascii_cap) {   // (ascii_bytes: set by the caller before this call — the sum of the batch's sequence lengths)
-        const size_t want = std::max<size_t>(c.ascii_bytes + c.ascii_bytes / 8 + 4096, (size_t)cap_reads * 32ull * wpr / 2);
-        if (c.h_ascii) (void)hipHostFree(c.h_ascii);
-        if (c.d_ascii) (void)hipFree(c.d_ascii);
-        c.h_ascii = nullptr; c.d_ascii = nullptr;
-        c.ascii_cap = 0;
-        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_ascii, want, hipHostMallocDefault));
-        PA_INGEST_HIP_OK(hipMalloc(&c.d_ascii, want));
-        c.ascii_cap = want;
+    if (!c.in_place) {   // gathered ids and sequences (record stream)
+        if (n + 64 > c.soff_cap) {
+            const size_t cap = cap_reads + 64;
+            if (c.h_soff) (void)hipHostFree(c.h_soff);
+            if (c.h_idoff) (void)hipHostFree(c.h_idoff);
+            for (void** q : {&c.d_soff, &c.d_idoff}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+            c.h_soff = nullptr; c.h_idoff = nullptr;
+            c.soff_cap = 0;
+            PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_soff, (cap + 1) * 8, hipHostMallocDefault));
+            PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_idoff, (cap + 1) * 8, hipHostMallocDefault));
+            PA_INGEST_HIP_OK(hipMalloc(&c.d_soff, (cap + 1) * 8));
+            PA_INGEST_HIP_OK(hipMalloc(&c.d_idoff, (cap + 1) * 8));
+            c.soff_cap = cap;
+        }
+        if (c.ids_bytes + 64 > c.ids_cap) {
+            const size_t want = std::max<size_t>(c.ids_bytes + c.ids_bytes / 8 + 4096, (size_t)cap_reads * 16);
+            if (c.h_ids) (void)hipHostFree(c.h_ids);
+            if (c.d_ids) (void)hipFree(c.d_ids);
+            c.h_ids = nullptr; c.d_ids = nullptr;
+            c.ids_cap = 0;
+            PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_ids, want, hipHostMallocDefault));
+            PA_INGEST_HIP_OK(hipMalloc(&c.d_ids, want));
+            c.ids_cap = want;
+        }
+        if (c.ascii_bytes + 64 > c.ascii_cap) {   // (ascii_bytes: set by the caller before this call — the sum of the batch's sequence lengths)
+            const size_t want = std::max<size_t>(c.ascii_bytes + c.ascii_bytes / 8 + 4096, (size_t)cap_reads * 32ull * wpr / 2);
+            if (c.h_ascii) (void)hipHostFree(c.h_ascii);
+            if (c.d_ascii) (void)hipFree(c.d_ascii);
+            c.h_ascii = nullptr; c.d_ascii = nullptr;
+            c.ascii_cap = 0;
+            PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_ascii, want, hipHostMallocDefault));
+            PA_INGEST_HIP_OK(hipMalloc(&c.d_ascii, want));
+            c.ascii_cap = want;
+        }
     }
     const uint64_t hint = pa_map_arena_hint(idx, n);
     if (hint > c.arena_entries) {
@@ -370,9 +280,10 @@ struct RecPos {   // where a record lies in the text and what of it counts: foun
 
 
 struct IngestCache {   // the two batches in flight of a pa_process_reads call or a record stream; parked on the index in between (pa_common.hpp)
-    BatchCtx ctx[2];
-    std::vector<RecPos> rec_pos;   // 24 bytes per record of the file: kept, or every call would page 200 MB in again
-    std::vector<std::vector<uint32_t>> brk;   // the scan's line-break lists (4 bytes per line), kept for the same reason
+    BatchCtx ctx[4];   // (a record stream uses the first two; pa_process_reads keeps four windows per lane in flight: read | scan | map + render | write)
+    std::vector<RecPos> rec_pos;   // 24 bytes per record of a host-scanned window: kept, or every call would page them in again
+    std::vector<std::vector<uint32_t>> brk;   // the host scan's line-break lists (4 bytes per line), kept for the same reason
+    hipStream_t copy_stream = nullptr;   // pa_process_reads: the windows' text goes to the GPU on a stream of its own, beside the kernels of the window before
     // the stream the batches run on travels with the buffers: its launch context inside the index (2 GB of list-mode rows)
     // is then reused by the next call instead of being stranded behind a destroyed stream
     pa_index* idx = nullptr;
@@ -380,6 +291,7 @@ struct IngestCache {   // the two batches in flight of a pa_process_reads call o
     static void destroy(void* p) {
         IngestCache* c = static_cast<IngestCache*>(p);
         for (BatchCtx& b : c->ctx) b.release();
+        if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
         if (c->stream) {
             if (c->idx) (void)pa_index_release_stream(c->idx, c->stream);
             (void)hipStreamDestroy(c->stream);
@@ -394,26 +306,110 @@ inline double* last_stage_seconds() {
     return st;
 }
 
+// ---- windows of raw text (pa_process_reads) ----
+constexpr uint64_t WINDOW_HEAD_ROOM = 1ull << 20;   // bytes in front of a window's own text for the unfinished last record of the window before
+
+// pinned + device copy of a window of up to `bytes` bytes (grow-only; 64 spare bytes: the scan kernels load whole 16-byte groups)
+inline int window_ensure_raw(BatchCtx& c, uint64_t bytes) {
+    if (bytes + 64 <= c.raw_cap) return PA_OK;
+    const size_t want = (size_t)bytes + 64;
+    if (c.h_raw) (void)hipHostFree(c.h_raw);
+    if (c.d_raw) (void)hipFree(c.d_raw);
+    c.h_raw = nullptr; c.d_raw = nullptr;
+    c.raw_cap = 0;
+    PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_raw, want, hipHostMallocDefault));
+    PA_INGEST_HIP_OK(hipMalloc(&c.d_raw, want));
+    c.raw_cap = want;
+    return PA_OK;
+}
+inline int window_ensure_events(BatchCtx& c) {
+    if (!c.ev_h2d) PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_h2d, hipEventDisableTiming));
+    if (!c.ev_info) PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_info, hipEventDisableTiming));
+    if (!c.h_info) {
+        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_info, sizeof(FqInfo), hipHostMallocDefault));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_info, sizeof(FqInfo)));
+    }
+    return PA_OK;
+}
+// records of a window: room for `recs` of them on the device (and in pinned memory when the host fills them in)
+inline int window_ensure_recs(BatchCtx& c, uint64_t recs, bool host_side) {
+    if (recs + 1 > c.rec_cap) {
+        const size_t want = (size_t)(recs + recs / 8 + 1024);
+        if (c.d_rec) (void)hipFree(c.d_rec);
+        c.d_rec = nullptr;
+        c.rec_cap = 0;
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_rec, want * sizeof(uint4)));
+        c.rec_cap = want;
+    }
+    if (host_side && recs + 1 > c.h_rec_cap) {
+        const size_t want = (size_t)(recs + recs / 8 + 1024);
+        if (c.h_rec) (void)hipHostFree(c.h_rec);
+        c.h_rec = nullptr;
+        c.h_rec_cap = 0;
+        PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_rec, want * sizeof(uint4), hipHostMallocDefault));
+        c.h_rec_cap = want;
+    }
+    return PA_OK;
+}
+// scratch of the GPU scan of the window [raw_begin, raw_end): chunk counts and prefixes, line starts for `lines` lines (0: a guess from the
+// window's size — FASTQ of 150-base reads has a line break per 79 bytes, of 60-base reads per 36)
+inline int window_ensure_scan(BatchCtx& c, uint64_t lines) {
+    int e = window_ensure_events(c);
+    if (e != PA_OK) return e;
+    const uint32_t chunks = fq_chunks(c.raw_begin, c.raw_end);
+    if ((size_t)chunks + 1 > c.chunk_cap) {
+        const size_t want = (size_t)chunks + chunks / 8 + 64;
+        for (void** q : {&c.d_chunk, &c.d_first, &c.d_fq_tmp}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        c.chunk_cap = 0;
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_chunk, want * 4));
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_first, want * 4));
+        c.fq_tmp_bytes = fq_scan_tmp_bytes((uint32_t)want);
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_fq_tmp, c.fq_tmp_bytes ? c.fq_tmp_bytes : 16));
+        c.chunk_cap = want;
+    }
+    const uint64_t need = lines ? lines + 8 : (c.raw_end - c.raw_begin) / 32 + 1024;
+    if (need > c.ls_cap) {
+        const size_t want = (size_t)(need + need / 8);
+        if (c.d_ls) (void)hipFree(c.d_ls);
+        c.d_ls = nullptr;
+        c.ls_cap = 0;
+        PA_INGEST_HIP_OK(hipMalloc(&c.d_ls, want * 4));
+        c.ls_cap = want;
+    }
+    return window_ensure_recs(c, c.ls_cap / 4, false);
+}
+// the window's records found on the GPU, asynchronous on `stream`: c.h_info is valid once c.ev_info has passed
+inline int window_scan_enqueue(BatchCtx& c, bool rescan, hipStream_t stream) {
+    const int k = launch_fq_scan((const uint8_t*)c.d_raw, c.raw_begin, c.raw_end, (uint32_t*)c.d_chunk, (uint32_t*)c.d_first, c.d_fq_tmp, c.fq_tmp_bytes, (uint32_t*)c.d_ls, c.ls_cap,
+                                 (uint4*)c.d_rec, c.rec_cap, (FqInfo*)c.d_info, rescan, stream);
+    if (k) return fail(PA_ERR_HIP, "FASTQ scan: %s", hipGetErrorString((hipError_t)k));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_info, c.d_info, sizeof(FqInfo), hipMemcpyDeviceToHost, stream));
+    PA_INGEST_HIP_OK(hipEventRecord(c.ev_info, stream));
+    return PA_OK;
+}
+
 // The batch's output tuples (:455-461, :490) rendered where the records, the class table and the novel class ids are (render.hip):
 // lengths + scan (d_off[n] = the text's bytes, copied to h_tot with the number of flagged reads), then — when buffers exist — the
 // bytes and their copy to pinned memory, c.spec_bytes of them: a guess from the batch before (the host only learns the exact length
 // when the batch is finished; a text that turns out longer is rendered again by batch_finish)
+inline const uint8_t* batch_id_bytes(const BatchCtx& c) { return (const uint8_t*)(c.in_place ? c.d_raw : c.d_ids); }
+inline const uint4* batch_rec(const BatchCtx& c) { return c.in_place ? (const uint4*)c.d_rec : nullptr; }
 inline int batch_render_enqueue(pa_index* idx, BatchCtx& c, hipStream_t stream) {
     const uint64_t* d_cls_off = nullptr;
     const uint8_t* d_cls_txt = nullptr;
     int e = index_device_class_text(idx, &d_cls_off, &d_cls_txt);
     if (e != PA_OK) return e;
-    PA_INGEST_HIP_OK(hipMemsetAsync(c.d_flag, 0, 8, stream));
-    int k = launch_render_len((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n, c.arena_entries,
-                              (uint32_t*)c.d_len, (uint64_t*)c.d_off, (unsigned long long*)c.d_flag, c.d_scan, c.scan_bytes, stream);
+    PA_INGEST_HIP_OK(hipMemsetAsync(c.d_flag, 0, PA_RENDER_FLAG_BUCKETS * 8, stream));
+    int k = launch_render_len((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, batch_id_bytes(c), (const uint64_t*)c.d_idoff, batch_rec(c), d_cls_off, d_cls_txt, c.n,
+                              c.arena_entries, c.flag_mark, (uint32_t*)c.d_len, (uint64_t*)c.d_off, (unsigned long long*)c.d_flag, c.d_scan, c.scan_bytes, stream);
     if (k) return fail(PA_ERR_HIP, "render (lengths): %s", hipGetErrorString((hipError_t)k));
     PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_tot, (const uint64_t*)c.d_off + c.n, 8, hipMemcpyDeviceToHost, stream));
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_tot + 1, c.d_flag, 8, hipMemcpyDeviceToHost, stream));
+    PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_tot + 1, c.d_flag, PA_RENDER_FLAG_BUCKETS * 8, hipMemcpyDeviceToHost, stream));
     c.spec_bytes = 0;
     if (c.text_cap && c.text_guess) {
         c.spec_bytes = std::min(c.text_cap, c.text_guess);
-        k = launch_render_write((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n, c.arena_entries,
-                                (const uint64_t*)c.d_off, (uint8_t*)c.d_text, c.spec_bytes, stream);
+        k = launch_render_write((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, batch_id_bytes(c), (const uint64_t*)c.d_idoff, batch_rec(c), d_cls_off, d_cls_txt, c.n,
+                                c.arena_entries, (const uint64_t*)c.d_off, (uint8_t*)c.d_text, c.spec_bytes, stream);
         if (k) return fail(PA_ERR_HIP, "render (text): %s", hipGetErrorString((hipError_t)k));
         PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_text, c.d_text, c.spec_bytes, hipMemcpyDeviceToHost, stream));
     }
@@ -421,12 +417,17 @@ inline int batch_render_enqueue(pa_index* idx, BatchCtx& c, hipStream_t stream) 
 }
 
 inline int batch_launch(pa_index* idx, BatchCtx& c, hipStream_t stream) {
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_ascii, c.h_ascii, c.ascii_bytes, hipMemcpyHostToDevice, stream));
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_soff, c.h_soff, (c.n + 1) * 8, hipMemcpyHostToDevice, stream));
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_ids, c.h_ids, c.ids_bytes, hipMemcpyHostToDevice, stream));
-    PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_idoff, c.h_idoff, (c.n + 1) * 8, hipMemcpyHostToDevice, stream));
-    const int e0 = pa_encode_reads_device(idx, (const uint8_t*)c.d_ascii, (const uint64_t*)c.d_soff, c.n, c.wpr, (uint64_t*)c.d_tiles, (uint32_t*)c.d_lens, stream);   // :450
-    if (e0 != PA_OK) return e0;
+    if (c.in_place) {   // sequences and ids are read where they lie in the window's text (already in HBM, records in d_rec)
+        const int k = launch_encode_rec((const uint8_t*)c.d_raw, (const uint4*)c.d_rec, c.n, c.wpr, (uint64_t*)c.d_tiles, (uint32_t*)c.d_lens, stream);   // :450
+        if (k) return fail(PA_ERR_HIP, "encode launch: %s", hipGetErrorString((hipError_t)k));
+    } else {
+        PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_ascii, c.h_ascii, c.ascii_bytes, hipMemcpyHostToDevice, stream));
+        PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_soff, c.h_soff, (c.n + 1) * 8, hipMemcpyHostToDevice, stream));
+        PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_ids, c.h_ids, c.ids_bytes, hipMemcpyHostToDevice, stream));
+        PA_INGEST_HIP_OK(hipMemcpyAsync(c.d_idoff, c.h_idoff, (c.n + 1) * 8, hipMemcpyHostToDevice, stream));
+        const int e0 = pa_encode_reads_device(idx, (const uint8_t*)c.d_ascii, (const uint64_t*)c.d_soff, c.n, c.wpr, (uint64_t*)c.d_tiles, (uint32_t*)c.d_lens, stream);   // :450
+        if (e0 != PA_OK) return e0;
+    }
     const int e = pa_map_batch_device(idx, (const uint64_t*)c.d_tiles, (const uint32_t*)c.d_lens, c.n, c.wpr, PA_DEFAULT_ALLOWED_MISMATCHES,
                                       (pa_read_result*)c.d_results, (uint32_t*)c.d_arena, c.arena_entries, nullptr, stream);
     if (e != PA_OK) return e;
@@ -449,7 +450,8 @@ inline int batch_finish(pa_index* idx, BatchCtx& c, hipStream_t stream) {
     if (e != PA_OK) return e;
     // (pa_map_finish synchronised the stream: the lengths — and the speculative text, if any — have arrived)
     c.text_bytes = (size_t)c.h_tot[0];
-    c.flagged = c.h_tot[1];
+    c.flagged = 0;
+    for (uint32_t j = 0; j < PA_RENDER_FLAG_BUCKETS; ++j) c.flagged += c.h_tot[1 + j];
     c.text_guess = c.text_bytes + c.text_bytes / 8 + (64 << 10);
     if (c.text_bytes > c.spec_bytes) {   // no guess yet (first batches) or a text longer than guessed: size the buffers, write it, fetch it
         if (c.text_bytes + 64 > c.text_cap) {
@@ -465,8 +467,8 @@ inline int batch_finish(pa_index* idx, BatchCtx& c, hipStream_t stream) {
         const uint64_t* d_cls_off = nullptr;
         const uint8_t* d_cls_txt = nullptr;
         if ((e = index_device_class_text(idx, &d_cls_off, &d_cls_txt)) != PA_OK) return e;
-        const int k = launch_render_write((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, (const uint8_t*)c.d_ids, (const uint64_t*)c.d_idoff, d_cls_off, d_cls_txt, c.n, c.arena_entries,
-                                          (const uint64_t*)c.d_off, (uint8_t*)c.d_text, c.text_cap, stream);
+        const int k = launch_render_write((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, batch_id_bytes(c), (const uint64_t*)c.d_idoff, batch_rec(c), d_cls_off, d_cls_txt, c.n,
+                                          c.arena_entries, (const uint64_t*)c.d_off, (uint8_t*)c.d_text, c.text_cap, stream);
         if (k) return fail(PA_ERR_HIP, "render (text): %s", hipGetErrorString((hipError_t)k));
         if (c.text_bytes) PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_text, c.d_text, c.text_bytes, hipMemcpyDeviceToHost, stream));
     }

@@ -89,13 +89,33 @@ int launch_simulate(const uint64_t* packed, const uint64_t* tx_start, const uint
 int launch_count(const pa_read_result* results, const uint32_t* arena, const uint32_t* colour, uint64_t n, const DevIndexView& ix,
                  const uint32_t* class_table, uint64_t class_table_size, unsigned long long* counts, hipStream_t stream);
 
-// the reference's output tuples rendered on the GPU (render.hip)
+// the reference's output tuples rendered on the GPU (render.hip). The ids are either back to back with offsets (d_id_off[n + 1], d_rec == nullptr)
+// or where they lie in a window's text: d_rec[i] = {id offset, id length, sequence offset, sequence length} into d_ids (fastq_scan.hip).
+// d_flagged[PA_RENDER_FLAG_BUCKETS]: reads flagged by the rule of :455 — [0] += those among the first `flag_mark` reads of the batch, [j] += those
+// of the j-th million behind them (the progress line of :497-503 is printed with the counts of exactly the first 10^6 m reads).
+constexpr uint32_t PA_RENDER_FLAG_BUCKETS = 64;
 size_t render_scan_bytes(uint64_t n);
-int launch_render_len(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint64_t* d_cls_off,
-                      const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, uint32_t* d_len, uint64_t* d_off, unsigned long long* d_flagged, void* d_tmp, size_t tmp_bytes,
-                      hipStream_t stream);
-int launch_render_write(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint64_t* d_cls_off,
+int launch_render_len(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint4* d_rec, const uint64_t* d_cls_off,
+                      const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, uint64_t flag_mark, uint32_t* d_len, uint64_t* d_off, unsigned long long* d_flagged, void* d_tmp,
+                      size_t tmp_bytes, hipStream_t stream);
+int launch_render_write(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint4* d_rec, const uint64_t* d_cls_off,
                         const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, const uint64_t* d_off, uint8_t* d_text, uint64_t text_cap, hipStream_t stream);
+
+// record finding on the GPU (fastq_scan.hip): what the host learns about a window of FASTQ text
+struct FqInfo {
+    uint64_t lines;      // line breaks in the window
+    uint64_t n;          // whole records (lines / 4)
+    uint64_t consumed;   // bytes they take: the next window's first record starts here
+    uint32_t max_seq;    // longest record.seq()
+    uint32_t odd;        // a first line without '@' or a third without '+': not four-line text (the host scans it with its tolerant rules)
+    uint32_t overflow;   // line_start / rec were too small for `lines` / `n`: grow them and scan again
+    uint32_t pad;
+};
+uint32_t fq_chunks(uint64_t begin, uint64_t end);
+size_t fq_scan_tmp_bytes(uint32_t n_chunks);
+int launch_fq_scan(const uint8_t* d_text, uint64_t begin, uint64_t end, uint32_t* d_chunk, uint32_t* d_first, void* d_tmp, size_t tmp_bytes, uint32_t* d_line_start,
+                   uint64_t cap_lines, uint4* d_rec, uint64_t cap_recs, FqInfo* d_info, bool rescan, hipStream_t stream);
+int launch_encode_rec(const uint8_t* d_text, const uint4* d_rec, uint64_t n, uint32_t wpr, uint64_t* tiles, uint32_t* lens, hipStream_t stream);
 
 // per-barcode counts (barcode_counts.hip)
 int barcode_counts(const DevIndexView& ix, const uint32_t* class_table, uint64_t class_table_size, const pa_read_result* d_results,

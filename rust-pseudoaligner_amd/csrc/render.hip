@@ -9,8 +9,9 @@
 //
 // A class that IS an index class (pa_read_result.class_off & PA_CLASS_REF) is copied from the index's table of rendered classes
 // (device copy of index_host_class_text: every class as "1, 5, 9", built once per index); any other class is rendered from its
-// ids in the arena. Ids follow Rust's `impl Debug for str` as far as ingest.hpp's debug_str does: \t \r \n \\ \" escaped, other
-// control bytes as \u{hex}, everything from 0x20 on (but 0x7f) copied.
+// ids in the arena. Ids follow Rust's `impl Debug for str` for ASCII: \t \r \n \\ \" \0 escaped, other control bytes as \u{hex},
+// everything from 0x20 on (but 0x7f) copied — bytes from 0x80 on too: the few non-printable code points beyond ASCII (U+0085, U+00A0 ...),
+// which Rust prints as \u{..}, are copied as they are (documented limitation).
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_scan.hpp>
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ uint8_t* put_dec(uint8_t* o, uint32_t v) {
 // bytes one byte of an id takes inside the quotes
 __device__ __forceinline__ uint32_t esc_len(uint8_t c) {
     if (c >= 0x20 && c != 0x7f && c != '\\' && c != '"') return 1;
-    if (c == '\t' || c == '\r' || c == '\n' || c == '\\' || c == '"') return 2;
+    if (c == '\t' || c == '\r' || c == '\n' || c == '\\' || c == '"' || c == 0) return 2;   // (char::escape_debug prints NUL as \0)
     return c < 0x10 ? 5u : 6u;   // \u{f} / \u{1f}
 }
 __device__ __forceinline__ uint8_t* put_esc(uint8_t* o, uint8_t c) {
@@ -46,6 +47,7 @@ __device__ __forceinline__ uint8_t* put_esc(uint8_t* o, uint8_t c) {
         case '\n': *o++ = 'n'; break;
         case '\\': *o++ = '\\'; break;
         case '"': *o++ = '"'; break;
+        case 0: *o++ = '0'; break;
         default: {
             *o++ = 'u'; *o++ = '{';
             const uint8_t hi = c >> 4, lo = c & 15;
@@ -61,13 +63,19 @@ struct RenderArgs {
     const pa_read_result* results;
     const uint32_t* arena;
     const uint8_t* ids;           // the reads' ids back to back
-    const uint64_t* id_off;       // [n + 1]
+    const uint64_t* id_off;       // [n + 1]; or
+    const uint4* rec;             // [n] {id offset, id length, -, -} into `ids` (a window's text, fastq_scan.hip) when not null
     const uint64_t* cls_off;      // [num_classes + 1] into cls_txt
     const uint8_t* cls_txt;
     uint64_t n;
+    uint64_t flag_mark;           // flagged reads among the first flag_mark count in n_flagged[0], those of the j-th million behind them in n_flagged[j]
     uint64_t arena_cap;           // entries of `arena`: a launch whose arena overflowed leaves records that point beyond it (the host maps that batch
                                   // again with a larger one, PA_ERR_ARENA_FULL); such a class is rendered as empty here, never read
 };
+__device__ __forceinline__ void id_range(const RenderArgs& a, uint64_t i, uint64_t& b, uint64_t& e) {
+    if (a.rec) { const uint4 q = a.rec[i]; b = q.x; e = (uint64_t)q.x + q.y; }
+    else { b = a.id_off[i]; e = a.id_off[i + 1]; }
+}
 __device__ __forceinline__ uint32_t arena_len(const RenderArgs& a, const pa_read_result& r) {
     return (uint64_t)r.class_off + r.class_len <= a.arena_cap ? r.class_len : 0u;
 }
@@ -87,7 +95,8 @@ __global__ __launch_bounds__(256) void pa_render_len_kernel(const RenderArgs a, 
             const bool flag = flag_of(r);
             flagged = flag;
             l = (flag ? 7u : 8u) + 2u;                                        // "(true, " / "(false, " and the id's quotes
-            const uint64_t b = a.id_off[i], e = a.id_off[i + 1];
+            uint64_t b, e;
+            id_range(a, i, b, e);
             for (uint64_t j = b; j < e; ++j) l += esc_len(a.ids[j]);
             l += 3u;                                                          // ", ["
             if (r.class_off & PA_CLASS_REF) {
@@ -102,9 +111,14 @@ __global__ __launch_bounds__(256) void pa_render_len_kernel(const RenderArgs a, 
         }
         len[i] = l;                                                           // (len[n] = 0: the scan's last entry is the total)
     }
-    // flagged reads of the block -> one atomic
-    const unsigned long long m = __ballot(flagged);
-    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_flagged, (unsigned long long)__popcll(m));
+    // flagged reads -> their bucket (a wave's 64 consecutive reads touch at most two): one atomic per wave and bucket
+    const uint32_t bucket = i < a.flag_mark ? 0u : (uint32_t)min((uint64_t)PA_RENDER_FLAG_BUCKETS - 1, 1 + (i - a.flag_mark) / 1000000ull);
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bucket);
+    const unsigned long long m0 = __ballot(flagged && bucket == b0), m1 = __ballot(flagged && bucket != b0);
+    if ((threadIdx.x & 63u) == 0) {
+        if (m0) atomicAdd(n_flagged + b0, (unsigned long long)__popcll(m0));
+        if (m1) atomicAdd(n_flagged + min(b0 + 1, PA_RENDER_FLAG_BUCKETS - 1), (unsigned long long)__popcll(m1));
+    }
 }
 
 __global__ __launch_bounds__(256) void pa_render_write_kernel(const RenderArgs a, const uint64_t* __restrict__ off, uint8_t* __restrict__ text, uint64_t cap) {
@@ -116,7 +130,9 @@ __global__ __launch_bounds__(256) void pa_render_write_kernel(const RenderArgs a
     if (flag_of(r)) { const char s[] = "(true, "; for (int k = 0; k < 7; ++k) *o++ = (uint8_t)s[k]; }
     else { const char s[] = "(false, "; for (int k = 0; k < 8; ++k) *o++ = (uint8_t)s[k]; }
     *o++ = '"';
-    for (uint64_t j = a.id_off[i], e = a.id_off[i + 1]; j < e; ++j) o = put_esc(o, a.ids[j]);
+    uint64_t ib, ie;
+    id_range(a, i, ib, ie);
+    for (uint64_t j = ib; j < ie; ++j) o = put_esc(o, a.ids[j]);
     *o++ = '"'; *o++ = ','; *o++ = ' '; *o++ = '[';
     if (r.class_off & PA_CLASS_REF) {
         const uint32_t c = r.class_off & ~PA_CLASS_REF;
@@ -145,10 +161,10 @@ size_t render_scan_bytes(uint64_t n) {
 }
 
 // lengths + offsets of the tuples of a finished batch: d_len[n + 1], d_off[n + 1] (d_off[n] = bytes of the whole text), *d_flagged += flagged reads
-int launch_render_len(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint64_t* d_cls_off,
-                      const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, uint32_t* d_len, uint64_t* d_off, unsigned long long* d_flagged, void* d_tmp, size_t tmp_bytes,
-                      hipStream_t stream) {
-    const RenderArgs a{d_results, d_arena, d_ids, d_id_off, d_cls_off, d_cls_txt, n, arena_cap};
+int launch_render_len(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint4* d_rec, const uint64_t* d_cls_off,
+                      const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, uint64_t flag_mark, uint32_t* d_len, uint64_t* d_off, unsigned long long* d_flagged, void* d_tmp,
+                      size_t tmp_bytes, hipStream_t stream) {
+    const RenderArgs a{d_results, d_arena, d_ids, d_id_off, d_rec, d_cls_off, d_cls_txt, n, flag_mark, arena_cap};
     hipLaunchKernelGGL(pa_render_len_kernel, dim3((uint32_t)((n + 1 + 255) / 256)), dim3(256), 0, stream, a, d_len, d_flagged);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -156,10 +172,10 @@ int launch_render_len(const pa_read_result* d_results, const uint32_t* d_arena, 
     return (int)e;
 }
 
-int launch_render_write(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint64_t* d_cls_off,
+int launch_render_write(const pa_read_result* d_results, const uint32_t* d_arena, const uint8_t* d_ids, const uint64_t* d_id_off, const uint4* d_rec, const uint64_t* d_cls_off,
                         const uint8_t* d_cls_txt, uint64_t n, uint64_t arena_cap, const uint64_t* d_off, uint8_t* d_text, uint64_t text_cap, hipStream_t stream) {
     if (n == 0) return 0;
-    const RenderArgs a{d_results, d_arena, d_ids, d_id_off, d_cls_off, d_cls_txt, n, arena_cap};
+    const RenderArgs a{d_results, d_arena, d_ids, d_id_off, d_rec, d_cls_off, d_cls_txt, n, 0, arena_cap};
     hipLaunchKernelGGL(pa_render_write_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, a, d_off, d_text, text_cap);
     return (int)hipGetLastError();
 }

@@ -20,7 +20,7 @@ def rust_type_to_c(t: str) -> str:
         inner = rust_type_to_c(m.group(2))
         if m.group(1) == "const":
             # const applies to the pointee
-            return ("const " + inner + "*") if not inner.endswith("*") else (inner + " const*")
+            return ("const " + inner + "*") if not inner.endswith("*") else (inner + "const*")   # (`T*const*`: as the header's side is normalised)
         return inner + "*"
     if t not in RUST_SCALARS:
         raise ValueError("unmapped Rust type %r" % t)

@@ -1,0 +1,162 @@
+"""`-m gpu` tier of the window pipeline behind pa_process_reads / pa_process_reads_multi (src/pseudoaligner.rs:420-514): windows of raw
+FASTQ text go to HBM as the file holds them, the GPU finds the records (csrc/fastq_scan.hip), sequences and ids are read in place.
+Whatever the window size, the number of lanes, and whether the GPU or the host finds the records: the same bytes come out, and they
+are the oracle's tuples."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+pa = helpers.pa
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aligner(small_index):
+    if pa.lib().pa_device_count() < 1:
+        raise RuntimeError("the gpu tier needs a GPU and the HIP library: %s" % pa.lib().pa_last_error().decode())
+    return pa.Pseudoaligner(small_index(24), 0)
+
+
+def expected_lines(a, ids, seqs):
+    res, coff, cids, _ = helpers.Oracle(a.host).map_reads(seqs, 2, 8)
+    want = []
+    for i, rid in enumerate(ids):
+        cl = cids[int(coff[i]):int(coff[i + 1])].tolist()
+        flag = bool(res["mapped"][i]) and res["coverage"][i] >= 32 and not cl
+        want.append('(%s, "%s", [%s], %d)' % ("true" if flag else "false", rid, ", ".join(map(str, cl)), res["coverage"][i] if res["mapped"][i] else 0))
+    return want
+
+
+def make_reads(n, seed, lo=1, hi=181):
+    ids, seqs = helpers.read_fastq()
+    rng = np.random.default_rng(seed)
+    pick = rng.integers(0, len(seqs), n)
+    out_ids, out_seqs = [], []
+    for j, i in enumerate(pick):
+        s = seqs[i] + seqs[(i + 1) % len(seqs)] + seqs[(i + 2) % len(seqs)]
+        out_seqs.append(s[: int(rng.integers(lo, hi))])
+        out_ids.append("%s/%d" % (ids[i], j))
+    return out_ids, out_seqs
+
+
+def write_fastq(path, ids, seqs, eol="\n", tail=""):
+    path.write_text("".join("@%s some description%s%s%s+%s%s%s" % (i, eol, s, eol, eol, "I" * len(s), eol) for i, s in zip(ids, seqs)) + tail, newline="")
+
+
+@pytest.mark.parametrize("window", [700, 4096, 65536, 1 << 20])
+def test_lanes_and_windows_give_the_same_bytes(aligner, tmp_path, monkeypatch, window):
+    """pa_process_reads_multi over 1, 2 and 3 lanes (the same handle listed several times: streams of one GPU) and pa_process_reads:
+    byte-identical output == the oracle's tuples, windows that end inside every kind of line"""
+    ids, seqs = make_reads(20000, 3)
+    want = expected_lines(aligner, ids, seqs)
+    fq = tmp_path / "r.fq"
+    write_fastq(fq, ids, seqs)
+    monkeypatch.setenv("PA_INGEST_WINDOW", str(window))
+    outs = []
+    for lanes in (0, 1, 2, 3):
+        out = tmp_path / ("o%d.txt" % lanes)
+        if lanes == 0:
+            n, flagged = pa.process_reads(str(fq), aligner, str(out), 4)
+        else:
+            n, flagged = pa.process_reads_multi(str(fq), [aligner] * lanes, str(out), 4)
+        assert n == len(ids) and flagged == sum(1 for w in want if w.startswith("(true")), lanes
+        outs.append(out.read_bytes())
+    assert outs[0].decode().splitlines() == want
+    assert all(o == outs[0] for o in outs[1:])
+    st = pa.process_reads_stage_seconds()
+    assert st["reads"] == len(ids) and st["scan_s"] < st["total_s"]
+
+
+def test_gpu_scan_and_host_scan_agree(aligner, tmp_path, monkeypatch):
+    """the records the GPU finds are the records the host's scan finds: CRLF, ids with spaces / tabs / trailing blanks / quotes /
+    control bytes, empty sequences, reads shorter than k, a window far smaller than the line table's first guess (short reads: the
+    scan regrows it and fills it again)"""
+    ids, seqs = make_reads(30000, 5, 0, 40)           # short reads: more lines per byte than the first guess allows for
+    ids[7], ids[8], ids[9] = 'qu"ote', "back\\slash\x01ctl", "tab\tinside"
+    seqs[11] = ""
+    for eol in ("\n", "\r\n"):
+        fq = tmp_path / ("s%d.fq" % len(eol))
+        fq.write_text("".join("@%s  two spaces and a tab\t %s%s%s+%s%s%s" % (i, eol, s, eol, eol, "#" * len(s), eol) for i, s in zip(ids, seqs)), newline="")
+        got = {}
+        for mode in ("gpu", "host"):
+            if mode == "host":
+                monkeypatch.setenv("PA_INGEST_HOST_SCAN", "1")
+            else:
+                monkeypatch.delenv("PA_INGEST_HOST_SCAN", raising=False)
+            monkeypatch.setenv("PA_INGEST_WINDOW", "300000")
+            out = tmp_path / "o.txt"
+            n, _ = pa.process_reads(str(fq), aligner, str(out), 3)
+            assert n == len(ids)
+            got[mode] = out.read_bytes()
+        monkeypatch.delenv("PA_INGEST_HOST_SCAN", raising=False)
+        assert got["gpu"] == got["host"]
+        lines = got["gpu"].decode().splitlines()
+        want = expected_lines(aligner, ids, seqs)
+        want[7] = want[7].replace('qu"ote', 'qu\\"ote')
+        want[8] = want[8].replace("back\\slash\x01ctl", "back\\\\slash\\u{1}ctl")
+        want[9] = want[9].replace("tab\tinside", "tab\\tinside")
+        assert lines == want, eol
+
+
+def test_default_window_and_long_headers(aligner, tmp_path, monkeypatch):
+    """the production window (128 MiB: the whole of a small file minus its end, which is the host's), a record longer than a small
+    window's head room would be, and gzip text through the same windows"""
+    import gzip
+    monkeypatch.delenv("PA_INGEST_WINDOW", raising=False)
+    monkeypatch.delenv("PA_INGEST_BATCH", raising=False)
+    ids, seqs = make_reads(60000, 8, 20, 181)
+    ids[100] = "long" + "x" * 5000                       # longer than a window of the small-window run below
+    want = expected_lines(aligner, ids, seqs)
+    fq = tmp_path / "d.fq"
+    write_fastq(fq, ids, seqs, tail="\n\n")
+    out = tmp_path / "o.txt"
+    assert pa.process_reads(str(fq), aligner, str(out), 8)[0] == len(ids)
+    assert out.read_text().splitlines() == want
+    monkeypatch.setenv("PA_INGEST_WINDOW", "1500")
+    assert pa.process_reads_multi(str(fq), [aligner, aligner], str(out), 8)[0] == len(ids)
+    assert out.read_text().splitlines() == want
+    gz = tmp_path / "d.fq.gz"
+    gz.write_bytes(gzip.compress(fq.read_bytes(), 1))
+    monkeypatch.setenv("PA_INGEST_WINDOW", "50000")
+    assert pa.process_reads(str(gz), aligner, str(out), 8)[0] == len(ids)
+    assert out.read_text().splitlines() == want
+
+
+def test_replicas_are_checked(aligner, small_index, tmp_path):
+    other = pa.Pseudoaligner(small_index(20), 0)
+    fq = tmp_path / "x.fq"
+    fq.write_text("@r\nACGT\n+\nIIII\n")
+    with pytest.raises(pa.PaError):
+        pa.process_reads_multi(str(fq), [aligner, other], str(tmp_path / "o.txt"), 2)
+
+
+def test_progress_line_is_the_references(small_index, tmp_path, monkeypatch, capfd):
+    """`Done Mapping {} reads w/ Rate: {}` (src/pseudoaligner.rs:497-503) at exactly every 10^6-th read with the flagged count of exactly
+    the first 10^6 m reads, the rate printed as Rust prints an f32 (shortest digits that round-trip, no exponent); 2.3 M reads of
+    small.fq (12 in 9 309 flagged at K = 20), windows that do not end on a million"""
+    monkeypatch.setenv("PA_INGEST_WINDOW", str(24 << 20))
+    a = pa.Pseudoaligner(small_index(20), 0)
+    _, seqs = helpers.read_fastq()
+    rng = np.random.default_rng(2)
+    n = 2300000
+    pick = rng.integers(0, len(seqs), n)
+    fq = tmp_path / "big.fq"
+    with open(fq, "w") as f:
+        for lo in range(0, n, 100000):
+            f.write("".join("@r%d\n%s\n+\n%s\n" % (j, seqs[pick[j]], "I" * len(seqs[pick[j]])) for j in range(lo, min(n, lo + 100000))))
+    out = tmp_path / "o.txt"
+    capfd.readouterr()
+    got_n, flagged = pa.process_reads(str(fq), a, str(out), 8)
+    err = capfd.readouterr().err
+    assert got_n == n
+    flags = np.fromiter((l.startswith("(true") for l in open(out)), bool, n)
+    assert flagged == int(flags.sum()) and flagged > 1000
+    marks = [m for m in err.split("\r") if m.startswith("Done Mapping")]
+    assert len(marks) == 2, err
+    for m, at in zip(marks, (1000000, 2000000)):
+        rate = np.float32(np.float32(flags[:at].sum()) * np.float32(100.0) / np.float32(at))
+        assert m.rstrip("\n") == "Done Mapping %d reads w/ Rate: %s" % (at, np.format_float_positional(rate, unique=True, trim="-")), (m, rate)
+    assert err.endswith("\n")                                                  # `eprintln!()` behind the progress line (:508)
