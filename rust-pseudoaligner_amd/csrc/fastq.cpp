@@ -554,6 +554,7 @@ struct Win {
     int lane = 0, slot = 0;
     uint64_t from = 0;          // text offset of its first record
     uint64_t first_read = 0;    // number of the reads before it
+    bool launched = false;      // its kernels are on the lane's stream
 };
 
 struct TextPipe {
@@ -619,6 +620,7 @@ struct TextPipe {
     int retire_finished(uint64_t upto) {
         while (!wins.empty()) {
             Win& w = wins.front();
+            if (!w.launched) break;   // (the window being launched right now)
             Lane& l = lanes[(size_t)w.lane];
             if (l.unfinished == (int64_t)w.id) {
                 if (w.id >= upto) break;
@@ -681,6 +683,7 @@ struct TextPipe {
         if ((e = batch_ensure(l.idx, c, c.n, c.wpr, std::min<uint64_t>(std::max<uint64_t>(c.n + c.n / 8, 1 << 16), std::max<uint64_t>(batch_reads, c.n)))) != PA_OK) return e;
         if ((e = batch_launch(l.idx, c, l.stream)) != PA_OK) return e;
         l.unfinished = (int64_t)w.id;
+        w.launched = true;
         launched_reads += c.n;
         t_launch += now() - t0;
         return PA_OK;

@@ -155,7 +155,7 @@ int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads
     if (!s->cache) { delete s; return fail(PA_ERR_OOM, "out of memory"); }
     s->cache->idx = idx;
     s->ctx = s->cache->ctx;
-    for (int k = 0; k < 2; ++k) { s->ctx[k].recs.clear(); s->ctx[k].n = 0; s->ctx[k].first = 0; }   // (a parked set still names its last batch)
+    for (int k = 0; k < 2; ++k) { s->ctx[k].recs.clear(); s->ctx[k].n = 0; s->ctx[k].first = 0; s->ctx[k].in_place = false; s->ctx[k].flag_mark = 0; }   // (a parked set still names its last batch — or a window of pa_process_reads)
     if (hipSetDevice(s->device) != hipSuccess) {   // (a stream the parked cache brought along stays with it: destroy releases it and its launch context)
         pa_record_stream_destroy(s);
         return fail(PA_ERR_HIP, "hipSetDevice(%d) failed", s->device);
