@@ -507,9 +507,11 @@ static int map_launch_locked(pa_index* idx, LaunchCtx* cx, const uint64_t* d_til
 }
 
 static int map_finish_locked(pa_index* idx, LaunchCtx* cx, hipStream_t stream, uint64_t* arena_used, uint64_t* arena_needed) {
-    HIP_TRY(hipStreamSynchronize(stream));
+    // (the control block comes back ON the launch's stream: a plain hipMemcpy runs on the null stream and waits for every other stream
+    // of the process — a caller that copies its next batch in on another stream meanwhile would find this call waiting for that copy)
     struct { unsigned long long top; uint32_t status; uint32_t pad; } ctl;
-    HIP_TRY(hipMemcpy(&ctl, cx->ctl.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(&ctl, cx->ctl.p, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     if (env_int("PA_MAP_STATS", 0)) {
         constexpr uint32_t NS = ST_COUNT + 4;   // ST_NSTAT of map_pool.hip: one entry per state, the dual iterations, the forward step in three parts
         unsigned long long d[3 * NS];

@@ -724,7 +724,7 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
 
     uint64_t BATCH_READS = DEFAULT_BATCH_READS;
     if (const char* v = getenv("PA_INGEST_BATCH")) { const long long x = atoll(v); if (x >= 64) BATCH_READS = (uint64_t)x / 64 * 64; }
-    uint64_t W = 128ull << 20;   // bytes of a window the GPU scans (PA_INGEST_WINDOW; never more than 256 bytes per read of a batch: the tests' small batches give small windows)
+    uint64_t W = 64ull << 20;   // bytes of a window the GPU scans (64 MiB: 128 MiB leaves more of the first read and the last kernels unoverlapped, 16 MiB costs launches) (PA_INGEST_WINDOW; never more than 256 bytes per read of a batch: the tests' small batches give small windows)
     if (const char* v = getenv("PA_INGEST_WINDOW")) { const long long x = atoll(v); if (x >= 1) W = (uint64_t)x; }
     W = std::min<uint64_t>(std::min<uint64_t>(W, BATCH_READS * 256), 1ull << 31);
     const bool verbose = getenv("PA_VERBOSE") != nullptr;
@@ -744,8 +744,8 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
         l.cache = static_cast<IngestCache*>(index_take_ingest_cache(l.idx));
         if (!l.cache) l.cache = new IngestCache();
         l.cache->idx = l.idx;
-        if (!l.cache->stream && hipStreamCreate(&l.cache->stream) != hipSuccess) { l.cache->stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); break; }
-        if (!l.cache->copy_stream && hipStreamCreate(&l.cache->copy_stream) != hipSuccess) { l.cache->copy_stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); break; }
+        if (!l.cache->stream && hipStreamCreateWithFlags(&l.cache->stream, hipStreamNonBlocking) != hipSuccess) { l.cache->stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); break; }
+        if (!l.cache->copy_stream && hipStreamCreateWithFlags(&l.cache->copy_stream, hipStreamNonBlocking) != hipSuccess) { l.cache->copy_stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); break; }
         l.stream = l.cache->stream;
         l.copy = l.cache->copy_stream;
     }
@@ -759,6 +759,9 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
     bool gpu_mode = rc == PA_OK && !host_only && fsize0 > KEEP;
     bool have_pending = false;
     Win pending;              // the window whose records the GPU is finding
+    hipEvent_t vt0[8] = {nullptr}, vt1[8] = {nullptr};   // PA_VERBOSE: how long the windows' copies to the GPU took (eight windows back)
+    uint64_t vbytes[8] = {0};
+    double v_h2d_ms = 0, v_h2d_bytes = 0;
 
     // the pending window's scan: waited for; its records are launched, the next window's first record is known
     auto resolve = [&]() -> int {
@@ -802,8 +805,15 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
         double t0 = TextPipe::now();
         if ((rc = tp.read_text(read_to, main_len, c.h_raw + WINDOW_HEAD_ROOM)) != PA_OK) break;
         tp.t_read += TextPipe::now() - t0;
+        if (verbose) {
+            if (!vt0[id % 8]) { (void)hipEventCreate(&vt0[id % 8]); (void)hipEventCreate(&vt1[id % 8]); }
+            else { float ms = 0; if (hipEventElapsedTime(&ms, vt0[id % 8], vt1[id % 8]) == hipSuccess) { v_h2d_ms += ms; v_h2d_bytes += vbytes[id % 8]; } }
+            (void)hipEventRecord(vt0[id % 8], l.copy);
+            vbytes[id % 8] = main_len;
+        }
         if (hipMemcpyAsync((uint8_t*)c.d_raw + WINDOW_HEAD_ROOM, c.h_raw + WINDOW_HEAD_ROOM, main_len, hipMemcpyHostToDevice, l.copy) != hipSuccess ||
             hipEventRecord(c.ev_h2d, l.copy) != hipSuccess) { rc = fail(PA_ERR_HIP, "copy of a text window to the GPU failed"); break; }
+        if (verbose) (void)hipEventRecord(vt1[id % 8], l.copy);
         const uint64_t main_from = read_to;
         read_to += main_len;
         bool discard = false;
@@ -939,6 +949,8 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
         fprintf(stderr, "\n[pa ingest] %llu reads, %d threads, %d lane(s): %llu windows scanned on the GPU (%llu scanned twice), %llu batches by the host; host scan %.3f s, read %.3f s, wait GPU %.3f s, launch %.3f s, wait text %.3f s, wait writer %.3f s, total %.3f s (before the first window %.3f s)\n",
                 (unsigned long long)tp.reported, pool.size(), nidx, (unsigned long long)tp.gpu_windows, (unsigned long long)tp.rescans, (unsigned long long)tp.host_windows, tp.t_scan, tp.t_read, tp.t_wait,
                 tp.t_launch, tp.t_text, tp.t_push, TextPipe::now() - t_begin, t_begin - t_enter);
+    if (verbose && v_h2d_ms > 0) fprintf(stderr, "[pa ingest] windows to the GPU: %.1f MB in %.2f ms of copies = %.1f GB/s\n", v_h2d_bytes / 1e6, v_h2d_ms, v_h2d_bytes / v_h2d_ms / 1e6);
+    for (int i = 0; i < 8; ++i) { if (vt0[i]) (void)hipEventDestroy(vt0[i]); if (vt1[i]) (void)hipEventDestroy(vt1[i]); }
     if (tp.reported >= 1000000) fputc('\n', stderr);   // (`eprintln!()` behind the progress line, :508)
     for (Lane& l : lanes) {
         if (!l.cache) continue;

@@ -160,7 +160,7 @@ int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads
         pa_record_stream_destroy(s);
         return fail(PA_ERR_HIP, "hipSetDevice(%d) failed", s->device);
     }
-    if (!s->cache->stream && hipStreamCreate(&s->cache->stream) != hipSuccess) {
+    if (!s->cache->stream && hipStreamCreateWithFlags(&s->cache->stream, hipStreamNonBlocking) != hipSuccess) {
         s->cache->stream = nullptr;
         pa_record_stream_destroy(s);
         return fail(PA_ERR_HIP, "hipStreamCreate failed");
