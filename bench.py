@@ -37,6 +37,8 @@ WORKLOADS = {
                     desc="same transcriptome at K=31, 150bp reads with 1% substitutions"),
     "config3k64": dict(genes=58000, transcripts=203000, txome_seed=7, k=64, read_len=150, read_seed=2, ppm=0, batch=100_000_000,
                        desc="config 3 rebuilt at K=64 (two-word k-mers, the other k of the reference's CLI), error-free 150bp reads"),
+    "config3r": dict(genes=58000, transcripts=203000, txome_seed=7, k=24, read_len=150, read_seed=2, ppm=0, batch=100_000_000, repeats=True,
+                     desc="config 3 with real-graph structure: 40 repeat families at 10-15 % divergence + 10 at 3-6 % (300-base elements in the last exon of 13 % of the genes) and 200 low-complexity tracts"),
     "config2": dict(fasta=str(ROOT / "tests" / "golden" / "gencode_small.fa"), k=24, read_len=100, read_seed=1, ppm=0, batch=10_000_000,
                     desc="gencode_small (1832 transcripts) index (K=24), error-free 100bp reads"),
 }
@@ -78,7 +80,9 @@ class Run:
         pa, torch = env["pa"], env["torch"]
         wl = self.wl
         t0 = time.time()
-        self.txome = pa.Txome.from_fasta(wl["fasta"]) if "fasta" in wl else pa.Txome.synthesize(wl["genes"], wl["transcripts"], wl["txome_seed"])
+        self.txome = (pa.Txome.from_fasta(wl["fasta"]) if "fasta" in wl else
+                      pa.Txome.synthesize_repeats(wl["genes"], wl["transcripts"], wl["txome_seed"]) if wl.get("repeats") else
+                      pa.Txome.synthesize(wl["genes"], wl["transcripts"], wl["txome_seed"]))
         log("%s transcriptome: %d transcripts (%.1f s)" % (name, self.txome.num_transcripts, time.time() - t0))
         # index: built on this rank's GPU (csrc/index_build.hip: the same index, array for array, as the CPU builder gives; every rank builds
         # its own copy in well under a second, so nothing is handed over between ranks). --cpu-build takes the CPU builder.
@@ -466,29 +470,40 @@ def main() -> None:
             del b_tiles, b_lens
         del oracle
 
-    # ---- BASELINE.json's error-read configuration on the same box, driver-visible: a few steps of config 5 (K = 31, 1 % substitutions)
+    # ---- the other workloads on the same box, driver-visible extra keys (never `value`): BASELINE.json's error-read configuration (config 5:
+    # K = 31, 1 % substitutions), the headline's robustness to real graph structure (config3r: repeat families, low-complexity tracts) and the
+    # one index built from real gene structure (config 2: gencode_small) at the headline's 100 M reads per launch
     if n_gpus == 1 and rank == 0 and args.workload == "config3" and not args.no_config5 and not args.batch:
-        try:
-            buffers = run.buffers
-            run.aligner = None
-            run.host = None
-            torch.cuda.empty_cache()
-            r5 = Run(env, "config5", 0)
-            K5, W5 = min(K, 10), min(W, 2)
-            r5.make_batches(K5, W5, buffers)
-            e5, step5, map5 = r5.timed(K5, W5)
-            assert int(r5.counts.sum().item()) == K5 * r5.B
-            _, ctr5, _ = r5.check_sample(100_000, usable_cpus())
-            rf = roofline_of(r5, ctr5, map5, step5)
-            out["config5"] = {"workload": "config5: %s" % WORKLOADS["config5"]["desc"], "value": K5 * r5.B / e5, "unit": "reads/s", "steps": K5, "warmup": W5,
-                              "ms_per_step": 1000.0 * e5 / K5, "kernel_ms": rf["kernel_ms"], "step_device_ms": rf["step_device_ms"],
-                              "roofline": {kk: rf[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_note", "algorithmic_bytes_per_read",
-                                                                "reads_per_launch", "kernel_ms_steps")},
-                              "parity_sample": {"reads": 100_000, "bit_exact_vs_oracle": True},
-                              "index_build_s": round(r5.t_build, 3), "index_upload_s": round(r5.t_create, 3)}
-        except Exception as e:   # an extra report: never lose the bench line over it
-            log("config5 leg failed: %r" % (e,))
-            out["config5_error"] = repr(e)
+        buffers = run.buffers
+        run.aligner = None
+        run.host = None
+        for name, batch in (("config5", 0), ("config3r", 0), ("config2", 100_000_000)):
+            try:
+                torch.cuda.empty_cache()
+                r5 = Run(env, name, batch)
+                K5, W5 = min(K, 10), min(W, 2)
+                r5.make_batches(K5, W5, buffers if r5.wpr == run.wpr else None)
+                e5, step5, map5 = r5.timed(K5, W5)
+                assert int(r5.counts.sum().item()) == K5 * r5.B
+                _, ctr5, _ = r5.check_sample(100_000, usable_cpus())
+                rf = roofline_of(r5, ctr5, map5, step5)
+                out[name] = {"workload": "%s: %s" % (name, WORKLOADS[name]["desc"]), "value": K5 * r5.B / e5, "unit": "reads/s", "steps": K5, "warmup": W5,
+                             "reads_per_step": r5.B, "ms_per_step": 1000.0 * e5 / K5, "kernel_ms": rf["kernel_ms"], "step_device_ms": rf["step_device_ms"],
+                             "roofline": {kk: rf[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_note", "algorithmic_bytes_per_read",
+                                                               "reads_per_launch", "kernel_ms_steps")},
+                             "parity_sample": {"reads": 100_000, "bit_exact_vs_oracle": True},
+                             "index": {"kmers": int(r5.st.num_kmers), "nodes": int(r5.st.num_nodes), "classes": int(r5.st.num_classes), "max_class_len": int(r5.st.max_class_len),
+                                       "bytes": int(r5.st.bytes_total)},
+                             "oracle_counters_per_read": {kk: round(ctr5[kk] / max(ctr5["reads"], 1), 3) for kk in ("probes", "node_visits", "bases_compared", "class_sizes", "result_sizes")},
+                             "index_build_s": round(r5.t_build, 3), "index_upload_s": round(r5.t_create, 3)}
+                if name == "config3r":
+                    out[name]["frac_of_config3"] = rf["frac"] / out["roofline"]["frac"] if out.get("roofline", {}).get("frac") else None
+                    out[name]["class_structure"] = class_structure(np, r5.host)
+                r5.aligner = None
+                del r5
+            except Exception as e:   # an extra report: never lose the bench line over it
+                log("%s leg failed: %r" % (name, e))
+                out[name + "_error"] = repr(e)
 
     out.pop("_e2e_sample", None)
     if rank == 0:
@@ -496,6 +511,28 @@ def main() -> None:
     barrier()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def class_structure(np, host):
+    """how far the index's classes are from the window mode's home ground: classes that do not fit two windows of 32 consecutive transcript
+    ids (the reads that meet one go through the list tiers of map_pool.hip), and the share of the graph's k-mers that carry such a class"""
+    a = host.arrays()
+    off = a["ec_offset"].astype(np.int64)
+    ids = a["ec_ids"].astype(np.int64)
+    nc = int(a["num_classes"])
+    clen = off[1:] - off[:-1]
+    first = ids[off[:-1]]
+    owner = np.repeat(np.arange(nc), clen)
+    beyond1 = ids > first[owner] + 31
+    big = np.int64(1) << 40
+    second = np.minimum.reduceat(np.where(beyond1, ids, big), off[:-1])
+    beyond2 = beyond1 & (ids > second[owner] + 31)
+    is_list = np.add.reduceat(beyond2.astype(np.int64), off[:-1]) > 0
+    kmers = (a["node_len"].astype(np.int64) - int(a["k"]) + 1)
+    list_kmers = int(kmers[is_list[a["node_colour"]]].sum())
+    return {"classes": nc, "classes_beyond_two_windows": int(is_list.sum()), "kmer_share_of_those_classes": list_kmers / max(int(kmers.sum()), 1),
+            "classes_over_32_ids": int((clen > 32).sum()), "classes_over_100_ids": int((clen > 100).sum()), "max_class_len": int(clen.max()),
+            "kmer_weighted_mean_class_len": float((kmers * clen[a["node_colour"]]).sum() / max(int(kmers.sum()), 1))}
 
 
 def write_fastq(txome, path, n, read_len, read_seed, wpr, np):

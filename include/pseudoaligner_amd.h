@@ -413,6 +413,19 @@ int pa_overflow_allgather(pa_overflow* ovf, pa_comm* comm, void* stream, const u
 /* GENCODE-like transcriptome: returns a host index-less transcript set. */
 typedef struct pa_txome pa_txome;
 int pa_txome_synthesize(uint32_t num_genes, uint32_t target_transcripts, uint64_t seed, pa_txome** out);
+/* The same transcriptome (same genes, exons and isoforms for the same seed) with REAL-GRAPH structure added (bench.py's workload
+ * "config3r"): interspersed repeats — `families` + `young_families` consensus elements of `element_len` random bases; a gene is hit with
+ * probability gene_fraction_ppm / 1e6 and then carries ONE copy of a random family in its last exon ("3' UTR": every isoform that keeps
+ * that exon has it), every base of the copy substituted with a probability drawn per copy from [div_lo_ppm, div_hi_ppm] (old families,
+ * Alu-like) or [young_div_lo_ppm, young_div_hi_ppm] — and `low_complexity_genes` genes whose last exon ends in a poly-A, (CA)n or (CAG)n
+ * tract of 30..89 units. Result: k-mers shared by tens to hundreds of transcripts of unrelated genes (classes far beyond two 32-id
+ * windows), branch-dense unitigs inside the elements, self-loops in the tracts. */
+typedef struct pa_synth_repeats {
+    uint32_t families, element_len, div_lo_ppm, div_hi_ppm;
+    uint32_t young_families, young_div_lo_ppm, young_div_hi_ppm;
+    uint32_t gene_fraction_ppm, low_complexity_genes;
+} pa_synth_repeats;
+int pa_txome_synthesize_repeats(uint32_t num_genes, uint32_t target_transcripts, uint64_t seed, const pa_synth_repeats* repeats, pa_txome** out);
 int pa_txome_from_host_index(const pa_host_index* h, pa_txome** out);
 int pa_txome_from_fasta(const char* fasta_path, pa_txome** out);
 int pa_txome_view(const pa_txome* t, const uint64_t** packed, const uint64_t** tx_start, uint32_t* num_tx);

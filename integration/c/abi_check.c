@@ -90,6 +90,16 @@ int main(int argc, char** argv) {
 
     pa_txome *tx = NULL, *tx2 = NULL, *tx3 = NULL;
     EXPECT(pa_txome_synthesize(50, 120, 7, &tx) == PA_OK);
+    {   /* the same genes with repeat families and low-complexity tracts in their last exons */
+        pa_txome* txr = NULL;
+        const pa_synth_repeats rep = {4, 100, 100000, 150000, 1, 30000, 60000, 500000, 3};
+        uint32_t ntx_plain = 0, ntx_rep = 0;
+        const uint64_t *st_plain = NULL, *st_rep = NULL;
+        EXPECT(pa_txome_synthesize_repeats(50, 120, 7, &rep, &txr) == PA_OK);
+        EXPECT(pa_txome_view(tx, NULL, &st_plain, &ntx_plain) == PA_OK && pa_txome_view(txr, NULL, &st_rep, &ntx_rep) == PA_OK);
+        EXPECT(ntx_plain == ntx_rep && st_rep[ntx_rep] > st_plain[ntx_plain]);
+        pa_txome_destroy(txr);
+    }
     EXPECT(pa_txome_from_host_index(h, &tx2) == PA_OK);
     EXPECT(pa_txome_from_fasta(fasta, &tx3) == PA_OK);
     EXPECT(pa_txome_view(tx2, &packed, &tx_start, &ntx2) == PA_OK && ntx2 == ntx);

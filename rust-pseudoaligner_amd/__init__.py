@@ -199,6 +199,19 @@ class Txome:
         check(lib().pa_txome_synthesize(num_genes, target_transcripts, seed, C.byref(h)))
         return cls(h.value)
 
+    # bench.py's "config3r": 40 old (10-15 % diverged) + 10 young (3-6 %) repeat families of 300 bases in the last exon of 13 % of the genes, 200 low-complexity tracts
+    REPEATS_DEFAULT = dict(families=40, element_len=300, div_lo_ppm=100000, div_hi_ppm=150000, young_families=10, young_div_lo_ppm=30000, young_div_hi_ppm=60000,
+                           gene_fraction_ppm=130000, low_complexity_genes=200)
+
+    @classmethod
+    def synthesize_repeats(cls, num_genes: int, target_transcripts: int, seed: int, **repeats) -> "Txome":
+        """pa_txome_synthesize_repeats: the transcriptome of synthesize() with interspersed repeats and low-complexity tracts"""
+        cfg = dict(cls.REPEATS_DEFAULT, **repeats)
+        r = _ffi.SynthRepeats(**cfg)
+        h = vp()
+        check(lib().pa_txome_synthesize_repeats(num_genes, target_transcripts, seed, C.byref(r), C.byref(h)))
+        return cls(h.value)
+
     @classmethod
     def from_fasta(cls, path: str) -> "Txome":
         h = vp()

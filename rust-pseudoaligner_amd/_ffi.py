@@ -35,6 +35,11 @@ class ReadResult(C.Structure):
     _fields_ = [("coverage", C.c_uint32), ("mismatches", C.c_uint32), ("class_off", C.c_uint32), ("class_len", C.c_uint32)]
 
 
+class SynthRepeats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("families", "element_len", "div_lo_ppm", "div_hi_ppm", "young_families", "young_div_lo_ppm", "young_div_hi_ppm",
+                                          "gene_fraction_ppm", "low_complexity_genes")]
+
+
 class IndexStats(C.Structure):
     _fields_ = [("num_kmers", C.c_uint64), ("table_slots", C.c_uint64), ("bytes_table", C.c_uint64), ("bytes_graph", C.c_uint64),
                 ("bytes_classes", C.c_uint64), ("bytes_total", C.c_uint64), ("num_nodes", C.c_uint32), ("num_classes", C.c_uint32),
@@ -117,6 +122,7 @@ SIGNATURES = {
     "pa_counts_allreduce": (C.c_int, [vp, vp, vp, vp]),
     "pa_overflow_allgather": (C.c_int, [vp, vp, vp, C.POINTER(vp), u64p]),
     "pa_txome_synthesize": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(vp)]),
+    "pa_txome_synthesize_repeats": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(SynthRepeats), C.POINTER(vp)]),
     "pa_txome_from_host_index": (C.c_int, [vp, C.POINTER(vp)]),
     "pa_txome_from_fasta": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
     "pa_txome_view": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), u32p]),

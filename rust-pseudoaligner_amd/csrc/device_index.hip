@@ -97,8 +97,9 @@ struct pa_index {
     std::vector<char> h_class_text;
     std::vector<uint32_t> h_arena;
     void *d_class_text_off = nullptr, *d_class_text = nullptr;   // device copy of the rendered classes (uploaded on first use, under `mu`)
-    void* ingest_cache = nullptr;   // parked by fastq.cpp between pa_process_reads calls (guarded by `mu`)
-    void (*ingest_cache_free)(void*) = nullptr;
+    // parked by fastq.cpp / record_stream.cpp between calls (guarded by `mu`): the buffer sets of up to four lanes (pa_process_reads_multi with the
+    // handle listed several times, concurrent callers)
+    std::vector<std::pair<void*, void (*)(void*)>> ingest_caches;
 };
 
 extern "C" {
@@ -210,16 +211,16 @@ int index_device_class_text(pa_index* idx, const uint64_t** d_off, const uint8_t
 }
 void* index_take_ingest_cache(pa_index* idx) {
     std::lock_guard<std::mutex> g(idx->mu);
-    void* c = idx->ingest_cache;
-    idx->ingest_cache = nullptr;
+    if (idx->ingest_caches.empty()) return nullptr;
+    void* c = idx->ingest_caches.back().first;
+    idx->ingest_caches.pop_back();
     return c;
 }
 void index_put_ingest_cache(pa_index* idx, void* cache, void (*free_fn)(void*)) {
     {
         std::lock_guard<std::mutex> g(idx->mu);
-        if (!idx->ingest_cache) {
-            idx->ingest_cache = cache;
-            idx->ingest_cache_free = free_fn;
+        if (idx->ingest_caches.size() < 4) {
+            idx->ingest_caches.emplace_back(cache, free_fn);
             return;
         }
     }
@@ -234,7 +235,11 @@ void pa_index_destroy(pa_index* idx) {
     for (void* p : {idx->d_table, idx->d_blobs, idx->d_ledge, idx->d_seg_g, idx->d_seg_nid, idx->d_ec, idx->d_class_ref, idx->d_class_len, idx->d_class_table, idx->d_wtable,
                     idx->d_class_text_off, idx->d_class_text})
         if (p) (void)hipFree(p);
-    if (idx->ingest_cache && idx->ingest_cache_free) { idx->ingest_cache_free(idx->ingest_cache); idx->ingest_cache = nullptr; }   // (releases its stream's context)
+    {   // (releases their streams' contexts)
+        std::vector<std::pair<void*, void (*)(void*)>> parked;
+        { std::lock_guard<std::mutex> g(idx->mu); parked.swap(idx->ingest_caches); }
+        for (auto& c : parked) c.second(c.first);
+    }
     for (auto& kv : idx->ctxs) kv.second->release();
     for (DevBuf* b : {&idx->b_ascii, &idx->b_offsets, &idx->b_tiles, &idx->b_lens, &idx->b_results,
                       &idx->b_arena, &idx->b_colour, &idx->b_nodes, &idx->b_nodes_len})

@@ -1,5 +1,6 @@
 // Synthetic workloads for BASELINE.json's configs: a GENCODE-like transcriptome and the read
 // simulator (host version; the device version in kernels.hip computes the same function of (seed, read index)).
+#include <algorithm>
 #include <cmath>
 
 #include "pa_common.hpp"
@@ -36,8 +37,18 @@ extern "C" {
 // GENCODE-like: genes of 4..16 exons, exon length log-normal (median 130, sigma 0.9, min 30), isoforms = random exon
 // subsets (each exon kept with p = 0.75, at least 2), 1 + Exp(mean target/genes - 1) isoforms per gene, 5 % of the genes
 // are paralogs: a copy of an earlier gene's exons with 3 % substitutions.
-int pa_txome_synthesize(uint32_t num_genes, uint32_t target_transcripts, uint64_t seed, pa_txome** out) {
+static int synthesize_impl(uint32_t num_genes, uint32_t target_transcripts, uint64_t seed, const pa_synth_repeats* rep, pa_txome** out) {
     if (!out || num_genes == 0 || target_transcripts < num_genes) return fail(PA_ERR_INVALID_ARG, "bad synth arguments");
+    // interspersed repeats and low-complexity tracts (config3r): decided by a generator of their OWN, so that the genes, exons and isoforms
+    // are those of the plain transcriptome of the same seed — only the last exons of some genes grow
+    Xoshiro rrng(seed ^ 0x5265706561747321ull);
+    std::vector<std::vector<uint8_t>> families;
+    if (rep) {
+        if (rep->element_len == 0 || rep->element_len > 5000) return fail(PA_ERR_INVALID_ARG, "bad repeat element length");
+        families.resize((size_t)rep->families + rep->young_families);
+        for (auto& f : families) { f.resize(rep->element_len); for (auto& b : f) b = (uint8_t)(rrng.next() >> 62); }
+    }
+    uint32_t low_left = rep ? rep->low_complexity_genes : 0;
     pa_txome* t = new pa_txome();
     Txome& x = t->t;
     x.tx_start.push_back(0);
@@ -73,6 +84,30 @@ int pa_txome_synthesize(uint32_t num_genes, uint32_t target_transcripts, uint64_
                 for (auto& b : e) b = (uint8_t)(rng.next() >> 62);
             }
         }
+        std::vector<uint8_t> grown;   // the last exon with its repeat / tract (the exons themselves stay as they are: paralogs copy them, and the base generator's stream must not move)
+        if (rep && !exons.empty()) {   // the gene's last exon ("3' UTR") takes a copy of a repeat family / a low-complexity tract: every isoform that keeps the exon carries it
+            grown = exons.back();
+            std::vector<uint8_t>& last = grown;
+            if (!families.empty() && rrng.below(1000000) < rep->gene_fraction_ppm) {
+                const size_t f = (size_t)rrng.below(families.size());
+                const bool young = f >= rep->families;
+                const uint32_t lo = young ? rep->young_div_lo_ppm : rep->div_lo_ppm, hi = young ? rep->young_div_hi_ppm : rep->div_hi_ppm;
+                const uint32_t div = lo + (uint32_t)rrng.below((uint64_t)(hi > lo ? hi - lo : 0) + 1);   // this copy's distance from its family's consensus
+                const size_t at = last.size() - (size_t)rrng.below(std::min<uint64_t>(last.size(), 40) + 1);
+                std::vector<uint8_t> copy = families[f];
+                for (auto& b : copy)
+                    if (rrng.below(1000000) < div) b = (uint8_t)((b + 1 + rrng.below(3)) & 3);
+                last.insert(last.begin() + (long)at, copy.begin(), copy.end());
+            }
+            if (low_left && rrng.below(num_genes - g) < low_left) {   // (exactly low_complexity_genes genes, spread over the whole set)
+                --low_left;
+                const uint32_t kind = (uint32_t)rrng.below(3), units = 30 + (uint32_t)rrng.below(60);
+                static const uint8_t unit[3][3] = {{0, 0, 0}, {1, 0, 1}, {1, 0, 2}};   // poly-A, (CA)n, (CAG)n
+                const uint32_t ulen = kind == 0 ? 1u : kind == 1 ? 2u : 3u;
+                for (uint32_t u = 0; u < units; ++u)
+                    for (uint32_t j = 0; j < ulen; ++j) last.push_back(unit[kind][j]);
+            }
+        }
         uint32_t niso = 1;
         if (extra > 0) niso += (uint32_t)(-std::log(1.0 - rng.uniform()) * extra);
         if (niso > 60) niso = 60;
@@ -84,7 +119,7 @@ int pa_txome_synthesize(uint32_t num_genes, uint32_t target_transcripts, uint64_
                     if (rng.uniform() < 0.75) keep.push_back(e);
             } while (keep.size() < 2);
             for (uint32_t e : keep)
-                for (uint8_t b : exons[e]) push(b);
+                for (uint8_t b : (rep && e + 1 == exons.size() ? grown : exons[e])) push(b);
             x.tx_start.push_back(pos);
             snprintf(name, sizeof name, "SYNT%08u.%u", g, i);
             x.names.push_back(name);
@@ -97,6 +132,15 @@ int pa_txome_synthesize(uint32_t num_genes, uint32_t target_transcripts, uint64_
     x.packed.push_back(0);
     *out = t;
     return PA_OK;
+}
+
+int pa_txome_synthesize(uint32_t num_genes, uint32_t target_transcripts, uint64_t seed, pa_txome** out) {
+    return synthesize_impl(num_genes, target_transcripts, seed, nullptr, out);
+}
+
+int pa_txome_synthesize_repeats(uint32_t num_genes, uint32_t target_transcripts, uint64_t seed, const pa_synth_repeats* repeats, pa_txome** out) {
+    if (!repeats) return fail(PA_ERR_INVALID_ARG, "null argument");
+    return synthesize_impl(num_genes, target_transcripts, seed, repeats, out);
 }
 
 int pa_txome_from_host_index(const pa_host_index* h, pa_txome** out) {

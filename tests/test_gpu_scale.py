@@ -208,3 +208,24 @@ def test_golden_synthetic_error_reads_through_hip(small_index, k):
     res, coff, cids = a.map_batch(reads, 2)
     got = helpers.result_lines(reads, res["mismatches"] >> 31, res["coverage"], res["mismatches"] & 0x7FFFFFFF, coff, cids)
     assert [g.rstrip("\n") for g in got] == lines
+
+
+def test_config3r_repeat_families_two_million_reads_bit_exact():
+    """bench.py's "config3r" (VERDICT r5 item 4): the config-3 transcriptome with 50 repeat families in the last exons of 13 % of the genes
+    and 200 low-complexity tracts — k-mers shared by tens to hundreds of transcripts of unrelated genes (classes far beyond two 32-id
+    windows: the list tiers of map_pool.hip at scale), branch-dense unitigs, self-loops. 2 M error-free reads and 1 M reads with 1 %
+    substitutions bit-exact incl. the count table (src/pseudoaligner.rs:323-356, :389-418)"""
+    if pa.lib().pa_device_count() < 1:
+        raise RuntimeError("the gpu tier needs a GPU and the HIP library: %s" % pa.lib().pa_last_error().decode())
+    tx = pa.Txome.synthesize_repeats(GENES, TRANSCRIPTS, TX_SEED)
+    plain_bases = int(pa.Txome.synthesize(GENES, TRANSCRIPTS, TX_SEED).arrays()[1][-1])
+    assert tx.num_transcripts > 190_000 and int(tx.arrays()[1][-1]) > plain_bases + 3_000_000       # the same genes, longer last exons
+    host = pa.HostIndex.from_txome_device(tx, 24, 0)
+    a = host.arrays()
+    clen = (a["ec_offset"][1:] - a["ec_offset"][:-1]).astype(np.int64)
+    assert int(clen.max()) > 150 and int((clen > 32).sum()) > 500                                   # hub classes exist
+    aligner, oracle = pa.Pseudoaligner(host, 0), helpers.Oracle(host)
+    ctr, want = _bit_exact_with_counts(tx, host, aligner, oracle, 24, 150, 2, 0, 2_000_000, 0, "config3r, 2 M reads")
+    assert ctr["mapped"] == 2_000_000 and ctr["class_sizes"] / ctr["reads"] > 12                   # (config 3: 10.7 ids per read over the visited classes)
+    ctr, _ = _bit_exact_with_counts(tx, host, aligner, oracle, 24, 150, 5, 10000, 1_000_000, 0, "config3r, 1 M reads with 1 % substitutions")
+    assert ctr["reseeks"] > 20_000
