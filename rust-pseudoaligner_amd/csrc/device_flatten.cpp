@@ -39,6 +39,8 @@ DevIndexView FlatDevice::host_view() const {
     v.num_classes = num_classes;
     v.num_segs = (uint32_t)seg_g.size();
     v.stream_nt = 0;
+    v.bitmap_min = bitmap_min;
+    v.bitmap_words = bitmap_words;
     return v;
 }
 
@@ -161,22 +163,8 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
     const KT mask = KmerOps<KT>::mask(k);
     const uint32_t topshift = 2 * (k - 1);
 
-    // ---- classes: 16-byte aligned records {class id, id0, id1, ...} ----
+    // ---- classes: their windows first (ids in [cmin, cmin + 32) U [cmin2, cmin2 + 32), cmin2 = first id beyond window 1; cmask = 0 if it does not fit) ----
     if (f.num_transcripts >= 0xFFFFFFFFu) return fail(PA_ERR_UNSUPPORTED, "too many transcripts");   // 0xFFFFFFFF pads the records
-    out.class_ref.resize(f.num_classes);
-    out.class_len.resize(f.num_classes);
-    for (uint32_t c = 0; c < f.num_classes; ++c) {
-        const uint64_t len = f.ec_offset[c + 1] - f.ec_offset[c];
-        if (len >= 0xFFFFFFFFull || out.ec.size() / 4 >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "class id lists too large");
-        out.class_ref[c] = (uint32_t)(out.ec.size() / 4);
-        out.class_len[c] = (uint32_t)len;
-        out.max_class_len = std::max(out.max_class_len, (uint32_t)len);
-        out.ec.push_back(c);
-        out.ec.insert(out.ec.end(), f.ec_ids + f.ec_offset[c], f.ec_ids + f.ec_offset[c + 1]);
-        while (out.ec.size() % 4 || out.ec.size() - 4ull * out.class_ref[c] < 8) out.ec.push_back(0xFFFFFFFFu);   // >= 8 words, 0xFFFFFFFF padded
-    }
-    out.ec.resize(out.ec.size() + 8, 0xFFFFFFFFu);   // tail pad: records are read two 16-byte words at a time
-    // class windows: ids in [cmin, cmin + 32) U [cmin2, cmin2 + 32), cmin2 = first id beyond window 1; cmask = 0 if it does not fit
     std::vector<U4> cwin(f.num_classes, U4{0, 0, 0, 0});
     uint64_t nwin = 0;
     for (uint32_t c = 0; c < f.num_classes; ++c) {
@@ -194,6 +182,42 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
         cwin[c] = w;
         ++nwin;
     }
+    // membership bitmaps for the window-less classes of at least bitmap_min ids (device_layout.hpp, class_bitmap): 16 ids and up (a shorter
+    // list is one round of four 16-byte loads anyway) unless that would take more than 4 GB — then only the longer ones, or none
+    out.bitmap_words = ((f.num_transcripts + 31) / 32 + 2 + 3) & ~3u;
+    out.bitmap_min = 16;
+    for (;;) {
+        uint64_t n = 0;
+        for (uint32_t c = 0; c < f.num_classes; ++c)
+            n += cwin[c].y == 0 && f.ec_offset[c + 1] - f.ec_offset[c] >= out.bitmap_min;
+        out.num_bitmaps = n;
+        if (n * out.bitmap_words * 4ull <= (4ull << 30)) break;
+        if (out.bitmap_min >= (1u << 24)) { out.bitmap_min = 0; out.num_bitmaps = 0; break; }
+        out.bitmap_min *= 2;
+    }
+    // ---- 16-byte aligned records {class id, id0, id1, ...} ----
+    out.class_ref.resize(f.num_classes);
+    out.class_len.resize(f.num_classes);
+    for (uint32_t c = 0; c < f.num_classes; ++c) {
+        const uint64_t len = f.ec_offset[c + 1] - f.ec_offset[c];
+        if (len >= 0xFFFFFFFFull || out.ec.size() / 4 >= 0xFFFFFFFFull) return fail(PA_ERR_UNSUPPORTED, "class id lists too large");
+        out.class_ref[c] = (uint32_t)(out.ec.size() / 4);
+        out.class_len[c] = (uint32_t)len;
+        out.max_class_len = std::max(out.max_class_len, (uint32_t)len);
+        out.ec.push_back(c);
+        out.ec.insert(out.ec.end(), f.ec_ids + f.ec_offset[c], f.ec_ids + f.ec_offset[c + 1]);
+        while (out.ec.size() % 4 || out.ec.size() - 4ull * out.class_ref[c] < 8) out.ec.push_back(0xFFFFFFFFu);   // >= 8 words, 0xFFFFFFFF padded
+        if (out.bitmap_min && cwin[c].y == 0 && len >= out.bitmap_min) {
+            const size_t at = out.ec.size();
+            if (at != class_bitmap(out.class_ref[c], (uint32_t)len)) return fail(PA_ERR_INTERNAL, "class record of %llu ids is not %u chunks", (unsigned long long)len, class_record_chunks((uint32_t)len));
+            out.ec.resize(at + out.bitmap_words, 0u);
+            for (uint64_t j = f.ec_offset[c]; j < f.ec_offset[c + 1]; ++j) {
+                if (f.ec_ids[j] >= f.num_transcripts) return fail(PA_ERR_INVALID_ARG, "class %u names transcript %u of %u", c, f.ec_ids[j], f.num_transcripts);
+                out.ec[at + (f.ec_ids[j] >> 5)] |= 1u << (f.ec_ids[j] & 31u);
+            }
+        }
+    }
+    out.ec.resize(out.ec.size() + 8, 0xFFFFFFFFu);   // tail pad: records are read two 16-byte words at a time
     // window table: canonical windows -> class id
     out.wbuckets = (uint32_t)std::max<uint64_t>(1, (uint64_t)((double)nwin / (WT_ENTRIES * 0.5)) + 1);
     out.wtable.assign((size_t)out.wbuckets * 16, 0);

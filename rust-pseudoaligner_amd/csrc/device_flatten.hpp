@@ -22,6 +22,8 @@ struct FlatDevice {
     uint32_t wbuckets = 0;
     uint64_t num_kmers = 0;
     uint32_t k = 0, num_nodes = 0, num_classes = 0, max_class_len = 0;
+    uint32_t bitmap_min = 0, bitmap_words = 0;     // membership bitmaps of the window-less classes (device_layout.hpp, class_bitmap)
+    uint64_t num_bitmaps = 0;
     // device_dict mode only: k-mers before node i (num_nodes + 1 entries)
     std::vector<uint64_t> node_kcum;
     DevIndexView host_view() const;   // pointers into the vectors above

@@ -88,7 +88,7 @@ struct pa_index {
     // host-buffer convenience path
     DevBuf b_ascii, b_offsets, b_tiles, b_lens, b_results, b_arena, b_colour, b_nodes, b_nodes_len;
     std::vector<uint32_t> h_class_ids;
-    std::vector<uint32_t> h_ec, h_class_ref;
+    std::vector<uint32_t> h_ec, h_class_ref, h_class_len;
     // every index class rendered once as the reference prints it between the brackets ("1, 5, 9"): text of class c =
     // h_class_text[h_class_text_off[c] .. h_class_text_off[c + 1]). Built on first use by the ingest pipelines (ingest.hpp): a read
     // whose class comes back by reference then costs one copy instead of a table walk and a decimal conversion per id.
@@ -139,16 +139,14 @@ void index_host_class_text(pa_index* idx, const uint64_t** off, const char** tex
         const uint32_t nc = idx->stats.num_classes;
         const uint32_t* ec = idx->h_ec.data();
         const uint32_t* cref = idx->h_class_ref.data();
-        // class lengths: a record is {class id, ids..., 0xFFFFFFFF padding} (device_layout.hpp); the id lists are sorted and never hold 0xFFFFFFFF
         auto digits = [](uint32_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; ++d; } return d; };
         std::vector<uint64_t>& off_v = idx->h_class_text_off;
         off_v.assign((size_t)nc + 1, 0);
         const int T = std::max(1, std::min(16, usable_threads()));
-        auto ids_of = [&](uint32_t c, const uint32_t*& ids, uint32_t& n) {
+        const uint32_t* clen = idx->h_class_len.data();
+        auto ids_of = [&](uint32_t c, const uint32_t*& ids, uint32_t& n) {   // (the length the flattener noted: nothing is derived from where the next record lies)
             ids = ec + 4ull * cref[c] + 1;
-            const uint32_t next = c + 1 < nc ? cref[c + 1] : (uint32_t)(idx->h_ec.size() / 4 - 2);   // (records lie in class order; the table ends with an 8-word pad)
-            n = 4 * (next - cref[c]) - 1;
-            while (n && ids[n - 1] == 0xFFFFFFFFu) --n;
+            n = clen[c];
         };
         {
             std::vector<std::thread> th;
@@ -294,6 +292,7 @@ int pa_index_create(const pa_flat_index* flat, int device, pa_index** out) {
     idx->dv.seg_nid = static_cast<const uint32_t*>(idx->d_seg_nid);
     idx->h_ec = fd.ec;   // host copy of the class table: pa_map_batch resolves by-reference classes from it
     idx->h_class_ref = fd.class_ref;
+    idx->h_class_len = fd.class_len;
     idx->dv.ec = static_cast<const uint32_t*>(idx->d_ec);
     idx->dv.class_ref = static_cast<const uint32_t*>(idx->d_class_ref);
     idx->dv.class_len = static_cast<const uint32_t*>(idx->d_class_len);

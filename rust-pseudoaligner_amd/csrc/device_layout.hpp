@@ -77,6 +77,9 @@
 //   ec          class records, 16-byte aligned, at least 32 bytes, padded with 0xFFFFFFFF: record r = words [4r, ...) =
 //               {class id, id0, id1, ...} — the sorted transcript-id lists of eq_classes: Vec<Vec<u32>>
 //               (src/pseudoaligner.rs:29); a class of <= 7 ids is two 16-byte loads and needs no length checks.
+//               A class WITHOUT windows (its ids do not fit two windows of 32 consecutive ids) of at least bitmap_min ids is followed by its
+//               membership BITMAP: bitmap_words u32, bit t = transcript t belongs to the class (class_bitmap below). Records are found
+//               through class_ref / the chain blocks' extension slots only, never by walking from one record to the next.
 //   class_ref/class_len  u32[num_classes] record ref and length by class id (list mode: the record of a one-window class)
 //   wtable      window classes by content: open addressing over 64-byte lines of three {cmin, cmask, cmin2, cmask2, class
 //               id} entries (class id 0xFFFFFFFF = empty), line = mulhi32(hash(windows), wbuckets), linear probing —
@@ -159,6 +162,17 @@ struct DevIndexView {
     uint32_t num_nodes, num_classes;
     uint32_t num_segs;        // entries of seg_g / seg_nid (nodes and their copies in tails)
     uint32_t stream_nt;       // 1: the dictionary is larger than the caches — its lines and the read words are loaded non-temporal (lane_steps.hpp, ld_stream)
+    uint32_t bitmap_min;      // != 0: every class WITHOUT windows of at least this many ids has a membership bitmap behind its record (class_bitmap)
+    uint32_t bitmap_words;    // u32 words of such a bitmap (bit t = transcript t is in the class; two spare words: windows are read as 64 bits)
 };
+
+// 16-byte chunks of the record of a class of `len` ids ({class id, ids..., padding}: at least two)
+PA_HD uint32_t class_record_chunks(uint32_t len) { return len < 4 ? 2u : (len + 4) >> 2; }
+// Where the membership bitmap of the window-less class (ref, len) starts, as a word index into ec (only when ix.bitmap_min != 0 and
+// len >= ix.bitmap_min). A class that does not fit two windows of 32 ids — a repeat shared by unrelated genes — can only REMOVE ids from
+// a read's running window (lane_steps.hpp, mask_pending); with the bitmap "which ids of [b, b + 32) are in the class" is two loads of
+// consecutive words instead of a binary search into the id list and a scan from there (tens of dependent round trips for a read that
+// crosses a repeat element: 37 % of the mapping kernel's time on a transcriptome with repeat families).
+PA_HD uint64_t class_bitmap(uint32_t ref, uint32_t len) { return 4ull * ((uint64_t)ref + class_record_chunks(len)); }
 
 }  // namespace pa

@@ -360,6 +360,13 @@ PA_HD uint32_t window_class(const DevIndexView& ix, uint32_t b1, uint32_t m1, ui
     }
 }
 
+// the 32 bits of a membership bitmap that start at bit b (transcripts b .. b + 31; the bitmap has two spare words)
+PA_HD uint32_t window_bits(const uint32_t* bits, uint32_t b) {
+    const uint32_t w = b >> 5, sh = b & 31u;
+    const uint64_t v = (uint64_t)bits[w] | ((uint64_t)bits[w + 1] << 32);
+    return (uint32_t)(v >> sh);
+}
+
 // mask of the window (base c, mask n) expressed relative to base b
 PA_HD uint32_t window_at(uint32_t b, uint32_t c, uint32_t n) {
     // one 64-bit shift instead of two branches: n sits in the upper half of a 64-bit value, d = 32 + b - c moves it down;
@@ -467,6 +474,15 @@ PA_HD void list_window_mask(const DevIndexView& ix, uint32_t ref, uint32_t len, 
         if (d1 < CLASS_WINDOW) m1 |= 1u << d1;
         if (d2 < CLASS_WINDOW) m2 |= 1u << d2;
     }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // the class's membership bitmap (what the kernel reads instead of the list: class_bitmap) must say the same — the emulator's check of
+    // the flattener's bitmaps, on every pending class of every read it maps
+    if (ix.bitmap_min && len >= ix.bitmap_min) {
+        const uint32_t* bits = ix.ec + class_bitmap(ref, len);
+        const uint32_t x1 = window_bits(bits, b1), x2 = window_bits(bits, b2);
+        if (x1 != m1 || x2 != m2) { m1 = m2 = 0xDEADBEEFu; }   // (poisons the result: the parity test fails loudly)
+    }
+#endif
 }
 // the pending classes of a window-mode read applied to its window; leaves the read as a plain window-mode result
 PA_HD void mask_pending(Lane& s, const DevIndexView& ix, ColRef c) {

@@ -71,7 +71,7 @@ __device__ __forceinline__ DevIndexView view_of(karg_ptr p) {   // member-wise: 
     DevIndexView v;
     v.table = p->ix.table; v.nbuckets = p->ix.nbuckets; v.blobs = p->ix.blobs; v.ledge = p->ix.ledge;
     v.seg_g = p->ix.seg_g; v.seg_nid = p->ix.seg_nid; v.ec = p->ix.ec; v.class_ref = p->ix.class_ref; v.class_len = p->ix.class_len;
-    v.wtable = p->ix.wtable; v.wbuckets = p->ix.wbuckets; v.kmask = p->ix.kmask; v.kmask_hi = p->ix.kmask_hi; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes; v.num_segs = p->ix.num_segs; v.stream_nt = p->ix.stream_nt;
+    v.wtable = p->ix.wtable; v.wbuckets = p->ix.wbuckets; v.kmask = p->ix.kmask; v.kmask_hi = p->ix.kmask_hi; v.k = p->ix.k; v.num_nodes = p->ix.num_nodes; v.num_classes = p->ix.num_classes; v.num_segs = p->ix.num_segs; v.stream_nt = p->ix.stream_nt; v.bitmap_min = p->ix.bitmap_min; v.bitmap_words = p->ix.bitmap_words;
     return v;
 }
 
@@ -245,7 +245,18 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // lane_steps.hpp, one list per lane). Lists of up to 64 ids are scanned whole, 16-byte chunks, four in flight; in a longer one the
 // first id >= b1 (>= b2) is found by binary search and the nine chunks from there are scanned (32 ids and the chunk they start
 // in). Every loop runs to the wave's longest range; lanes with act == false do nothing.
-__device__ __forceinline__ void window_hits(glb_u32 ec, uint32_t xref, uint32_t len, bool act, uint32_t b1, uint32_t b2, uint32_t& m1, uint32_t& m2) {
+__device__ __forceinline__ void window_hits(glb_u32 ec, uint32_t xref, uint32_t len, bool act, uint32_t b1, uint32_t b2, uint32_t bitmap_min, uint32_t& m1, uint32_t& m2) {
+    // a class with a membership bitmap (every window-less class of bitmap_min ids and more: device_layout.hpp): the 32 bits from b1 and from
+    // b2 on — four loads, all in flight at once, whatever the length of the list
+    const bool bm = act && bitmap_min != 0 && len >= bitmap_min;
+    uint32_t bw[4] = {0u, 0u, 0u, 0u};
+    if (__ballot(bm)) {
+        if (bm) {
+            const glb_u32 bits = ec + class_bitmap(xref, len);
+            bw[0] = bits[b1 >> 5]; bw[1] = bits[(b1 >> 5) + 1]; bw[2] = bits[b2 >> 5]; bw[3] = bits[(b2 >> 5) + 1];
+        }
+    }
+    act = act && !bm;
     const glb_v4 rec = (glb_v4)(ec + 4ull * xref);
     const uint32_t nch = act ? (len + 4) >> 2 : 0u;
     uint32_t c[2] = {0u, 0u}, e[2] = {nch, 0u};
@@ -287,6 +298,10 @@ __device__ __forceinline__ void window_hits(glb_u32 ec, uint32_t xref, uint32_t 
                     }
                 }
         }
+    }
+    if (bm) {
+        m1 = (uint32_t)((((uint64_t)bw[1] << 32) | bw[0]) >> (b1 & 31u));
+        m2 = (uint32_t)((((uint64_t)bw[3] << 32) | bw[2]) >> (b2 & 31u));
     }
 }
 
@@ -689,7 +704,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                 uint32_t xref = 0, xlen = 0;
                 if (gact) { xref = rowL[2 * jg]; xlen = rowL[2 * jg + 1]; }
                 uint32_t m1, m2;
-                window_hits(ec, xref, xlen, gact, b1, b2, m1, m2);
+                window_hits(ec, xref, xlen, gact, b1, b2, ix.bitmap_min, m1, m2);
                 for (uint32_t o = 1; o < 64; o <<= 1) {   // AND over the lanes of a read: lane `start` ends up with all of them
                     const uint32_t t1 = (uint32_t)__shfl_down((int)m1, o, 64), t2 = (uint32_t)__shfl_down((int)m2, o, 64);
                     if (gact && lane + o < seg_end) { m1 &= t1; m2 &= t2; }
@@ -709,7 +724,7 @@ __global__ __launch_bounds__(PA_MAP_BLOCK, PA_MAP_MIN_BLOCKS) void pa_map_pool_k
                     uint32_t xref = 0, xlen = 0;
                     if (gact) { xref = rowL[2 * ci]; xlen = rowL[2 * ci + 1]; }
                     uint32_t m1, m2;
-                    window_hits(ec, xref, xlen, gact, b1, b2, m1, m2);
+                    window_hits(ec, xref, xlen, gact, b1, b2, ix.bitmap_min, m1, m2);
                     if (gact) { r1 &= m1; r2 &= m2; }
                 }
                 for (uint32_t o = 32; o; o >>= 1) {

@@ -42,6 +42,8 @@ uint64_t emu_index_info(const emu_index* e, int what) {
         case 1: return e->fd.nbuckets;
         case 2: return e->fd.blobs.size();
         case 4: return e->fd.num_chains;
+        case 8: return e->fd.num_bitmaps;   // window-less classes with a membership bitmap behind their record
+        case 9: return e->fd.bitmap_min;
         case 5: return e->fd.seg_g.size();
         case 6: {   // chain blocks that break a rule of device_layout.hpp: slots in order record [extension] [edges | link], ends ascending,
                     // the record mask of slot 0 naming exactly the records, edges / link only behind a chain's last record

@@ -221,7 +221,8 @@ class Emu:
         L = emu_lib()
         return dict(num_kmers=L.emu_index_info(self._h, 0), nbuckets=L.emu_index_info(self._h, 1), blob_bytes=L.emu_index_info(self._h, 2),
                     max_class_len=L.emu_index_info(self._h, 3), num_chains=L.emu_index_info(self._h, 4), num_segs=L.emu_index_info(self._h, 5),
-                    bad_blocks=L.emu_index_info(self._h, 6), branch_records=L.emu_index_info(self._h, 7))
+                    bad_blocks=L.emu_index_info(self._h, 6), branch_records=L.emu_index_info(self._h, 7),
+                    num_bitmaps=L.emu_index_info(self._h, 8), bitmap_min=L.emu_index_info(self._h, 9))
 
     def map_tiles(self, tiles, lens, wpr, allowed=2, col_cap=8, want_nodes=False):
         n = len(lens)

@@ -209,3 +209,28 @@ def test_long_chain_left_extensions(tmp_path, seed):
     tiles, lens, wpr = pa.encode_reads_host(reads)
     r, (o_res, _, _, ctr) = check(host, tiles, lens, wpr, allowed)
     assert ctr["left_extensions"] > 50
+
+
+def test_repeat_families_pending_classes_and_bitmaps():
+    """a slice of bench.py's "config3r" transcriptome (repeat families in the last exons, low-complexity tracts): reads that cross a
+    repeat element meet classes WITHOUT windows — tens to hundreds of ids spread over unrelated genes — which window mode keeps pending and
+    applies after the walk (mask_pending). The kernel answers "which ids of the window are in the class" from the class's membership
+    bitmap (device_layout.hpp, class_bitmap); the emulator computes the mask from the id list AND from the flattener's bitmap and
+    poisons the result when they differ — so this test is the bitmaps' parity check on the CPU tier"""
+    tx = pa.Txome.synthesize_repeats(1500, 5200, 7, gene_fraction_ppm=400000, young_div_lo_ppm=10000, young_div_hi_ppm=30000)
+    host = pa.HostIndex.from_txome(tx, 24, 4)
+    a = host.arrays()
+    clen = (a["ec_offset"][1:] - a["ec_offset"][:-1]).astype(np.int64)
+    assert int(clen.max()) > 60
+    emu = helpers.Emu(host)
+    info = emu.info()
+    assert info["bitmap_min"] == 16 and info["num_bitmaps"] > 50 and info["bad_blocks"] == 0
+    o = helpers.Oracle(host)
+    for ppm, allowed in ((0, 2), (10000, 2), (30000, 1)):
+        tiles, lens = tx.simulate_host(150, 9, 40000, ppm)
+        wpr = pa.lib().pa_words_per_read(150)
+        want = o.map_tiles(tiles, lens, wpr, allowed, 4)
+        r = emu.map_tiles(tiles, lens, wpr, allowed, 8)
+        helpers.assert_same_as_oracle(r["results"], r["coff"], r["ids"], want[0], want[1], want[2], "repeat families ppm=%d" % ppm)
+        assert r["steps"][4] > 500                     # reads with pending classes were met (mask_pending ran)
+        assert want[3]["class_sizes"] / want[3]["reads"] > 15
