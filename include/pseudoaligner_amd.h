@@ -250,6 +250,24 @@ int pa_map_stage_ms(pa_index* idx, void* stream, float ms[3]);
 /* arena capacity (u32 entries) that suffices for typical batches of n_reads; the exact need is data dependent */
 uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads);
 
+/* Compact records for the way back to the host (SURVEY.md §8d measures host to host; the 16-byte records are 40 % of what a 150-base read
+ * costs the link in the other direction): what map_read_with_mismatch returns (src/pseudoaligner.rs:361-376) in 8 bytes per read,
+ *   bits  0..13  coverage        bits 14..27  mismatches        bit 28  mapped (Some / None)
+ *   bit  29      PA_COMPACT_BY_REF: the class IS index class (record >> 32), i.e. eq_classes[id] of the flat index
+ *   bit  30      PA_COMPACT_PACKED: the class is no index class: its ids are the next entry of the PACKED stream — entries {length, id0,
+ *                id1, ...} back to back in READ order (record >> 32 = the entry's word offset modulo 2^32)
+ *   neither bit: the class is empty (or the read unmapped); both bits: the ids did not fit the launch's arena (pa_map_finish said so)
+ * made from a launch's records and arena on the device: d_compact[n_reads] u64, d_packed[packed_cap] u32, *d_packed_words (device u64) =
+ * words the packed stream needs (entries that would end beyond packed_cap are not written). d_scratch: pa_compact_scratch_bytes(n_reads)
+ * bytes. Asynchronous on `stream`, behind the launch that wrote d_results. */
+#define PA_COMPACT_MAPPED 0x10000000u
+#define PA_COMPACT_BY_REF 0x20000000u
+#define PA_COMPACT_PACKED 0x40000000u
+size_t pa_compact_scratch_bytes(uint64_t n_reads);
+int pa_results_compact_device(pa_index* idx, const pa_read_result* d_results, const uint32_t* d_arena, uint64_t arena_cap, uint64_t n_reads,
+                              uint64_t* d_compact, uint32_t* d_packed, uint64_t packed_cap, uint64_t* d_packed_words, void* d_scratch,
+                              size_t scratch_bytes, void* stream);
+
 /* Host-buffer convenience (H2D, map, D2H; grows its own arena). results[n], class ids returned as a
  * CSR in read order: class_offsets[n+1], class_ids (library-owned, valid until the next call on idx
  * from this thread or pa_index_destroy). Reads are ASCII, concatenated, offsets[n+1]. */

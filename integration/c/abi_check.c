@@ -232,6 +232,28 @@ int main(int argc, char** argv) {
         EXPECT(pa_map_finish(idx, NULL, &used, &need) == PA_OK);
         { float kms = -1.0f, st[3] = {-1.0f, -1.0f, -1.0f}; EXPECT(pa_map_kernel_ms(idx, NULL, &kms) == PA_OK && kms > 0.0f);
           EXPECT(pa_map_stage_ms(idx, NULL, st) == PA_OK && st[0] > 0.0f && st[1] >= 0.0f && st[2] >= 0.0f); EXPECT(pa_index_set_timing(idx, 0) == PA_OK); }
+        {   /* the records in their 8-byte form + the packed stream of the classes that are no index classes */
+            void *d_compact = NULL, *d_packed = NULL, *d_pw = NULL, *d_scr = NULL;
+            const size_t scr = pa_compact_scratch_bytes(nsim);
+            uint64_t* hc = (uint64_t*)malloc(nsim * 8);
+            pa_read_result* hr = (pa_read_result*)malloc(nsim * sizeof(pa_read_result));
+            uint64_t pw = ~0ull;
+            EXPECT(pa_device_malloc(0, nsim * 8, &d_compact) == PA_OK && pa_device_malloc(0, (arena_cap + 16) * 4, &d_packed) == PA_OK &&
+                   pa_device_malloc(0, 8, &d_pw) == PA_OK && pa_device_malloc(0, scr, &d_scr) == PA_OK);
+            EXPECT(pa_results_compact_device(idx, (const pa_read_result*)d_res, (const uint32_t*)d_arena, arena_cap, nsim, (uint64_t*)d_compact, (uint32_t*)d_packed,
+                                             arena_cap + 16, (uint64_t*)d_pw, d_scr, scr, NULL) == PA_OK);
+            EXPECT(pa_memcpy_d2h(hc, d_compact, nsim * 8, NULL) == PA_OK && pa_memcpy_d2h(&pw, d_pw, 8, NULL) == PA_OK &&
+                   pa_memcpy_d2h(hr, d_res, nsim * sizeof(pa_read_result), NULL) == PA_OK && pa_stream_synchronize(NULL) == PA_OK);
+            for (uint64_t i = 0; i < nsim; ++i) {
+                const uint32_t lo = (uint32_t)hc[i];
+                EXPECT((lo & 0x3FFFu) == hr[i].coverage && ((lo >> 14) & 0x3FFFu) == (hr[i].mismatches & 0x3FFFu) &&
+                       ((lo & PA_COMPACT_MAPPED) != 0) == ((hr[i].mismatches & PA_MAPPED_BIT) != 0));
+                if (lo & PA_COMPACT_BY_REF) EXPECT((uint32_t)(hc[i] >> 32) == (hr[i].class_off & ~PA_CLASS_REF) && (hr[i].class_off & PA_CLASS_REF));
+            }
+            EXPECT(pw <= arena_cap + 16);
+            free(hc); free(hr);
+            pa_device_free(d_compact); pa_device_free(d_packed); pa_device_free(d_pw); pa_device_free(d_scr);
+        }
         {   /* the same batch as a uniform one (the simulator's reads all have 60 bases): the same records without a length array */
             void* d_res2 = NULL;
             pa_read_result *r1 = (pa_read_result*)malloc(nsim * sizeof(pa_read_result)), *r2 = (pa_read_result*)malloc(nsim * sizeof(pa_read_result));

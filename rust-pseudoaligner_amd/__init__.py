@@ -21,7 +21,7 @@ from ._ffi import (PA_DEFAULT_ALLOWED_MISMATCHES, PA_ERR_ARENA_FULL, PA_MAPPED_B
                    IndexStats, PaError, ReadResult, check, lib, vp)
 
 __all__ = ["HostIndex", "Txome", "Pseudoaligner", "build_index", "process_reads", "process_reads_multi", "PaError", "lib", "concat_reads",
-           "gather_classes", "unpack_tiles", "RESULT_DTYPE", "PA_MAPPED_BIT", "PA_DEFAULT_ALLOWED_MISMATCHES",
+           "gather_classes", "unpack_compact", "unpack_tiles", "RESULT_DTYPE", "PA_MAPPED_BIT", "PA_DEFAULT_ALLOWED_MISMATCHES",
            "PA_READ_COVERAGE_THRESHOLD", "PA_CLASS_REF", "Overflow", "Comm", "parse_overflow", "serialise_overflow", "overflow_merge"]
 
 PA_CLASS_REF = 0x80000000
@@ -657,6 +657,52 @@ def fastq_scan(fastq_path: str, num_threads: int = 2) -> Tuple[np.ndarray, np.nd
         check(lib().pa_fastq_scan_host(str(fastq_path).encode(), num_threads, C.byref(n), starts.ctypes.data_as(_ffi.u64p),
                                        hdr.ctypes.data_as(_ffi.u32p), seq.ctypes.data_as(_ffi.u32p), len(starts), C.byref(kind)))
     return starts, hdr, seq, kind.value
+
+
+PA_COMPACT_MAPPED, PA_COMPACT_BY_REF, PA_COMPACT_PACKED = 0x10000000, 0x20000000, 0x40000000
+
+
+def unpack_compact(compact: np.ndarray, packed: np.ndarray, index: "HostIndex") -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """pa_results_compact_device's 8-byte records + packed stream -> (results RESULT_DTYPE with class_off = 0, class_offsets[n+1], class_ids)
+    in read order (vectorised): a by-reference class is eq_classes[id] of the flat index, a packed one the next {length, ids...} entry"""
+    a = index.arrays()
+    lo = (compact & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (compact >> np.uint64(32)).astype(np.int64)
+    n = len(compact)
+    res = np.zeros(n, RESULT_DTYPE)
+    res["coverage"] = lo & 0x3FFF
+    res["mismatches"] = ((lo >> 14) & 0x3FFF) | np.where(lo & PA_COMPACT_MAPPED, np.uint32(PA_MAPPED_BIT), np.uint32(0))
+    by_ref = (lo & PA_COMPACT_BY_REF) != 0
+    pk = (lo & PA_COMPACT_PACKED) != 0
+    assert not (by_ref & pk).any(), "a class was lost to a full arena"
+    ec_offset = a["ec_offset"].astype(np.int64)
+    lens = np.zeros(n, np.int64)
+    lens[by_ref] = (ec_offset[1:] - ec_offset[:-1])[hi[by_ref]]
+    packed = np.asarray(packed, np.uint32)
+    # packed entries in read order: walk their lengths
+    pidx = np.flatnonzero(pk)
+    pstart = np.zeros(len(pidx), np.int64)
+    pos = 0
+    plen = np.zeros(len(pidx), np.int64)
+    for j in range(len(pidx)):     # (sequential by construction: entry j starts where entry j - 1 ends)
+        plen[j] = int(packed[pos])
+        pstart[j] = pos + 1
+        pos += 1 + int(plen[j])
+    assert pos == len(packed), "packed stream: %d words walked, %d given" % (pos, len(packed))
+    assert len(pidx) == 0 or np.array_equal((pstart - 1) & 0xFFFFFFFF, hi[pidx] & 0xFFFFFFFF)
+    lens[pidx] = plen
+    res["class_len"] = lens
+    coff = np.zeros(n + 1, np.uint64)
+    coff[1:] = np.cumsum(lens)
+    total = int(coff[-1])
+    if total == 0:
+        return res, coff, np.zeros(0, np.uint32)
+    src = np.concatenate([packed, a["ec_ids"]])
+    start = np.zeros(n, np.int64)
+    start[by_ref] = len(packed) + ec_offset[hi[by_ref]]
+    start[pidx] = pstart
+    within = np.arange(total, dtype=np.int64) - np.repeat(coff[:-1].astype(np.int64), lens)
+    return res, coff, src[np.repeat(start, lens) + within].astype(np.uint32)
 
 
 def gather_classes(results: np.ndarray, arena: np.ndarray, index: "HostIndex") -> Tuple[np.ndarray, np.ndarray]:

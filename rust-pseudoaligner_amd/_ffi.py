@@ -97,6 +97,8 @@ SIGNATURES = {
     "pa_process_reads_stage_seconds": (C.c_int, [C.POINTER(C.c_double)]),
     "pa_record_stream_stage_seconds": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "pa_map_arena_hint": (C.c_uint64, [vp, C.c_uint64]),
+    "pa_compact_scratch_bytes": (C.c_size_t, [C.c_uint64]),
+    "pa_results_compact_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint64, vp, vp, C.c_size_t, vp]),
     "pa_map_batch": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.POINTER(vp)]),
     "pa_map_read": (C.c_int, [vp, C.c_char_p, C.c_uint32, vp, C.c_uint32, u32p, u32p]),
     "pa_map_read_with_mismatch": (C.c_int, [vp, C.c_char_p, C.c_uint32, C.c_uint32, vp, C.c_uint32, u32p, u32p, u32p]),

@@ -160,3 +160,39 @@ def test_progress_line_is_the_references(small_index, tmp_path, monkeypatch, cap
         rate = np.float32(np.float32(flags[:at].sum()) * np.float32(100.0) / np.float32(at))
         assert m.rstrip("\n") == "Done Mapping %d reads w/ Rate: %s" % (at, np.format_float_positional(rate, unique=True, trim="-")), (m, rate)
     assert err.endswith("\n")                                                  # `eprintln!()` behind the progress line (:508)
+
+
+@pytest.mark.parametrize("k,ppm", [(24, 0), (24, 20000), (31, 40000)])
+def test_compact_records_are_the_records(small_index, k, ppm):
+    """pa_results_compact_device: the 8-byte records + the packed stream of the classes that are no index classes, unpacked on the host,
+    are what map_read_with_mismatch returns (src/pseudoaligner.rs:361-376) — against the oracle, with novel classes present"""
+    import torch
+    host = small_index(k)
+    a = pa.Pseudoaligner(host, 0)
+    tx = pa.Txome.from_host_index(host)
+    n, read_len = 300000, 150
+    wpr = pa.lib().pa_words_per_read(read_len)
+    tiles, lens = tx.simulate_host(read_len, 6, n, ppm, 0, wpr)
+    dev = torch.device("cuda", 0)
+    d_tiles = torch.from_numpy(tiles.view(np.int64)).to(dev)
+    d_lens = torch.from_numpy(lens.view(np.int32)).to(dev)
+    cap = a.arena_hint(n)
+    d_res = torch.zeros(n * 4, dtype=torch.int32, device=dev)
+    d_arena = torch.zeros(cap, dtype=torch.int32, device=dev)
+    a.map_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, 2)
+    used, need = a.map_finish()
+    scr = pa.lib().pa_compact_scratch_bytes(n)
+    d_scr = torch.zeros(scr, dtype=torch.uint8, device=dev)
+    d_compact = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_packed = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_pw = torch.zeros(1, dtype=torch.int64, device=dev)
+    pa.check(pa.lib().pa_results_compact_device(a._h, d_res.data_ptr(), d_arena.data_ptr(), cap, n, d_compact.data_ptr(), d_packed.data_ptr(), cap, d_pw.data_ptr(),
+                                                d_scr.data_ptr(), scr, None))
+    torch.cuda.synchronize()
+    pw = int(d_pw.item())
+    assert pw <= used + n                                    # no padding travels: ids + one length word per packed class
+    res, coff, ids = pa.unpack_compact(d_compact.cpu().numpy().view(np.uint64), d_packed[:pw].cpu().numpy().view(np.uint32), host)
+    want = helpers.Oracle(host).map_tiles(tiles, lens, wpr, 2, 8)
+    helpers.assert_same_as_oracle(res, coff, ids, want[0], want[1], want[2], "compact records K=%d ppm=%d" % (k, ppm))
+    npacked = int(((d_compact.cpu().numpy().view(np.uint64) & np.uint64(pa.PA_COMPACT_PACKED)) != 0).sum())
+    assert (npacked > 100) == (ppm > 0) or npacked > 0      # error reads produce intersections that are no index class
