@@ -652,105 +652,54 @@ def ingest_leg(env, run, n):
 
 
 def host_to_host_leg(env, run):
-    """SURVEY §8d's literal metric: the batch from PINNED HOST tiles to COMPLETE per-read outputs on the host — the 16-byte records, the
-    ids of every class that is not an index class (the used part of each chunk's arena) and the count table. Chunks of a few million
-    reads rotate over several streams of the one index handle: H2D of chunk i+1 and D2H of chunk i-1 overlap the kernels of chunk i.
-    The batch is uniform (every read has read_len bases): no length array crosses the link (pa_map_count_batch_uniform_device)."""
+    """SURVEY §8d's literal metric: the batch from PINNED HOST tiles to COMPLETE per-read outputs on the host — through the product's own
+    host-to-host entry (pa_map_tiles_host, csrc/host_batch.cpp): chunks of 2 M reads rotate over four streams of the one index handle (H2D
+    of chunk i + 1, the kernels of chunk i and D2H of chunk i - 1 overlap); back come the COMPACT 8-byte records, the packed classes that
+    are no index classes ({length, ids...} in read order) and the count table. The batch is uniform (every read has read_len bases): no
+    length array crosses the link."""
     pa, torch, dev, np = env["pa"], env["torch"], env["dev"], env["np"]
     aligner, B, wpr = run.aligner, run.B, run.wpr
     read_len = WORKLOADS[run.name]["read_len"]
     b = run.W % run.n_batches
-    words = pa.lib().pa_tiles_words
     h_tiles = torch.empty(run.tile_words, dtype=torch.int64, pin_memory=True)
-    h_compact = torch.empty(B, dtype=torch.int64, pin_memory=True)            # the 8-byte records (pa_results_compact_device)
+    h_compact = torch.empty(B, dtype=torch.int64, pin_memory=True)
     h_counts = torch.empty(aligner.counts_len(), dtype=torch.int64, pin_memory=True)
     h_tiles.copy_(run.tiles[b])
     assert bool((run.lens[b] == read_len).all())
-    NS = int(os.environ.get("PA_E2E_STREAMS", "4"))   # chunks in flight (one stream + one set of staging buffers each)
+    NS = int(os.environ.get("PA_E2E_STREAMS", "4"))
     chunk = min(B, int(os.environ.get("PA_E2E_CHUNK", str(min(B, 2_000_000))))) // 64 * 64 or B
-    n_chunks = (B + chunk - 1) // chunk
-    arena_cap = aligner.arena_hint(chunk)
-    # the chunks' classes that are no index classes, packed {length, ids...} in read order, back to back on the host
-    h_packed = torch.empty(max(arena_cap, B // 2), dtype=torch.int32, pin_memory=True)
-    h_pw = torch.zeros(NS, dtype=torch.int64, pin_memory=True)
-    scr = pa.lib().pa_compact_scratch_bytes(chunk)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-    stage = [dict(tiles=torch.empty(words(chunk, wpr), dtype=torch.int64, device=dev), res=torch.empty(chunk * 4, dtype=torch.int32, device=dev),
-                  arena=torch.empty(arena_cap, dtype=torch.int32, device=dev), compact=torch.empty(chunk, dtype=torch.int64, device=dev),
-                  packed=torch.empty(arena_cap, dtype=torch.int32, device=dev), pw=torch.zeros(1, dtype=torch.int64, device=dev),
-                  scr=torch.empty(scr, dtype=torch.uint8, device=dev), busy=-1) for _ in range(NS)]
-    e_counts = torch.zeros(aligner.counts_len(), dtype=torch.int64, device=dev)
-    packed_base = np.zeros(n_chunks + 1, np.int64)      # chunk c's packed classes are h_packed[packed_base[c] : packed_base[c + 1]]
-
-    def collect(st, S, k):
-        """chunk st['busy'] is done on its stream: how many words its packed classes take is known, they follow its records to the host"""
-        c = st["busy"]
-        aligner.map_finish(S.cuda_stream)
-        st["busy"] = -1
-        return c, int(h_pw[k])
+    h_packed = torch.empty(max(aligner.arena_hint(chunk), B // 2), dtype=torch.int32, pin_memory=True)
+    torch.cuda.synchronize()
 
     def host_to_host():
-        for st in stage:
-            st["busy"] = -1
-        e_counts.zero_()
-        packed_base[:] = 0
-        torch.cuda.synchronize()
-        t_e2e = time.perf_counter()
-        copied_upto, off = 0, 0
-        for c in range(n_chunks + NS):
-            k = c % NS
-            st, S = stage[k], streams[k]
-            if st["busy"] >= 0:
-                cc, used = collect(st, S, k)
-                # chunks complete in launch order on their stream and streams are visited round-robin: cc == copied_upto
-                assert cc == copied_upto
-                if used:
-                    if off + used > h_packed.numel() or used > st["packed"].numel():
-                        raise RuntimeError("host buffer of %d entries is too small for the chunks' packed classes (%d so far)" % (h_packed.numel(), off + used))
-                    with torch.cuda.stream(S):
-                        h_packed[off: off + used].copy_(st["packed"][:used], non_blocking=True)
-                packed_base[cc] = off
-                off += used
-                copied_upto += 1
-            if c < n_chunks:
-                lo, nn = c * chunk, min(chunk, B - c * chunk)          # chunk is a multiple of 64: tile aligned
-                with torch.cuda.stream(S):
-                    st["tiles"][: words(nn, wpr)].copy_(h_tiles[(lo // 64) * wpr * 64: (lo // 64) * wpr * 64 + words(nn, wpr)], non_blocking=True)
-                    aligner.map_count_batch_uniform_device(st["tiles"].data_ptr(), read_len, nn, wpr, st["res"].data_ptr(), st["arena"].data_ptr(),
-                                                           st["arena"].numel(), e_counts.data_ptr(), 2, S.cuda_stream)
-                    pa.check(pa.lib().pa_results_compact_device(aligner._h, st["res"].data_ptr(), st["arena"].data_ptr(), st["arena"].numel(), nn, st["compact"].data_ptr(),
-                                                                st["packed"].data_ptr(), st["packed"].numel(), st["pw"].data_ptr(), st["scr"].data_ptr(), scr, S.cuda_stream))
-                    h_compact[lo: lo + nn].copy_(st["compact"][:nn], non_blocking=True)
-                    h_pw[k: k + 1].copy_(st["pw"], non_blocking=True)
-                st["busy"] = c
-        packed_base[n_chunks] = off
-        h_counts.copy_(e_counts)
-        torch.cuda.synchronize()
-        return time.perf_counter() - t_e2e, off
-    host_to_host()                       # warm-up: the per-stream launch contexts (scratch rows, key streams) are created on first use
-    e2e_s, packed_words = min((host_to_host() for _ in range(3)), key=lambda r: r[0])
+        t0 = time.perf_counter()
+        words = aligner.map_tiles_host(h_tiles.data_ptr(), B, wpr, h_compact.data_ptr(), h_packed.data_ptr(), h_packed.numel(), uniform_len=read_len,
+                                       h_counts=h_counts.data_ptr(), chunk_reads=chunk, n_streams=NS)
+        return time.perf_counter() - t0, words
+    host_to_host()                       # warm-up: the streams' launch contexts and the staging buffers are created on first use
+    runs = [host_to_host() for _ in range(4)]
+    e2e_s, packed_words = min(runs, key=lambda r: r[0])
     assert os.environ.get("PA_MAP_ABLATE") or int(h_counts.sum()) == B
-    # parity of THIS leg's outputs: the first chunk's compact records + packed classes as they arrived on the host, unpacked, against the oracle
+    # parity of THIS leg's outputs: the first reads' compact records + packed classes as they arrived on the host, unpacked, against the oracle
     nn = min(chunk, 100_000)
-    first_packed = h_packed[: int(packed_base[1])].numpy().view(np.uint32)
     lo32 = (h_compact[:nn].numpy().view(np.uint64) & np.uint64(0xFFFFFFFF))
     n_pk = int(((lo32 & np.uint64(pa.PA_COMPACT_PACKED)) != 0).sum())
-    # (the sample's packed entries are the first n_pk of the chunk's stream: walk that many)
+    first_packed = h_packed[: int(packed_words)].numpy().view(np.uint32)
     pos = 0
-    for _ in range(n_pk):
+    for _ in range(n_pk):                # (the sample's packed entries are the first n_pk of the stream: walk that many)
         pos += 1 + int(first_packed[pos])
-    part, coff, cids = pa.unpack_compact(h_compact[:nn].numpy().view(np.uint64).copy(), first_packed[:pos], run.host)
+    part, coff, cids = pa.unpack_compact(h_compact[:nn].numpy().view(np.uint64).copy(), first_packed[:pos].copy(), run.host)
     sample = (part, coff, cids, nn, b)       # compared with the oracle once it is built (main, checker section)
-    for S in streams:                    # the leg's streams go away: so do their launch contexts inside the index
-        aligner.release_stream(S.cuda_stream)
     h2d_bytes = B * wpr * 8
+    n_chunks = (B + chunk - 1) // chunk
     return {"e2e_reads_per_s": B / e2e_s, "e2e_pcie_frac": h2d_bytes / e2e_s / 63e9, "e2e_link_frac_of_measured_57": h2d_bytes / e2e_s / 57e9,
-            "e2e": {"ms": 1000.0 * e2e_s, "chunks": n_chunks, "reads_per_chunk": chunk, "streams": NS, "h2d_bytes": h2d_bytes,
-                    "d2h_bytes": B * 8 + 4 * int(packed_words) + 8 * aligner.counts_len(), "record_bytes": 8, "packed_class_words_on_host": int(packed_words), "novel_class_ids_left_on_device": 0,
-                    "parity_sample": None,
-                    "what": "pinned host 2-bit tiles (uniform batch: no length array) -> H2D || kernels || D2H of the COMPACT 8-byte records (pa_results_compact_device) and of "
-                            "each chunk's packed classes ({length, ids...} of the classes that are no index classes, no padding) on several streams of one index handle -> "
-                            "records + ids + count table on the host; best of three passes; link = PCIe Gen5 x16, 63 GB/s per direction spec, 57 GB/s measured (profiles/r02_pcie_bw.json)"},
+            "e2e": {"ms": 1000.0 * e2e_s, "runs_ms": [round(1000.0 * r[0], 2) for r in runs], "chunks": n_chunks, "reads_per_chunk": chunk, "streams": NS, "h2d_bytes": h2d_bytes,
+                    "d2h_bytes": B * 8 + 4 * int(packed_words) + 8 * aligner.counts_len(), "record_bytes": 8, "packed_class_words_on_host": int(packed_words),
+                    "novel_class_ids_left_on_device": 0, "parity_sample": None,
+                    "what": "pa_map_tiles_host: pinned host 2-bit tiles (uniform batch: no length array) -> H2D || kernels || D2H of the COMPACT 8-byte records "
+                            "(pa_results_compact_device) and of each chunk's packed classes ({length, ids...} of the classes that are no index classes, no padding) on several "
+                            "streams of one index handle -> records + ids + count table on the host; best of four calls; link = PCIe Gen5 x16, 63 GB/s per direction spec, "
+                            "57 GB/s measured (profiles/r02_pcie_bw.json)"},
             "_e2e_sample": sample}
 
 

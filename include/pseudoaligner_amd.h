@@ -268,6 +268,19 @@ int pa_results_compact_device(pa_index* idx, const pa_read_result* d_results, co
                               uint64_t* d_compact, uint32_t* d_packed, uint64_t packed_cap, uint64_t* d_packed_words, void* d_scratch,
                               size_t scratch_bytes, void* stream);
 
+/* The hot path HOST TO HOST (SURVEY.md §8d's literal metric): a batch that lies in host memory in the tile layout — pinned memory
+ * (pa_host_alloc_pinned, hipHostMalloc, hipHostRegister) for the copies to run at the link's rate and beside the kernels — mapped in chunks
+ * of chunk_reads reads (0: 2 M) that rotate over n_streams streams of the handle (0: 4; at most 8): the copy of chunk i + 1 to the GPU, the
+ * kernels of chunk i and the copy of chunk i - 1's outputs back overlap. h_lens NULL: every read has uniform_len bases (no length array
+ * crosses the link). Outputs in read order: h_compact[n_reads] (the 8-byte records above), h_packed[*packed_words] (their packed classes;
+ * PA_ERR_ARENA_FULL when packed_cap is too small), h_counts[pa_counts_len(idx)] (the class-count table of the batch, overwritten; may
+ * be NULL). Synchronous: everything has arrived when the call returns. Streams and staging buffers stay parked on the handle. */
+int pa_map_tiles_host(pa_index* idx, const uint64_t* h_tiles, const uint32_t* h_lens, uint32_t uniform_len, uint64_t n_reads,
+                      uint32_t words_per_read, uint32_t allowed_mismatches, uint64_t* h_compact, uint32_t* h_packed, uint64_t packed_cap,
+                      uint64_t* packed_words, uint64_t* h_counts, uint64_t chunk_reads, int n_streams);
+int pa_host_alloc_pinned(size_t bytes, void** out);
+int pa_host_free_pinned(void* p);
+
 /* Host-buffer convenience (H2D, map, D2H; grows its own arena). results[n], class ids returned as a
  * CSR in read order: class_offsets[n+1], class_ids (library-owned, valid until the next call on idx
  * from this thread or pa_index_destroy). Reads are ASCII, concatenated, offsets[n+1]. */

@@ -254,6 +254,20 @@ int main(int argc, char** argv) {
             free(hc); free(hr);
             pa_device_free(d_compact); pa_device_free(d_packed); pa_device_free(d_pw); pa_device_free(d_scr);
         }
+        {   /* host to host: the simulated batch from pinned host tiles to compact records + count table, chunks of 64 reads on two streams */
+            void *ph_tiles = NULL, *ph_compact = NULL, *ph_packed = NULL, *ph_counts = NULL;
+            const uint64_t clen = pa_counts_len(idx);
+            uint64_t pwords = ~0ull, total = 0;
+            EXPECT(pa_host_alloc_pinned(pa_tiles_words(nsim, sim_wpr) * 8, &ph_tiles) == PA_OK && pa_host_alloc_pinned(nsim * 8, &ph_compact) == PA_OK &&
+                   pa_host_alloc_pinned((arena_cap + 16) * 4, &ph_packed) == PA_OK && pa_host_alloc_pinned(clen * 8, &ph_counts) == PA_OK);
+            memcpy(ph_tiles, sim_tiles, pa_tiles_words(nsim, sim_wpr) * 8);
+            EXPECT(pa_map_tiles_host(idx, (const uint64_t*)ph_tiles, sim_lens, 0, nsim, sim_wpr, 2, (uint64_t*)ph_compact, (uint32_t*)ph_packed, arena_cap + 16, &pwords,
+                                     (uint64_t*)ph_counts, 64, 2) == PA_OK);
+            for (uint64_t i = 0; i < clen; ++i) total += ((uint64_t*)ph_counts)[i];
+            EXPECT(total == nsim && pwords <= arena_cap + 16);
+            EXPECT(pa_map_tiles_host(idx, (const uint64_t*)ph_tiles, NULL, 60, nsim, sim_wpr, 2, (uint64_t*)ph_compact, (uint32_t*)ph_packed, arena_cap + 16, &pwords, NULL, 0, 0) == PA_OK);
+            EXPECT(pa_host_free_pinned(ph_tiles) == PA_OK && pa_host_free_pinned(ph_compact) == PA_OK && pa_host_free_pinned(ph_packed) == PA_OK && pa_host_free_pinned(ph_counts) == PA_OK);
+        }
         {   /* the same batch as a uniform one (the simulator's reads all have 60 bases): the same records without a length array */
             void* d_res2 = NULL;
             pa_read_result *r1 = (pa_read_result*)malloc(nsim * sizeof(pa_read_result)), *r2 = (pa_read_result*)malloc(nsim * sizeof(pa_read_result));

@@ -407,6 +407,15 @@ class Pseudoaligner:
         check(lib().pa_map_count_batch_uniform_device(self._h, d_tiles, read_len, n_reads, words_per_read, allowed_mismatches, d_results, d_arena,
                                                       arena_cap, d_counts, stream or None))
 
+    def map_tiles_host(self, h_tiles: int, n_reads: int, words_per_read: int, h_compact: int, h_packed: int, packed_cap: int, h_lens: int = 0, uniform_len: int = 0,
+                       h_counts: int = 0, allowed_mismatches: int = PA_DEFAULT_ALLOWED_MISMATCHES, chunk_reads: int = 0, n_streams: int = 0) -> int:
+        """pa_map_tiles_host: a batch in (pinned) host memory -> compact records + packed classes (+ count table) on the host, chunks pipelined
+        over several streams; returns the words of the packed stream. Raw host pointers."""
+        pw = C.c_uint64()
+        check(lib().pa_map_tiles_host(self._h, h_tiles, h_lens or None, uniform_len, n_reads, words_per_read, allowed_mismatches, h_compact, h_packed or None, packed_cap,
+                                      C.byref(pw), h_counts or None, chunk_reads, n_streams))
+        return pw.value
+
     def map_finish(self, stream: int = 0) -> Tuple[int, int]:
         used, need = C.c_uint64(), C.c_uint64()
         check(lib().pa_map_finish(self._h, stream or None, C.byref(used), C.byref(need)))

@@ -12,7 +12,7 @@ CSRC = PKG / "csrc"
 
 PRODUCT_SO = PKG / "libpseudoaligner_amd.so"
 
-HOST_SOURCES = ["host_index.cpp", "dbg_build.cpp", "device_flatten.cpp", "synth.cpp", "fastq.cpp", "record_stream.cpp"]
+HOST_SOURCES = ["host_index.cpp", "dbg_build.cpp", "device_flatten.cpp", "synth.cpp", "fastq.cpp", "record_stream.cpp", "host_batch.cpp"]
 HIP_SOURCES = ["kernels.hip", "map_pool.hip", "device_index.hip", "collective.hip", "barcode_counts.hip", "index_build.hip", "index_fill.hip", "count_sort.hip", "resolve.hip", "render.hip", "fastq_scan.hip", "compact.hip"]
 
 

@@ -97,6 +97,9 @@ SIGNATURES = {
     "pa_process_reads_stage_seconds": (C.c_int, [C.POINTER(C.c_double)]),
     "pa_record_stream_stage_seconds": (C.c_int, [vp, C.POINTER(C.c_double)]),
     "pa_map_arena_hint": (C.c_uint64, [vp, C.c_uint64]),
+    "pa_map_tiles_host": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, u64p, vp, C.c_uint64, C.c_int]),
+    "pa_host_alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+    "pa_host_free_pinned": (C.c_int, [vp]),
     "pa_compact_scratch_bytes": (C.c_size_t, [C.c_uint64]),
     "pa_results_compact_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, C.c_uint64, vp, vp, C.c_size_t, vp]),
     "pa_map_batch": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.POINTER(vp)]),

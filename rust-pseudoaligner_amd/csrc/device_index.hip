@@ -100,6 +100,7 @@ struct pa_index {
     // parked by fastq.cpp / record_stream.cpp between calls (guarded by `mu`): the buffer sets of up to four lanes (pa_process_reads_multi with the
     // handle listed several times, concurrent callers)
     std::vector<std::pair<void*, void (*)(void*)>> ingest_caches;
+    std::vector<std::pair<void*, void (*)(void*)>> host_pipes;   // ... and of pa_map_tiles_host (host_batch.cpp): streams + staging buffers of the chunks in flight
 };
 
 extern "C" {
@@ -214,6 +215,23 @@ void* index_take_ingest_cache(pa_index* idx) {
     idx->ingest_caches.pop_back();
     return c;
 }
+void* index_take_host_pipe(pa_index* idx) {
+    std::lock_guard<std::mutex> g(idx->mu);
+    if (idx->host_pipes.empty()) return nullptr;
+    void* c = idx->host_pipes.back().first;
+    idx->host_pipes.pop_back();
+    return c;
+}
+void index_put_host_pipe(pa_index* idx, void* pipe, void (*free_fn)(void*)) {
+    {
+        std::lock_guard<std::mutex> g(idx->mu);
+        if (idx->host_pipes.size() < 2) {
+            idx->host_pipes.emplace_back(pipe, free_fn);
+            return;
+        }
+    }
+    free_fn(pipe);
+}
 void index_put_ingest_cache(pa_index* idx, void* cache, void (*free_fn)(void*)) {
     {
         std::lock_guard<std::mutex> g(idx->mu);
@@ -235,7 +253,7 @@ void pa_index_destroy(pa_index* idx) {
         if (p) (void)hipFree(p);
     {   // (releases their streams' contexts)
         std::vector<std::pair<void*, void (*)(void*)>> parked;
-        { std::lock_guard<std::mutex> g(idx->mu); parked.swap(idx->ingest_caches); }
+        { std::lock_guard<std::mutex> g(idx->mu); parked.swap(idx->ingest_caches); parked.insert(parked.end(), idx->host_pipes.begin(), idx->host_pipes.end()); idx->host_pipes.clear(); }
         for (auto& c : parked) c.second(c.first);
     }
     for (auto& kv : idx->ctxs) kv.second->release();

@@ -28,6 +28,9 @@ int index_device_class_text(pa_index* idx, const uint64_t** d_off, const uint8_t
 // it; put() stores it back (or frees it with `free_fn` when another call already parked one). pa_index_destroy frees it.
 void* index_take_ingest_cache(pa_index* idx);
 void index_put_ingest_cache(pa_index* idx, void* cache, void (*free_fn)(void*));
+// the same for the streams and staging buffers of pa_map_tiles_host (host_batch.cpp)
+void* index_take_host_pipe(pa_index* idx);
+void index_put_host_pipe(pa_index* idx, void* pipe, void (*free_fn)(void*));
 
 // A/B tuning knobs (PA_MAP_ABLATE, PA_MAP_STATS, PA_POOL_SLOTS, PA_MAP_BLOCKS_PER_CU, PA_DICT_LOAD, PA_SIM_TX_LIMIT) exist only
 // in builds made with -DPA_DEBUG_KNOBS (tools/build_variant.sh). The shipped library never reads them: an exported variable

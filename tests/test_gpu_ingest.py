@@ -196,3 +196,38 @@ def test_compact_records_are_the_records(small_index, k, ppm):
     helpers.assert_same_as_oracle(res, coff, ids, want[0], want[1], want[2], "compact records K=%d ppm=%d" % (k, ppm))
     npacked = int(((d_compact.cpu().numpy().view(np.uint64) & np.uint64(pa.PA_COMPACT_PACKED)) != 0).sum())
     assert (npacked > 100) == (ppm > 0) or npacked > 0      # error reads produce intersections that are no index class
+
+
+@pytest.mark.parametrize("uniform", [False, True])
+def test_host_to_host_batches(small_index, uniform):
+    """pa_map_tiles_host (host tiles -> per-read outputs + count table on the host): chunks of 4 096 reads over three streams,
+    ragged and uniform batches, compact records + packed classes unpacked == the oracle's results, the count table == their histogram;
+    a packed buffer that is too small is reported, not overrun"""
+    import torch
+    host = small_index(24)
+    a = pa.Pseudoaligner(host, 0)
+    tx = pa.Txome.from_host_index(host)
+    n, read_len = 150000, 100
+    wpr = pa.lib().pa_words_per_read(read_len)
+    tiles, lens = tx.simulate_host(read_len, 12, n, 20000, 0, wpr)
+    if not uniform:                                  # ragged: shorten every third read (the tile words beyond a read's length are ignored)
+        lens = lens.copy()
+        lens[::3] = (np.arange(len(lens[::3])) % 101).astype(np.uint32)
+    h_tiles = torch.from_numpy(tiles.view(np.int64)).pin_memory()
+    h_lens = torch.from_numpy(lens.view(np.int32)).pin_memory()
+    h_compact = torch.zeros(n, dtype=torch.int64).pin_memory()
+    cap = a.arena_hint(n)
+    h_packed = torch.zeros(cap, dtype=torch.int32).pin_memory()
+    h_counts = torch.zeros(a.counts_len(), dtype=torch.int64).pin_memory()
+    for _ in range(2):                               # (the second call finds streams and staging buffers parked on the handle)
+        words = a.map_tiles_host(h_tiles.data_ptr(), n, wpr, h_compact.data_ptr(), h_packed.data_ptr(), cap, h_lens=0 if uniform else h_lens.data_ptr(),
+                                 uniform_len=read_len if uniform else 0, h_counts=h_counts.data_ptr(), chunk_reads=4096, n_streams=3)
+    res, coff, ids = pa.unpack_compact(h_compact.numpy().view(np.uint64), h_packed[:words].numpy().view(np.uint32), host)
+    want = helpers.Oracle(host).map_tiles(tiles, lens, wpr, 2, 8)
+    helpers.assert_same_as_oracle(res, coff, ids, want[0], want[1], want[2], "host to host, uniform=%s" % uniform)
+    assert np.array_equal(h_counts.numpy().astype(np.int64), helpers.counts_reference_fast(want[0], want[1], want[2], host))
+    assert words > 100
+    with pytest.raises(pa.PaError) as err:
+        a.map_tiles_host(h_tiles.data_ptr(), n, wpr, h_compact.data_ptr(), h_packed.data_ptr(), 50, h_lens=0 if uniform else h_lens.data_ptr(),
+                         uniform_len=read_len if uniform else 0, chunk_reads=4096, n_streams=3)
+    assert err.value.code == pa._ffi.PA_ERR_ARENA_FULL
