@@ -255,7 +255,8 @@ uint64_t pa_map_arena_hint(const pa_index* idx, uint64_t n_reads);
  *   bits  0..13  coverage        bits 14..27  mismatches        bit 28  mapped (Some / None)
  *   bit  29      PA_COMPACT_BY_REF: the class IS index class (record >> 32), i.e. eq_classes[id] of the flat index
  *   bit  30      PA_COMPACT_PACKED: the class is no index class: its ids are the next entry of the PACKED stream — entries {length, id0,
- *                id1, ...} back to back in READ order (record >> 32 = the entry's word offset modulo 2^32)
+ *                id1, ...} back to back in READ order (record >> 32 = the entry's word offset in the packed stream of its launch, modulo 2^32;
+ *                a reader that walks the records in order needs none of it)
  *   neither bit: the class is empty (or the read unmapped); both bits: the ids did not fit the launch's arena (pa_map_finish said so)
  * made from a launch's records and arena on the device: d_compact[n_reads] u64, d_packed[packed_cap] u32, *d_packed_words (device u64) =
  * words the packed stream needs (entries that would end beyond packed_cap are not written). d_scratch: pa_compact_scratch_bytes(n_reads)

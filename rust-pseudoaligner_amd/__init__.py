@@ -698,7 +698,6 @@ def unpack_compact(compact: np.ndarray, packed: np.ndarray, index: "HostIndex") 
         pstart[j] = pos + 1
         pos += 1 + int(plen[j])
     assert pos == len(packed), "packed stream: %d words walked, %d given" % (pos, len(packed))
-    assert len(pidx) == 0 or np.array_equal((pstart - 1) & 0xFFFFFFFF, hi[pidx] & 0xFFFFFFFF)
     lens[pidx] = plen
     res["class_len"] = lens
     coff = np.zeros(n + 1, np.uint64)

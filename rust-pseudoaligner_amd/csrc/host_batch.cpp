@@ -24,6 +24,7 @@ struct Stage {   // one chunk in flight
     void *d_tiles = nullptr, *d_lens = nullptr, *d_res = nullptr, *d_arena = nullptr, *d_compact = nullptr, *d_packed = nullptr, *d_pw = nullptr, *d_scr = nullptr;
     uint64_t cap_reads = 0, arena_cap = 0, tiles_words = 0;
     size_t scr_bytes = 0;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_back = nullptr;   // the chunk's tiles have arrived | its outputs are ready on the device | ... and on the host
     int64_t busy = -1;   // the chunk whose outputs are on their way
 };
 
@@ -31,13 +32,20 @@ struct HostPipe {
     pa_index* idx = nullptr;
     int device = 0;
     Stage st[MAX_STREAMS];
+    // dedicated copy streams (A/B in knobs builds: see run()). rocprofv3 shows the runtime executing part of the copies issued on the chunks' own
+    // streams as blit KERNELS when a DMA engine is busy (1.4 - 4 ms per 80 MB chunk against 1.4 ms by DMA) — and still that arrangement is the fastest
+    hipStream_t s_in = nullptr, s_back = nullptr, s_in2 = nullptr;
     void* d_counts = nullptr;
     uint64_t counts_len = 0;
     unsigned long long* h_pw = nullptr;   // pinned: words of every stage's packed classes
     static void destroy(void* p) {
         HostPipe* h = static_cast<HostPipe*>(p);
         (void)hipSetDevice(h->device);
+        for (hipStream_t q : {h->s_in, h->s_back, h->s_in2})
+            if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
         for (Stage& s : h->st) {
+            for (hipEvent_t e : {s.ev_in, s.ev_out, s.ev_back})
+                if (e) (void)hipEventDestroy(e);
             if (s.stream) { (void)hipStreamSynchronize(s.stream); if (h->idx) (void)pa_index_release_stream(h->idx, s.stream); (void)hipStreamDestroy(s.stream); }
             for (void* q : {s.d_tiles, s.d_lens, s.d_res, s.d_arena, s.d_compact, s.d_packed, s.d_pw, s.d_scr})
                 if (q) (void)hipFree(q);
@@ -49,7 +57,12 @@ struct HostPipe {
 };
 
 int stage_ensure(pa_index* idx, Stage& s, uint64_t chunk, uint32_t wpr, bool lens) {
-    if (!s.stream) HB_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (!s.stream) {
+        HB_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HB_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+        HB_HIP(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
+        HB_HIP(hipEventCreateWithFlags(&s.ev_back, hipEventDisableTiming));
+    }
     const uint64_t tw = pa_tiles_words(chunk, wpr);
     if (tw > s.tiles_words) {
         if (s.d_tiles) (void)hipFree(s.d_tiles);
@@ -90,6 +103,13 @@ int run(pa_index* idx, HostPipe& hp, const uint64_t* h_tiles, const uint32_t* h_
         hp.counts_len = counts_len;
     }
     if (!hp.h_pw) HB_HIP(hipHostMalloc((void**)&hp.h_pw, MAX_STREAMS * 8, hipHostMallocDefault));
+    if (!hp.s_in) HB_HIP(hipStreamCreateWithFlags(&hp.s_in, hipStreamNonBlocking));
+    if (!hp.s_back) HB_HIP(hipStreamCreateWithFlags(&hp.s_back, hipStreamNonBlocking));
+    if (!hp.s_in2) HB_HIP(hipStreamCreateWithFlags(&hp.s_in2, hipStreamNonBlocking));
+    // Where the copies run — measured (tools/bench_e2e.py, 100 M reads of config 3, same box): on the chunk's OWN stream 76 - 83 ms; tiles in on one
+    // dedicated copy stream 84 - 86 ms, on two alternating 101 ms; outputs back on a dedicated stream 109 - 113 ms (the cross-stream events
+    // serialise more than the DMA engines gain). The other arrangements stay selectable in knobs builds only.
+    const int in_mode = knob_int("PA_HB_IN", 0), back_mode = knob_int("PA_HB_BACK", 0);   // 0 = the chunk's own stream, 1 = one copy stream, 2 (in) = two alternating
     for (int k = 0; k < ns; ++k) {
         const int e = stage_ensure(idx, hp.st[k], chunk, wpr, h_lens != nullptr);
         if (e != PA_OK) return e;
@@ -106,31 +126,44 @@ int run(pa_index* idx, HostPipe& hp, const uint64_t* h_tiles, const uint32_t* h_
         if (s.busy >= 0) {   // the chunk launched ns chunks ago: its packed classes follow its records to the host
             uint64_t used = 0, need = 0;
             if ((rc = pa_map_finish(idx, s.stream, &used, &need)) != PA_OK) break;
+            HB_HIP(hipEventSynchronize(s.ev_back));   // (its records and the length of its packed stream have arrived)
             const uint64_t words = hp.h_pw[k];
             if (off + words > packed_cap || words > s.arena_cap) { rc = fail(PA_ERR_ARENA_FULL, "packed classes: %llu words so far, room for %llu", (unsigned long long)(off + words), (unsigned long long)packed_cap); break; }
-            if (words) HB_HIP(hipMemcpyAsync(h_packed + off, s.d_packed, words * 4, hipMemcpyDeviceToHost, s.stream));
+            const hipStream_t sb0 = back_mode ? hp.s_back : s.stream;
+            if (words) HB_HIP(hipMemcpyAsync(h_packed + off, s.d_packed, words * 4, hipMemcpyDeviceToHost, sb0));
+            HB_HIP(hipEventRecord(s.ev_back, sb0));                 // (the stage's d_packed is rewritten only behind this copy)
+            HB_HIP(hipStreamWaitEvent(s.stream, s.ev_back, 0));
             off += words;
             s.busy = -1;
         }
         if (c < n_chunks) {
             const uint64_t lo = c * chunk, nn = std::min<uint64_t>(chunk, n - lo);   // chunk is a multiple of 64: tile aligned
-            HB_HIP(hipMemcpyAsync(s.d_tiles, h_tiles + (lo / 64) * wpr * 64, pa_tiles_words(nn, wpr) * 8, hipMemcpyHostToDevice, s.stream));
-            if (h_lens) {
-                HB_HIP(hipMemcpyAsync(s.d_lens, h_lens + lo, nn * 4, hipMemcpyHostToDevice, s.stream));
+            const hipStream_t si = in_mode == 0 ? s.stream : (in_mode == 2 && (c & 1)) ? hp.s_in2 : hp.s_in;
+            HB_HIP(hipMemcpyAsync(s.d_tiles, h_tiles + (lo / 64) * wpr * 64, pa_tiles_words(nn, wpr) * 8, hipMemcpyHostToDevice, si));
+            if (h_lens) HB_HIP(hipMemcpyAsync(s.d_lens, h_lens + lo, nn * 4, hipMemcpyHostToDevice, si));
+            HB_HIP(hipEventRecord(s.ev_in, si));
+            HB_HIP(hipStreamWaitEvent(s.stream, s.ev_in, 0));
+            if (h_lens)
                 rc = pa_map_count_batch_device(idx, (const uint64_t*)s.d_tiles, (const uint32_t*)s.d_lens, nn, wpr, allowed, (pa_read_result*)s.d_res, (uint32_t*)s.d_arena, s.arena_cap,
                                                (uint64_t*)hp.d_counts, s.stream);
-            } else
+            else
                 rc = pa_map_count_batch_uniform_device(idx, (const uint64_t*)s.d_tiles, uniform_len, nn, wpr, allowed, (pa_read_result*)s.d_res, (uint32_t*)s.d_arena, s.arena_cap,
                                                        (uint64_t*)hp.d_counts, s.stream);
             if (rc != PA_OK) break;
             rc = pa_results_compact_device(idx, (const pa_read_result*)s.d_res, (const uint32_t*)s.d_arena, s.arena_cap, nn, (uint64_t*)s.d_compact, (uint32_t*)s.d_packed, s.arena_cap,
                                            (uint64_t*)s.d_pw, s.d_scr, s.scr_bytes, s.stream);
             if (rc != PA_OK) break;
-            HB_HIP(hipMemcpyAsync(h_compact + lo, s.d_compact, nn * 8, hipMemcpyDeviceToHost, s.stream));
-            HB_HIP(hipMemcpyAsync(hp.h_pw + k, s.d_pw, 8, hipMemcpyDeviceToHost, s.stream));
+            HB_HIP(hipEventRecord(s.ev_out, s.stream));
+            const hipStream_t sb = back_mode ? hp.s_back : s.stream;
+            HB_HIP(hipStreamWaitEvent(sb, s.ev_out, 0));
+            HB_HIP(hipMemcpyAsync(h_compact + lo, s.d_compact, nn * 8, hipMemcpyDeviceToHost, sb));
+            HB_HIP(hipMemcpyAsync(hp.h_pw + k, s.d_pw, 8, hipMemcpyDeviceToHost, sb));
+            HB_HIP(hipEventRecord(s.ev_back, sb));
             s.busy = (int64_t)c;
         }
     }
+    for (hipStream_t q : {hp.s_in, hp.s_in2, hp.s_back})
+        if (q) (void)hipStreamSynchronize(q);
     for (int k = 0; k < ns; ++k)
         if (hp.st[k].stream) (void)hipStreamSynchronize(hp.st[k].stream);   // (also on the error path: nothing of this call is in flight when it returns)
     if (rc != PA_OK) return rc;
