@@ -634,3 +634,122 @@ def error_reads(host, read_len, n, ppm, seed):
     tx = pa.Txome.from_host_index(host)
     tiles, lens = tx.simulate_host(read_len, seed, n, ppm)
     return tiles, lens, pa.lib().pa_words_per_read(read_len)
+
+
+def _mutate(rng, r, rate):
+    r = list(r)
+    for j in range(len(r)):
+        if rng.rand() < rate:
+            r[j] = "ACGT"[("ACGT".index(r[j]) + 1 + rng.randint(3)) % 4]
+    return r
+
+
+def branch_case(seed, tmp_path, nreads=600):
+    """fuzz family: BRANCH POINTS on and around multiples of 64 with skewed multiplicities, and bubbles. Every locus is
+    prefix + one of 2..4 branches + (for a bubble) a common suffix; the prefix's length puts the branch point at 64 j + d, d in -2..2, of
+    its unitig (the chain blocks' seams); branch 0 is carried by most transcripts (the flattener's FAVOURED branch: its copy follows the
+    branch record), the others by one or two. Reads start before a branch point and run over it along favoured and other branches, some
+    to 700 bases over several loci, with clustered errors (2..5 substitutions inside ten bases), dense errors at their head, or none;
+    allowed in {0, 1, 2, 3, 6, 12}; K in {12 .. 64}. Returns (host index, reads, allowed)."""
+    rng = np.random.RandomState(31000 + seed)
+    k = int(rng.choice([12, 16, 21, 24, 31, 32, 33, 47, 64]))
+    rnd = lambda n: "".join(rng.choice(list("ACGT"), n))
+    nloci = int(rng.randint(2, 5))
+    loci = []
+    for _ in range(nloci):
+        j, d = int(rng.randint(1, 5)), int(rng.randint(-2, 3))
+        plen = max(k + 1, 64 * j + d + int(rng.choice([0, k - 1, k])))     # the branch point (or its last k-mer) on / beside a multiple of 64
+        prefix = rnd(plen)
+        nb = int(rng.randint(2, 5))
+        kind = rng.randint(3)                                               # 0: branches of any length; 1: SNP bubble; 2: short indel-like bubble
+        if kind == 1:
+            base = rnd(int(rng.randint(1, 40)))
+            branches = [("ACGT"[i] + base) for i in rng.permutation(4)[:nb]]
+        elif kind == 2:
+            branches = [rnd(int(rng.randint(0, 6))) for _ in range(nb)]
+            branches = list(dict.fromkeys(branches))
+        else:
+            branches = [rnd(int(rng.randint(1, 150))) for _ in range(nb)]
+        suffix = rnd(int(rng.randint(k, 200))) if rng.rand() < 0.7 else ""   # a bubble closes again, a fork does not
+        mult = [int(rng.randint(4, 12))] + [int(rng.randint(1, 3)) for _ in branches[1:]]
+        loci.append((prefix, branches, suffix, mult))
+    txs = []
+    ntx = int(rng.randint(6, 30))
+    for t in range(ntx):
+        s = ""
+        for prefix, branches, suffix, mult in loci:
+            w = np.array(mult[:len(branches)], float)
+            b = rng.choice(len(branches), p=w / w.sum())
+            s += prefix + branches[b] + suffix
+            if rng.rand() < 0.3:
+                break
+        txs.append(s)
+    fa = tmp_path / ("br%d.fa" % seed)
+    fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i // 2, s) for i, s in enumerate(txs)))
+    host = pa.HostIndex.build_fasta(str(fa), k, 3)
+    if host.arrays()["num_nodes"] == 0:
+        return None, [], 0
+    allowed = int(rng.choice([0, 1, 2, 3, 6, 12]))
+    reads = []
+    for _ in range(nreads):
+        t = txs[rng.randint(len(txs))]
+        n = int(rng.randint(k, min(len(t), 700) + 1)) if len(t) >= k else len(t)
+        lo = rng.randint(0, len(t) - n + 1)
+        r = list(t[lo:lo + n])
+        kind = rng.randint(4)
+        if kind == 0 and n > 12:                                            # a cluster of errors
+            at = rng.randint(0, n - 10)
+            for j in rng.choice(10, rng.randint(2, 6), replace=False):
+                r[at + j] = "ACGT"[("ACGT".index(r[at + j]) + 1 + rng.randint(3)) % 4]
+        elif kind == 1 and n > 2 * k:                                       # dense errors at the head: the first hit lies behind them
+            for j in range(rng.randint(0, k // 2 + 1), min(n - k, rng.randint(k, 3 * k)), max(2, k // 2)):
+                r[j] = "ACGT"[("ACGT".index(r[j]) + 1 + rng.randint(3)) % 4]
+        elif kind == 2:
+            r = _mutate(rng, r, 0.02)
+        reads.append("".join(r))
+    return host, reads, allowed
+
+
+def tandem_case(seed, tmp_path, nreads=500):
+    """fuzz family: TANDEM REPEATS and low-complexity sequence over 1..4-letter alphabets — k-mer cycles, self-loops, nodes
+    of exactly one k-mer — with reads of exactly K, K + 1, K + 2 ... 1 200 bases. Transcripts are runs of a short unit (1..12 bases) of
+    different lengths between random flanks, and some pure runs. K in {8 .. 64}. Returns (host index, reads, allowed)."""
+    rng = np.random.RandomState(47000 + seed)
+    k = int(rng.choice([8, 11, 16, 20, 24, 31, 32, 33, 48, 64]))
+    alpha = list("ACGT"[: int(rng.randint(1, 5))])
+    rnd = lambda n, a=alpha: "".join(rng.choice(a, n))
+    units = [rnd(int(rng.randint(1, 13))) for _ in range(int(rng.randint(1, 4)))]
+    txs = []
+    for _ in range(int(rng.randint(3, 25))):
+        u = units[rng.randint(len(units))]
+        run = (u * (int(rng.randint(k, 4 * k + 200)) // len(u) + 2))[: int(rng.randint(k, 4 * k + 200))]
+        kind = rng.randint(4)
+        if kind == 0:
+            txs.append(run)                                                   # a pure run (a k-mer cycle when it is long enough)
+        elif kind == 1:
+            txs.append(rnd(int(rng.randint(0, 80)), list("ACGT")) + run + rnd(int(rng.randint(0, 80)), list("ACGT")))
+        elif kind == 2:
+            v = units[rng.randint(len(units))]
+            txs.append(run + (v * 60)[: int(rng.randint(k, 300))] + run[: int(rng.randint(1, len(run) + 1))])
+        else:
+            txs.append("".join(_mutate(rng, run, 0.01)))                      # an imperfect repeat
+    fa = tmp_path / ("td%d.fa" % seed)
+    fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i // 3, s) for i, s in enumerate(txs)))
+    host = pa.HostIndex.build_fasta(str(fa), k, 3)
+    if host.arrays()["num_nodes"] == 0:
+        return None, [], 0
+    allowed = int(rng.choice([0, 1, 2, 3]))
+    reads = []
+    for i in range(nreads):
+        t = txs[rng.randint(len(txs))]
+        if len(t) < k:
+            reads.append(t)
+            continue
+        n = k + i % 3 if i % 4 == 0 else int(rng.randint(k, min(len(t), 1200) + 1))   # exactly K, K + 1, K + 2 bases, and anything up to 1 200
+        n = min(n, len(t))
+        lo = rng.randint(0, len(t) - n + 1)
+        r = list(t[lo:lo + n])
+        if rng.rand() < 0.4:
+            r = _mutate(rng, r, 0.03)
+        reads.append("".join(r))
+    return host, reads, allowed

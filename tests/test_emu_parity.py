@@ -234,3 +234,25 @@ def test_repeat_families_pending_classes_and_bitmaps():
         helpers.assert_same_as_oracle(r["results"], r["coff"], r["ids"], want[0], want[1], want[2], "repeat families ppm=%d" % ppm)
         assert r["steps"][4] > 500                     # reads with pending classes were met (mask_pending ran)
         assert want[3]["class_sizes"] / want[3]["reads"] > 15
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_branch_points_on_block_seams(tmp_path, seed):
+    """helpers.branch_case: branch records, favoured-branch tails and bubbles on / beside multiples of 64, clustered and dense-head errors,
+    reads to 700 bases, allowed to 12 — the lane steps on the host vs the oracle"""
+    host, reads, allowed = helpers.branch_case(seed, tmp_path)
+    if host is None:
+        pytest.skip("no k-mer")
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    r, _ = check(host, tiles, lens, wpr, allowed)
+    assert helpers.Emu(host).info()["bad_blocks"] == 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_tandem_repeats_and_reads_of_exactly_k(tmp_path, seed):
+    """helpers.tandem_case: k-mer cycles and self-loops over 1..4-letter alphabets, reads of exactly K, K + 1, K + 2 ... 1 200 bases"""
+    host, reads, allowed = helpers.tandem_case(seed, tmp_path)
+    if host is None:
+        pytest.skip("no k-mer")
+    tiles, lens, wpr = pa.encode_reads_host(reads)
+    check(host, tiles, lens, wpr, allowed)
