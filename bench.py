@@ -227,7 +227,7 @@ def roofline_of(run, ctr, stage_ms, step_ms):
     pool_avg_ms, resolve_avg_ms, count_avg_ms = (sum(m[i] for m in stage_ms) / n for i in range(3))
     kernel_avg_ms = sum(map_ms) / n
     achieved = bytes_per_read * B / (kernel_avg_ms * 1e-3) / 1e9
-    requests = raw_traffic = traffic = miss_block_bytes = None
+    requests = raw_traffic = traffic = miss_block_bytes = box_step_ms = None
     traffic_note = None
     # HBM bytes per step from committed rocprofv3 PMC passes of this same workload (bench.py cannot run PMC itself). The file names the
     # hash of the kernel sources it was measured on: a kernel change without a new PMC pass reports no traffic instead of stale bytes.
@@ -250,6 +250,7 @@ def roofline_of(run, ctr, stage_ms, step_ms):
             rd_bytes = pmc.get("READ_REQUEST_BYTES") or 2.0 * pmc["FETCH_SIZE_KB"] * 1024.0
             traffic = rd_bytes + pmc["WRITE_SIZE_KB"] * 1024.0
             raw_traffic = raw
+            box_step_ms = pmc.get("profiled_box_step_ms")
             miss_block_bytes = 128.0 * pmc["map_kernel_l2_misses"] / B if pmc.get("map_kernel_l2_misses") else None
             per_launch = raw / 64.0
             step_avg = sum(step_ms) / max(len(step_ms), 1)
@@ -268,12 +269,15 @@ def roofline_of(run, ctr, stage_ms, step_ms):
     step_avg = sum(step_ms) / max(len(step_ms), 1)
     return {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
             "traffic": traffic, "traffic_raw_counters": raw_traffic, "traffic_note": traffic_note,
-            # rocprof HBM GB/s against the chip's peak (north_star): the counters' bytes of a step over its device time
-            "traffic_gbps": (traffic / (step_avg * 1e-3) / 1e9) if traffic else None,
+            # the counters' bytes of a step: memory-side requests LEAVING THE L2 (x 128 B) + WRITE_SIZE. The guide says these counters also count
+            # requests the Infinity Cache answers (the chain blocks, 0.38 GB, mostly live there), so this is traffic out of the L2, an upper bound of
+            # HBM traffic — and it was measured on the builder's box (profiles/latest_pmc.json), not on this one
+            "traffic_what": "bytes of memory-side requests leaving the L2 per launch (Infinity-Cache hits included), rocprofv3 --pmc on the profiled box",
+            "traffic_gbps": (traffic / (step_avg * 1e-3) / 1e9) if traffic else None,                      # ... over THIS run's step time
             "traffic_frac_of_peak": (traffic / (step_avg * 1e-3) / 1e9 / 8000.0) if traffic else None,
-            # ... and against what the chip's memory system sustains (6.29 TB/s float4 copy, MI355X_MICROARCH.md; 128-byte random gathers
-            # reach the same: tools/microbench/gather.hip, 49 G requests/s x 128 B)
-            "traffic_frac_of_achievable_6_3": (traffic / (step_avg * 1e-3) / 1e9 / 6290.0) if traffic else None,
+            # the same bytes over the step time of the box they were measured on, against the 6.29 TB/s a streaming copy sustains (MI355X_MICROARCH.md)
+            "l2_outbound_frac_of_6_3_on_profiled_box": (traffic / (box_step_ms * 1e-3) / 1e9 / 6290.0) if traffic and box_step_ms else None,
+            "profiled_box_step_ms": box_step_ms,
             "l2_miss_block_bytes_per_read": miss_block_bytes,
             "kernel": "pa_map_pool_kernel + pa_resolve_kernel", "kernel_ms": kernel_avg_ms, "map_pool_kernel_ms": pool_avg_ms, "resolve_kernel_ms": resolve_avg_ms,
             "kernel_ms_min": min(map_ms) if map_ms else None, "kernel_ms_max": max(map_ms) if map_ms else None,

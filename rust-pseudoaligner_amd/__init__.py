@@ -558,11 +558,20 @@ class RecordStream:
         s_data, s_off = concat_reads(seqs)
         check(lib().pa_records_push(self._h, i_data.ctypes.data, i_off.ctypes.data, s_data.ctypes.data, s_off.ctypes.data, len(i_off) - 1))
 
-    def pull(self, cap: int = 1 << 20) -> bytes:
-        buf = C.create_string_buffer(cap)
-        n = C.c_size_t()
-        check(lib().pa_records_pull(self._h, buf, cap, C.byref(n)))
-        return buf.raw[: n.value]
+    def pull(self, cap: int = 1 << 20, grow: bool = True) -> bytes:
+        """rendered tuples, whole lines. A tuple longer than `cap` (a class of ~100 k ids) makes the library answer PA_ERR_BUFFER_TOO_SMALL with the
+        bytes it needs: the buffer is grown to that and the pull repeated (grow=False: the error is raised instead)"""
+        from ._ffi import PA_ERR_BUFFER_TOO_SMALL
+        for _ in range(4):
+            buf = C.create_string_buffer(cap)
+            n = C.c_size_t()
+            rc = lib().pa_records_pull(self._h, buf, cap, C.byref(n))
+            if rc == PA_ERR_BUFFER_TOO_SMALL and grow and n.value > cap:
+                cap = int(n.value)
+                continue
+            check(rc)
+            return buf.raw[: n.value]
+        raise PaError(PA_ERR_BUFFER_TOO_SMALL, "pa_records_pull keeps asking for a larger buffer")
 
     def flush(self) -> None:
         check(lib().pa_records_flush(self._h))

@@ -67,6 +67,25 @@ def build_product(force: bool = False) -> Path:
     return PRODUCT_SO
 
 
+MAXBINS_SO = OBJ_DIR / "libpseudoaligner_amd_maxbins2.so"
+
+
+def build_maxbins_variant(force: bool = False) -> Path:
+    """A TEST build of the product: count_sort.hip compiled with -DPA_MAX_BINS=2, everything else the product's own objects. A class-count table
+    of more than 65 536 slots is then "beyond MAX_BINS" and takes the plain-atomics path of count_sort.hip for batches of ANY size — the path
+    that in the product only tables beyond 8.4 M classes take for large batches (tests/test_gpu_scale.py loads it through PA_PRODUCT_SO)."""
+    build_product()
+    hipcc = hipcc_path()
+    src = CSRC / "count_sort.hip"
+    obj = OBJ_DIR / "count_sort.maxbins2.o"
+    if force or _stale(obj, _deps_of(src)):
+        _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function", "-DPA_MAX_BINS=2", "-x", "hip", "-c", str(src), "-o", str(obj)])
+    objs = [OBJ_DIR / (s + ".o") for s in HOST_SOURCES + HIP_SOURCES if s != "count_sort.hip"] + [obj]
+    if force or _stale(MAXBINS_SO, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + [str(o) for o in objs] + ["-ldl", "-lz", "-o", str(MAXBINS_SO)])
+    return MAXBINS_SO
+
+
 ABI_CHECK_SRC = ROOT / "integration" / "c" / "abi_check.c"
 ABI_CHECK_BIN = ROOT / "integration" / "c" / "abi_check"
 

@@ -25,7 +25,10 @@ namespace pa {
 namespace {
 
 constexpr uint32_t NO_KEY = 0xFFFFFFFFu;
-constexpr uint32_t MAX_BINS = 256;                       // tables of up to 8.4 M slots; beyond, keys are counted with plain atomics
+#ifndef PA_MAX_BINS
+#define PA_MAX_BINS 256   // (-DPA_MAX_BINS=2: the test build in which a table of 100 k classes already is "beyond MAX_BINS", _build.build_maxbins_variant)
+#endif
+constexpr uint32_t MAX_BINS = PA_MAX_BINS;               // tables of up to 8.4 M slots; beyond, keys are counted with plain atomics
 constexpr uint64_t PA_COUNT_DIRECT_MAX_READS = 1u << 16; // ... and so are the keys of batches this small
 constexpr uint32_t BIN_SLOTS = 1u << PA_KEY_BIN_SHIFT;
 constexpr uint32_t CS_BLOCK = 1024;

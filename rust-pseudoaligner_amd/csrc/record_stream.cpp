@@ -20,6 +20,7 @@
 #include <deque>
 #include <memory>
 #include <new>
+#include <stdexcept>
 
 #include "ingest.hpp"
 #include "pa_common.hpp"
@@ -182,7 +183,20 @@ void pa_record_stream_destroy(pa_record_stream* s) {
     delete s;
 }
 
+static int records_push_impl(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs, const uint64_t* seq_offsets, uint64_t n);
+static int records_flush_impl(pa_record_stream* s);
+// (std::bad_alloc out of the growable buffers, std::system_error out of the worker pool: nothing crosses the C ABI)
+#define PA_RS_GUARD(call) \
+    try { return call; } \
+    catch (const std::bad_alloc&) { return s ? fail_sticky(s, fail(PA_ERR_OOM, "out of host memory in the record stream")) : PA_ERR_OOM; } \
+    catch (const std::exception& ex) { return s ? fail_sticky(s, fail(PA_ERR_INTERNAL, "record stream: %s", ex.what())) : PA_ERR_INTERNAL; }
 int pa_records_push(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs, const uint64_t* seq_offsets, uint64_t n) {
+    PA_RS_GUARD(records_push_impl(s, ids, id_offsets, seqs, seq_offsets, n))
+}
+int pa_records_flush(pa_record_stream* s) {
+    PA_RS_GUARD(records_flush_impl(s))
+}
+static int records_push_impl(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs, const uint64_t* seq_offsets, uint64_t n) {
     if (!s || (n && (!id_offsets || !seq_offsets))) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (s->rc != PA_OK) return fail(s->rc, "%s", s->why.c_str());
     if (hipSetDevice(s->device) != hipSuccess) return fail_sticky(s, fail(PA_ERR_HIP, "hipSetDevice failed"));
@@ -233,7 +247,7 @@ int pa_records_push(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_
     return PA_OK;
 }
 
-int pa_records_flush(pa_record_stream* s) {
+static int records_flush_impl(pa_record_stream* s) {
     if (!s) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (s->rc != PA_OK) return fail(s->rc, "%s", s->why.c_str());
     if (hipSetDevice(s->device) != hipSuccess) return fail_sticky(s, fail(PA_ERR_HIP, "hipSetDevice failed"));

@@ -229,3 +229,45 @@ def test_config3r_repeat_families_two_million_reads_bit_exact():
     assert ctr["mapped"] == 2_000_000 and ctr["class_sizes"] / ctr["reads"] > 12                   # (config 3: 10.7 ids per read over the visited classes)
     ctr, _ = _bit_exact_with_counts(tx, host, aligner, oracle, 24, 150, 5, 10000, 1_000_000, 0, "config3r, 1 M reads with 1 % substitutions")
     assert ctr["reseeks"] > 20_000
+
+
+def test_count_table_beyond_max_bins_full_batch(tmp_path):
+    """count_sort.hip's plain-atomics path (tables beyond MAX_BINS bins) on a LARGE batch: in the product only a table of more than 8.4 M classes
+    gets there with more than 65 536 reads; the test build _build.build_maxbins_variant() (count_sort.hip with MAX_BINS = 2, everything else the
+    product's objects) sends a 100 k-class table down that path. A subprocess loads it through PA_PRODUCT_SO: 1.5 M reads with 1 % errors, the
+    table against the histogram of the oracle's results."""
+    import subprocess, sys
+    _b = helpers._build
+    so = _b.MAXBINS_SO
+    if not so.exists():
+        so = _b.build_maxbins_variant()
+    code = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, numpy as np
+import helpers
+pa = helpers.pa
+tx = pa.Txome.synthesize(12000, 42000, 7)
+host = pa.HostIndex.from_txome_device(tx, 24, 0)
+a = pa.Pseudoaligner(host, 0)
+assert a.counts_len() > 3 * 32768, a.counts_len()
+n, wpr = 1500000, 5
+dev = torch.device("cuda", 0)
+d_tiles = torch.empty(pa.lib().pa_tiles_words(n, wpr), dtype=torch.int64, device=dev)
+d_lens = torch.empty(n, dtype=torch.int32, device=dev)
+tx.simulate_device(150, 3, n, d_tiles.data_ptr(), d_lens.data_ptr(), 10000, 0, wpr)
+h_tiles, h_lens = tx.simulate_host(150, 3, n, 10000, 0, wpr)
+cap = a.arena_hint(n)
+d_res = torch.empty(n * 4, dtype=torch.int32, device=dev); d_arena = torch.empty(cap, dtype=torch.int32, device=dev)
+d_counts = torch.zeros(a.counts_len(), dtype=torch.int64, device=dev)
+a.map_count_batch_device(d_tiles.data_ptr(), d_lens.data_ptr(), n, wpr, d_res.data_ptr(), d_arena.data_ptr(), cap, d_counts.data_ptr(), 2)
+a.map_finish()
+o = helpers.Oracle(host).map_tiles(h_tiles, h_lens, wpr, 2, 16)
+want = helpers.counts_reference_fast(o[0], o[1], o[2], host)
+got = d_counts.cpu().numpy()
+assert int(got.sum()) == n and np.array_equal(got, want), "count table differs"
+print("OK", a.counts_len())
+''' % (str(helpers.ROOT), str(helpers.ROOT / "tests"))
+    env = dict(os.environ, PA_PRODUCT_SO=str(so))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

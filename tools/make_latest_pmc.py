@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/latest_pmc.json from the PMC summaries of tools/gpurun/profile_r03.sh: FETCH_SIZE + WRITE_SIZE per STEP (every kernel of
 a pa_map_count_batch_device call) and the sha256 of the kernel sources they were measured on (bench.py compares it with the built
-sources and reports no traffic figure on a mismatch). usage: make_latest_pmc.py config3=<pmc.txt> config5=<pmc.txt> [reads_per_launch]"""
+sources and reports no traffic figure on a mismatch). usage: make_latest_pmc.py config3=<pmc.txt>[:<bench.json of the same box>] config5=<pmc.txt>[:...] [reads_per_launch]
+(the bench line of the profiled box gives its own step time: bytes measured there are divided by the time measured THERE)"""
 import importlib.util
 import json
 import sys
@@ -24,6 +25,13 @@ for arg in sys.argv[1:]:
         reads = int(arg)
         continue
     name, path = arg.split("=", 1)
+    box_step_ms = None
+    if ":" in path:
+        path, bench_json = path.split(":", 1)
+        try:
+            box_step_ms = json.load(open(bench_json))["roofline"]["step_device_ms"]
+        except (OSError, ValueError, KeyError):
+            box_step_ms = None
     per_kernel = {}
     for line in open(path):
         f = line.split()
@@ -39,6 +47,7 @@ for arg in sys.argv[1:]:
                                                         32.0 * k.get("TCC_EA0_RDREQ_32B_sum", 0.0) for k in per_kernel.values()),
                               "read_requests": sum(k.get("TCC_EA0_RDREQ_sum", 0.0) for k in per_kernel.values()),
                               "write_requests": sum(k.get("TCC_EA0_WRREQ_sum", 0.0) for k in per_kernel.values()),
-                              "map_kernel_l2_misses": per_kernel.get("pa_map_pool", {}).get("TCC_MISS_sum"), "source": "profiles/r05_%s_pmc.txt" % name}
+                              "map_kernel_l2_misses": per_kernel.get("pa_map_pool", {}).get("TCC_MISS_sum"), "profiled_box_step_ms": box_step_ms,
+                              "source": "profiles/r06_%s_pmc.txt" % name}
 json.dump(out, open(ROOT / "profiles" / "latest_pmc.json", "w"), indent=1)
 print(json.dumps({k: (v["FETCH_SIZE_KB"], v["WRITE_SIZE_KB"]) for k, v in out["workloads"].items()}))
