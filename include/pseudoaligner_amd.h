@@ -48,8 +48,11 @@ extern "C" {
 #define PA_NO_EDGE 0xFFFFFFFFu
 #define PA_MIN_K 8u
 #define PA_MAX_K 64u                     /* one or two 64-bit words per k-mer (Kmer20..Kmer32, Kmer48, Kmer64 of the debruijn crate) */
-#define PA_MAX_READ_LEN 16383u           /* 14-bit read positions; the reference has no limit (its validate_dbg maps whole transcripts,
-                                            src/build_index.rs:309: up to 16 355 bases in test/gencode_small.fa) */
+#define PA_MAX_READ_LEN 1048575u         /* 2^20 - 1 bases. The reference has no limit: its validate_dbg maps whole transcripts (src/build_index.rs:309; the
+                                            longest of GENCODE are a few hundred kb). Reads of more than 512 bases stay in their HBM tile while they are
+                                            mapped and take the wide lane state (28-bit positions: csrc/lane_steps.hpp); per slot of the pool such a launch
+                                            keeps 8 x length words of class-list scratch, so the grid shrinks with the length (a batch of Mb reads is
+                                            mapped by a handful of waves: completeness, not throughput) */
 #define PA_MAX_SIM_READ_LEN 2048u        /* pa_simulate_reads_*: longest synthetic read */
 
 typedef enum pa_status {

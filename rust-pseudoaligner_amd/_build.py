@@ -42,7 +42,7 @@ OBJ_DIR = PKG / "_build"   # per-source objects (git-ignored): only what changed
 
 def _deps_of(src: Path):
     """the source plus every header it can see (all of csrc/*.hpp and the public header: coarse, always safe)"""
-    return [src] + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
+    return [src] + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + [ROOT / "include" / "pseudoaligner_amd.h"]
 
 
 def build_product(force: bool = False) -> Path:

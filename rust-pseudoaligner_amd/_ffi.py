@@ -16,7 +16,7 @@ PA_ERR_BUFFER_TOO_SMALL = -10
 PA_MAPPED_BIT = 0x80000000
 PA_DEFAULT_ALLOWED_MISMATCHES = 2
 PA_READ_COVERAGE_THRESHOLD = 32
-PA_MAX_READ_LEN = 16383
+PA_MAX_READ_LEN = 1048575
 
 
 class PaError(RuntimeError):

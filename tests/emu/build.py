@@ -10,7 +10,7 @@ EMU_SO = HERE / "_build" / "libpa_emu.so"
 
 def build_emu(force: bool = False) -> Path:
     srcs = [HERE / "emu_map.cpp"] + [CSRC / s for s in ("host_index.cpp", "dbg_build.cpp", "device_flatten.cpp")]
-    deps = srcs + list(CSRC.glob("*.hpp")) + [ROOT / "include" / "pseudoaligner_amd.h"]
+    deps = srcs + list(CSRC.glob("*.hpp")) + [HERE / "emu_loop.inc"] + [ROOT / "include" / "pseudoaligner_amd.h"]
     if force or not EMU_SO.exists() or any(s.stat().st_mtime > EMU_SO.stat().st_mtime for s in deps):
         EMU_SO.parent.mkdir(parents=True, exist_ok=True)
         # (-DPA_DEBUG_KNOBS: the emulator's flattener honours PA_DICT_LOAD, so that the tests can build DENSE dictionaries — keys in other

@@ -83,109 +83,30 @@ uint64_t emu_index_info(const emu_index* e, int what) {
     }
 }
 
-// results as pa_read_result; class ids as malloc'd CSR in read order; optional step counters [5] = seek, fwd, left steps, spills, reads whose pending classes were masked
+}  // extern "C"
+
+struct emu_index;
+namespace pa {
+namespace narrow {
+#include "emu_loop.inc"
+}
+namespace wide {
+#include "emu_loop.inc"
+}
+}  // namespace pa
+
+extern "C" {
+
+// results as pa_read_result; class ids as malloc'd CSR in read order; optional step counters [5] = seek, fwd, left steps, spills, reads whose pending
+// classes were masked. The lane packing follows the kernel's choice: reads of more than PA_LDS_READ_WORDS (16) words take the WIDE lane state
+// (lane_steps.hpp), PA_EMU_WIDE=1 forces it for every batch (the wide text on short reads too)
 int emu_map_batch(const emu_index* e, const uint64_t* tiles, uint32_t wpr, const uint32_t* lens, uint64_t n, uint32_t allowed,
                   uint32_t col_cap, pa_read_result* results, uint64_t* class_offsets, uint32_t** class_ids, uint32_t* colour_out,
                   uint64_t* steps, uint32_t* nodes_out, uint32_t nodes_stride, uint32_t* nodes_len) {
-    const DevIndexView ix = e->fd.host_view();
-    std::vector<uint32_t> all;
-    std::vector<uint64_t> rd(wpr + 2);
-    alignas(16) uint32_t refs[4], lens4[4], cids4[4], win4[4];
-    uint32_t wcand[2];
-    std::vector<uint32_t> spill, trace, pend;
-    (void)col_cap;
-    uint64_t st_seek = 0, st_fwd = 0, st_left = 0, st_spill = 0, st_mask = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t t = i >> 6, r = i & 63;
-        for (uint32_t w = 0; w < wpr; ++w) rd[w] = tiles[(t * wpr + w) * 64 + r];
-        rd[wpr] = rd[wpr + 1] = 0;
-        const uint32_t L = lens[i];
-        spill.assign(8 * (size_t)L + 8, 0);
-        trace.assign(8 * (size_t)L + 8, 0);
-        pend.assign(8 * (size_t)L + 8, 0);
-        Lane s;
-        lane_start(s, (uint32_t)i, L, ix.k);
-        const ReadRef rr{rd.data(), 1, wpr};
-        const ColRef cr{win4, wcand, refs, lens4, cids4, spill.data(), (uint32_t)spill.size(), pend.data(), trace.data()};
-        for (;;) {
-            while (l_st(s) == ST_SEEK || l_st(s) == ST_FWD || l_st(s) == ST_LEFT) {
-                if (l_st(s) == ST_SEEK) { seek_step(s, ix, rr); ++st_seek; }
-                else if (l_st(s) == ST_FWD) {   // a traced batch takes the general form of the step, any other the kernel's common text
-                    if (nodes_out) fwd_step<true>(s, ix, rr, cr, allowed); else fwd_step<false>(s, ix, rr, cr, allowed);
-                    ++st_fwd;
-                } else {
-                    if (nodes_out) left_step<true>(s, ix, rr, cr, allowed); else left_step<false>(s, ix, rr, cr, allowed);
-                    ++st_left;
-                }
-            }
-            if (l_st(s) != ST_ISECT || (l_flags(s) & F_LISTS)) break;
-            const uint32_t todo = window_todo(s);   // window mode: classes without windows still to apply?
-            if (todo == 2) { restart_lists(s, ix.k); continue; }
-            if (todo == 1) { mask_pending(s, ix, cr); ++st_mask; }
-            break;
-        }
-        if (l_flags(s) & F_SPILL_OVERFLOW) return PA_ERR_INTERNAL;
-        if ((l_flags(s) & F_LISTS) && l_ncol(s) > LDS_CLASSES) ++st_spill;
-        if (nodes_out) {
-            nodes_len[i] = l_ntrace(s);
-            for (uint32_t j = 0; j < l_ntrace(s) && j < nodes_stride; ++j) nodes_out[i * nodes_stride + j] = trace[j];
-        }
-        class_offsets[i] = all.size();
-        pa_read_result res{0, 0, 0, 0};
-        uint32_t colour = 0xFFFFFFFFu;
-        if (l_st(s) == ST_ISECT && !(l_flags(s) & F_LISTS)) {   // window mode: {base1, mask1, base2, mask2} + class id or NO_CLASS
-            const uint32_t cand = wcand[0];
-            const uint32_t count = (uint32_t)(__builtin_popcount(win4[1]) + __builtin_popcount(win4[3]));
-            const size_t o = all.size();
-            all.resize(o + count);
-            uint32_t j = 0;
-            for (uint32_t t = win4[1]; t; t &= t - 1) all[o + j++] = win4[0] + (uint32_t)__builtin_ctz(t);
-            for (uint32_t t = win4[3]; t; t &= t - 1) all[o + j++] = win4[2] + (uint32_t)__builtin_ctz(t);
-            res.coverage = l_cov(s);
-            res.mismatches = l_mism(s) | PA_MAPPED_BIT;
-            res.class_len = count;
-            res.class_off = (uint32_t)o;
-            const std::vector<uint32_t> ids(all.begin() + o, all.end());
-            const auto it = e->by_list.find(ids);
-            const uint32_t truth = it == e->by_list.end() ? NO_CLASS : it->second;
-            if (cand != NO_CLASS) {   // returned by reference: must be exactly that index class
-                colour = cand;
-                res.class_off = PA_CLASS_REF | colour;
-                if (colour != truth) return PA_ERR_INTERNAL;
-            } else if (count) {       // strict subset of every class seen: the window table says whether it is a class anyway
-                uint32_t b1 = win4[0], m1 = win4[1], b2 = win4[2], m2 = win4[3];
-                window_canon(b1, m1, b2, m2);
-                colour = window_class(ix, b1, m1, b2, m2);
-                if (colour != truth) return PA_ERR_INTERNAL;
-            }
-        } else if (l_st(s) == ST_ISECT) {
-            const Isect is = isect_count(s, ix, cr);
-            const size_t o = all.size();
-            all.resize(o + is.count);
-            res.coverage = l_cov(s);
-            res.mismatches = l_mism(s) | PA_MAPPED_BIT;
-            res.class_len = is.count;
-            if (is.count == is.base_len) {   // the class is index class base_colour: returned by reference; the CSR the
-                colour = is.base_colour;     // tests compare is resolved from the class table like a host would
-                res.class_off = PA_CLASS_REF | colour;
-                const uint32_t* cls = pa::class_ids(ix, ix.class_ref[colour]);
-                for (uint32_t j = 0; j < is.count; ++j) all[o + j] = cls[j];
-                if (ix.class_len[colour] != is.count || ix.class_ref[colour] != is.base_ref) return PA_ERR_INTERNAL;
-            } else {
-                isect_write(s, ix, cr, is, all.data() + o);
-                res.class_off = (uint32_t)o;
-            }
-        }
-        results[i] = res;
-        if (colour_out) colour_out[i] = colour;
-    }
-    class_offsets[n] = all.size();
-    uint32_t* p = (uint32_t*)malloc((all.size() ? all.size() : 1) * 4);
-    if (!p) return PA_ERR_OOM;
-    memcpy(p, all.data(), all.size() * 4);
-    *class_ids = p;
-    if (steps) { steps[0] = st_seek; steps[1] = st_fwd; steps[2] = st_left; steps[3] = st_spill; steps[4] = st_mask; }
-    return PA_OK;
+    const char* force = getenv("PA_EMU_WIDE");
+    if (wpr > 16 || (force && *force == '1'))
+        return pa::wide::emu_map_batch_impl(e, tiles, wpr, lens, n, allowed, col_cap, results, class_offsets, class_ids, colour_out, steps, nodes_out, nodes_stride, nodes_len);
+    return pa::narrow::emu_map_batch_impl(e, tiles, wpr, lens, n, allowed, col_cap, results, class_offsets, class_ids, colour_out, steps, nodes_out, nodes_stride, nodes_len);
 }
 
 void emu_free(void* p) { free(p); }

@@ -753,3 +753,21 @@ def tandem_case(seed, tmp_path, nreads=500):
             r = _mutate(rng, r, 0.03)
         reads.append("".join(r))
     return host, reads, allowed
+
+
+def long_transcript_case(tmp_path, k=24, long_len=120000, seed=5):
+    """validate_dbg's self-mapping property (src/build_index.rs:300-367) beyond 2^14 bases: a small synthetic transcriptome plus two LONG
+    transcripts — one of `long_len` random bases, one that shares stretches with it and with the short ones (so that the walk crosses many
+    nodes and classes) — every transcript is also a read. Returns (host index, transcript strings)."""
+    rng = np.random.RandomState(seed)
+    tx = pa.Txome.synthesize(40, 130, 11)
+    packed, tx_start = tx.arrays()
+    all_codes = unpack_bases(packed, int(tx_start[-1]))
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    seqs = [lut[all_codes[int(tx_start[t]):int(tx_start[t + 1])]].tobytes().decode() for t in range(len(tx_start) - 1)]
+    big = "".join(rng.choice(list("ACGT"), long_len))
+    pieces = [big[20000:52000], seqs[3], big[70000:100000], seqs[7][:900], "".join(rng.choice(list("ACGT"), 9000)), big[5000:9000]]
+    seqs += [big, "".join(pieces)]
+    fa = tmp_path / "long.fa"
+    fa.write_text("".join(">t%d|g%d\n%s\n" % (i, i // 3, s) for i, s in enumerate(seqs)))
+    return pa.HostIndex.build_fasta(str(fa), k, 4), seqs

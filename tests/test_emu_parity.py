@@ -256,3 +256,26 @@ def test_tandem_repeats_and_reads_of_exactly_k(tmp_path, seed):
         pytest.skip("no k-mer")
     tiles, lens, wpr = pa.encode_reads_host(reads)
     check(host, tiles, lens, wpr, allowed)
+
+
+def test_transcripts_of_a_hundred_kilobases_map_onto_themselves(tmp_path):
+    """validate_dbg (src/build_index.rs:300-367: every transcript mapped onto its own graph has coverage == its length and a class that
+    contains it) for transcripts of 120 kb and 86 kb — reads far beyond the 2^14 bases the narrow lane state can count: the WIDE packing of
+    lane_steps.hpp (28-bit positions, what the kernel's GREAD instantiations run), on the host, against the oracle; with substitutions too"""
+    host, seqs = helpers.long_transcript_case(tmp_path)
+    assert max(len(s) for s in seqs) == 120000
+    tiles, lens, wpr = pa.encode_reads_host(seqs)
+    r, (o_res, o_coff, o_ids, ctr) = check(host, tiles, lens, wpr, 2)
+    for t, s in enumerate(seqs):
+        if len(s) >= host.k:
+            assert o_res["mapped"][t] and o_res["coverage"][t] == len(s) and t in o_ids[int(o_coff[t]):int(o_coff[t + 1])].tolist(), t
+    rng = np.random.RandomState(3)
+    noisy = []
+    for s in seqs[-2:] + seqs[:6]:
+        r_ = list(s)
+        for j in rng.randint(0, len(r_), max(1, len(r_) // 400)):
+            r_[j] = "ACGT"[("ACGT".index(r_[j]) + 1 + rng.randint(3)) % 4]
+        noisy.append("".join(r_))
+    tiles, lens, wpr = pa.encode_reads_host(noisy)
+    _, (_, _, _, ctr) = check(host, tiles, lens, wpr, 2)
+    assert ctr["reseeks"] > 50

@@ -198,9 +198,10 @@ def test_long_reads_and_max_length(aligners):
     gpu_vs_oracle(a, longer + [seqs[0][:40], "", seqs[1][:700]], 2, "reads kept in HBM")
     top = max(seqs, key=len)
     assert len(top) > 16000
-    gpu_vs_oracle(a, [(top * 2)[:16383]], 2, "PA_MAX_READ_LEN")
+    gpu_vs_oracle(a, [(top * 2)[:16383]], 2, "16 383 bases (the narrow lane state's limit; such reads take the wide one)")
+    gpu_vs_oracle(a, [(top * 2)[:16384], (top * 3)[:40000]], 2, "beyond 2^14 bases")
     with pytest.raises(pa.PaError):
-        a.map_batch(["A" * 16384])                                               # beyond PA_MAX_READ_LEN
+        a.map_batch(["A" * (pa._ffi.PA_MAX_READ_LEN + 1)])                       # beyond PA_MAX_READ_LEN
 
 
 def test_self_mapping_of_transcripts(aligners):
@@ -865,3 +866,28 @@ def test_long_chain_left_extensions(tmp_path, seed):
     a = pa.Pseudoaligner(host)
     _, _, _, ctr = gpu_vs_oracle(a, reads, allowed, "long chains seed %d" % seed)
     assert ctr["left_extensions"] > 50
+
+
+@pytest.mark.parametrize("long_len", [120000, 500000])
+def test_transcripts_of_hundreds_of_kilobases_map_onto_themselves(tmp_path, long_len):
+    """validate_dbg's property (src/build_index.rs:300-367: a transcript mapped onto its own graph has coverage == its length and a class
+    that contains it) for transcripts of 120 kb / 500 kb — the reference has no length limit and its own test maps whole transcripts (:309).
+    Reads of more than 512 bases stay in HBM and take the WIDE lane state (lane_steps.hpp); bit-exact against the oracle, with substitutions too;
+    pa_map_read on the longest one"""
+    host, seqs = helpers.long_transcript_case(tmp_path, long_len=long_len)
+    a = pa.Pseudoaligner(host, 0)
+    res, coff, cids, ctr = gpu_vs_oracle(a, seqs, 2, "transcripts as reads, longest %d" % long_len)
+    for t, s in enumerate(seqs):
+        if len(s) >= host.k:
+            assert res["mismatches"][t] >> 31 and res["coverage"][t] == len(s) and t in cids[int(coff[t]):int(coff[t + 1])].tolist(), t
+    rng = np.random.RandomState(3)
+    noisy = []
+    for s in seqs[-2:] + seqs[:6]:
+        r_ = list(s)
+        for j in rng.randint(0, len(r_), max(1, len(r_) // 400)):
+            r_[j] = "ACGT"[("ACGT".index(r_[j]) + 1 + rng.randint(3)) % 4]
+        noisy.append("".join(r_))
+    _, _, _, ctr = gpu_vs_oracle(a, noisy, 2, "long reads with substitutions")
+    assert ctr["reseeks"] > 50
+    got = a.map_read(seqs[-2])
+    assert got is not None and got[1] == long_len and (len(seqs) - 2) in got[0]
