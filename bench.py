@@ -476,12 +476,13 @@ def main() -> None:
 
     # ---- the other workloads on the same box, driver-visible extra keys (never `value`): BASELINE.json's error-read configuration (config 5:
     # K = 31, 1 % substitutions), the headline's robustness to real graph structure (config3r: repeat families, low-complexity tracts) and the
-    # one index built from real gene structure (config 2: gencode_small) at the headline's 100 M reads per launch
+    # the other k of the reference's CLI (config3k64: two-word k-mers) and the one index built from real gene structure (config 2: gencode_small)
+    # at the headline's 100 M reads per launch
     if n_gpus == 1 and rank == 0 and args.workload == "config3" and not args.no_config5 and not args.batch:
         buffers = run.buffers
         run.aligner = None
         run.host = None
-        for name, batch in (("config5", 0), ("config3r", 0), ("config2", 100_000_000)):
+        for name, batch in (("config5", 0), ("config3r", 0), ("config3k64", 0), ("config2", 100_000_000)):
             try:
                 torch.cuda.empty_cache()
                 r5 = Run(env, name, batch)

@@ -547,6 +547,10 @@ struct SeekProbe {
     uint32_t klo, khi;       // the k-mer
     uint32_t pending;        // l_pending of the lane at issue (0: v is the home slot)
 };
+struct SeekProbe2 {          // K > 32: the line of the two-word dictionary a probe looks at (two whole entries) and the k-mer's four words
+    U4 k0, v0, k1, v1;
+    uint32_t w0, w1, w2, w3;
+};
 // what a probe that goes on remembers (Lane::rm bits 0..3): the named slots still to look at as a mask over i = 0..2 (slot (home + 1 + i) & 3)
 // and the home slot's overflow flag
 constexpr uint32_t SK_NAMED = 7u, SK_FULL = 8u, SK_MASK = 15u;
@@ -680,22 +684,32 @@ PA_HD uint64_t pa_mix128(uint64_t lo, uint64_t hi) { return pa_mix64(lo ^ (pa_mi
 
 #if PA_LS_LANE
 // One dictionary probe of find_kmer_match (:91-114): dbg_index.get + verification collapse into one bucket line.
-PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
-    const uint32_t K = ix.k, kp = l_kp(s), probe = l_probe(s);
-    if (K > 32) {   // two-word k-mers: a line holds two whole entries {key word 0..3, handle, off, -, -}
-        const uint64_t klo = read_window(rd, kp), khi = read_window(rd, kp + 32) & ix.kmask_hi;   // read_seq.get_kmer(kmer_pos) (:93)
+// K > 32 (two-word k-mers: a line holds two whole entries {key word 0..3, handle, off, -, -}) in the same two pieces as seek_issue / seek_complete, so
+// that the pooled kernel can let such a probe ride in a forward iteration too (round 6; it used to be a step of its own)
+PA_HD void seek_issue_k2(const Lane& s, const DevIndexView& ix, ReadRef rd, SeekProbe2& q) {
+    const uint32_t kp = l_kp(s), probe = l_probe(s);
+    const uint64_t klo = read_window(rd, kp), khi = read_window(rd, kp + 32) & ix.kmask_hi;   // read_seq.get_kmer(kmer_pos) (:93)
 #if defined(__HIP_DEVICE_COMPILE__)
-        uint32_t b = __umulhi((uint32_t)(pa_mix128(klo, khi) >> 32), (uint32_t)ix.nbuckets) + probe;
+    uint32_t b = __umulhi((uint32_t)(pa_mix128(klo, khi) >> 32), (uint32_t)ix.nbuckets) + probe;
 #else
-        uint32_t b = (uint32_t)(((pa_mix128(klo, khi) >> 32) * (uint32_t)ix.nbuckets) >> 32) + probe;
+    uint32_t b = (uint32_t)(((pa_mix128(klo, khi) >> 32) * (uint32_t)ix.nbuckets) >> 32) + probe;
 #endif
-        if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
-        const U4* line = reinterpret_cast<const U4*>(ix.table + (uint64_t)b * BUCKET_WORDS);
-        const U4 k0 = line[0], v0 = line[1], k1 = line[2], v1 = line[3];   // (never non-temporal: four loads of one line, config 3 at K = 64 +9 % time with the hint)
-        const uint32_t w0 = (uint32_t)klo, w1 = (uint32_t)(klo >> 32), w2 = (uint32_t)khi, w3 = (uint32_t)(khi >> 32);
-        const bool h0 = k0.x == w0 && k0.y == w1 && k0.z == w2 && k0.w == w3 && v0.x != NO_HANDLE,
-                   h1 = k1.x == w0 && k1.y == w1 && k1.z == w2 && k1.w == w3 && v1.x != NO_HANDLE;
-        seek_finish(s, K, h0 ? v0.x : h1 ? v1.x : NO_HANDLE, h0 ? v0.y : v1.y, v0.x != NO_HANDLE && v1.x != NO_HANDLE, probe);
+    if (b >= (uint32_t)ix.nbuckets) b -= (uint32_t)ix.nbuckets;
+    const U4* line = reinterpret_cast<const U4*>(ix.table + (uint64_t)b * BUCKET_WORDS);
+    q.k0 = line[0]; q.v0 = line[1]; q.k1 = line[2]; q.v1 = line[3];   // (never non-temporal: four loads of one line, config 3 at K = 64 +9 % time with the hint)
+    q.w0 = (uint32_t)klo; q.w1 = (uint32_t)(klo >> 32); q.w2 = (uint32_t)khi; q.w3 = (uint32_t)(khi >> 32);
+}
+PA_HD void seek_complete_k2(Lane& s, uint32_t K, const SeekProbe2& q) {
+    const bool h0 = q.k0.x == q.w0 && q.k0.y == q.w1 && q.k0.z == q.w2 && q.k0.w == q.w3 && q.v0.x != NO_HANDLE,
+               h1 = q.k1.x == q.w0 && q.k1.y == q.w1 && q.k1.z == q.w2 && q.k1.w == q.w3 && q.v1.x != NO_HANDLE;
+    seek_finish(s, K, h0 ? q.v0.x : h1 ? q.v1.x : NO_HANDLE, h0 ? q.v0.y : q.v1.y, q.v0.x != NO_HANDLE && q.v1.x != NO_HANDLE, l_probe(s));
+}
+PA_HD void seek_step(Lane& s, const DevIndexView& ix, ReadRef rd) {
+    const uint32_t K = ix.k;
+    if (K > 32) {
+        SeekProbe2 q2;
+        seek_issue_k2(s, ix, rd, q2);
+        seek_complete_k2(s, K, q2);
         return;
     }
     SeekProbe q, q1;

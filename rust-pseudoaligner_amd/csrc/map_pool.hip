@@ -308,6 +308,9 @@ int launch_map_pool(const MapParams& p, uint32_t grid, size_t lds_bytes, hipStre
 #ifdef PA_DEBUG_KNOBS   // the statistics / ablation instantiation exists in A/B builds only
     if (p.dbg || p.ablate) return launch_kernel(&narrow::pa_map_pool_kernel<false, false, true, false>, p, grid, lds_bytes, stream);
 #endif
+    if (p.ix.k > 32)   // two-word k-mers: their probes ride in forward iterations through the two-word dictionary's own issue / complete pair
+        return p.pool_slots == 128 ? launch_kernel(&narrow::pa_map_pool_kernel<false, false, false, true, true>, p, grid, lds_bytes, stream)
+                                   : launch_kernel(&narrow::pa_map_pool_kernel<false, false, false, false, true>, p, grid, lds_bytes, stream);
     if (p.pool_slots == 128) return launch_kernel(&narrow::pa_map_pool_kernel<false, false, false, true>, p, grid, lds_bytes, stream);
     return launch_kernel(&narrow::pa_map_pool_kernel<false, false, false, false>, p, grid, lds_bytes, stream);
 }
