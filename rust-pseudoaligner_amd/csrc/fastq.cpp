@@ -576,27 +576,42 @@ struct TextPipe {
     BatchCtx& ctx_of(const Win& w) { return lanes[(size_t)w.lane].cache->ctx[w.slot]; }
     int use(const Lane& l) { return hipSetDevice(l.device) == hipSuccess ? PA_OK : fail(PA_ERR_HIP, "hipSetDevice(%d) failed", l.device); }
 
-    // bytes [off, off + len) of the text into dst (pinned): pread for a file (no page of a mapping is touched), memcpy for text in memory
-    int read_text(uint64_t off, uint64_t len, uint8_t* dst) {
-        if (len == 0) return PA_OK;
+    // bytes [off, off + len) of the text into dst (pinned): pread for a file (no page of a mapping is touched), memcpy for text in memory.
+    // read_begin hands the pieces to the worker pool and returns; read_end waits for them (small reads are done at once by the caller)
+    std::atomic<int> read_bad{0};
+    bool read_async = false;
+    void read_piece(uint64_t off, uint64_t len, uint8_t* dst, int t, int ntask) {
+        const uint64_t a = off + len * (uint64_t)t / (uint64_t)ntask, b = off + len * (uint64_t)(t + 1) / (uint64_t)ntask;
+        if (text.mapped && text.fd >= 0 && text.data == text.map_base) {
+            uint64_t p = a;
+            while (p < b) {
+                const ssize_t got = pread(text.fd, dst + (p - off), (size_t)(b - p), (off_t)p);
+                if (got < 0 && errno == EINTR) continue;
+                if (got <= 0) { read_bad.store(1); return; }
+                p += (uint64_t)got;
+            }
+        } else memcpy(dst + (a - off), text.data + a, (size_t)(b - a));
+    }
+    void read_begin(uint64_t off, uint64_t len, uint8_t* dst) {
+        read_async = false;
+        if (len == 0) return;
         const uint64_t PIECE = 2ull << 20;
         const int ntask = (int)std::min<uint64_t>((len + PIECE - 1) / PIECE, 1u << 20);
-        std::atomic<int> bad{0};
-        auto piece = [&](int t) {
-            const uint64_t a = off + len * (uint64_t)t / (uint64_t)ntask, b = off + len * (uint64_t)(t + 1) / (uint64_t)ntask;
-            if (text.mapped && text.fd >= 0 && text.data == text.map_base) {
-                uint64_t p = a;
-                while (p < b) {
-                    const ssize_t got = pread(text.fd, dst + (p - off), (size_t)(b - p), (off_t)p);
-                    if (got < 0 && errno == EINTR) continue;
-                    if (got <= 0) { bad.store(1); return; }
-                    p += (uint64_t)got;
-                }
-            } else memcpy(dst + (a - off), text.data + a, (size_t)(b - a));
-        };
-        if (ntask == 1) piece(0);
-        else pool.run(ntask, piece);
-        return bad.load() ? fail(PA_ERR_IO, "%s: read failed: %s", fastq_path, strerror(errno)) : PA_OK;
+        if (ntask == 1) { read_piece(off, len, dst, 0, 1); return; }
+        read_async = true;
+        pool.begin(ntask, [this, off, len, dst, ntask](int t) { read_piece(off, len, dst, t, ntask); });
+    }
+    int read_end() {
+        if (read_async) { pool.end(); read_async = false; }
+        return read_bad.exchange(0) ? fail(PA_ERR_IO, "%s: read failed: %s", fastq_path, strerror(errno)) : PA_OK;
+    }
+    int read_text(uint64_t off, uint64_t len, uint8_t* dst) {
+        read_begin(off, len, dst);
+        return read_end();
+    }
+    int read_small(uint64_t off, uint64_t len, uint8_t* dst) {   // by the caller itself, whatever the pool is doing (a window's head: <= 1 MiB)
+        if (len) read_piece(off, len, dst, 0, 1);
+        return read_bad.load() ? fail(PA_ERR_IO, "%s: read failed: %s", fastq_path, strerror(errno)) : PA_OK;
     }
 
     // the kernels of the window launched before on this lane's stream: waited for (they share the stream's launch context inside the index)
@@ -793,18 +808,34 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
 
     try {
     // ---- windows the GPU scans ----
-    while (rc == PA_OK && gpu_mode) {
-        if (read_to + KEEP >= text.fsize) { gpu_mode = false; break; }
-        const uint64_t main_len = std::min<uint64_t>(W, text.fsize - KEEP - read_to);
-        const uint64_t id = tp.next_id;
-        BatchCtx* cp = nullptr;
-        if ((rc = tp.acquire(id, &cp)) != PA_OK) break;
-        BatchCtx& c = *cp;
-        Lane& l = tp.lane_of(id);
-        if ((rc = window_ensure_raw(c, WINDOW_HEAD_ROOM + main_len)) != PA_OK) break;
+    // The text of window w + 1 is read (by the pool's workers, asynchronously) while this thread waits for window w - 1's scan, launches its kernels and
+    // enqueues window w's scan: the reads follow each other without a gap, and so do the copies to the GPU behind them.
+    struct Pre { bool active = false; uint64_t id = 0, main_from = 0, main_len = 0; BatchCtx* c = nullptr; Lane* l = nullptr; };
+    auto start_read = [&](Pre& p, uint64_t id) -> int {
+        p.active = false;
+        if (!gpu_mode || read_to + KEEP >= text.fsize) return PA_OK;
+        p.main_len = std::min<uint64_t>(W, text.fsize - KEEP - read_to);
+        p.main_from = read_to;
+        p.id = id;
+        int e = tp.acquire(id, &p.c);
+        if (e != PA_OK) return e;
+        p.l = &tp.lane_of(id);
+        if ((e = window_ensure_raw(*p.c, WINDOW_HEAD_ROOM + p.main_len)) != PA_OK) return e;
+        tp.read_begin(read_to, p.main_len, p.c->h_raw + WINDOW_HEAD_ROOM);
+        read_to += p.main_len;
+        p.active = true;
+        return PA_OK;
+    };
+    Pre cur, nxt;
+    if (rc == PA_OK) rc = start_read(cur, tp.next_id);
+    while (rc == PA_OK && cur.active) {
+        const uint64_t id = cur.id, main_len = cur.main_len, main_from = cur.main_from;
+        BatchCtx& c = *cur.c;
+        Lane& l = *cur.l;
         double t0 = TextPipe::now();
-        if ((rc = tp.read_text(read_to, main_len, c.h_raw + WINDOW_HEAD_ROOM)) != PA_OK) break;
+        if ((rc = tp.read_end()) != PA_OK) break;                       // this window's text is in pinned memory
         tp.t_read += TextPipe::now() - t0;
+        if ((rc = tp.use(l)) != PA_OK) break;
         if (verbose) {
             if (!vt0[id % 8]) { (void)hipEventCreate(&vt0[id % 8]); (void)hipEventCreate(&vt1[id % 8]); }
             else { float ms = 0; if (hipEventElapsedTime(&ms, vt0[id % 8], vt1[id % 8]) == hipSuccess) { v_h2d_ms += ms; v_h2d_bytes += vbytes[id % 8]; } }
@@ -814,27 +845,28 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
         if (hipMemcpyAsync((uint8_t*)c.d_raw + WINDOW_HEAD_ROOM, c.h_raw + WINDOW_HEAD_ROOM, main_len, hipMemcpyHostToDevice, l.copy) != hipSuccess ||
             hipEventRecord(c.ev_h2d, l.copy) != hipSuccess) { rc = fail(PA_ERR_HIP, "copy of a text window to the GPU failed"); break; }
         if (verbose) (void)hipEventRecord(vt1[id % 8], l.copy);
-        const uint64_t main_from = read_to;
-        read_to += main_len;
+        if ((rc = start_read(nxt, id + 1)) != PA_OK) break;             // the next window's text starts to arrive
         bool discard = false;
         if (have_pending) {
             const int r = resolve();
             if (r == WIN_ODD) { gpu_mode = false; discard = true; rec_start = pending.from; tp.next_id = pending.id; }               // not four-line text from here on: the host's scan takes over
             else if (r == WIN_EMPTY) { W = std::max<uint64_t>(2 * W, 2 * (main_from - pending.from)); discard = true; rec_start = pending.from; tp.next_id = pending.id; }   // no whole record in the window: a longer one
             else if (r != PA_OK) { rc = r; break; }
-            if (rc == PA_OK && (rc = tp.use(l)) != PA_OK) break;
         }
+        if ((rc = tp.use(l)) != PA_OK) break;
         const uint64_t head = main_from - rec_start;   // the unfinished record of the window before
         if (!discard && head > WINDOW_HEAD_ROOM) { W = std::max<uint64_t>(W, 2 * head); discard = true; }
-        if (discard) {   // this window's text is read again, from the first record not yet taken
+        if (discard) {   // this window's text (and what was being read behind it) is read again, from the first record not yet taken
+            if (nxt.active) { (void)tp.read_end(); nxt.active = false; }
             (void)hipStreamSynchronize(l.copy);
             read_to = rec_start;
             if (W > (1ull << 31)) gpu_mode = false;   // (a record of gigabytes: the host's scan says what it is)
+            if ((rc = start_read(cur, tp.next_id)) != PA_OK) break;
             continue;
         }
         t0 = TextPipe::now();
         if (head) {
-            if ((rc = tp.read_text(rec_start, head, c.h_raw + WINDOW_HEAD_ROOM - head)) != PA_OK) break;
+            if ((rc = tp.read_small(rec_start, head, c.h_raw + WINDOW_HEAD_ROOM - head)) != PA_OK) break;
             if (hipMemcpyAsync((uint8_t*)c.d_raw + WINDOW_HEAD_ROOM - head, c.h_raw + WINDOW_HEAD_ROOM - head, head, hipMemcpyHostToDevice, l.stream) != hipSuccess) { rc = fail(PA_ERR_HIP, "copy of a window's head failed"); break; }
         }
         tp.t_read += TextPipe::now() - t0; t0 = TextPipe::now();
@@ -852,7 +884,11 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
         have_pending = true;
         tp.next_id = id + 1;
         if ((rc = tp.retire_finished(0)) != PA_OK) break;
+        cur = nxt;
+        nxt.active = false;
     }
+    if (cur.active || nxt.active) (void)tp.read_end();   // (an error path: nothing of the pool's job is left behind)
+    gpu_mode = false;
     if (rc == PA_OK && have_pending) {
         const int r = resolve();
         if (r == WIN_ODD || r == WIN_EMPTY) { rec_start = pending.from; tp.next_id = pending.id; }

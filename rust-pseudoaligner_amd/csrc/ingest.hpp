@@ -45,6 +45,20 @@ public:
         fn_ = nullptr;
     }
 
+    // the same without the caller: begin() hands the tasks to the workers and returns, end() waits for them (pa_process_reads reads the next window of the
+    // text while the caller launches the kernels of the one before). One job at a time: run() / begin() only after end(). Without workers begin() runs the tasks.
+    void begin(int ntasks, std::function<void(int)> fn) {
+        if (ntasks <= 0) return;
+        if (workers_.empty()) { for (int t = 0; t < ntasks; ++t) fn(t); return; }
+        { std::lock_guard<std::mutex> g(mu_); async_fn_ = std::move(fn); fn_ = &async_fn_; ntasks_ = ntasks; next_ = 0; pending_ = ntasks; ++epoch_; }
+        cv_.notify_all();
+    }
+    void end() {
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
 private:
     void work() {
         for (;;) {
@@ -67,6 +81,7 @@ private:
     std::mutex mu_;
     std::condition_variable cv_, done_;
     const std::function<void(int)>* fn_ = nullptr;
+    std::function<void(int)> async_fn_;
     int ntasks_ = 0, next_ = 0, pending_ = 0;
     uint64_t epoch_ = 0;
     bool stop_ = false;
@@ -186,7 +201,7 @@ inline int batch_ensure(pa_index* idx, BatchCtx& c, uint64_t n, uint32_t wpr, ui
     if (!c.h_tot) {
         PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_tot, (1 + PA_RENDER_FLAG_BUCKETS) * 8, hipHostMallocDefault));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_flag, PA_RENDER_FLAG_BUCKETS * 8));
-        PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_text, hipEventDisableTiming));
+        PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_text, hipEventDisableTiming | hipEventBlockingSync));
     }
     if (!c.in_place) {   // gathered ids and sequences (record stream)
         if (n + 64 > c.soff_cap) {
@@ -324,7 +339,9 @@ inline int window_ensure_raw(BatchCtx& c, uint64_t bytes) {
 }
 inline int window_ensure_events(BatchCtx& c) {
     if (!c.ev_h2d) PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_h2d, hipEventDisableTiming));
-    if (!c.ev_info) PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_info, hipEventDisableTiming));
+    // (blocking: the thread that waits for a window's scan sleeps — the pool's workers are reading the next window on every CPU of the quota, and a spinning
+    // waiter on top of them gets the whole process throttled)
+    if (!c.ev_info) PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_info, hipEventDisableTiming | hipEventBlockingSync));
     if (!c.h_info) {
         PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_info, sizeof(FqInfo), hipHostMallocDefault));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_info, sizeof(FqInfo)));
