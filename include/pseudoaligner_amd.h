@@ -362,6 +362,10 @@ int pa_process_reads_multi(pa_index* const* idx, int n_idx, const char* fastq_pa
  * object returns it. */
 typedef struct pa_record_stream pa_record_stream;
 int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads, pa_record_stream** out);
+/* The same over several handles of one index (pa_index_create_multi: the GPUs of a node; a handle may be listed twice): full batches go round-robin to the
+ * handles, each on its own stream with its own buffers, and the tuples come back in PUSH order — byte for byte what one handle gives. (The reader-fed form is
+ * bound by its reader long before one GPU is: INTEGRATION.md §1; this entry is for callers that parse FASTQ on many threads of their own.) */
+int pa_record_stream_create_multi(pa_index* const* idx, int n_idx, int num_threads, uint64_t batch_reads, pa_record_stream** out);
 int pa_records_push(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs,
                     const uint64_t* seq_offsets, uint64_t n_records);
 int pa_records_pull(pa_record_stream* s, char* buf, size_t cap, size_t* n_bytes);

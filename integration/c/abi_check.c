@@ -199,6 +199,14 @@ int main(int argc, char** argv) {
             { double st[PA_INGEST_STAGES]; EXPECT(pa_record_stream_stage_seconds(rs, st) == PA_OK && st[7] == 2.0 && st[6] >= 0.0);
               EXPECT(pa_process_reads_stage_seconds(st) == PA_OK); }
             pa_record_stream_destroy(rs);
+            {   /* the same stream over two lanes of the handle: the same tuples */
+                pa_index* two[2]; char text2[4096]; size_t nb2 = 0;
+                two[0] = idx; two[1] = idx;
+                EXPECT(pa_record_stream_create_multi(two, 2, 2, 64, &rs) == PA_OK && rs);
+                EXPECT(pa_records_push(rs, ids2, ioff, ascii, offsets, 2) == PA_OK && pa_records_flush(rs) == PA_OK);
+                EXPECT(pa_records_pull(rs, text2, sizeof text2, &nb2) == PA_OK && nb2 == nb && memcmp(text, text2, nb) == 0);
+                pa_record_stream_destroy(rs);
+            }
         }
         uint32_t nodes_flat[2 * 64], nodes_len[2];
         EXPECT(pa_map_batch_nodes(idx, ascii, offsets, 2, 2, res, nodes_flat, 64, nodes_len) == PA_OK);

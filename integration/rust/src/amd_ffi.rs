@@ -74,6 +74,7 @@ extern "C" {
                               class_cap: u32, class_len: *mut u32, coverage: *mut u32, mismatches: *mut u32) -> c_int;
     // process_reads for a caller that holds the reader: push records, pull the Debug tuples (overlapped batch pipeline inside)
     pub fn pa_record_stream_create(idx: *mut PaIndex, num_threads: c_int, batch_reads: u64, out: *mut *mut PaRecordStream) -> c_int;
+    pub fn pa_record_stream_create_multi(idx: *const *mut PaIndex, n_idx: c_int, num_threads: c_int, batch_reads: u64, out: *mut *mut PaRecordStream) -> c_int;
     pub fn pa_records_push(s: *mut PaRecordStream, ids: *const u8, id_offsets: *const u64, seqs: *const u8, seq_offsets: *const u64, n_records: u64) -> c_int;
     pub fn pa_records_pull(s: *mut PaRecordStream, buf: *mut c_char, cap: usize, n_bytes: *mut usize) -> c_int;
     pub fn pa_records_flush(s: *mut PaRecordStream) -> c_int;

@@ -547,9 +547,14 @@ class Overflow:
 class RecordStream:
     """pa_record_stream: process_reads for a caller that holds the reader — push records, pull the reference's Debug tuples"""
 
-    def __init__(self, aligner: "Pseudoaligner", num_threads: int = 0, batch_reads: int = 0):
+    def __init__(self, aligner, num_threads: int = 0, batch_reads: int = 0):
+        """aligner: a Pseudoaligner, or a list of them (replicas of one index: pa_record_stream_create_multi — batches round-robin over the handles)"""
         h = vp()
-        check(lib().pa_record_stream_create(aligner._h, num_threads, batch_reads, C.byref(h)))
+        if isinstance(aligner, (list, tuple)):
+            hs = (vp * len(aligner))(*[a._h for a in aligner])
+            check(lib().pa_record_stream_create_multi(hs, len(aligner), num_threads, batch_reads, C.byref(h)))
+        else:
+            check(lib().pa_record_stream_create(aligner._h, num_threads, batch_reads, C.byref(h)))
         self._h = h
         self._aligner = aligner   # (the index must outlive the stream)
 

@@ -86,6 +86,7 @@ SIGNATURES = {
     "pa_map_batch_packed": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_uint32, vp, vp, C.POINTER(vp)]),
     "pa_map_read_packed": (C.c_int, [vp, vp, C.c_uint32, C.c_int, C.c_uint32, vp, C.c_uint32, u32p, u32p, u32p]),
     "pa_record_stream_create": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "pa_record_stream_create_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_uint64, C.POINTER(vp)]),
     "pa_records_push": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64]),
     "pa_records_pull": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "pa_records_flush": (C.c_int, [vp]),

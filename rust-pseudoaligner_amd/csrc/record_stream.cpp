@@ -47,19 +47,22 @@ struct RawText {
     void clear() { n = 0; }
 };
 
-struct pa_record_stream {
+struct RsLane {   // one index handle (one GPU) of a record stream: its parked buffers (two batches) and its HIP stream
     pa_index* idx = nullptr;
-    std::unique_ptr<Pool> pool;
-    IngestCache* cache = nullptr;   // the batches' pinned and device buffers and their HIP stream: taken from the index (warm, if a
-    hipStream_t stream = nullptr;   // pa_process_reads call or another record stream left them there) and parked there again at the end
     int device = 0;
-    const uint32_t *h_ec = nullptr, *h_class_ref = nullptr;
+    IngestCache* cache = nullptr;   // taken from the handle (warm, if a pa_process_reads call or another record stream left it there) and parked there again at the end
+    hipStream_t stream = nullptr;
+};
+
+struct pa_record_stream {
+    std::vector<RsLane> lanes;     // pa_record_stream_create_multi: batches go round-robin to the lanes, their tuples come back in push order
+    std::unique_ptr<Pool> pool;
     uint64_t batch_reads = 2u << 20;
-    BatchCtx* ctx = nullptr;       // = cache->ctx
-    RawText text[2];               // ids and sequences of the batch's records (Record offsets point into it)
-    uint32_t maxlen[2] = {0, 0};
-    bool inflight[2] = {false, false};
-    int cur = 0;                   // the batch being filled
+    // slot = 2 * lane + half: the batch being filled, and per lane the batch in flight before it
+    std::vector<RawText> text;     // ids and sequences of the slot's records (Record offsets point into it)
+    std::vector<uint32_t> maxlen;
+    std::vector<char> inflight;
+    uint64_t seq = 0;              // batches submitted so far: batch b uses lane b % L, half (b / L) % 2
     std::deque<TextBuf> outq;      // rendered text in order; out_off = bytes of the front buffer already pulled
     std::vector<TextBuf> spare;    // buffers the caller has pulled empty: the next batches' text goes into them (fresh memory is paged in again every time)
     size_t out_off = 0;
@@ -67,6 +70,11 @@ struct pa_record_stream {
     double stage[PA_INGEST_STAGES] = {0, 0, 0, 0, 0, 0, 0, 0};   // pa_record_stream_stage_seconds
     int rc = PA_OK;                // sticky: after a failure every call reports it
     std::string why;
+    int L() const { return (int)lanes.size(); }
+    int slot_of(uint64_t b) const { return 2 * (int)(b % (uint64_t)L()) + (int)((b / (uint64_t)L()) & 1u); }
+    RsLane& lane_of_slot(int k) { return lanes[(size_t)(k >> 1)]; }
+    BatchCtx& ctx(int k) { return lanes[(size_t)(k >> 1)].cache->ctx[k & 1]; }
+    int cur() const { return slot_of(seq); }
 };
 
 namespace {
@@ -82,7 +90,8 @@ int render(pa_record_stream* s, int k) {
     // the batch's tuples were rendered on the GPU (batch_finish -> render.hip): wait for their copy in pinned memory and move it into the
     // output queue as ONE buffer (it ends with a line break; pull hands out whole lines), the pool sharing the copy
     const double t_render = now_s();
-    BatchCtx& c = s->ctx[k];
+    BatchCtx& c = s->ctx(k);
+    if (hipSetDevice(s->lane_of_slot(k).device) != hipSuccess) return fail(PA_ERR_HIP, "hipSetDevice failed");
     const int rc = batch_text_wait(c);
     if (rc != PA_OK) return rc;
     if (c.text_bytes) {
@@ -100,40 +109,43 @@ int render(pa_record_stream* s, int k) {
     }
     s->n_flagged += c.flagged;
     s->n_reads += c.n;
-    s->inflight[k] = false;
+    s->inflight[(size_t)k] = 0;
     c.recs.clear();
     c.n = 0;
-    s->text[k].clear();
-    s->maxlen[k] = 0;
+    s->text[(size_t)k].clear();
+    s->maxlen[(size_t)k] = 0;
     s->stage[4] += now_s() - t_render;
     s->stage[7] = (double)s->n_reads;
     return PA_OK;
 }
 
-// the batch being filled goes to the GPU; the one before it is waited for and rendered. (Both batches share the stream and
-// with it ONE launch context inside the index — its control block says how much of the arena a launch used — so the previous
-// batch is finished before the next is launched; the GPU then works on batch k while the host renders batch k - 1 and packs k + 1.)
+// The batch being filled goes to its lane's GPU; the batch launched on that lane before it is waited for and rendered. (The two batches of a lane share
+// its stream and with it ONE launch context inside the index — its control block says how much of the arena a launch used — so the previous batch is
+// finished before the next is launched; the GPU then works on batch b while the host renders batch b - L and packs b + 1.) With L lanes the batch waited
+// for is b - L: the oldest one not yet rendered, so the tuples come out in push order.
 int submit(pa_record_stream* s) {
-    const int k = s->cur, o = k ^ 1;
-    BatchCtx& c = s->ctx[k];
+    const int k = s->cur(), o = k ^ 1;
+    RsLane& lane = s->lane_of_slot(k);
+    BatchCtx& c = s->ctx(k);
     c.n = c.recs.size();
     if (c.n == 0) return PA_OK;
-    if (s->maxlen[k] > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
-    c.wpr = pa_words_per_read(s->maxlen[k] ? s->maxlen[k] : 1);
+    if (s->maxlen[(size_t)k] > PA_MAX_READ_LEN) return fail(PA_ERR_UNSUPPORTED, "read longer than %u bases", PA_MAX_READ_LEN);
+    if (hipSetDevice(lane.device) != hipSuccess) return fail(PA_ERR_HIP, "hipSetDevice(%d) failed", lane.device);
+    c.wpr = pa_words_per_read(s->maxlen[(size_t)k] ? s->maxlen[(size_t)k] : 1);
     double t0 = now_s();
     std::vector<uint64_t> part;
     batch_offsets(*s->pool, c, part);
-    int rc = batch_ensure(s->idx, c, c.n, c.wpr, s->batch_reads);
+    int rc = batch_ensure(lane.idx, c, c.n, c.wpr, s->batch_reads);
     if (rc != PA_OK) return rc;
-    batch_gather_ascii(*s->pool, c, s->text[k].data(), part);
+    batch_gather_ascii(*s->pool, c, s->text[(size_t)k].data(), part);
     s->stage[1] += now_s() - t0; t0 = now_s();
-    if (s->inflight[o] && (rc = batch_finish(s->idx, s->ctx[o], s->stream)) != PA_OK) return rc;
+    if (s->inflight[(size_t)o] && (rc = batch_finish(lane.idx, s->ctx(o), lane.stream)) != PA_OK) return rc;
     s->stage[2] += now_s() - t0; t0 = now_s();
-    if ((rc = batch_launch(s->idx, c, s->stream)) != PA_OK) return rc;
+    if ((rc = batch_launch(lane.idx, c, lane.stream)) != PA_OK) return rc;
     s->stage[3] += now_s() - t0;
-    s->inflight[k] = true;
-    if (s->inflight[o] && (rc = render(s, o)) != PA_OK) return rc;
-    s->cur = o;
+    s->inflight[(size_t)k] = 1;
+    if (s->inflight[(size_t)o] && (rc = render(s, o)) != PA_OK) return rc;
+    ++s->seq;
     return PA_OK;
 }
 
@@ -141,55 +153,85 @@ int submit(pa_record_stream* s) {
 
 extern "C" {
 
-int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads, pa_record_stream** out) {
-    if (!idx || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+int pa_record_stream_create_multi(pa_index* const* idxs, int n_idx, int num_threads, uint64_t batch_reads, pa_record_stream** out) {
+    if (!idxs || n_idx < 1 || !out) return fail(PA_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < n_idx; ++i)
+        if (!idxs[i]) return fail(PA_ERR_INVALID_ARG, "null index handle");
+    {
+        pa_index_stats s0, si;
+        if (pa_index_get_stats(idxs[0], &s0) != PA_OK) return PA_ERR_INVALID_ARG;
+        for (int i = 1; i < n_idx; ++i) {
+            if (pa_index_get_stats(idxs[i], &si) != PA_OK) return PA_ERR_INVALID_ARG;
+            if (si.k != s0.k || si.num_nodes != s0.num_nodes || si.num_classes != s0.num_classes || si.num_kmers != s0.num_kmers)
+                return fail(PA_ERR_INVALID_ARG, "handle %d is not a replica of handle 0 (k / nodes / classes / k-mers differ)", i);
+        }
+    }
     pa_record_stream* s = new (std::nothrow) pa_record_stream();
     if (!s) return fail(PA_ERR_OOM, "out of memory");
-    s->idx = idx;
-    index_host_classes(idx, &s->h_ec, &s->h_class_ref, &s->device);
     if (batch_reads) s->batch_reads = std::max<uint64_t>(64, batch_reads / 64 * 64);
     int T = num_threads > 0 ? num_threads : usable_threads();
     if (T < 1) T = 1;
-    s->pool.reset(new Pool(T));
-    s->cache = static_cast<IngestCache*>(index_take_ingest_cache(idx));   // buffers of an earlier call, if any: allocating them costs more than packing a batch
-    if (!s->cache) s->cache = new (std::nothrow) IngestCache();
-    if (!s->cache) { delete s; return fail(PA_ERR_OOM, "out of memory"); }
-    s->cache->idx = idx;
-    s->ctx = s->cache->ctx;
-    for (int k = 0; k < 2; ++k) { s->ctx[k].recs.clear(); s->ctx[k].n = 0; s->ctx[k].first = 0; s->ctx[k].in_place = false; s->ctx[k].flag_mark = 0; }   // (a parked set still names its last batch — or a window of pa_process_reads)
-    if (hipSetDevice(s->device) != hipSuccess) {   // (a stream the parked cache brought along stays with it: destroy releases it and its launch context)
-        pa_record_stream_destroy(s);
-        return fail(PA_ERR_HIP, "hipSetDevice(%d) failed", s->device);
+    try {
+        s->pool.reset(new Pool(T));
+        s->lanes.resize((size_t)n_idx);
+        s->text.resize(2 * (size_t)n_idx);
+        s->maxlen.assign(2 * (size_t)n_idx, 0);
+        s->inflight.assign(2 * (size_t)n_idx, 0);
+    } catch (const std::exception& ex) {
+        delete s;
+        return fail(PA_ERR_OOM, "record stream: %s", ex.what());
     }
-    if (!s->cache->stream && hipStreamCreateWithFlags(&s->cache->stream, hipStreamNonBlocking) != hipSuccess) {
-        s->cache->stream = nullptr;
-        pa_record_stream_destroy(s);
-        return fail(PA_ERR_HIP, "hipStreamCreate failed");
+    for (int i = 0; i < n_idx; ++i) {
+        RsLane& l = s->lanes[(size_t)i];
+        l.idx = idxs[i];
+        const uint32_t *h_ec = nullptr, *h_ref = nullptr;
+        index_host_classes(l.idx, &h_ec, &h_ref, &l.device);
+        l.cache = static_cast<IngestCache*>(index_take_ingest_cache(l.idx));   // buffers of an earlier call, if any: allocating them costs more than packing a batch
+        if (!l.cache) l.cache = new (std::nothrow) IngestCache();
+        if (!l.cache) { pa_record_stream_destroy(s); return fail(PA_ERR_OOM, "out of memory"); }
+        l.cache->idx = l.idx;
+        for (int k = 0; k < 2; ++k) { BatchCtx& c = l.cache->ctx[k]; c.recs.clear(); c.n = 0; c.first = 0; c.in_place = false; c.flag_mark = 0; }   // (a parked set still names its last batch — or a window of pa_process_reads)
+        if (hipSetDevice(l.device) != hipSuccess) {   // (a stream the parked cache brought along stays with it: destroy releases it and its launch context)
+            pa_record_stream_destroy(s);
+            return fail(PA_ERR_HIP, "hipSetDevice(%d) failed", l.device);
+        }
+        if (!l.cache->stream && hipStreamCreateWithFlags(&l.cache->stream, hipStreamNonBlocking) != hipSuccess) {
+            l.cache->stream = nullptr;
+            pa_record_stream_destroy(s);
+            return fail(PA_ERR_HIP, "hipStreamCreate failed");
+        }
+        l.stream = l.cache->stream;
     }
-    s->stream = s->cache->stream;
     *out = s;
     return PA_OK;
 }
 
+int pa_record_stream_create(pa_index* idx, int num_threads, uint64_t batch_reads, pa_record_stream** out) {
+    pa_index* one[1] = {idx};
+    return pa_record_stream_create_multi(one, 1, num_threads, batch_reads, out);
+}
+
 void pa_record_stream_destroy(pa_record_stream* s) {
     if (!s) return;
-    (void)hipSetDevice(s->device);
-    if (s->cache) {
-        if (s->stream) (void)hipStreamSynchronize(s->stream);
-        for (int k = 0; k < 2; ++k) { s->ctx[k].recs.clear(); s->ctx[k].n = 0; }
-        if (s->rc == PA_OK && s->stream) index_put_ingest_cache(s->idx, s->cache, IngestCache::destroy);   // the next stream / pa_process_reads call starts warm
-        else IngestCache::destroy(s->cache);   // (releases the stream's launch context inside the index and the stream)
+    for (RsLane& l : s->lanes) {
+        if (!l.cache) continue;
+        (void)hipSetDevice(l.device);
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        for (int k = 0; k < 2; ++k) { l.cache->ctx[k].recs.clear(); l.cache->ctx[k].n = 0; }
+        if (s->rc == PA_OK && l.stream) index_put_ingest_cache(l.idx, l.cache, IngestCache::destroy);   // the next stream / pa_process_reads call starts warm
+        else IngestCache::destroy(l.cache);   // (releases the stream's launch context inside the index and the stream)
+        l.cache = nullptr;
     }
     delete s;
 }
 
-static int records_push_impl(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs, const uint64_t* seq_offsets, uint64_t n);
-static int records_flush_impl(pa_record_stream* s);
 // (std::bad_alloc out of the growable buffers, std::system_error out of the worker pool: nothing crosses the C ABI)
 #define PA_RS_GUARD(call) \
     try { return call; } \
     catch (const std::bad_alloc&) { return s ? fail_sticky(s, fail(PA_ERR_OOM, "out of host memory in the record stream")) : PA_ERR_OOM; } \
     catch (const std::exception& ex) { return s ? fail_sticky(s, fail(PA_ERR_INTERNAL, "record stream: %s", ex.what())) : PA_ERR_INTERNAL; }
+static int records_push_impl(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs, const uint64_t* seq_offsets, uint64_t n);
+static int records_flush_impl(pa_record_stream* s);
 int pa_records_push(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs, const uint64_t* seq_offsets, uint64_t n) {
     PA_RS_GUARD(records_push_impl(s, ids, id_offsets, seqs, seq_offsets, n))
 }
@@ -199,7 +241,6 @@ int pa_records_flush(pa_record_stream* s) {
 static int records_push_impl(pa_record_stream* s, const uint8_t* ids, const uint64_t* id_offsets, const uint8_t* seqs, const uint64_t* seq_offsets, uint64_t n) {
     if (!s || (n && (!id_offsets || !seq_offsets))) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (s->rc != PA_OK) return fail(s->rc, "%s", s->why.c_str());
-    if (hipSetDevice(s->device) != hipSuccess) return fail_sticky(s, fail(PA_ERR_HIP, "hipSetDevice failed"));
     // every record of the call is checked before the first one is taken: a call that fails has appended (and submitted) nothing,
     // so the caller may correct it and push the same records again
     for (uint64_t i = 0; i < n; ++i) {
@@ -210,11 +251,11 @@ static int records_push_impl(pa_record_stream* s, const uint8_t* ids, const uint
     // the records go into the batch being filled as two blocks — all their ids, then all their sequences — copied and indexed
     // by the worker pool (the caller's buffers are laid out like that already: a per-record copy cost 70 ns per record)
     for (uint64_t i = 0; i < n;) {
-        const int k = s->cur;
-        BatchCtx& c = s->ctx[k];
+        const int k = s->cur();
+        BatchCtx& c = s->ctx(k);
         const uint64_t have = c.recs.size(), m = std::min<uint64_t>(n - i, s->batch_reads - have);
         const uint64_t ib = id_offsets[i + m] - id_offsets[i], sb = seq_offsets[i + m] - seq_offsets[i];
-        RawText& t = s->text[k];
+        RawText& t = s->text[(size_t)k];
         if (!t.grow(ib + sb)) return fail_sticky(s, fail(PA_ERR_OOM, "out of memory for %llu bytes of records", (unsigned long long)(ib + sb)));
         const uint64_t id_base = t.n, seq_base = t.n + ib;
         t.n += ib + sb;
@@ -237,7 +278,7 @@ static int records_push_impl(pa_record_stream* s, const uint8_t* ids, const uint
             }
             tmax[(size_t)w] = mx;
         });
-        for (uint32_t v : tmax) s->maxlen[k] = std::max(s->maxlen[k], v);
+        for (uint32_t v : tmax) s->maxlen[(size_t)k] = std::max(s->maxlen[(size_t)k], v);
         i += m;
         if (c.recs.size() >= s->batch_reads) {
             const int rc = submit(s);
@@ -250,16 +291,19 @@ static int records_push_impl(pa_record_stream* s, const uint8_t* ids, const uint
 static int records_flush_impl(pa_record_stream* s) {
     if (!s) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (s->rc != PA_OK) return fail(s->rc, "%s", s->why.c_str());
-    if (hipSetDevice(s->device) != hipSuccess) return fail_sticky(s, fail(PA_ERR_HIP, "hipSetDevice failed"));
-    int rc = submit(s);   // what is left of the batch being filled (renders the batch before it)
+    int rc = submit(s);   // what is left of the batch being filled (renders the batch launched on its lane before it)
     if (rc != PA_OK) return fail_sticky(s, rc);
-    for (int k = 0; k < 2; ++k) {
-        const int b = s->cur ^ 1 ^ k;   // the batch launched last is the one before `cur`
-        if (!s->inflight[b]) continue;
+    // the batches still in flight, oldest first: the last L submitted (one per lane)
+    const uint64_t L = (uint64_t)s->L();
+    for (uint64_t b = s->seq >= L ? s->seq - L : 0; b < s->seq; ++b) {
+        const int k = s->slot_of(b);
+        if (!s->inflight[(size_t)k]) continue;
+        RsLane& lane = s->lane_of_slot(k);
+        if (hipSetDevice(lane.device) != hipSuccess) return fail_sticky(s, fail(PA_ERR_HIP, "hipSetDevice failed"));
         const double t0 = now_s();
-        if ((rc = batch_finish(s->idx, s->ctx[b], s->stream)) != PA_OK) return fail_sticky(s, rc);
+        if ((rc = batch_finish(lane.idx, s->ctx(k), lane.stream)) != PA_OK) return fail_sticky(s, rc);
         s->stage[2] += now_s() - t0;
-        if ((rc = render(s, b)) != PA_OK) return fail_sticky(s, rc);
+        if ((rc = render(s, k)) != PA_OK) return fail_sticky(s, rc);
     }
     return PA_OK;
 }

@@ -231,3 +231,26 @@ def test_host_to_host_batches(small_index, uniform):
         a.map_tiles_host(h_tiles.data_ptr(), n, wpr, h_compact.data_ptr(), h_packed.data_ptr(), 50, h_lens=0 if uniform else h_lens.data_ptr(),
                          uniform_len=read_len if uniform else 0, chunk_reads=4096, n_streams=3)
     assert err.value.code == pa._ffi.PA_ERR_ARENA_FULL
+
+
+def test_record_stream_over_several_lanes(aligner):
+    """pa_record_stream_create_multi: full batches go round-robin to the lanes (the same handle listed one, two and three times: streams of one GPU), the
+    tuples come back in push order — byte for byte what a single lane gives, and what the oracle says"""
+    ids, seqs = make_reads(9000, 21, 0, 181)
+    want = "\n".join(expected_lines(aligner, ids, seqs)) + "\n"
+    rng = np.random.default_rng(4)
+    for lanes, batch in ((1, 512), (2, 512), (3, 320), (2, 64)):
+        rs = pa.RecordStream([aligner] * lanes, 3, batch)
+        got, i = b"", 0
+        while i < len(ids):
+            n = int(rng.integers(1, 1500))
+            rs.push(ids[i:i + n], seqs[i:i + n])
+            got += rs.drain(1 << 14)
+            i += n
+        rs.flush()
+        got += rs.drain()
+        assert rs.stats()[0] == len(ids)
+        assert got.decode() == want, (lanes, batch)
+        rs.flush()
+        assert rs.drain() == b""
+        rs.close()
