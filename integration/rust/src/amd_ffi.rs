@@ -11,6 +11,9 @@ pub const PA_ERR_BUFFER_TOO_SMALL: c_int = -10;
 pub const PA_MAPPED_BIT: u32 = 0x8000_0000;
 pub const PA_CLASS_REF: u32 = 0x8000_0000;
 pub const PA_MAX_ARENA_ENTRIES: u64 = 0x7FFF_FFFF;
+pub const PA_COMPACT_MAPPED: u32 = 0x1000_0000;     // pa_results_compact_device: bit 28 of a record's low word
+pub const PA_COMPACT_BY_REF: u32 = 0x2000_0000;     // the class is index class (record >> 32)
+pub const PA_COMPACT_PACKED: u32 = 0x4000_0000;     // the class is the next {length, ids...} entry of the packed stream
 
 #[repr(C)]
 pub struct PaFlatIndex {            // pa_flat_index
@@ -100,6 +103,16 @@ extern "C" {
     pub fn pa_map_count_batch_uniform_device(idx: *mut PaIndex, d_tiles: *const u64, read_len: u32, n_reads: u64,
                                              words_per_read: u32, allowed_mismatches: u32, d_results: *mut PaReadResult,
                                              d_arena: *mut u32, arena_cap: u64, d_counts: *mut u64, stream: *mut c_void) -> c_int;
+    // host to host: a batch in (pinned) host memory -> compact 8-byte records + packed classes + count table, chunks pipelined over streams
+    pub fn pa_map_tiles_host(idx: *mut PaIndex, h_tiles: *const u64, h_lens: *const u32, uniform_len: u32, n_reads: u64, words_per_read: u32,
+                             allowed_mismatches: u32, h_compact: *mut u64, h_packed: *mut u32, packed_cap: u64, packed_words: *mut u64, h_counts: *mut u64,
+                             chunk_reads: u64, n_streams: c_int) -> c_int;
+    pub fn pa_host_alloc_pinned(bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn pa_host_free_pinned(p: *mut c_void) -> c_int;
+    pub fn pa_compact_scratch_bytes(n_reads: u64) -> usize;
+    pub fn pa_results_compact_device(idx: *mut PaIndex, d_results: *const PaReadResult, d_arena: *const u32, arena_cap: u64, n_reads: u64, d_compact: *mut u64,
+                                     d_packed: *mut u32, packed_cap: u64, d_packed_words: *mut u64, d_scratch: *mut c_void, scratch_bytes: usize,
+                                     stream: *mut c_void) -> c_int;
     pub fn pa_map_finish(idx: *mut PaIndex, stream: *mut c_void, arena_used: *mut u64, arena_needed: *mut u64) -> c_int;
     pub fn pa_index_release_stream(idx: *mut PaIndex, stream: *mut c_void) -> c_int;
     pub fn pa_index_set_timing(idx: *mut PaIndex, on: c_int) -> c_int;

@@ -184,7 +184,9 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
     }
     // membership bitmaps for the window-less classes of at least bitmap_min ids (device_layout.hpp, class_bitmap): 16 ids and up (a shorter
     // list is one round of four 16-byte loads anyway) unless that would take more than 4 GB — then only the longer ones, or none
-    out.bitmap_words = ((f.num_transcripts + 31) / 32 + 2 + 3) & ~3u;
+    uint32_t id_span = f.num_transcripts;   // (an exporter that does not know tx_names.len() may pass less than the ids say: the largest id decides)
+    for (uint64_t j = 0; j < f.ec_offset[f.num_classes]; ++j) id_span = std::max(id_span, f.ec_ids[j] + 1u);
+    out.bitmap_words = ((id_span + 31) / 32 + 2 + 3) & ~3u;
     out.bitmap_min = 16;
     for (;;) {
         uint64_t n = 0;
@@ -212,7 +214,6 @@ static int flatten_t(const pa_flat_index& f, int threads, FlatDevice& out, bool 
             if (at != class_bitmap(out.class_ref[c], (uint32_t)len)) return fail(PA_ERR_INTERNAL, "class record of %llu ids is not %u chunks", (unsigned long long)len, class_record_chunks((uint32_t)len));
             out.ec.resize(at + out.bitmap_words, 0u);
             for (uint64_t j = f.ec_offset[c]; j < f.ec_offset[c + 1]; ++j) {
-                if (f.ec_ids[j] >= f.num_transcripts) return fail(PA_ERR_INVALID_ARG, "class %u names transcript %u of %u", c, f.ec_ids[j], f.num_transcripts);
                 out.ec[at + (f.ec_ids[j] >> 5)] |= 1u << (f.ec_ids[j] & 31u);
             }
         }
