@@ -279,3 +279,22 @@ def test_transcripts_of_a_hundred_kilobases_map_onto_themselves(tmp_path):
     tiles, lens, wpr = pa.encode_reads_host(noisy)
     _, (_, _, _, ctr) = check(host, tiles, lens, wpr, 2)
     assert ctr["reseeks"] > 50
+
+
+@pytest.mark.parametrize("k,read_len,ppm,allowed", [(24, 150, 10000, 2), (31, 150, 30000, 0), (64, 100, 5000, 2), (20, 75, 50000, 2)])
+def test_wide_lane_packing_on_short_reads(small_index, monkeypatch, k, read_len, ppm, allowed):
+    """the WIDE packing of the lane state (lane_steps.hpp: what reads of more than 512 bases take on the GPU) forced onto short reads
+    (PA_EMU_WIDE=1): the same text with 28-bit positions and counters in words of their own gives the same results as the oracle — and as the
+    narrow packing, step for step"""
+    host = small_index(k) if k in (20, 24, 31) else pa.build_index(str(helpers.FASTA), k, 8)
+    tx = pa.Txome.from_host_index(host)
+    tiles, lens = tx.simulate_host(read_len, 4, 20000, ppm)
+    wpr = pa.lib().pa_words_per_read(read_len)
+    narrow, _ = check(host, tiles, lens, wpr, allowed)
+    monkeypatch.setenv("PA_EMU_WIDE", "1")
+    wide, _ = check(host, tiles, lens, wpr, allowed)
+    assert np.array_equal(narrow["steps"][1:3], wide["steps"][1:3])          # the same number of forward / left steps (probe steps depend on which keys the
+                                                                             # parallel dictionary build happened to give their home slots)
+    _, seqs = helpers.read_fastq()
+    t2, l2, w2 = pa.encode_reads_host(seqs[:3000])
+    check(host, t2, l2, w2, 2)
