@@ -531,7 +531,9 @@ std::string rust_f32(float v) {
 // ---- process_reads over WINDOWS of raw text ----
 // The host does not look at the text: worker threads read a window of the file into pinned memory (pread: one copy out of the page
 // cache, no page faults), the window goes to HBM as it is on a copy stream, the GPU finds its records (fastq_scan.hip) and the encode /
-// map / render kernels read sequences and ids where they lie. A window ends where the file offset says, not where a record does: the
+// map / render kernels read sequences and ids where they lie. A lane has FOUR streams: copy (text in), scan (a window's records: waits for its
+// text and the scan before, not for the kernels of the window before), the kernels' stream, and back (the tuples' 14 MB per window to the host):
+// on one stream the chain scan | encode | map | render | copy back + two host round trips was as long as a window's copy, and every hiccup a gap on the link. A window ends where the file offset says, not where a record does: the
 // scan reports how many bytes its whole records take, and the unfinished record is read once more as the HEAD of the next window.
 // Windows are dealt round-robin to LANES — one per index handle (pa_process_reads_multi: the GPUs of a node; the same handle twice
 // gives two streams on one GPU) — and their tuples are written in input order. What the GPU scan does not take goes through the
@@ -544,7 +546,7 @@ struct Lane {
     pa_index* idx = nullptr;
     int device = 0;
     IngestCache* cache = nullptr;
-    hipStream_t stream = nullptr, copy = nullptr;
+    hipStream_t stream = nullptr, copy = nullptr, scan = nullptr, back = nullptr;
     int64_t unfinished = -1;             // the window whose kernels were launched last on `stream` and have not been waited for
     uint64_t text_job[LANE_SLOTS] = {0, 0, 0, 0};   // the writer's job that reads the slot's pinned text (0: none)
 };
@@ -677,6 +679,7 @@ struct TextPipe {
         int e = use(l);
         if (e != PA_OK) return e;
         if ((e = window_ensure_events(c)) != PA_OK) return e;
+        c.back = l.back;
         *out = &c;
         return PA_OK;
     }
@@ -761,8 +764,13 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
         l.cache->idx = l.idx;
         if (!l.cache->stream && hipStreamCreateWithFlags(&l.cache->stream, hipStreamNonBlocking) != hipSuccess) { l.cache->stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); break; }
         if (!l.cache->copy_stream && hipStreamCreateWithFlags(&l.cache->copy_stream, hipStreamNonBlocking) != hipSuccess) { l.cache->copy_stream = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); break; }
+        for (hipStream_t* sp : {&l.cache->scan_stream, &l.cache->back_stream})
+            if (rc == PA_OK && !*sp && hipStreamCreateWithFlags(sp, hipStreamNonBlocking) != hipSuccess) { *sp = nullptr; rc = fail(PA_ERR_HIP, "hipStreamCreate failed"); }
+        if (rc != PA_OK) break;
         l.stream = l.cache->stream;
         l.copy = l.cache->copy_stream;
+        l.scan = l.cache->scan_stream;
+        l.back = l.cache->back_stream;
     }
 
     Writer writer(out);
@@ -793,7 +801,7 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
             if (attempt == 2) return fail(PA_ERR_INTERNAL, "FASTQ scan: line table too small after regrowing");
             ++tp.rescans;   // more lines than guessed (short reads): grow the line table, fill it again from the counts already there
             if ((e = window_ensure_scan(c, c.h_info->lines)) != PA_OK) return e;
-            if ((e = window_scan_enqueue(c, true, l.stream)) != PA_OK) return e;
+            if ((e = window_scan_enqueue(c, true, l.scan)) != PA_OK) return e;
         }
         if (c.h_info->odd) return WIN_ODD;
         if (c.h_info->n == 0) return WIN_EMPTY;
@@ -867,14 +875,14 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
         t0 = TextPipe::now();
         if (head) {
             if ((rc = tp.read_small(rec_start, head, c.h_raw + WINDOW_HEAD_ROOM - head)) != PA_OK) break;
-            if (hipMemcpyAsync((uint8_t*)c.d_raw + WINDOW_HEAD_ROOM - head, c.h_raw + WINDOW_HEAD_ROOM - head, head, hipMemcpyHostToDevice, l.stream) != hipSuccess) { rc = fail(PA_ERR_HIP, "copy of a window's head failed"); break; }
+            if (hipMemcpyAsync((uint8_t*)c.d_raw + WINDOW_HEAD_ROOM - head, c.h_raw + WINDOW_HEAD_ROOM - head, head, hipMemcpyHostToDevice, l.scan) != hipSuccess) { rc = fail(PA_ERR_HIP, "copy of a window's head failed"); break; }
         }
         tp.t_read += TextPipe::now() - t0; t0 = TextPipe::now();
         c.raw_begin = WINDOW_HEAD_ROOM - head;
         c.raw_end = WINDOW_HEAD_ROOM + main_len;
         if ((rc = window_ensure_scan(c, 0)) != PA_OK) break;
-        if (hipStreamWaitEvent(l.stream, c.ev_h2d, 0) != hipSuccess) { rc = fail(PA_ERR_HIP, "hipStreamWaitEvent failed"); break; }
-        if ((rc = window_scan_enqueue(c, false, l.stream)) != PA_OK) break;
+        if (hipStreamWaitEvent(l.scan, c.ev_h2d, 0) != hipSuccess) { rc = fail(PA_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        if ((rc = window_scan_enqueue(c, false, l.scan)) != PA_OK) break;
         tp.t_launch += TextPipe::now() - t0;
         pending = Win();
         pending.id = id;
@@ -991,7 +999,8 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
     for (Lane& l : lanes) {
         if (!l.cache) continue;
         (void)hipSetDevice(l.device);
-        if (l.copy) (void)hipStreamSynchronize(l.copy);
+        for (hipStream_t s : {l.copy, l.scan, l.back})
+            if (s) (void)hipStreamSynchronize(s);
         if (l.stream) (void)hipStreamSynchronize(l.stream);   // (the streams stay with the parked buffers; IngestCache::destroy releases them)
     }
     bool wrote = true;

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -163,10 +164,14 @@ struct BatchCtx {   // pinned host buffers + device buffers of one batch in flig
     uint4* h_rec = nullptr;
     FqInfo* h_info = nullptr;
     hipEvent_t ev_h2d = nullptr, ev_info = nullptr;
+    // the tuples' way back on a stream of its own (the lane's; not owned here): the next window's kernels do not queue behind 14 MB of text going to the host
+    hipStream_t back = nullptr;
+    hipEvent_t ev_render = nullptr;
+    bool text_on_back = false;
     void release() {
         for (void* p : {(void*)h_ascii, (void*)h_soff, (void*)h_ids, (void*)h_idoff, (void*)h_tot, (void*)h_text, (void*)h_raw, (void*)h_rec, (void*)h_info})
             if (p) (void)hipHostFree(p);
-        for (hipEvent_t e : {ev_text, ev_h2d, ev_info})
+        for (hipEvent_t e : {ev_text, ev_h2d, ev_info, ev_render})
             if (e) (void)hipEventDestroy(e);
         for (void* p : {d_tiles, d_lens, d_results, d_arena, d_ascii, d_soff, d_ids, d_idoff, d_len, d_off, d_scan, d_flag, d_text, d_raw, d_chunk, d_first, d_fq_tmp, d_ls, d_rec, d_info})
             if (p) (void)hipFree(p);
@@ -299,6 +304,8 @@ struct IngestCache {   // the two batches in flight of a pa_process_reads call o
     std::vector<RecPos> rec_pos;   // 24 bytes per record of a host-scanned window: kept, or every call would page them in again
     std::vector<std::vector<uint32_t>> brk;   // the host scan's line-break lists (4 bytes per line), kept for the same reason
     hipStream_t copy_stream = nullptr;   // pa_process_reads: the windows' text goes to the GPU on a stream of its own, beside the kernels of the window before
+    hipStream_t scan_stream = nullptr;   // ... their records are found on another (a window's scan waits for its text and the scan before, not for the kernels of the window before)
+    hipStream_t back_stream = nullptr;   // ... and the tuples go to the host on a third
     // the stream the batches run on travels with the buffers: its launch context inside the index (2 GB of list-mode rows)
     // is then reused by the next call instead of being stranded behind a destroyed stream
     pa_index* idx = nullptr;
@@ -306,7 +313,8 @@ struct IngestCache {   // the two batches in flight of a pa_process_reads call o
     static void destroy(void* p) {
         IngestCache* c = static_cast<IngestCache*>(p);
         for (BatchCtx& b : c->ctx) b.release();
-        if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+        for (hipStream_t s : {c->copy_stream, c->scan_stream, c->back_stream})
+            if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
         if (c->stream) {
             if (c->idx) (void)pa_index_release_stream(c->idx, c->stream);
             (void)hipStreamDestroy(c->stream);
@@ -342,6 +350,7 @@ inline int window_ensure_events(BatchCtx& c) {
     // (blocking: the thread that waits for a window's scan sleeps — the pool's workers are reading the next window on every CPU of the quota, and a spinning
     // waiter on top of them gets the whole process throttled)
     if (!c.ev_info) PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_info, hipEventDisableTiming | hipEventBlockingSync));
+    if (!c.ev_render) PA_INGEST_HIP_OK(hipEventCreateWithFlags(&c.ev_render, hipEventDisableTiming));
     if (!c.h_info) {
         PA_INGEST_HIP_OK(hipHostMalloc((void**)&c.h_info, sizeof(FqInfo), hipHostMallocDefault));
         PA_INGEST_HIP_OK(hipMalloc(&c.d_info, sizeof(FqInfo)));
@@ -428,7 +437,12 @@ inline int batch_render_enqueue(pa_index* idx, BatchCtx& c, hipStream_t stream) 
         k = launch_render_write((const pa_read_result*)c.d_results, (const uint32_t*)c.d_arena, batch_id_bytes(c), (const uint64_t*)c.d_idoff, batch_rec(c), d_cls_off, d_cls_txt, c.n,
                                 c.arena_entries, (const uint64_t*)c.d_off, (uint8_t*)c.d_text, c.spec_bytes, stream);
         if (k) return fail(PA_ERR_HIP, "render (text): %s", hipGetErrorString((hipError_t)k));
-        PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_text, c.d_text, c.spec_bytes, hipMemcpyDeviceToHost, stream));
+        c.text_on_back = c.back && c.ev_render;
+        if (c.text_on_back) {
+            PA_INGEST_HIP_OK(hipEventRecord(c.ev_render, stream));
+            PA_INGEST_HIP_OK(hipStreamWaitEvent(c.back, c.ev_render, 0));
+        }
+        PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_text, c.d_text, c.spec_bytes, hipMemcpyDeviceToHost, c.text_on_back ? c.back : stream));
     }
     return PA_OK;
 }
@@ -470,7 +484,9 @@ inline int batch_finish(pa_index* idx, BatchCtx& c, hipStream_t stream) {
     c.flagged = 0;
     for (uint32_t j = 0; j < PA_RENDER_FLAG_BUCKETS; ++j) c.flagged += c.h_tot[1 + j];
     c.text_guess = c.text_bytes + c.text_bytes / 8 + (64 << 10);
+    bool on_back = c.text_on_back && c.spec_bytes != 0;
     if (c.text_bytes > c.spec_bytes) {   // no guess yet (first batches) or a text longer than guessed: size the buffers, write it, fetch it
+        if (on_back) { PA_INGEST_HIP_OK(hipStreamSynchronize(c.back)); on_back = false; }   // (the copy of the guessed part is not left in flight beside this one)
         if (c.text_bytes + 64 > c.text_cap) {
             const size_t want = c.text_bytes + c.text_bytes / 4 + (1 << 20);
             if (c.h_text) (void)hipHostFree(c.h_text);
@@ -489,7 +505,7 @@ inline int batch_finish(pa_index* idx, BatchCtx& c, hipStream_t stream) {
         if (k) return fail(PA_ERR_HIP, "render (text): %s", hipGetErrorString((hipError_t)k));
         if (c.text_bytes) PA_INGEST_HIP_OK(hipMemcpyAsync(c.h_text, c.d_text, c.text_bytes, hipMemcpyDeviceToHost, stream));
     }
-    PA_INGEST_HIP_OK(hipEventRecord(c.ev_text, stream));
+    PA_INGEST_HIP_OK(hipEventRecord(c.ev_text, on_back ? c.back : stream));
     return PA_OK;
 }
 // the batch's tuples have arrived in c.h_text[0 .. c.text_bytes)

@@ -190,7 +190,7 @@ int pa_record_stream_create_multi(pa_index* const* idxs, int n_idx, int num_thre
         if (!l.cache) l.cache = new (std::nothrow) IngestCache();
         if (!l.cache) { pa_record_stream_destroy(s); return fail(PA_ERR_OOM, "out of memory"); }
         l.cache->idx = l.idx;
-        for (int k = 0; k < 2; ++k) { BatchCtx& c = l.cache->ctx[k]; c.recs.clear(); c.n = 0; c.first = 0; c.in_place = false; c.flag_mark = 0; }   // (a parked set still names its last batch — or a window of pa_process_reads)
+        for (int k = 0; k < 2; ++k) { BatchCtx& c = l.cache->ctx[k]; c.recs.clear(); c.n = 0; c.first = 0; c.in_place = false; c.flag_mark = 0; c.back = nullptr; c.text_on_back = false; }   // (a parked set still names its last batch — or a window of pa_process_reads)
         if (hipSetDevice(l.device) != hipSuccess) {   // (a stream the parked cache brought along stays with it: destroy releases it and its launch context)
             pa_record_stream_destroy(s);
             return fail(PA_ERR_HIP, "hipSetDevice(%d) failed", l.device);

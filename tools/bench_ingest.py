@@ -6,6 +6,9 @@ import argparse, importlib, json, os, sys, time
 from pathlib import Path
 import numpy as np
 
+if any(a.startswith("--ballast") for a in sys.argv):
+    import torch  # noqa: F401  (before the product library: one HIP runtime in the process)
+
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 pa = importlib.import_module("rust-pseudoaligner_amd")
@@ -17,6 +20,9 @@ def main():
     ap.add_argument("--index-cache", default="/tmp/g.idx")
     ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
     ap.add_argument("--threads", default="")
+    ap.add_argument("--ballast-device-gb", type=float, default=0, help="diagnosis: this much device memory allocated (torch) before the calls")
+    ap.add_argument("--ballast-pinned-gb", type=float, default=0, help="diagnosis: this much pinned host memory allocated (torch) before the calls")
+    ap.add_argument("--ballast-touch", action="store_true", help="diagnosis: the device ballast is written once")
     args = ap.parse_args()
     t0 = time.time()
     tx = pa.Txome.synthesize(58000, 203000, 7)
@@ -57,6 +63,16 @@ def main():
     except OSError:
         pass
     threads = [int(x) for x in args.threads.split(",") if x] or sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(16, ncpu)}, reverse=True)
+    ballast = []
+    if args.ballast_device_gb or args.ballast_pinned_gb:
+        import torch
+        for _ in range(int(args.ballast_device_gb)):
+            ballast.append(torch.empty(1 << 30, dtype=torch.uint8, device="cuda"))
+            if args.ballast_touch:
+                ballast[-1].zero_()
+        for _ in range(int(args.ballast_pinned_gb)):
+            ballast.append(torch.empty(1 << 30, dtype=torch.uint8, pin_memory=True))
+        torch.cuda.synchronize()
     pa.process_reads(str(fq), al, "/dev/null", ncpu)   # warm-up (page cache, pinned buffers, kernels)
     os.environ["PA_VERBOSE"] = "1"
     for t in threads:
