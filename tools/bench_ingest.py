@@ -75,11 +75,20 @@ def main():
         torch.cuda.synchronize()
     pa.process_reads(str(fq), al, "/dev/null", ncpu)   # warm-up (page cache, pinned buffers, kernels)
     os.environ["PA_VERBOSE"] = "1"
+    def throttled():   # the cgroup's CPU-quota throttling so far (cgroup v2): periods throttled, microseconds
+        try:
+            st = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines())
+            return int(st.get("nr_throttled", 0)), int(st.get("throttled_usec", 0))
+        except OSError:
+            return 0, 0
     for t in threads:
+        th0 = throttled()
         t0 = time.time()
         got, flagged = pa.process_reads(str(fq), al, "/dev/null", t)
         dt = time.time() - t0
+        th1 = throttled()
         assert got == n
+        print("[ingest] threads %d: %.1f M reads/s, cgroup throttled %d periods / %.1f ms during the call" % (t, n / dt / 1e6, th1[0] - th0[0], (th1[1] - th0[1]) / 1e3), file=sys.stderr)
         print(json.dumps({"metric": "reads/sec FASTQ text -> Debug tuples (pa_process_reads, /dev/null)", "value": n / dt, "unit": "reads/s",
                           "threads": t, "reads": n, "seconds": dt, "fastq_GBps": size / dt / 1e9, "flagged": flagged}))
     fq.unlink()
