@@ -44,7 +44,7 @@ WORKLOADS = {
 }
 
 # the device sources whose text decides what the PMC counters of profiles/latest_pmc.json were measured on
-KERNEL_SOURCES = ["map_pool.hip", "lane_steps.hpp", "device_layout.hpp", "count_sort.hip", "kernels.hpp", "dict_slots.hpp", "resolve.hip", "kernel_utils.hpp",
+KERNEL_SOURCES = ["map_pool.hip", "map_pool_kernel.inc", "lane_steps.hpp", "lane_steps_body.hpp", "device_layout.hpp", "count_sort.hip", "kernels.hpp", "dict_slots.hpp", "resolve.hip", "kernel_utils.hpp",
                   "device_index.hip", "device_flatten.cpp", "index_fill.hip"]
 
 
