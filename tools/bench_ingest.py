@@ -56,6 +56,21 @@ def main():
             f.write(rec.tobytes())
     size = fq.stat().st_size
     print("[ingest] %d reads, %.2f GB FASTQ written in %.1f s" % (n, size / 1e9, time.time() - t0), file=sys.stderr)
+    try:   # where the file's page cache lives (NUMA nodes of a sample of its pages) and where the GPU hangs
+        import mmap
+        with open(fq, "rb") as f:
+            mm = mmap.mmap(f.fileno(), 0, prot=mmap.PROT_READ)
+            for off in range(0, size, 1 << 22):
+                mm[off]
+            base = None
+            for line in open("/proc/self/numa_maps"):
+                if "pa_ingest_bench.fq" in line:
+                    base = line.strip()
+            mm.close()
+        gpu_nodes = [open(p).read().strip() for p in sorted(__import__("glob").glob("/sys/class/drm/card*/device/numa_node"))]
+        print("[ingest] file pages: %s ; GPU numa nodes by card: %s ; writer thread ran on cpu %d" % (base, ",".join(gpu_nodes), os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1), file=sys.stderr)
+    except Exception as e:  # noqa: BLE001
+        print("[ingest] numa probe failed: %r" % (e,), file=sys.stderr)
     ncpu = os.cpu_count() or 1
     try:
         print("[ingest] cpu_count %d, affinity %d, cgroup cpu.max %s" % (ncpu, len(os.sched_getaffinity(0)),
