@@ -125,6 +125,25 @@ def test_default_window_and_long_headers(aligner, tmp_path, monkeypatch):
     assert out.read_text().splitlines() == want
 
 
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_tuples_that_grow_from_window_to_window(aligner, tmp_path, monkeypatch, lanes):
+    """a window's tuples are rendered and sent back ahead of knowing their length, sized by the window before (on the lane's copy-back
+    stream); text that turns out longer is rendered again. Ids that grow in steps — 8, 60, 400, 30, 1500 characters — make every kind
+    of window: longer than guessed, much shorter, first of its call"""
+    ids, seqs = make_reads(30000, 21, 30, 181)
+    steps = [8, 60, 400, 30, 1500, 12]
+    ids = [("%07d" % j) + "q" * (steps[j * len(steps) // len(ids)] - 7) for j in range(len(ids))]
+    want = expected_lines(aligner, ids, seqs)
+    fq = tmp_path / "g.fq"
+    fq.write_text("".join("@%s\n%s\n+\n%s\n" % (i, s, "I" * len(s)) for i, s in zip(ids, seqs)))
+    out = tmp_path / "o.txt"
+    for window in (40000, 300000):
+        monkeypatch.setenv("PA_INGEST_WINDOW", str(window))
+        for _ in range(2):   # (the second call starts with the first one's parked buffers and guesses)
+            assert pa.process_reads_multi(str(fq), [aligner] * lanes, str(out), 8)[0] == len(ids)
+            assert out.read_text().splitlines() == want
+
+
 def test_replicas_are_checked(aligner, small_index, tmp_path):
     other = pa.Pseudoaligner(small_index(20), 0)
     fq = tmp_path / "x.fq"
