@@ -578,7 +578,7 @@ def ingest_leg(env, run, n):
         pa.process_reads(fq, run.aligner, "/dev/null", ncpu)           # warm-up: page cache, pinned buffers
         best = None
         runs = []
-        for _ in range(4):
+        for _ in range(6):
             t0 = time.perf_counter()
             got, _ = pa.process_reads(fq, run.aligner, "/dev/null", ncpu)
             dt = time.perf_counter() - t0
@@ -592,7 +592,7 @@ def ingest_leg(env, run, n):
         bound = max(("scan_s", "pack_s", "gpu_wait_s", "render_s", "writer_wait_s"), key=lambda k: st[k])
         out = {"ingest_reads_per_s": n / dt, "ingest_bound_stage": bound.replace("_s", ""),
                "ingest": {"what": "pa_process_reads: %d reads of %d bp, %.2f GB FASTQ in the page cache -> tuples to /dev/null, %d worker threads (the box's CPU quota); "
-                                  "best of four calls; stages: scan = the host's own record scan (the text's last MiB), pack = reading the windows into pinned memory, "
+                                  "best of six calls (the host's read of the file varies from call to call: runs_Mreads_per_s); stages: scan = the host's own record scan (the text's last MiB), pack = reading the windows into pinned memory, "
                                   "gpu_wait = waiting for a window's copy and scan" % (n, wl["read_len"], size / 1e9, ncpu),
                           "seconds": dt, "fastq_GBps": size / dt / 1e9, "stages": stages, "runs_Mreads_per_s": runs,
                           "text_bytes_per_read": size / n,
