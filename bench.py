@@ -52,6 +52,7 @@ def kernel_source_sha256() -> str:
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
         h.update((ROOT / "rust-pseudoaligner_amd" / "csrc" / name).read_bytes())
+    h.update((ROOT / "rust-pseudoaligner_amd" / "_build.py").read_bytes())   # (the compiler flags of the kernels)
     return h.hexdigest()
 
 

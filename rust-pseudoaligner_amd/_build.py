@@ -16,6 +16,11 @@ HOST_SOURCES = ["host_index.cpp", "dbg_build.cpp", "device_flatten.cpp", "synth.
 HIP_SOURCES = ["kernels.hip", "map_pool.hip", "device_index.hip", "collective.hip", "barcode_counts.hip", "index_build.hip", "index_fill.hip", "count_sort.hip", "resolve.hip", "render.hip", "fastq_scan.hip", "compact.hip"]
 
 
+# flags of single sources. map_pool.hip: without LLVM's machine-sinking pass the mapping kernel is 1 % faster at config 3 (7.608 -> 7.536 ms, three interleaved
+# pairs on one box), 0.2 % at config 5, 0.5-1.7 % at config3r (profiles/r06_compiler_flags_ab.txt; eight other scheduler / if-conversion flags: within noise or slower)
+EXTRA_FLAGS = {"map_pool.hip": ["-mllvm", "-disable-machine-sink"]}
+
+
 def _stale(target: Path, sources) -> bool:
     if not target.exists():
         return True
@@ -42,7 +47,7 @@ OBJ_DIR = PKG / "_build"   # per-source objects (git-ignored): only what changed
 
 def _deps_of(src: Path):
     """the source plus every header it can see (all of csrc/*.hpp and the public header: coarse, always safe)"""
-    return [src] + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + [ROOT / "include" / "pseudoaligner_amd.h"]
+    return [src] + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc")) + [ROOT / "include" / "pseudoaligner_amd.h", Path(__file__)]
 
 
 def build_product(force: bool = False) -> Path:
@@ -57,7 +62,7 @@ def build_product(force: bool = False) -> Path:
     for s in srcs:
         obj = OBJ_DIR / (s.name + ".o")
         if force or _stale(obj, _deps_of(s)):
-            jobs.append([hipcc] + flags + ["-x", "hip", "-c", str(s), "-o", str(obj)])
+            jobs.append([hipcc] + flags + EXTRA_FLAGS.get(s.name, []) + ["-x", "hip", "-c", str(s), "-o", str(obj)])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             list(ex.map(_run, jobs))
