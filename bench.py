@@ -683,7 +683,7 @@ def host_to_host_leg(env, run):
                                        h_counts=h_counts.data_ptr(), chunk_reads=chunk, n_streams=NS)
         return time.perf_counter() - t0, words
     host_to_host()                       # warm-up: the streams' launch contexts and the staging buffers are created on first use
-    runs = [host_to_host() for _ in range(4)]
+    runs = [host_to_host() for _ in range(6)]
     e2e_s, packed_words = min(runs, key=lambda r: r[0])
     assert os.environ.get("PA_MAP_ABLATE") or int(h_counts.sum()) == B
     # parity of THIS leg's outputs: the first reads' compact records + packed classes as they arrived on the host, unpacked, against the oracle
@@ -704,7 +704,7 @@ def host_to_host_leg(env, run):
                     "novel_class_ids_left_on_device": 0, "parity_sample": None,
                     "what": "pa_map_tiles_host: pinned host 2-bit tiles (uniform batch: no length array) -> H2D || kernels || D2H of the COMPACT 8-byte records "
                             "(pa_results_compact_device) and of each chunk's packed classes ({length, ids...} of the classes that are no index classes, no padding) on several "
-                            "streams of one index handle -> records + ids + count table on the host; best of four calls; link = PCIe Gen5 x16, 63 GB/s per direction spec, "
+                            "streams of one index handle -> records + ids + count table on the host; best of six calls (runs_ms lists all); link = PCIe Gen5 x16, 63 GB/s per direction spec, "
                             "57 GB/s measured (profiles/r02_pcie_bw.json)"},
             "_e2e_sample": sample}
 
