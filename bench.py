@@ -659,7 +659,7 @@ def ingest_leg(env, run, n):
 
 def host_to_host_leg(env, run):
     """SURVEY §8d's literal metric: the batch from PINNED HOST tiles to COMPLETE per-read outputs on the host — through the product's own
-    host-to-host entry (pa_map_tiles_host, csrc/host_batch.cpp): chunks of 2 M reads rotate over four streams of the one index handle (H2D
+    host-to-host entry (pa_map_tiles_host, csrc/host_batch.cpp): chunks of 1 M reads rotate over four streams of the one index handle (H2D
     of chunk i + 1, the kernels of chunk i and D2H of chunk i - 1 overlap); back come the COMPACT 8-byte records, the packed classes that
     are no index classes ({length, ids...} in read order) and the count table. The batch is uniform (every read has read_len bases): no
     length array crosses the link."""
@@ -673,7 +673,7 @@ def host_to_host_leg(env, run):
     h_tiles.copy_(run.tiles[b])
     assert bool((run.lens[b] == read_len).all())
     NS = int(os.environ.get("PA_E2E_STREAMS", "4"))
-    chunk = min(B, int(os.environ.get("PA_E2E_CHUNK", str(min(B, 2_000_000))))) // 64 * 64 or B
+    chunk = min(B, int(os.environ.get("PA_E2E_CHUNK", str(min(B, 1_000_000))))) // 64 * 64 or B
     h_packed = torch.empty(max(aligner.arena_hint(chunk), B // 2), dtype=torch.int32, pin_memory=True)
     torch.cuda.synchronize()
 

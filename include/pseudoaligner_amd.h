@@ -274,7 +274,7 @@ int pa_results_compact_device(pa_index* idx, const pa_read_result* d_results, co
 
 /* The hot path HOST TO HOST (SURVEY.md §8d's literal metric): a batch that lies in host memory in the tile layout — pinned memory
  * (pa_host_alloc_pinned, hipHostMalloc, hipHostRegister) for the copies to run at the link's rate and beside the kernels — mapped in chunks
- * of chunk_reads reads (0: 2 M) that rotate over n_streams streams of the handle (0: 4; at most 8): the copy of chunk i + 1 to the GPU, the
+ * of chunk_reads reads (0: 1 M) that rotate over n_streams streams of the handle (0: 4; at most 8): the copy of chunk i + 1 to the GPU, the
  * kernels of chunk i and the copy of chunk i - 1's outputs back overlap. h_lens NULL: every read has uniform_len bases (no length array
  * crosses the link). Outputs in read order: h_compact[n_reads] (the 8-byte records above), h_packed[*packed_words] (their packed classes;
  * PA_ERR_ARENA_FULL when packed_cap is too small), h_counts[pa_counts_len(idx)] (the class-count table of the batch, overwritten; may

@@ -32,8 +32,7 @@ struct HostPipe {
     pa_index* idx = nullptr;
     int device = 0;
     Stage st[MAX_STREAMS];
-    // dedicated copy streams (A/B in knobs builds: see run()). rocprofv3 shows the runtime executing part of the copies issued on the chunks' own
-    // streams as blit KERNELS when a DMA engine is busy (1.4 - 4 ms per 80 MB chunk against 1.4 ms by DMA) — and still that arrangement is the fastest
+    // dedicated copy streams (A/B in knobs builds: see run())
     hipStream_t s_in = nullptr, s_back = nullptr, s_in2 = nullptr;
     void* d_counts = nullptr;
     uint64_t counts_len = 0;
@@ -106,10 +105,13 @@ int run(pa_index* idx, HostPipe& hp, const uint64_t* h_tiles, const uint32_t* h_
     if (!hp.s_in) HB_HIP(hipStreamCreateWithFlags(&hp.s_in, hipStreamNonBlocking));
     if (!hp.s_back) HB_HIP(hipStreamCreateWithFlags(&hp.s_back, hipStreamNonBlocking));
     if (!hp.s_in2) HB_HIP(hipStreamCreateWithFlags(&hp.s_in2, hipStreamNonBlocking));
-    // Where the copies run — measured (tools/bench_e2e.py, 100 M reads of config 3, same box): on the chunk's OWN stream 76 - 83 ms; tiles in on one
-    // dedicated copy stream 84 - 86 ms, on two alternating 101 ms; outputs back on a dedicated stream 109 - 113 ms (the cross-stream events
-    // serialise more than the DMA engines gain). The other arrangements stay selectable in knobs builds only.
-    const int in_mode = knob_int("PA_HB_IN", 0), back_mode = knob_int("PA_HB_BACK", 0);   // 0 = the chunk's own stream, 1 = one copy stream, 2 (in) = two alternating
+    // Where the copies run — measured (tools/bench_e2e.py, 100 M reads of config 3, same box, profiles/r06_e2e_copy_streams.txt): every copy on its chunk's OWN stream,
+    // nothing else: 76 - 113 ms, different from call to call — with several copies of one direction queued at once the runtime runs some of them as blit KERNELS
+    // (rocprofv3: 8 - 16 of the 50 tile copies, 1.4 - 4 ms each against 1.4 ms by DMA). The same streams with every copy BACK waiting for the one before it
+    // (an event of the chunk before: one copy back at a time): 72.9 - 73.7 ms, every call (default: back_mode 2). Also the copies IN one at a time: 74.1 - 75.1 ms.
+    // Tiles in on one dedicated copy stream 84 - 86 ms, on two alternating 101 ms; outputs back on a dedicated stream 109 - 113 ms. The other
+    // arrangements stay selectable in knobs builds only.
+    const int in_mode = knob_int("PA_HB_IN", 0), back_mode = knob_int("PA_HB_BACK", 2);   // in: 0 = the chunk's own stream, 1 = one copy stream, 2 = two alternating, 3 = own stream, one at a time; back: 0 = own stream, 1 = one copy stream, 2 = own stream, one at a time
     for (int k = 0; k < ns; ++k) {
         const int e = stage_ensure(idx, hp.st[k], chunk, wpr, h_lens != nullptr);
         if (e != PA_OK) return e;
@@ -129,7 +131,7 @@ int run(pa_index* idx, HostPipe& hp, const uint64_t* h_tiles, const uint32_t* h_
             HB_HIP(hipEventSynchronize(s.ev_back));   // (its records and the length of its packed stream have arrived)
             const uint64_t words = hp.h_pw[k];
             if (off + words > packed_cap || words > s.arena_cap) { rc = fail(PA_ERR_ARENA_FULL, "packed classes: %llu words so far, room for %llu", (unsigned long long)(off + words), (unsigned long long)packed_cap); break; }
-            const hipStream_t sb0 = back_mode ? hp.s_back : s.stream;
+            const hipStream_t sb0 = back_mode == 1 ? hp.s_back : s.stream;
             if (words) HB_HIP(hipMemcpyAsync(h_packed + off, s.d_packed, words * 4, hipMemcpyDeviceToHost, sb0));
             HB_HIP(hipEventRecord(s.ev_back, sb0));                 // (the stage's d_packed is rewritten only behind this copy)
             HB_HIP(hipStreamWaitEvent(s.stream, s.ev_back, 0));
@@ -138,7 +140,8 @@ int run(pa_index* idx, HostPipe& hp, const uint64_t* h_tiles, const uint32_t* h_
         }
         if (c < n_chunks) {
             const uint64_t lo = c * chunk, nn = std::min<uint64_t>(chunk, n - lo);   // chunk is a multiple of 64: tile aligned
-            const hipStream_t si = in_mode == 0 ? s.stream : (in_mode == 2 && (c & 1)) ? hp.s_in2 : hp.s_in;
+            const hipStream_t si = (in_mode == 0 || in_mode == 3) ? s.stream : (in_mode == 2 && (c & 1)) ? hp.s_in2 : hp.s_in;
+            if (in_mode == 3 && c > 0) HB_HIP(hipStreamWaitEvent(si, hp.st[(int)((c - 1) % (uint64_t)ns)].ev_in, 0));   // one copy to the GPU at a time, each on its chunk's own stream
             HB_HIP(hipMemcpyAsync(s.d_tiles, h_tiles + (lo / 64) * wpr * 64, pa_tiles_words(nn, wpr) * 8, hipMemcpyHostToDevice, si));
             if (h_lens) HB_HIP(hipMemcpyAsync(s.d_lens, h_lens + lo, nn * 4, hipMemcpyHostToDevice, si));
             HB_HIP(hipEventRecord(s.ev_in, si));
@@ -154,8 +157,9 @@ int run(pa_index* idx, HostPipe& hp, const uint64_t* h_tiles, const uint32_t* h_
                                            (uint64_t*)s.d_pw, s.d_scr, s.scr_bytes, s.stream);
             if (rc != PA_OK) break;
             HB_HIP(hipEventRecord(s.ev_out, s.stream));
-            const hipStream_t sb = back_mode ? hp.s_back : s.stream;
+            const hipStream_t sb = back_mode == 1 ? hp.s_back : s.stream;
             HB_HIP(hipStreamWaitEvent(sb, s.ev_out, 0));
+            if (back_mode == 2 && c > 0) HB_HIP(hipStreamWaitEvent(sb, hp.st[(int)((c - 1) % (uint64_t)ns)].ev_back, 0));   // one copy back at a time
             HB_HIP(hipMemcpyAsync(h_compact + lo, s.d_compact, nn * 8, hipMemcpyDeviceToHost, sb));
             HB_HIP(hipMemcpyAsync(hp.h_pw + k, s.d_pw, 8, hipMemcpyDeviceToHost, sb));
             HB_HIP(hipEventRecord(s.ev_back, sb));
@@ -183,7 +187,7 @@ extern "C" int pa_map_tiles_host(pa_index* idx, const uint64_t* h_tiles, const u
     if (!idx || (n_reads && (!h_tiles || !h_compact)) || (packed_cap && !h_packed) || words_per_read == 0) return fail(PA_ERR_INVALID_ARG, "null argument");
     if (!h_lens && (uniform_len == 0 || uniform_len > PA_MAX_READ_LEN || uniform_len > 32ull * words_per_read)) return fail(PA_ERR_INVALID_ARG, "no length array and no usable uniform length");
     if (packed_words) *packed_words = 0;
-    if (chunk_reads == 0) chunk_reads = 2000000;
+    if (chunk_reads == 0) chunk_reads = 1000000;   // (1 M reads x 4 streams 71.8 - 73.3 ms per 100 M reads; 2 M 73.9 - 74.7; 4 M 72.3 - 76; 3 or 8 streams slower)
     chunk_reads = std::max<uint64_t>(64, std::min<uint64_t>(chunk_reads, std::max<uint64_t>(n_reads, 64)) / 64 * 64);
     if (n_streams <= 0) n_streams = 4;
     n_streams = std::min(n_streams, MAX_STREAMS);
