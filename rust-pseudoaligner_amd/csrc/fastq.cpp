@@ -547,6 +547,7 @@ struct Lane {
     int device = 0;
     IngestCache* cache = nullptr;
     hipStream_t stream = nullptr, copy = nullptr, scan = nullptr, back = nullptr;
+    hipEvent_t last_h2d = nullptr;       // behind the lane's last window copy (an event of one of its slots)
     int64_t unfinished = -1;             // the window whose kernels were launched last on `stream` and have not been waited for
     uint64_t text_job[LANE_SLOTS] = {0, 0, 0, 0};   // the writer's job that reads the slot's pinned text (0: none)
 };
@@ -746,6 +747,7 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
     if (const char* v = getenv("PA_INGEST_WINDOW")) { const long long x = atoll(v); if (x >= 1) W = (uint64_t)x; }
     W = std::min<uint64_t>(std::min<uint64_t>(W, BATCH_READS * 256), 1ull << 31);
     const bool verbose = getenv("PA_VERBOSE") != nullptr;
+    const bool lane_serial = knob_int("PA_LANE_SERIAL", 1) != 0;   // (knobs builds: A/B of the one-window-at-a-time rule for lanes that share a GPU)
     const bool host_only = getenv("PA_INGEST_HOST_SCAN") != nullptr;   // (diagnosis: every window through the host's scan)
     const double t_begin = TextPipe::now();
     Pool pool(num_threads);
@@ -850,8 +852,14 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
             (void)hipEventRecord(vt0[id % 8], l.copy);
             vbytes[id % 8] = main_len;
         }
+        // lanes that share a GPU (a handle listed twice) send their windows one at a time: with two copies of one direction queued at once the runtime
+        // runs one of them as a blit kernel, at a fraction of the DMA engine's rate (host_batch.cpp has the measurement)
+        for (size_t o = 0; o < lanes.size() && lane_serial; ++o)
+            if (&lanes[o] != &l && lanes[o].device == l.device && lanes[o].last_h2d && hipStreamWaitEvent(l.copy, lanes[o].last_h2d, 0) != hipSuccess) { rc = fail(PA_ERR_HIP, "hipStreamWaitEvent failed"); break; }
+        if (rc != PA_OK) break;
         if (hipMemcpyAsync((uint8_t*)c.d_raw + WINDOW_HEAD_ROOM, c.h_raw + WINDOW_HEAD_ROOM, main_len, hipMemcpyHostToDevice, l.copy) != hipSuccess ||
             hipEventRecord(c.ev_h2d, l.copy) != hipSuccess) { rc = fail(PA_ERR_HIP, "copy of a text window to the GPU failed"); break; }
+        l.last_h2d = c.ev_h2d;
         if (verbose) (void)hipEventRecord(vt1[id % 8], l.copy);
         if ((rc = start_read(nxt, id + 1)) != PA_OK) break;             // the next window's text starts to arrive
         bool discard = false;

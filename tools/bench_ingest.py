@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--index-cache", default="/tmp/g.idx")
     ap.add_argument("--dir", default="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
     ap.add_argument("--threads", default="")
+    ap.add_argument("--lanes", type=int, default=1, help="pa_process_reads_multi with the handle listed this many times (lanes of ONE GPU)")
     ap.add_argument("--ballast-device-gb", type=float, default=0, help="diagnosis: this much device memory allocated (torch) before the calls")
     ap.add_argument("--ballast-pinned-gb", type=float, default=0, help="diagnosis: this much pinned host memory allocated (torch) before the calls")
     ap.add_argument("--ballast-touch", action="store_true", help="diagnosis: the device ballast is written once")
@@ -99,7 +100,7 @@ def main():
     for t in threads:
         th0 = throttled()
         t0 = time.time()
-        got, flagged = pa.process_reads(str(fq), al, "/dev/null", t)
+        got, flagged = pa.process_reads(str(fq), al, "/dev/null", t) if args.lanes == 1 else pa.process_reads_multi(str(fq), [al] * args.lanes, "/dev/null", t)
         dt = time.time() - t0
         th1 = throttled()
         assert got == n
