@@ -60,6 +60,22 @@ def test_bench_under_torchrun_reduces_through_the_product(ranks):
     assert line["scaling"] == "weak" and line["parity_sample"]["bit_exact_vs_oracle"] is True
 
 
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """bench.py --gpus 2 with both ranks on THIS box's one GPU (PA_BENCH_BACKEND=gloo: RCCL refuses two ranks on a device, so the count tables are reduced
+    through torch.distributed's gloo spare and the line says so: rccl_ranks 0): the sharding of the reads by rank, the barrier + max-over-ranks timing, the
+    gather of every rank's kernel times and the whole-job value are the code the driver's N > 1 runs take"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PA_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(helpers.ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "config2", "--batch", "2000000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(helpers.ROOT))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 0 and line["scaling"] == "weak"
+    assert line["per_rank"]["ranks"] == 2 and len(line["per_rank"]["kernel_ms"]) == 2 and min(line["per_rank"]["kernel_ms"]) > 0
+    assert abs(line["value"] - 2 * 2 * 2_000_000 / (line["ms_per_step"] * 2 / 1000.0)) < 1e-6 * line["value"]   # both ranks' reads over the slower rank's time
+    assert line["parity_sample"]["bit_exact_vs_oracle"] is True
+
+
 def test_index_create_multi_one_thread_per_gpu(small_index):
     """pa_index_create_multi(ndev = all GPUs of the box) driven from ONE process with one thread per GPU: the shards' tables add up
     to the one-GPU table of the whole range (ndev = 1 on a one-GPU box: the same code path, one handle)"""
