@@ -329,8 +329,8 @@ int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offs
  * wrapped over several lines, which bio's reader accepts) is first rewritten into that form by a sequential pass (as many
  * quality lines as sequence lines, as bio 1.5 reads them), then scanned in parallel like any other. PA_ERR_FORMAT with
  * the record number for text that is no FASTQ or ends inside a record. Read ids are cut at the first space, as record.id() does.
- * How it runs (round 6): the host does not look at the text. Worker threads read WINDOWS of the file into pinned memory (pread; 64 MiB
- * each, PA_INGEST_WINDOW overrides), a window goes to HBM as it is on a copy stream, the GPU finds its records (line breaks, '@' / '+'
+ * How it runs (round 6): the host does not look at the text. Worker threads copy WINDOWS of the file into pinned memory (out of the file's
+ * mapping with streaming stores; 64 MiB each, PA_INGEST_WINDOW overrides), a window goes to HBM as it is on a copy stream, the GPU finds its records (line breaks, '@' / '+'
  * markers, record.id(), record.seq(): csrc/fastq_scan.hip) and the encode / map / render kernels read sequences and ids where they lie;
  * a window ends where the file offset says, the unfinished record is read again as the head of the next window. The last piece of the
  * text and any text that is not in four-line shape go through the host's tolerant scan (and the same kernels).

@@ -189,7 +189,7 @@ struct FastqText {   // the text of a FASTQ file as the scan sees it: the mapped
     uint64_t off = 0;               // text before this offset has been handed out as records (windowed scan of pa_process_reads)
     const char* map_base = nullptr; // the mapping as mmap returned it (data moves on when the rest of a file is rewritten)
     uint64_t map_size = 0;
-    int fd = -1;                    // of a mapped file: pa_process_reads reads its windows with pread (no page of the mapping is touched for them)
+    int fd = -1;                    // of a mapped file (kept open for the call)
     void release() {
         if (mapped) munmap((void*)map_base, map_size);   // (the whole mapping: nobody gives parts of it back any more)
         if (fd >= 0) close(fd);
@@ -529,8 +529,8 @@ std::string rust_f32(float v) {
 }
 
 // ---- process_reads over WINDOWS of raw text ----
-// The host does not look at the text: worker threads read a window of the file into pinned memory (pread: one copy out of the page
-// cache, no page faults), the window goes to HBM as it is on a copy stream, the GPU finds its records (fastq_scan.hip) and the encode /
+// The host does not look at the text: worker threads copy a window of the file into pinned memory (out of the file's mapping, page tables
+// filled and dropped piece by piece: TextPipe::read_piece), the window goes to HBM as it is on a copy stream, the GPU finds its records (fastq_scan.hip) and the encode /
 // map / render kernels read sequences and ids where they lie. A lane has FOUR streams: copy (text in), scan (a window's records: waits for its
 // text and the scan before, not for the kernels of the window before), the kernels' stream, and back (the tuples' 14 MB per window to the host):
 // on one stream the chain scan | encode | map | render | copy back + two host round trips was as long as a window's copy, and every hiccup a gap on the link. A window ends where the file offset says, not where a record does: the
@@ -579,13 +579,51 @@ struct TextPipe {
     BatchCtx& ctx_of(const Win& w) { return lanes[(size_t)w.lane].cache->ctx[w.slot]; }
     int use(const Lane& l) { return hipSetDevice(l.device) == hipSuccess ? PA_OK : fail(PA_ERR_HIP, "hipSetDevice(%d) failed", l.device); }
 
-    // bytes [off, off + len) of the text into dst (pinned): pread for a file (no page of a mapping is touched), memcpy for text in memory.
+    // bytes [off, off + len) of the text into dst (pinned): out of the file's mapping (read_piece), memcpy for text in memory (inflated gzip).
     // read_begin hands the pieces to the worker pool and returns; read_end waits for them (small reads are done at once by the caller)
     std::atomic<int> read_bad{0};
     bool read_async = false;
+    // bytes of the mapping into a pinned window with streaming stores: the window is read next by the copy engine, never by this CPU, so no line of it
+    // has to be fetched for ownership or kept in a cache
+    static void copy_streaming(uint8_t* d, const uint8_t* s, size_t n) {
+        size_t head = (64 - ((uintptr_t)d & 63)) & 63;
+        if (head > n) head = n;
+        memcpy(d, s, head);
+        d += head; s += head; n -= head;
+        const size_t body = n & ~(size_t)63;
+        for (size_t i = 0; i < body; i += 64) {
+            const __m128i v0 = _mm_loadu_si128((const __m128i*)(s + i)), v1 = _mm_loadu_si128((const __m128i*)(s + i + 16));
+            const __m128i v2 = _mm_loadu_si128((const __m128i*)(s + i + 32)), v3 = _mm_loadu_si128((const __m128i*)(s + i + 48));
+            _mm_stream_si128((__m128i*)(d + i), v0); _mm_stream_si128((__m128i*)(d + i + 16), v1);
+            _mm_stream_si128((__m128i*)(d + i + 32), v2); _mm_stream_si128((__m128i*)(d + i + 48), v3);
+        }
+        _mm_sfence();
+        memcpy(d + body, s + body, n - body);
+    }
+    bool use_pread = false;   // (knobs builds: the windows through pread, as before; tools/microbench/host_read.cpp has both side by side)
     void read_piece(uint64_t off, uint64_t len, uint8_t* dst, int t, int ntask) {
         const uint64_t a = off + len * (uint64_t)t / (uint64_t)ntask, b = off + len * (uint64_t)(t + 1) / (uint64_t)ntask;
-        if (text.mapped && text.fd >= 0 && text.data == text.map_base) {
+        if (text.mapped && text.data == text.map_base && !use_pread) {
+            // A file: out of its MAPPING. pread copies at 65 - 75 GB/s on 16 threads of the target host (one copy_to_user per page, the file's page-cache
+            // lock) — 1.2 x the link, no margin — the same bytes out of the mapping at 127 GB/s INCLUDING the page tables of the piece, which are
+            // filled in one call before the copy (MADV_POPULATE_READ, Linux 5.14; without it the copy faults them in: 115 GB/s) and dropped behind it
+            // (a 100 GB file would otherwise keep 25 M entries mapped until the call ends)
+            constexpr uint64_t PAGE = 4096;
+            const bool big = b - a >= (256u << 10);
+            if (big) {
+                const uint64_t pa = a & ~(PAGE - 1), pb = std::min<uint64_t>((b + PAGE - 1) & ~(PAGE - 1), text.map_size);
+#ifdef MADV_POPULATE_READ
+                (void)madvise((void*)(text.map_base + pa), (size_t)(pb - pa), MADV_POPULATE_READ);
+#else
+                (void)madvise((void*)(text.map_base + pa), (size_t)(pb - pa), 22);
+#endif
+            }
+            copy_streaming(dst + (a - off), (const uint8_t*)text.data + a, (size_t)(b - a));
+            if (big) {
+                const uint64_t qa = (a + PAGE - 1) & ~(PAGE - 1), qb = b & ~(PAGE - 1);
+                if (qb > qa) (void)madvise((void*)(text.map_base + qa), (size_t)(qb - qa), MADV_DONTNEED);
+            }
+        } else if (text.mapped && text.fd >= 0 && text.data == text.map_base) {
             uint64_t p = a;
             while (p < b) {
                 const ssize_t got = pread(text.fd, dst + (p - off), (size_t)(b - p), (off_t)p);
@@ -777,6 +815,7 @@ int process_reads_impl(pa_index* const* idxs, int nidx, const char* fastq_path, 
 
     Writer writer(out);
     TextPipe tp{fastq_path, text, pool, writer, lanes, BATCH_READS};
+    tp.use_pread = knob_int("PA_INGEST_PREAD", 0) != 0;
     const uint64_t fsize0 = text.fsize;
     const uint64_t KEEP = std::max<uint64_t>(4096, std::min<uint64_t>(W / 4, 1ull << 20));   // the end of the text is the host's: its rules for the last record live there
     uint64_t rec_start = 0;   // text offset of the first record no window has taken yet (known once the window before has been scanned)
