@@ -324,7 +324,8 @@ int pa_map_batch_nodes(pa_index* idx, const uint8_t* ascii, const uint64_t* offs
 /* process_reads (src/pseudoaligner.rs:420-514): FASTQ in, one Debug-formatted tuple per read on `out_path`
  * ("-" = stdout) in INPUT order (the reference's order is completion order, :490). num_threads sizes the
  * host parse/format pool. n_reads_out/n_flagged_out may be NULL.
- * Input: plain or gzip'ed (multi-member) FASTQ in the four-line form every sequencer writes — "@id ...", sequence, "+...",
+ * Input: plain or gzip'ed (multi-member) FASTQ (a gzip'ed file is inflated into host memory first — one zlib stream, some 0.4 GB/s, and the whole
+ * text resident: the reference's CLI takes plain files only, src/bin/pseudoaligner.rs:139; inflate large files upstream) in the four-line form every sequencer writes — "@id ...", sequence, "+...",
  * qualities; LF or CRLF; trailing blank lines tolerated (a last record with an empty sequence is still that record). A file whose records are not four lines each (sequence or qualities
  * wrapped over several lines, which bio's reader accepts) is first rewritten into that form by a sequential pass (as many
  * quality lines as sequence lines, as bio 1.5 reads them), then scanned in parallel like any other. PA_ERR_FORMAT with
